@@ -1,0 +1,382 @@
+/*
+ * bn254_oracle.c -- CPU ORACLE for the BN254 MSM / Fr-NTT hot path.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE.  It is a plain-C restatement of the arithmetic
+ * that scroll-prover reaches through halo2_proofs / halo2curves.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * (scroll-prover_amd/csrc + libmi355zk.so) never links, imports or calls it.
+ *
+ * Provenance.  /root/reference contains no proving arithmetic.
+ * The algorithm lives in two un-vendored git dependencies pinned by the reference:
+ *   halo2_proofs 1.1.0 = scroll-tech/halo2      @ e5ddf67e5ae16be38d6368ed355c7c41906272ab  [REF Cargo.lock:1886-1888]
+ *   halo2curves  0.1.0 = scroll-tech/halo2curves@ 112f5b9bf27f6b1708ba7d1c2fc14cb3c6e55604  [REF Cargo.lock:1911-1913]
+ * Their source is absent here, so each function below restates the *published*
+ * algorithm of those crates (names given per function, "[EXT-recalled]") and parity is
+ * anchored on the reference's own call sites ([REF integration/src/prove.rs:37,67,96])
+ * and on the golden vectors decoded from the reference's fixtures (tests/golden/,
+ * SURVEY.md Appendix A).  Those fixtures pin the encodings and the field / curve
+ * arithmetic; there is no MSM/NTT known-answer vector anywhere in the reference, so at
+ * the MSM/NTT function boundary the oracle is "parity unpinned": it is validated
+ * instead by (i) an independent pure-Python big-int oracle (oracle/pyref.py) that
+ * shares no code with this file and (ii) algebraic invariants (tests/).
+ *
+ * Data conventions (proved by fixture KAT A1/A2): field elements are
+ * 4 x u64 little-endian limbs, Montgomery form (R = 2^256), fully reduced.
+ * G1Affine = {x, y} (64 B), identity = (0, 0).  G1 = Jacobian {x, y, z} (96 B), identity z = 0.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <pthread.h>
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fe;
+typedef struct { fe m, r, r2; uint64_t inv; } fparams;
+typedef struct { fe x, y; } g1a;       /* affine */
+typedef struct { fe x, y, z; } g1j;    /* Jacobian */
+
+/* halo2curves bn256 constants [EXT-recalled src/bn256/fq.rs, fr.rs]; re-derived numerically in tests */
+static const fparams FQ = {
+  {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}},
+  {{0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL}},
+  {{0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL}},
+  0x87d20782e4866389ULL };
+static const fparams FR = {
+  {{0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}},
+  {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}},
+  {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}},
+  0xc2e1f593efffffffULL };
+
+/* ------------------------------------------------------------------ field ---- */
+static inline int fe_is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fe_eq(const fe *a, const fe *b) { return memcmp(a, b, sizeof(fe)) == 0; }
+static inline int fe_geq(const fe *a, const fe *m) {
+  for (int i = 3; i >= 0; i--) { if (a->l[i] > m->l[i]) return 1; if (a->l[i] < m->l[i]) return 0; }
+  return 1;
+}
+static inline void fe_sub_nored(fe *o, const fe *a, const fe *b, uint64_t *borrow) {
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a->l[i] - b->l[i] - br; o->l[i] = (uint64_t)d; br = (d >> 64) & 1; }
+  *borrow = (uint64_t)br;
+}
+static inline void fe_add(fe *o, const fe *a, const fe *b, const fparams *P) {
+  u128 c = 0; fe t;
+  for (int i = 0; i < 4; i++) { c += (u128)a->l[i] + b->l[i]; t.l[i] = (uint64_t)c; c >>= 64; }
+  /* moduli are < 2^254 so no carry out of 256 bits */
+  if (fe_geq(&t, &P->m)) { uint64_t br; fe_sub_nored(&t, &t, &P->m, &br); }
+  *o = t;
+}
+static inline void fe_sub(fe *o, const fe *a, const fe *b, const fparams *P) {
+  uint64_t br; fe t; fe_sub_nored(&t, a, b, &br);
+  if (br) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)t.l[i] + P->m.l[i]; t.l[i] = (uint64_t)c; c >>= 64; } }
+  *o = t;
+}
+static inline void fe_neg(fe *o, const fe *a, const fparams *P) {
+  if (fe_is_zero(a)) { *o = *a; return; }
+  uint64_t br; fe_sub_nored(o, &P->m, a, &br);
+}
+static inline void fe_dbl(fe *o, const fe *a, const fparams *P) { fe_add(o, a, a, P); }
+/* Montgomery multiplication, CIOS, 4 x 64 [EXT-recalled halo2curves field_arithmetic! macro: montgomery_reduce] */
+static inline void fe_mul(fe *o, const fe *a, const fe *b, const fparams *P) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a->l[j] * b->l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * P->inv;
+    c = (u128)m * P->m.l[0] + t[0]; c >>= 64;
+    for (int j = 1; j < 4; j++) { c += (u128)m * P->m.l[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  fe r = {{t[0], t[1], t[2], t[3]}};
+  if (t[4] || fe_geq(&r, &P->m)) { uint64_t br; fe_sub_nored(&r, &r, &P->m, &br); }
+  *o = r;
+}
+static inline void fe_sqr(fe *o, const fe *a, const fparams *P) { fe_mul(o, a, a, P); }
+static void fe_from_canonical(fe *o, const fe *a, const fparams *P) { fe_mul(o, a, &P->r2, P); }
+static void fe_to_canonical(fe *o, const fe *a, const fparams *P) { fe one = {{1, 0, 0, 0}}; fe_mul(o, a, &one, P); }
+/* a^e, e given as 4 canonical limbs */
+static void fe_pow(fe *o, const fe *a, const uint64_t e[4], const fparams *P) {
+  fe acc = P->r;
+  for (int i = 255; i >= 0; i--) { fe_sqr(&acc, &acc, P); if ((e[i >> 6] >> (i & 63)) & 1) fe_mul(&acc, &acc, a, P); }
+  *o = acc;
+}
+/* inverse by Fermat: a^(m-2); 0 -> 0 */
+static void fe_inv(fe *o, const fe *a, const fparams *P) {
+  uint64_t e[4] = {P->m.l[0] - 2, P->m.l[1], P->m.l[2], P->m.l[3]}; /* low limbs of both moduli are > 2 */
+  fe_pow(o, a, e, P);
+}
+
+/* exported field API: which = 0 -> Fq, 1 -> Fr */
+static const fparams *sel(int which) { return which ? &FR : &FQ; }
+void orc_f_add(int w, fe *o, const fe *a, const fe *b) { fe_add(o, a, b, sel(w)); }
+void orc_f_sub(int w, fe *o, const fe *a, const fe *b) { fe_sub(o, a, b, sel(w)); }
+void orc_f_neg(int w, fe *o, const fe *a) { fe_neg(o, a, sel(w)); }
+void orc_f_mul(int w, fe *o, const fe *a, const fe *b) { fe_mul(o, a, b, sel(w)); }
+void orc_f_inv(int w, fe *o, const fe *a) { fe_inv(o, a, sel(w)); }
+void orc_f_pow(int w, fe *o, const fe *a, const uint64_t *e) { fe_pow(o, a, e, sel(w)); }
+void orc_f_from_canonical(int w, fe *o, const fe *a) { fe_from_canonical(o, a, sel(w)); }
+void orc_f_to_canonical(int w, fe *o, const fe *a) { fe_to_canonical(o, a, sel(w)); }
+/* vector helpers */
+void orc_f_mul_vec(int w, fe *o, const fe *a, const fe *b, uint64_t n) { for (uint64_t i = 0; i < n; i++) fe_mul(&o[i], &a[i], &b[i], sel(w)); }
+void orc_f_from_canonical_vec(int w, fe *o, const fe *a, uint64_t n) { for (uint64_t i = 0; i < n; i++) fe_from_canonical(&o[i], &a[i], sel(w)); }
+void orc_f_to_canonical_vec(int w, fe *o, const fe *a, uint64_t n) { for (uint64_t i = 0; i < n; i++) fe_to_canonical(&o[i], &a[i], sel(w)); }
+
+/* Fq sqrt: p = 3 mod 4 -> a^((p+1)/4); returns 1 when a is a square */
+int orc_fq_sqrt(fe *o, const fe *a) {
+  /* (p+1)/4 */
+  static const uint64_t e[4] = {0x4f082305b61f3f52ULL, 0x65e05aa45a1c72a3ULL, 0x6e14116da0605617ULL, 0x0c19139cb84c680aULL};
+  fe s, c; fe_pow(&s, a, e, &FQ); fe_sqr(&c, &s, &FQ); *o = s; return fe_eq(&c, a);
+}
+
+/* ------------------------------------------------------------------ G1 ------- */
+/* y^2 = x^3 + 3 over Fq [EXT-recalled halo2curves src/bn256/curve.rs: new_curve_impl!(G1, ..., G1_B = 3)] */
+static fe FQ_B3(void) { fe three = {{3, 0, 0, 0}}, o; fe_from_canonical(&o, &three, &FQ); return o; }
+static inline int g1a_is_identity(const g1a *p) { return fe_is_zero(&p->x) && fe_is_zero(&p->y); }
+static inline int g1j_is_identity(const g1j *p) { return fe_is_zero(&p->z); }
+static inline void g1j_set_identity(g1j *p) { memset(p, 0, sizeof *p); }
+int orc_g1_is_on_curve(const g1a *p) {
+  if (g1a_is_identity(p)) return 1;
+  fe y2, x3, b = FQ_B3(); fe_sqr(&y2, &p->y, &FQ); fe_sqr(&x3, &p->x, &FQ); fe_mul(&x3, &x3, &p->x, &FQ); fe_add(&x3, &x3, &b, &FQ);
+  return fe_eq(&y2, &x3);
+}
+/* dbl-2009-l (a = 0) */
+static void g1j_double(g1j *o, const g1j *p) {
+  if (g1j_is_identity(p)) { *o = *p; return; }
+  fe a, b, c, d, e, f, t, x3, y3, z3;
+  fe_sqr(&a, &p->x, &FQ); fe_sqr(&b, &p->y, &FQ); fe_sqr(&c, &b, &FQ);
+  fe_add(&d, &p->x, &b, &FQ); fe_sqr(&d, &d, &FQ); fe_sub(&d, &d, &a, &FQ); fe_sub(&d, &d, &c, &FQ); fe_dbl(&d, &d, &FQ);
+  fe_dbl(&e, &a, &FQ); fe_add(&e, &e, &a, &FQ); fe_sqr(&f, &e, &FQ);
+  fe_mul(&z3, &p->y, &p->z, &FQ); fe_dbl(&z3, &z3, &FQ);
+  fe_dbl(&t, &d, &FQ); fe_sub(&x3, &f, &t, &FQ);
+  fe_sub(&t, &d, &x3, &FQ); fe_mul(&y3, &e, &t, &FQ); fe_dbl(&c, &c, &FQ); fe_dbl(&c, &c, &FQ); fe_dbl(&c, &c, &FQ); fe_sub(&y3, &y3, &c, &FQ);
+  o->x = x3; o->y = y3; o->z = z3;
+}
+/* add-2007-bl with the doubling / inverse special cases */
+static void g1j_add(g1j *o, const g1j *p, const g1j *q) {
+  if (g1j_is_identity(p)) { *o = *q; return; }
+  if (g1j_is_identity(q)) { *o = *p; return; }
+  fe z1z1, z2z2, u1, u2, s1, s2, h, i, j, r, v, t, x3, y3, z3;
+  fe_sqr(&z1z1, &p->z, &FQ); fe_sqr(&z2z2, &q->z, &FQ);
+  fe_mul(&u1, &p->x, &z2z2, &FQ); fe_mul(&u2, &q->x, &z1z1, &FQ);
+  fe_mul(&s1, &p->y, &q->z, &FQ); fe_mul(&s1, &s1, &z2z2, &FQ);
+  fe_mul(&s2, &q->y, &p->z, &FQ); fe_mul(&s2, &s2, &z1z1, &FQ);
+  if (fe_eq(&u1, &u2)) { if (fe_eq(&s1, &s2)) { g1j_double(o, p); } else { g1j_set_identity(o); } return; }
+  fe_sub(&h, &u2, &u1, &FQ); fe_dbl(&i, &h, &FQ); fe_sqr(&i, &i, &FQ); fe_mul(&j, &h, &i, &FQ);
+  fe_sub(&r, &s2, &s1, &FQ); fe_dbl(&r, &r, &FQ); fe_mul(&v, &u1, &i, &FQ);
+  fe_sqr(&x3, &r, &FQ); fe_sub(&x3, &x3, &j, &FQ); fe_sub(&x3, &x3, &v, &FQ); fe_sub(&x3, &x3, &v, &FQ);
+  fe_sub(&t, &v, &x3, &FQ); fe_mul(&y3, &r, &t, &FQ); fe_mul(&t, &s1, &j, &FQ); fe_dbl(&t, &t, &FQ); fe_sub(&y3, &y3, &t, &FQ);
+  fe_add(&z3, &p->z, &q->z, &FQ); fe_sqr(&z3, &z3, &FQ); fe_sub(&z3, &z3, &z1z1, &FQ); fe_sub(&z3, &z3, &z2z2, &FQ); fe_mul(&z3, &z3, &h, &FQ);
+  o->x = x3; o->y = y3; o->z = z3;
+}
+/* madd-2007-bl */
+static void g1j_add_affine(g1j *o, const g1j *p, const g1a *q) {
+  if (g1a_is_identity(q)) { *o = *p; return; }
+  if (g1j_is_identity(p)) { o->x = q->x; o->y = q->y; o->z = FQ.r; return; }
+  fe z1z1, u2, s2, h, hh, i, j, r, v, t, x3, y3, z3;
+  fe_sqr(&z1z1, &p->z, &FQ); fe_mul(&u2, &q->x, &z1z1, &FQ);
+  fe_mul(&s2, &q->y, &p->z, &FQ); fe_mul(&s2, &s2, &z1z1, &FQ);
+  if (fe_eq(&p->x, &u2)) { if (fe_eq(&p->y, &s2)) { g1j_double(o, p); } else { g1j_set_identity(o); } return; }
+  fe_sub(&h, &u2, &p->x, &FQ); fe_sqr(&hh, &h, &FQ); fe_dbl(&i, &hh, &FQ); fe_dbl(&i, &i, &FQ); fe_mul(&j, &h, &i, &FQ);
+  fe_sub(&r, &s2, &p->y, &FQ); fe_dbl(&r, &r, &FQ); fe_mul(&v, &p->x, &i, &FQ);
+  fe_sqr(&x3, &r, &FQ); fe_sub(&x3, &x3, &j, &FQ); fe_sub(&x3, &x3, &v, &FQ); fe_sub(&x3, &x3, &v, &FQ);
+  fe_sub(&t, &v, &x3, &FQ); fe_mul(&y3, &r, &t, &FQ); fe_mul(&t, &p->y, &j, &FQ); fe_dbl(&t, &t, &FQ); fe_sub(&y3, &y3, &t, &FQ);
+  fe_add(&z3, &p->z, &h, &FQ); fe_sqr(&z3, &z3, &FQ); fe_sub(&z3, &z3, &z1z1, &FQ); fe_sub(&z3, &z3, &hh, &FQ);
+  o->x = x3; o->y = y3; o->z = z3;
+}
+static void g1j_to_affine(g1a *o, const g1j *p) {
+  if (g1j_is_identity(p)) { memset(o, 0, sizeof *o); return; }
+  fe zi, zi2, zi3; fe_inv(&zi, &p->z, &FQ); fe_sqr(&zi2, &zi, &FQ); fe_mul(&zi3, &zi2, &zi, &FQ);
+  fe_mul(&o->x, &p->x, &zi2, &FQ); fe_mul(&o->y, &p->y, &zi3, &FQ);
+}
+static void g1a_to_j(g1j *o, const g1a *p) { if (g1a_is_identity(p)) { g1j_set_identity(o); } else { o->x = p->x; o->y = p->y; o->z = FQ.r; } }
+/* scalar given as 4 canonical LE limbs; plain double-and-add = the definitional oracle */
+static void g1_mul_canonical(g1j *o, const g1a *p, const uint64_t k[4]) {
+  g1j acc; g1j_set_identity(&acc);
+  for (int i = 255; i >= 0; i--) { g1j_double(&acc, &acc); if ((k[i >> 6] >> (i & 63)) & 1) g1j_add_affine(&acc, &acc, p); }
+  *o = acc;
+}
+void orc_g1_add(g1j *o, const g1j *p, const g1j *q) { g1j r; g1j_add(&r, p, q); *o = r; }
+void orc_g1_add_affine(g1j *o, const g1j *p, const g1a *q) { g1j r; g1j_add_affine(&r, p, q); *o = r; }
+void orc_g1_double(g1j *o, const g1j *p) { g1j r; g1j_double(&r, p); *o = r; }
+void orc_g1_to_affine(g1a *o, const g1j *p) { g1j_to_affine(o, p); }
+void orc_g1_to_affine_vec(g1a *o, const g1j *p, uint64_t n) { for (uint64_t i = 0; i < n; i++) g1j_to_affine(&o[i], &p[i]); }
+/* scalar in Montgomery form (as the ABI delivers it) */
+void orc_g1_mul(g1j *o, const g1a *p, const fe *scalar_mont) { fe k; fe_to_canonical(&k, scalar_mont, &FR); g1_mul_canonical(o, p, k.l); }
+void orc_g1_generator(g1a *o) { fe one = {{1, 0, 0, 0}}, two = {{2, 0, 0, 0}}; fe_from_canonical(&o->x, &one, &FQ); fe_from_canonical(&o->y, &two, &FQ); }
+
+/* Compressed G1 codec [EXT-recalled halo2curves derive/curve.rs: 32 B LE x, bit 6 of byte 31 (mask 0x40) = y parity flag...]
+ * pinned by KAT A4 (vk_chunk.vkey vs chunk.protocol): bit 254 = LSB of canonical y; identity = all zero */
+void orc_g1_compress(uint8_t out[32], const g1a *p) {
+  if (g1a_is_identity(p)) { memset(out, 0, 32); return; }
+  fe x, y; fe_to_canonical(&x, &p->x, &FQ); fe_to_canonical(&y, &p->y, &FQ);
+  memcpy(out, x.l, 32); out[31] |= (uint8_t)((y.l[0] & 1) << 6);
+}
+int orc_g1_decompress(g1a *o, const uint8_t in[32]) {
+  uint8_t b[32]; memcpy(b, in, 32); int sign = (b[31] >> 6) & 1; b[31] &= 0x3f;
+  fe x; memcpy(x.l, b, 32);
+  if (fe_is_zero(&x) && !sign) { memset(o, 0, sizeof *o); return 1; }
+  if (fe_geq(&x, &FQ.m)) return 0;
+  fe xm, y2, y, b3 = FQ_B3(); fe_from_canonical(&xm, &x, &FQ);
+  fe_sqr(&y2, &xm, &FQ); fe_mul(&y2, &y2, &xm, &FQ); fe_add(&y2, &y2, &b3, &FQ);
+  if (!orc_fq_sqrt(&y, &y2)) return 0;
+  fe yc; fe_to_canonical(&yc, &y, &FQ);
+  if ((int)(yc.l[0] & 1) != sign) fe_neg(&y, &y, &FQ);
+  o->x = xm; o->y = y; return 1;
+}
+
+/* ------------------------------------------------------------------ MSM ------ */
+/* definitional oracle: sum_i s_i * P_i by double-and-add */
+void orc_msm_naive(g1j *out, const fe *scalars_mont, const g1a *bases, uint64_t n) {
+  g1j acc; g1j_set_identity(&acc);
+  for (uint64_t i = 0; i < n; i++) { g1j t; orc_g1_mul(&t, &bases[i], &scalars_mont[i]); g1j_add(&acc, &acc, &t); }
+  *out = acc;
+}
+
+/* halo2_proofs::arithmetic::multiexp_serial [EXT-recalled src/arithmetic.rs]:
+ *   coeffs -> to_repr(); c = 1 (n<4) | 3 (n<32) | ceil(ln n); segments = 256/c + 1;
+ *   for segment from the top: c doublings of acc; buckets[(1<<c)-1] of enum {None, Affine, Projective};
+ *   bucket[coeff-1] += base; running-sum "summation by parts"; acc += running sums. */
+static inline uint64_t get_at(int segment, int c, const uint8_t repr[32]) {
+  int skip_bits = segment * c, skip_bytes = skip_bits / 8;
+  if (skip_bytes >= 32) return 0;
+  uint8_t v[8] = {0}; int len = 32 - skip_bytes; if (len > 8) len = 8; memcpy(v, repr + skip_bytes, len);
+  uint64_t tmp; memcpy(&tmp, v, 8); tmp >>= (skip_bits - skip_bytes * 8); return tmp % (1ULL << c);
+}
+typedef struct { uint8_t kind; g1j p; } bucket_t; /* kind 0 None, 1 Affine (x,y valid), 2 Projective */
+static void multiexp_serial(const fe *coeffs_mont, const g1a *bases, uint64_t n, g1j *acc) {
+  fe *repr = (fe *)malloc(n * sizeof(fe));
+  for (uint64_t i = 0; i < n; i++) fe_to_canonical(&repr[i], &coeffs_mont[i], &FR);
+  int c; if (n < 4) c = 1; else if (n < 32) c = 3; else c = (int)ceil(log((double)n));
+  int segments = 256 / c + 1; uint64_t nb = (1ULL << c) - 1;
+  bucket_t *buckets = (bucket_t *)malloc(nb * sizeof(bucket_t));
+  for (int seg = segments - 1; seg >= 0; seg--) {
+    for (int k = 0; k < c; k++) g1j_double(acc, acc);
+    for (uint64_t b = 0; b < nb; b++) buckets[b].kind = 0;
+    for (uint64_t i = 0; i < n; i++) {
+      uint64_t d = get_at(seg, c, (const uint8_t *)&repr[i]);
+      if (!d) continue;
+      bucket_t *bk = &buckets[d - 1];
+      if (bk->kind == 0) { bk->kind = 1; bk->p.x = bases[i].x; bk->p.y = bases[i].y; }
+      else if (bk->kind == 1) { g1a a = {bk->p.x, bk->p.y}; g1j j; g1a_to_j(&j, &a); g1j_add_affine(&bk->p, &j, &bases[i]); bk->kind = 2; }
+      else g1j_add_affine(&bk->p, &bk->p, &bases[i]);
+    }
+    g1j running; g1j_set_identity(&running);
+    for (uint64_t b = nb; b-- > 0;) {
+      bucket_t *bk = &buckets[b];
+      if (bk->kind == 1) { g1a a = {bk->p.x, bk->p.y}; g1j_add_affine(&running, &running, &a); }
+      else if (bk->kind == 2) g1j_add(&running, &running, &bk->p);
+      g1j_add(acc, acc, &running);
+    }
+  }
+  free(buckets); free(repr);
+}
+void orc_multiexp_serial(g1j *out, const fe *coeffs, const g1a *bases, uint64_t n) { g1j acc; g1j_set_identity(&acc); multiexp_serial(coeffs, bases, n, &acc); *out = acc; }
+
+/* halo2_proofs::arithmetic::best_multiexp [EXT-recalled]: if n > threads, chunk = n / threads, one
+ * multiexp_serial per chunk (point-range split), fold the partials with + */
+typedef struct { const fe *c; const g1a *b; uint64_t n; g1j acc; } msm_job;
+static void *msm_worker(void *arg) { msm_job *j = (msm_job *)arg; g1j_set_identity(&j->acc); multiexp_serial(j->c, j->b, j->n, &j->acc); return NULL; }
+void orc_best_multiexp(g1j *out, const fe *coeffs, const g1a *bases, uint64_t n, int num_threads) {
+  if (num_threads < 1) num_threads = 1;
+  if (n > (uint64_t)num_threads) {
+    uint64_t chunk = n / num_threads, nchunks = (n + chunk - 1) / chunk;
+    msm_job *jobs = (msm_job *)malloc(nchunks * sizeof(msm_job)); pthread_t *th = (pthread_t *)malloc(nchunks * sizeof(pthread_t));
+    for (uint64_t k = 0; k < nchunks; k++) { uint64_t s = k * chunk, l = (s + chunk <= n) ? chunk : n - s; jobs[k].c = coeffs + s; jobs[k].b = bases + s; jobs[k].n = l; pthread_create(&th[k], NULL, msm_worker, &jobs[k]); }
+    g1j acc; g1j_set_identity(&acc);
+    for (uint64_t k = 0; k < nchunks; k++) { pthread_join(th[k], NULL); g1j_add(&acc, &acc, &jobs[k].acc); }
+    *out = acc; free(jobs); free(th);
+  } else { g1j acc; g1j_set_identity(&acc); multiexp_serial(coeffs, bases, n, &acc); *out = acc; }
+}
+
+/* ------------------------------------------------------------------ NTT ------ */
+/* definitional oracle: a'[i] = sum_j a[j] * omega^(i j), O(n^2) */
+void orc_dft_naive(fe *out, const fe *a, uint64_t n, const fe *omega) {
+  fe wi = FR.r; /* omega^i */
+  for (uint64_t i = 0; i < n; i++) {
+    fe acc = {{0, 0, 0, 0}}, w = FR.r;
+    for (uint64_t j = 0; j < n; j++) { fe t; fe_mul(&t, &a[j], &w, &FR); fe_add(&acc, &acc, &t, &FR); fe_mul(&w, &w, &wi, &FR); }
+    out[i] = acc; fe_mul(&wi, &wi, omega, &FR);
+  }
+}
+static inline uint64_t bitreverse(uint64_t n, uint32_t l) { uint64_t r = 0; for (uint32_t i = 0; i < l; i++) { r = (r << 1) | (n & 1); n >>= 1; } return r; }
+
+/* halo2_proofs::arithmetic::best_fft [EXT-recalled src/arithmetic.rs]: in place, natural -> natural,
+ * bit-reverse swap, twiddles[i] = omega^i for i < n/2, then log_n radix-2 DIT layers (serial when
+ * log_n <= log2(threads), otherwise recursive_butterfly_arithmetic split across threads).
+ * The restatement keeps the layer structure; the thread split is over butterfly blocks per layer. */
+typedef struct { fe *a; const fe *tw; uint64_t n, chunk, twiddle_chunk, lo, hi; } fft_job;
+static void fft_layer_range(fe *a, const fe *tw, uint64_t chunk, uint64_t twiddle_chunk, uint64_t lo, uint64_t hi) {
+  /* butterflies numbered g in [lo,hi): block = g / (chunk/2), i = g % (chunk/2) */
+  uint64_t half = chunk / 2;
+  for (uint64_t g = lo; g < hi; g++) {
+    uint64_t blk = g / half, i = g % half; fe *x = &a[blk * chunk + i], *y = x + half, t;
+    if (i == 0) t = *y; else fe_mul(&t, y, &tw[i * twiddle_chunk], &FR);
+    fe_sub(y, x, &t, &FR); fe_add(x, x, &t, &FR);
+  }
+}
+static void *fft_worker(void *arg) { fft_job *j = (fft_job *)arg; fft_layer_range(j->a, j->tw, j->chunk, j->twiddle_chunk, j->lo, j->hi); return NULL; }
+void orc_best_fft(fe *a, const fe *omega, uint32_t log_n, int num_threads) {
+  uint64_t n = 1ULL << log_n;
+  for (uint64_t k = 0; k < n; k++) { uint64_t rk = bitreverse(k, log_n); if (k < rk) { fe t = a[rk]; a[rk] = a[k]; a[k] = t; } }
+  if (n == 1) return;
+  fe *tw = (fe *)malloc((n / 2) * sizeof(fe)); fe w = FR.r;
+  for (uint64_t i = 0; i < n / 2; i++) { tw[i] = w; fe_mul(&w, &w, omega, &FR); }
+  uint64_t chunk = 2, twiddle_chunk = n / 2;
+  if (num_threads < 1) num_threads = 1;
+  for (uint32_t s = 0; s < log_n; s++) {
+    uint64_t nb = n / 2;
+    if (num_threads == 1 || nb < 4096) fft_layer_range(a, tw, chunk, twiddle_chunk, 0, nb);
+    else {
+      pthread_t th[256]; fft_job jobs[256]; int T = num_threads > 256 ? 256 : num_threads;
+      for (int t = 0; t < T; t++) { jobs[t] = (fft_job){a, tw, n, chunk, twiddle_chunk, nb * t / T, nb * (t + 1) / T}; pthread_create(&th[t], NULL, fft_worker, &jobs[t]); }
+      for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+    }
+    chunk *= 2; twiddle_chunk /= 2;
+  }
+  free(tw);
+}
+
+/* EvaluationDomain pieces [EXT-recalled halo2_proofs src/poly/domain.rs] */
+/* ifft: best_fft(a, omega_inv, log_n) then a[i] *= divisor (= n^-1) */
+void orc_ifft(fe *a, const fe *omega_inv, uint32_t log_n, const fe *divisor, int num_threads) {
+  orc_best_fft(a, omega_inv, log_n, num_threads);
+  uint64_t n = 1ULL << log_n; for (uint64_t i = 0; i < n; i++) fe_mul(&a[i], &a[i], divisor, &FR);
+}
+/* distribute_powers_zeta: a[i] *= {1, c0, c1}[i % 3]; into_coset: (c0,c1) = (zeta, zeta^2); out of coset: (zeta^2, zeta) */
+void orc_distribute_powers_zeta(fe *a, uint64_t n, const fe *g_coset, const fe *g_coset_inv, int into_coset) {
+  const fe *c0 = into_coset ? g_coset : g_coset_inv, *c1 = into_coset ? g_coset_inv : g_coset;
+  for (uint64_t i = 0; i < n; i++) { uint64_t m = i % 3; if (m == 1) fe_mul(&a[i], &a[i], c0, &FR); else if (m == 2) fe_mul(&a[i], &a[i], c1, &FR); }
+}
+/* coeff_to_extended: zero-pad 2^k coeffs to 2^ext_k, distribute_powers_zeta(into), best_fft(extended_omega) */
+void orc_coeff_to_extended(fe *dst, const fe *coeffs, uint32_t k, uint32_t ext_k, const fe *g_coset, const fe *g_coset_inv, const fe *ext_omega, int num_threads) {
+  uint64_t n = 1ULL << k, en = 1ULL << ext_k; memcpy(dst, coeffs, n * sizeof(fe)); memset(dst + n, 0, (en - n) * sizeof(fe));
+  orc_distribute_powers_zeta(dst, en, g_coset, g_coset_inv, 1); orc_best_fft(dst, ext_omega, ext_k, num_threads);
+}
+/* extended_to_coeff: ifft(extended_omega_inv, extended_ifft_divisor), distribute_powers_zeta(out of coset); caller truncates */
+void orc_extended_to_coeff(fe *a, uint32_t ext_k, const fe *g_coset, const fe *g_coset_inv, const fe *ext_omega_inv, const fe *ext_divisor, int num_threads) {
+  orc_ifft(a, ext_omega_inv, ext_k, ext_divisor, num_threads);
+  orc_distribute_powers_zeta(a, 1ULL << ext_k, g_coset, g_coset_inv, 0);
+}
+/* eval_polynomial: Horner [EXT-recalled src/arithmetic.rs eval_polynomial] */
+void orc_eval_polynomial(fe *out, const fe *poly, uint64_t n, const fe *point) {
+  fe acc = {{0, 0, 0, 0}};
+  for (uint64_t i = n; i-- > 0;) { fe_mul(&acc, &acc, point, &FR); fe_add(&acc, &acc, &poly[i], &FR); }
+  *out = acc;
+}
+
+/* ParamsKZG::setup-style synthetic SRS [EXT-recalled src/poly/kzg/commitment.rs setup]:
+ * g[i] = tau^i * G,  g_lagrange[i] = L_i(tau) * G with L_i(tau) = omega^i (tau^n - 1) / (n (tau - omega^i)).
+ * scalars_out (optional) receives the Fr multipliers so tests can check commitments in the field. */
+void orc_srs_setup(g1a *g, g1a *g_lagrange, uint32_t k, const fe *tau, const fe *omega, fe *g_scalars_out, fe *gl_scalars_out) {
+  uint64_t n = 1ULL << k; g1a gen; orc_g1_generator(&gen);
+  fe s = FR.r;
+  for (uint64_t i = 0; i < n; i++) { g1j t; orc_g1_mul(&t, &gen, &s); g1j_to_affine(&g[i], &t); if (g_scalars_out) g_scalars_out[i] = s; fe_mul(&s, &s, tau, &FR); }
+  /* s == tau^n now */
+  fe tn1, nn = {{n, 0, 0, 0}}, nm, ninv, w = FR.r; fe_sub(&tn1, &s, &FR.r, &FR); fe_from_canonical(&nm, &nn, &FR); fe_inv(&ninv, &nm, &FR);
+  for (uint64_t i = 0; i < n; i++) {
+    fe d, l; fe_sub(&d, tau, &w, &FR); fe_inv(&d, &d, &FR); fe_mul(&l, &w, &tn1, &FR); fe_mul(&l, &l, &ninv, &FR); fe_mul(&l, &l, &d, &FR);
+    g1j t; orc_g1_mul(&t, &gen, &l); g1j_to_affine(&g_lagrange[i], &t); if (gl_scalars_out) gl_scalars_out[i] = l; fe_mul(&w, &w, omega, &FR);
+  }
+}

@@ -1,0 +1,201 @@
+"""
+cref.py -- ctypes binding of oracle/liboracle_bn254.so (the C restatement, see bn254_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Arrays are numpy uint64 of shape [n, 4] (field elements, Montgomery
+LE limbs), [n, 8] (G1Affine x|y) and [n, 12] / [12] (Jacobian x|y|z), i.e. exactly the byte
+layout the C-ABI of the product uses (include/mi355zk.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle_bn254.so")
+FQ, FR = 0, 1
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "bn254_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _fe(x=None):
+    a = np.zeros(4, dtype=np.uint64)
+    if x is not None:
+        a[:] = x
+    return a
+
+
+def f_mul(w, a, b):
+    o = _fe(); lib().orc_f_mul(w, _p(o), _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b))); return o
+
+
+def f_add(w, a, b):
+    o = _fe(); lib().orc_f_add(w, _p(o), _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b))); return o
+
+
+def f_sub(w, a, b):
+    o = _fe(); lib().orc_f_sub(w, _p(o), _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b))); return o
+
+
+def f_inv(w, a):
+    o = _fe(); lib().orc_f_inv(w, _p(o), _p(np.ascontiguousarray(a))); return o
+
+
+def f_pow(w, a, e: int):
+    o = _fe(); ee = np.array([(e >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    lib().orc_f_pow(w, _p(o), _p(np.ascontiguousarray(a)), _p(ee)); return o
+
+
+def f_from_canonical_vec(w, a):
+    a = np.ascontiguousarray(a, dtype=np.uint64); o = np.empty_like(a)
+    lib().orc_f_from_canonical_vec(w, _p(o), _p(a), C.c_uint64(a.shape[0])); return o
+
+
+def f_to_canonical_vec(w, a):
+    a = np.ascontiguousarray(a, dtype=np.uint64); o = np.empty_like(a)
+    lib().orc_f_to_canonical_vec(w, _p(o), _p(a), C.c_uint64(a.shape[0])); return o
+
+
+def f_mul_vec(w, a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b); o = np.empty_like(a)
+    lib().orc_f_mul_vec(w, _p(o), _p(a), _p(b), C.c_uint64(a.shape[0])); return o
+
+
+def int_to_limbs(x: int):
+    return np.array([(x >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+
+
+def limbs_to_int(l) -> int:
+    return sum(int(v) << (64 * i) for i, v in enumerate(l))
+
+
+def fr_mont(x: int):
+    """canonical int -> Montgomery limbs (through the C oracle)."""
+    return f_from_canonical_vec(FR, int_to_limbs(x % 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001)[None, :])[0]
+
+
+def g1_generator():
+    o = np.zeros(8, dtype=np.uint64); lib().orc_g1_generator(_p(o)); return o
+
+
+def g1_is_on_curve(p) -> bool:
+    return bool(lib().orc_g1_is_on_curve(_p(np.ascontiguousarray(p))))
+
+
+def g1_mul(p, s_mont):
+    o = np.zeros(12, dtype=np.uint64); lib().orc_g1_mul(_p(o), _p(np.ascontiguousarray(p)), _p(np.ascontiguousarray(s_mont))); return o
+
+
+def g1_add(p, q):
+    o = np.zeros(12, dtype=np.uint64); lib().orc_g1_add(_p(o), _p(np.ascontiguousarray(p)), _p(np.ascontiguousarray(q))); return o
+
+
+def g1_add_affine(p, q):
+    o = np.zeros(12, dtype=np.uint64); lib().orc_g1_add_affine(_p(o), _p(np.ascontiguousarray(p)), _p(np.ascontiguousarray(q))); return o
+
+
+def g1_double(p):
+    o = np.zeros(12, dtype=np.uint64); lib().orc_g1_double(_p(o), _p(np.ascontiguousarray(p))); return o
+
+
+def g1_to_affine(p):
+    p = np.ascontiguousarray(p, dtype=np.uint64)
+    if p.ndim == 1:
+        o = np.zeros(8, dtype=np.uint64); lib().orc_g1_to_affine(_p(o), _p(p)); return o
+    o = np.zeros((p.shape[0], 8), dtype=np.uint64); lib().orc_g1_to_affine_vec(_p(o), _p(p), C.c_uint64(p.shape[0])); return o
+
+
+def g1_compress(p) -> bytes:
+    o = (C.c_uint8 * 32)(); lib().orc_g1_compress(o, _p(np.ascontiguousarray(p))); return bytes(o)
+
+
+def g1_decompress(b: bytes):
+    o = np.zeros(8, dtype=np.uint64); buf = (C.c_uint8 * 32).from_buffer_copy(b)
+    ok = lib().orc_g1_decompress(_p(o), buf); return o if ok else None
+
+
+def msm_naive(scalars, bases):
+    o = np.zeros(12, dtype=np.uint64); s = np.ascontiguousarray(scalars); b = np.ascontiguousarray(bases)
+    lib().orc_msm_naive(_p(o), _p(s), _p(b), C.c_uint64(s.shape[0])); return o
+
+
+def multiexp_serial(scalars, bases):
+    o = np.zeros(12, dtype=np.uint64); s = np.ascontiguousarray(scalars); b = np.ascontiguousarray(bases)
+    lib().orc_multiexp_serial(_p(o), _p(s), _p(b), C.c_uint64(s.shape[0])); return o
+
+
+def best_multiexp(scalars, bases, threads: int | None = None):
+    threads = threads or os.cpu_count() or 1
+    o = np.zeros(12, dtype=np.uint64); s = np.ascontiguousarray(scalars); b = np.ascontiguousarray(bases)
+    assert s.shape[0] == b.shape[0]
+    lib().orc_best_multiexp(_p(o), _p(s), _p(b), C.c_uint64(s.shape[0]), C.c_int(threads)); return o
+
+
+def dft_naive(a, omega):
+    a = np.ascontiguousarray(a); o = np.empty_like(a)
+    lib().orc_dft_naive(_p(o), _p(a), C.c_uint64(a.shape[0]), _p(np.ascontiguousarray(omega))); return o
+
+
+def best_fft(a, omega, log_n: int, threads: int | None = None):
+    """in place on a copy; returns the transformed array."""
+    threads = threads or os.cpu_count() or 1
+    a = np.array(a, dtype=np.uint64, copy=True, order="C"); assert a.shape[0] == 1 << log_n
+    lib().orc_best_fft(_p(a), _p(np.ascontiguousarray(omega)), C.c_uint32(log_n), C.c_int(threads)); return a
+
+
+def ifft(a, omega_inv, log_n: int, divisor, threads: int | None = None):
+    threads = threads or os.cpu_count() or 1
+    a = np.array(a, dtype=np.uint64, copy=True, order="C")
+    lib().orc_ifft(_p(a), _p(np.ascontiguousarray(omega_inv)), C.c_uint32(log_n), _p(np.ascontiguousarray(divisor)), C.c_int(threads)); return a
+
+
+def coeff_to_extended(coeffs, k, ext_k, g_coset, g_coset_inv, ext_omega, threads: int | None = None):
+    threads = threads or os.cpu_count() or 1
+    coeffs = np.ascontiguousarray(coeffs); dst = np.zeros((1 << ext_k, 4), dtype=np.uint64)
+    lib().orc_coeff_to_extended(_p(dst), _p(coeffs), C.c_uint32(k), C.c_uint32(ext_k), _p(np.ascontiguousarray(g_coset)),
+                                _p(np.ascontiguousarray(g_coset_inv)), _p(np.ascontiguousarray(ext_omega)), C.c_int(threads))
+    return dst
+
+
+def extended_to_coeff(a, ext_k, g_coset, g_coset_inv, ext_omega_inv, ext_divisor, threads: int | None = None):
+    threads = threads or os.cpu_count() or 1
+    a = np.array(a, dtype=np.uint64, copy=True, order="C")
+    lib().orc_extended_to_coeff(_p(a), C.c_uint32(ext_k), _p(np.ascontiguousarray(g_coset)), _p(np.ascontiguousarray(g_coset_inv)),
+                                _p(np.ascontiguousarray(ext_omega_inv)), _p(np.ascontiguousarray(ext_divisor)), C.c_int(threads))
+    return a
+
+
+def eval_polynomial(poly, point):
+    o = _fe(); poly = np.ascontiguousarray(poly)
+    lib().orc_eval_polynomial(_p(o), _p(poly), C.c_uint64(poly.shape[0]), _p(np.ascontiguousarray(point))); return o
+
+
+def srs_setup(k: int, tau_mont, omega_mont):
+    n = 1 << k
+    g = np.zeros((n, 8), dtype=np.uint64); gl = np.zeros((n, 8), dtype=np.uint64)
+    gs = np.zeros((n, 4), dtype=np.uint64); gls = np.zeros((n, 4), dtype=np.uint64)
+    lib().orc_srs_setup(_p(g), _p(gl), C.c_uint32(k), _p(np.ascontiguousarray(tau_mont)), _p(np.ascontiguousarray(omega_mont)), _p(gs), _p(gls))
+    return g, gl, gs, gls

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""
+make_golden.py -- regenerates tests/golden/kat.json from the reference's own fixtures.
+
+Run in the build container (needs /root/reference); the output is committed because
+/root/reference does not exist on the GPU box.  Nothing here computes anything: it only
+copies/decodes bytes so that the tests can check OUR oracles and kernels against values
+that come from the reference (KATs A1-A9).
+
+Sources:
+  [REF release-v0.13.1/chunk.protocol]                     domain (k=25) + 7 preprocessed G1 points
+  [REF release-v0.13.1/vk_chunk.vkey, vk_batch.vkey, vk_bundle.vkey]
+  [REF integration/tests/test_data/vk_batch_agg.vkey]
+  [REF integration/tests/test_data/full_proof_1.json]        chunk proof (896 B), instances, vk, protocol
+  [REF integration/tests/test_data/full_proof_batch_agg_1.json]  batch proof (1312 B), vk, protocol (k=26)
+  [REF release-v0.13.1/evm_verifier.yul:17-18,1230-1239]    moduli, g2, s_g2 words
+  [REF release-v0.13.1/proof.data, pi.data]                 bundle EVM proof words
+"""
+import base64, json, os, re, sys
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def rd(p, mode="rb"):
+    with open(os.path.join(REF, p), mode) as f:
+        return f.read()
+
+
+def proto_digest(pr):
+    return {"domain": pr["domain"], "preprocessed": pr["preprocessed"], "num_witness": pr["num_witness"],
+            "num_instance": pr["num_instance"], "quotient_num_chunk": pr["quotient"]["num_chunk"],
+            "n_evaluations": len(pr["evaluations"])}
+
+
+out = {"_generated_by": "tests/golden/make_golden.py", "_source": "scroll-tech/scroll-prover fixtures (see docstring)"}
+out["chunk_protocol"] = proto_digest(json.loads(rd("release-v0.13.1/chunk.protocol", "r")))
+for name, path in [("vk_chunk", "release-v0.13.1/vk_chunk.vkey"), ("vk_batch", "release-v0.13.1/vk_batch.vkey"),
+                   ("vk_bundle", "release-v0.13.1/vk_bundle.vkey"), ("vk_batch_agg", "integration/tests/test_data/vk_batch_agg.vkey")]:
+    out[name] = rd(path).hex()
+cp = json.loads(rd("integration/tests/test_data/full_proof_1.json", "r"))["chunk_proofs"][0]
+out["chunk_proof"] = {"protocol": proto_digest(json.loads(base64.b64decode(cp["protocol"]))),
+                      "proof": base64.b64decode(cp["proof"]).hex(), "instances": base64.b64decode(cp["instances"]).hex(),
+                      "vk": base64.b64decode(cp["vk"]).hex()}
+bp = json.loads(rd("integration/tests/test_data/full_proof_batch_agg_1.json", "r"))
+out["batch_proof"] = {"protocol": proto_digest(json.loads(base64.b64decode(bp["protocol"]))),
+                      "proof": base64.b64decode(bp["proof"]).hex(), "instances": base64.b64decode(bp["instances"]).hex(),
+                      "vk": base64.b64decode(bp["vk"]).hex()}
+yul = rd("release-v0.13.1/evm_verifier.yul", "r").splitlines()
+out["yul"] = {"f_p": re.search(r"0x[0-9a-f]+", yul[16]).group(0), "f_q": re.search(r"0x[0-9a-f]+", yul[17]).group(0),
+              "g2_words": [re.search(r", (0x[0-9a-f]+)\)", yul[i]).group(1) for i in range(1229, 1233)],
+              "s_g2_words": [re.search(r", (0x[0-9a-f]+)\)", yul[i]).group(1) for i in range(1235, 1239)]}
+out["bundle_proof_data"] = rd("release-v0.13.1/proof.data").hex()
+out["bundle_pi_data"] = rd("release-v0.13.1/pi.data").hex()
+with open(os.path.join(HERE, "kat.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print("wrote", os.path.join(HERE, "kat.json"), os.path.getsize(os.path.join(HERE, "kat.json")), "bytes")
