@@ -1,0 +1,118 @@
+/*
+ * mi355zk.h -- C-ABI of libmi355zk.so: the MI355X (gfx950) BN254 G1-MSM / Fr-NTT hot path that slots in
+ * under scroll-prover's `halo2_proofs` dependency.
+ *
+ * Boundary.  scroll-prover itself holds no proving arithmetic; its GPU builds replace the whole
+ * `halo2_proofs` crate through a cargo path override [REF docker/chain-prover/gpu/Dockerfile:7-8],
+ * [REF docker/trace-prover/gpu/Dockerfile:6-7], next to the existing `[patch]` redirect [REF Cargo.toml:40-41].
+ * The functions below are what such a replacement crate's FFI binds (INTEGRATION.md shows the Rust `extern "C"`
+ * block and the patched call sites).  Each entry point names the halo2_proofs / halo2curves function it
+ * stands in for; those crates are pinned at scroll-tech/halo2@e5ddf67 and scroll-tech/halo2curves@112f5b9
+ * [REF Cargo.lock:1886-1888,1911-1913] and reached from [REF integration/src/prove.rs:37,67,96].
+ *
+ * Data conventions (pinned by fixture KATs A1-A4):
+ *   Fr, Fq       32 B   4 x u64 little-endian limbs, Montgomery form (R = 2^256), fully reduced
+ *   G1Affine     64 B   {x, y};  identity = (0, 0)                       == halo2curves::bn256::G1Affine
+ *   G1           96 B   Jacobian {x, y, z}; identity z = 0               == halo2curves::bn256::G1
+ * Results returned as G1 are normalised: (x, y, R) with R = Montgomery one, or (0, 0, 0) for the identity,
+ * so `to_affine()` on the Rust side is a no-op and byte comparison is meaningful.
+ *
+ * Pointer flavours: `*_host` arguments are ordinary process memory owned by the caller (Rust Vec<..>): the
+ * library copies to HBM, computes and copies back before returning.  `*_dev` arguments are HIP device
+ * pointers on the bound device (used by the bench and by callers that keep polynomials resident).
+ *
+ * Errors: every function returns 0 on success or one of MI355_E*; nothing throws, aborts or unwinds across
+ * the boundary.  mi355_last_error() gives a thread-local message.  There is NO CPU fallback inside the
+ * library: without a usable gfx950 device every compute entry point fails with MI355_ENODEVICE and the
+ * caller (the Rust shim) decides what to do.
+ *
+ * Threading: one device per process (one process per GPU); entry points are serialised by an
+ * internal mutex and may be called from any thread.
+ */
+#ifndef MI355ZK_H
+#define MI355ZK_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_EBADARG 1
+#define MI355_ENODEVICE 2
+#define MI355_EOOM 3
+#define MI355_EHIP 4
+#define MI355_ERCCL 5
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------- */
+/* Bind this process to HIP device `device_id` (ordinal within HIP_VISIBLE_DEVICES) and create the stream.    */
+int mi355_init(int device_id);
+int mi355_shutdown(void);
+const char *mi355_last_error(void);
+const char *mi355_version(void);
+/* Launch all kernels on `hip_stream` (a hipStream_t, e.g. torch's current stream); NULL = the library's own.  */
+int mi355_set_stream(void *hip_stream);
+/* Block until everything queued by the library has finished.                                                  */
+int mi355_synchronize(void);
+
+/* ---- SRS ownership: ParamsKZG { g, g_lagrange } [halo2_proofs poly/kzg/commitment.rs], held for the process
+ *      lifetime by the caller's params_map [REF bin/src/trace_prover.rs:35-43], [REF integration/src/prove.rs:12,26,58].
+ *      A handle is one basis (n affine points) resident in HBM.                                               */
+int mi355_srs_register_host(const void *bases_affine_host, uint64_t n, uint64_t *handle_out);
+int mi355_srs_register_dev(const void *bases_affine_dev, uint64_t n, int copy, uint64_t *handle_out);
+int mi355_srs_release(uint64_t handle);
+int mi355_srs_len(uint64_t handle, uint64_t *n_out);
+/* device pointer of the resident basis (n x 64 B), for tests and chained device-side work                     */
+int mi355_srs_dev_ptr(uint64_t handle, void **dev_ptr_out);
+
+/* ---- MSM: halo2_proofs::arithmetic::best_multiexp(coeffs, bases) -> C::Curve, and the two wrappers
+ *      ParamsKZG::commit / commit_lagrange = best_multiexp(poly, &g[..n] / &g_lagrange[..n]).
+ *      out_g1 receives 96 B (normalised Jacobian, see above) in host memory.                                  */
+int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *scalars_host, uint64_t n, void *out_g1_host);
+int mi355_msm_g1_dev(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_host);
+/* ad-hoc bases (best_multiexp with bases that are not a registered SRS)                                        */
+int mi355_msm_g1_adhoc_host(const void *bases_affine_host, const void *scalars_host, uint64_t n, void *out_g1_host);
+/* sum of `n` G1 (Jacobian, any representative) points: the fold `results.iter().fold(identity, |a, b| a + b)` of
+ * best_multiexp, used to combine per-GPU partial sums after the RCCL all-gather.                  */
+int mi355_g1_sum_host(const void *g1_points_host, uint64_t n, void *out_g1_host);
+/* tuning: window bits c for subsequent MSMs (0 = automatic from n)                                             */
+int mi355_msm_set_window_bits(int c);
+
+/* ---- NTT: halo2_proofs::arithmetic::best_fft(a, omega, log_n): in place, natural order in -> natural order out,
+ *      a'[i] = sum_j a[j] omega^(ij), no scaling.  omega: 32 B Montgomery, must have order 2^log_n.            */
+int mi355_ntt_fr_host(void *data_host, uint32_t log_n, const void *omega);
+int mi355_ntt_fr_dev(void *data_dev, uint32_t log_n, const void *omega);
+/* EvaluationDomain::ifft = best_fft(a, omega_inv, log_n) followed by a[i] *= divisor (= n^-1) [poly/domain.rs]   */
+int mi355_intt_fr_host(void *data_host, uint32_t log_n, const void *omega_inv, const void *divisor);
+int mi355_intt_fr_dev(void *data_dev, uint32_t log_n, const void *omega_inv, const void *divisor);
+/* EvaluationDomain::coeff_to_extended: dst[2^log_ext] = fft_{extended_omega}( zero-pad(coeffs[2^log_n]) with
+ * a[i] *= {1, g_coset, g_coset_inv}[i % 3] )  (distribute_powers_zeta, into the coset)                          */
+int mi355_coeff_to_extended_host(void *dst_host, const void *coeffs_host, uint32_t log_n, uint32_t log_ext,
+                                 const void *g_coset, const void *g_coset_inv, const void *extended_omega);
+int mi355_coeff_to_extended_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, uint32_t log_ext,
+                                const void *g_coset, const void *g_coset_inv, const void *extended_omega);
+/* EvaluationDomain::extended_to_coeff: in place ifft(extended_omega_inv, extended_ifft_divisor) then
+ * a[i] *= {1, g_coset_inv, g_coset}[i % 3]; the caller truncates.                                               */
+int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *g_coset, const void *g_coset_inv,
+                                 const void *extended_omega_inv, const void *extended_ifft_divisor);
+int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv,
+                                const void *extended_omega_inv, const void *extended_ifft_divisor);
+
+/* ---- synthetic SRS: ParamsKZG::setup(k, rng) restated on the device [poly/kzg/commitment.rs]:
+ *      g[i] = tau^i G,  g_lagrange[i] = L_i(tau) G.  Writes n = 2^k affine points per basis to device memory.   */
+int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const void *tau, const void *omega);
+/* points[i] = scalars[i] * G (fixed-base, batch-normalised); building block of the above                      */
+int mi355_g1_fixed_base_mul_dev(void *points_affine_dev, const void *scalars_dev, uint64_t n);
+
+/* ---- measurement hooks (bench.py): HIP-event timing of the kernels of the most recent MSM / NTT call.       */
+int mi355_profile_enable(int on);
+/* name in {"msm_total","msm_digits","msm_sort","msm_accumulate","msm_reduce","ntt_total","ntt_pass"}; returns the
+ * accumulated milliseconds and launch count since the last mi355_profile_reset().                             */
+int mi355_profile_get(const char *name, double *ms_out, uint64_t *launches_out);
+int mi355_profile_reset(void);
+/* (c, windows, entries) chosen by the last MSM, for G1-adds accounting                                        */
+int mi355_msm_last_plan(int *c_out, int *windows_out, uint64_t *entries_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,564 @@
+// capi.hip -- the C-ABI of libmi355zk.so (include/mi355zk.h): context, SRS handles, workspace arena,
+// MSM / NTT launch orchestration and HIP-event profiling.  Host logic only; all arithmetic runs in the
+// kernels of msm.cuh / ntt.cuh.  There is deliberately no CPU fallback: without a gfx950 device every
+// compute entry point returns MI355_ENODEVICE.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mi355zk.h"
+#include "msm.cuh"
+#include "ntt.cuh"
+
+using namespace zk;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                                     \
+  do {                                                                                                                   \
+    hipError_t _e = (expr);                                                                                              \
+    if (_e != hipSuccess) {                                                                                              \
+      char _b[512]; snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+      (void)hipGetLastError();                                                                                           \
+      return fail(_e == hipErrorOutOfMemory ? MI355_EOOM : MI355_EHIP, _b);                                              \
+    }                                                                                                                    \
+  } while (0)
+#define CHK(expr) do { int _r = (expr); if (_r != MI355_OK) return _r; } while (0)
+
+struct Srs { g1_affine_t *dev = nullptr; uint64_t n = 0; bool owned = false; };
+struct Buf { void *p = nullptr; size_t cap = 0; };
+struct NttPlan {
+  uint32_t log_n = 0, levels = 0, log_m[3] = {0, 0, 0};
+  fe_t *tw_m[3] = {nullptr, nullptr, nullptr};
+  fe_t *tw_s_lo[2] = {nullptr, nullptr}, *tw_s_hi[2] = {nullptr, nullptr};
+  uint32_t split[2] = {0, 0};
+};
+struct Prof { double ms = 0; uint64_t launches = 0; };
+
+struct Ctx {
+  std::mutex mu;
+  bool inited = false;
+  int device = -1;
+  hipDeviceProp_t prop;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::unordered_map<uint64_t, Srs> srs;
+  uint64_t next_handle = 1;
+  std::map<std::string, Buf> ws;           // grow-only workspace arena, keyed by role
+  std::map<std::string, NttPlan> ntt_plans;  // key = log_n | omega bytes
+  g1_affine_t *fixed_base_table = nullptr;
+  int force_c = 0;
+  bool profiling = false;
+  std::map<std::string, Prof> prof;
+  int last_c = 0, last_w = 0; uint64_t last_entries = 0;
+} g;
+
+int need_init() { return g.inited ? MI355_OK : fail(MI355_ENODEVICE, "mi355_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)"); }
+
+int ws_get(const char *role, size_t bytes, void **out) {
+  Buf &b = g.ws[role];
+  if (b.cap < bytes) {
+    if (b.p) { HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t cap = bytes + bytes / 8 + 256;
+    HIPCHK(hipMalloc(&b.p, cap)); b.cap = cap;
+  }
+  *out = b.p; return MI355_OK;
+}
+
+// ---- profiling: a list of (name, start, stop) event pairs resolved after the stream is idle
+struct Span { std::string name; hipEvent_t a, b; };
+std::vector<Span> g_spans;
+struct Scope {
+  bool on; hipEvent_t a = nullptr, b = nullptr; std::string name;
+  Scope(const char *n) : on(g.profiling), name(n) { if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, g.stream); } }
+  ~Scope() { if (on) { (void)hipEventRecord(b, g.stream); g_spans.push_back({name, a, b}); } }
+};
+void resolve_spans() {
+  if (g_spans.empty()) return;
+  hipStreamSynchronize(g.stream);
+  for (auto &s : g_spans) { float ms = 0; hipEventElapsedTime(&ms, s.a, s.b); Prof &p = g.prof[s.name]; p.ms += ms; p.launches++; hipEventDestroy(s.a); hipEventDestroy(s.b); }
+  g_spans.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ MSM
+uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+int choose_c(uint64_t n) {
+  if (g.force_c) return g.force_c;
+  // cost model: n*W mixed additions + ~3 full additions per bucket (running sums + fix-up), full add ~1.4x mixed
+  double best = 1e300; int best_c = 8;
+  for (int c = 4; c <= 22; c++) {
+    const double W = (255 + c - 1) / c, nb = (double)(1ull << (c - 1));
+    if (W * nb * sizeof(g1_xyzz_t) > 6.0e9) continue;
+    const double cost = W * ((double)n + 4.2 * nb);
+    if (cost < best) { best = cost; best_c = c; }
+  }
+  return best_c;
+}
+
+int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void *out_host) {
+  g1_jac_t result; memset(&result, 0, sizeof result);
+  if (n == 0) { memcpy(out_host, &result, sizeof result); return MI355_OK; }
+  if (n >= (1ull << 31)) return fail(MI355_EBADARG, "msm: n must be < 2^31");
+  MsmPlan P; P.n = (uint32_t)n; P.c = (uint32_t)choose_c(n); P.windows = (255 + P.c - 1) / P.c; P.nb = 1u << (P.c - 1);
+  const uint64_t emax = n * P.windows;
+  if (emax >= (1ull << 32)) return fail(MI355_EBADARG, "msm: n * windows must be < 2^32");
+  const uint64_t want_threads = (uint64_t)g.prop.multiProcessorCount * 256 * 16;   // ~16 segments per lane slot
+  uint64_t seg = (emax + want_threads - 1) / want_threads; if (seg < 16) seg = 16; if (seg > 4096) seg = 4096;
+  P.seg = (uint32_t)seg;
+  const uint32_t nbuckets = P.windows * P.nb;
+  const uint32_t acc_threads = ceil_div(emax, seg), acc_blocks = ceil_div(acc_threads, 256);
+  const uint32_t tn = acc_blocks * 256;
+  uint32_t chunk = 64; while (chunk > P.nb) chunk >>= 1;
+  // keep at least ~8k reduce threads busy when buckets are few, at most ~512k
+  while (chunk > 4 && (uint64_t)(P.nb / chunk) * P.windows < 16384) chunk >>= 1;
+  const uint32_t chunks_per_window = P.nb / chunk, nchunks = chunks_per_window * P.windows;
+
+  int32_t *digits; uint32_t *hist, *offsets, *cursor, *sorted, *scan_sums; g1_xyzz_t *buckets, *part, *chunk_out, *window_sums; int32_t *part_id; g1_jac_t *out_dev;
+  CHK(ws_get("msm.digits", emax * 4, (void **)&digits));
+  CHK(ws_get("msm.hist", ((size_t)nbuckets + 1) * 4, (void **)&hist));
+  CHK(ws_get("msm.offsets", ((size_t)nbuckets + 1) * 4, (void **)&offsets));
+  CHK(ws_get("msm.cursor", ((size_t)nbuckets + 1) * 4, (void **)&cursor));
+  CHK(ws_get("msm.sorted", emax * 4, (void **)&sorted));
+  const uint32_t scan_n = nbuckets + 1, scan_blocks = ceil_div(scan_n, SCAN_BLOCK * SCAN_ITEMS);
+  CHK(ws_get("msm.scan_sums", (size_t)scan_blocks * 4, (void **)&scan_sums));
+  CHK(ws_get("msm.buckets", (size_t)nbuckets * sizeof(g1_xyzz_t), (void **)&buckets));
+  CHK(ws_get("msm.part", (size_t)tn * 2 * sizeof(g1_xyzz_t), (void **)&part));
+  CHK(ws_get("msm.part_id", (size_t)tn * 2 * 4, (void **)&part_id));
+  CHK(ws_get("msm.chunk_out", (size_t)nchunks * sizeof(g1_xyzz_t), (void **)&chunk_out));
+  CHK(ws_get("msm.window_sums", (size_t)P.windows * sizeof(g1_xyzz_t), (void **)&window_sums));
+  CHK(ws_get("msm.out", sizeof(g1_jac_t), (void **)&out_dev));
+
+  hipStream_t s = g.stream;
+  const int grid_stream = g.prop.multiProcessorCount * 8;
+  {
+    Scope total("msm_total");
+    {
+      Scope sc("msm_digits");
+      HIPCHK(hipMemsetAsync(hist, 0, ((size_t)nbuckets + 1) * 4, s));
+      hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream), dim3(256), 0, s, scalars, digits, hist, P);
+    }
+    {
+      Scope sc("msm_sort");
+      hipLaunchKernelGGL(k_scan_partial, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, scan_n);
+      hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums, scan_blocks);
+      hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, offsets, cursor, scan_n);
+      hipLaunchKernelGGL(k_msm_scatter, dim3(grid_stream * 2), dim3(256), 0, s, digits, cursor, sorted, P);
+    }
+    {
+      Scope sc("msm_accumulate");
+      HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz_t), s));
+      hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg);
+    }
+    {
+      Scope sc("msm_reduce");
+      hipLaunchKernelGGL(k_msm_fixup, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg);
+      hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, P, chunk);
+      hipLaunchKernelGGL(k_msm_window_reduce, dim3(P.windows), dim3(256), 0, s, chunk_out, window_sums, chunks_per_window);
+      hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, window_sums, P.windows, P.c, out_dev);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&result, out_dev, sizeof result, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  resolve_spans();
+  memcpy(out_host, &result, sizeof result);
+  g.last_c = (int)P.c; g.last_w = (int)P.windows; g.last_entries = emax;
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ NTT
+std::string plan_key(uint32_t log_n, const void *omega) { std::string k((const char *)omega, 32); k.push_back((char)log_n); return k; }
+
+int pow_table(fe_t **out, const fe_t &base, uint64_t step, uint32_t count) {
+  HIPCHK(hipMalloc((void **)out, (size_t)count * sizeof(fe_t)));
+  hipLaunchKernelGGL(k_pow_table, dim3(ceil_div(count, 256)), dim3(256), 0, g.stream, *out, base, step, count);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+
+int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
+  const std::string key = plan_key(log_n, omega);
+  auto it = g.ntt_plans.find(key);
+  if (it != g.ntt_plans.end()) { *out = &it->second; return MI355_OK; }
+  NttPlan p; p.log_n = log_n;
+  if (log_n <= 8) { p.levels = 1; p.log_m[0] = log_n; }
+  else if (log_n <= 18) { p.levels = 2; p.log_m[0] = (log_n + 1) / 2; p.log_m[1] = log_n / 2; }
+  else { p.levels = 3; p.log_m[0] = (log_n + 2) / 3; p.log_m[1] = (log_n + 1) / 3; p.log_m[2] = log_n / 3; }
+  fe_t w; memcpy(&w, omega, 32);
+  const uint64_t N = 1ull << log_n;
+  uint32_t log_s = log_n;
+  for (uint32_t l = 0; l < p.levels; l++) {
+    const uint32_t lm = p.log_m[l];
+    if (lm >= 1) CHK(pow_table(&p.tw_m[l], w, N >> lm, std::max(1u, 1u << (lm - 1))));
+    if (l + 1 < p.levels) {
+      p.split[l] = (log_s + 1) / 2;
+      CHK(pow_table(&p.tw_s_lo[l], w, N >> log_s, 1u << p.split[l]));
+      CHK(pow_table(&p.tw_s_hi[l], w, (N >> log_s) << p.split[l], 1u << (log_s - p.split[l])));
+    }
+    log_s -= lm;
+  }
+  g.ntt_plans[key] = p; *out = &g.ntt_plans[key];
+  return MI355_OK;
+}
+
+uint32_t cols_for(uint32_t log_m) { uint32_t lc = 3; while (lc > 0 && log_m + lc > 12) lc--; return lc; }
+
+// dst[2^log_n] = NTT_omega( pre3-scaled, zero-padded src[src_len] ), then optional post3 scaling.  src may equal dst.
+int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, const void *omega, const fe_t *pre3_host, const fe_t *post3_host) {
+  if (log_n > 28) return fail(MI355_EBADARG, "ntt: log_n > 28 (BN254 Fr two-adicity)");
+  const uint64_t N = 1ull << log_n;
+  hipStream_t s = g.stream;
+  fe_t *pre3 = nullptr, *post3 = nullptr;
+  if (pre3_host || post3_host) {
+    fe_t *c; CHK(ws_get("ntt.consts", 6 * sizeof(fe_t), (void **)&c));
+    if (pre3_host) { HIPCHK(hipMemcpyAsync(c, pre3_host, 3 * sizeof(fe_t), hipMemcpyHostToDevice, s)); pre3 = c; }
+    if (post3_host) { HIPCHK(hipMemcpyAsync(c + 3, post3_host, 3 * sizeof(fe_t), hipMemcpyHostToDevice, s)); post3 = c + 3; }
+    HIPCHK(hipStreamSynchronize(s));  // the host copies may be stack temporaries of the caller
+  }
+  if (log_n == 0) {
+    if (src != dst || pre3 || post3 || src_len < 1) {
+      // size-1 transform = identity (apart from scalings); handle through the generic final kernel
+    }
+  }
+  NttPlan *p; CHK(get_plan(log_n, omega, &p));
+  Scope total("ntt_total");
+  if (p->levels == 1) {
+    const uint32_t lm = p->log_m[0], tile = 1u << lm;
+    const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
+    const size_t lds = (size_t)2 * 16 * (tile + 1);
+    Scope sc("ntt_pass");
+    hipLaunchKernelGGL(k_ntt_final, dim3(1), dim3(threads), lds, s, src, dst, lm, 0u, 0u, 0u, p->tw_m[0], src_len, pre3, post3);
+  } else {
+    fe_t *scratch; CHK(ws_get("ntt.scratch", N * sizeof(fe_t), (void **)&scratch));
+    uint32_t log_s = log_n;
+    const fe_t *cur = src; uint64_t cur_len = src_len; const fe_t *cur_pre = pre3;
+    for (uint32_t l = 0; l + 1 < p->levels; l++) {
+      NttLevel L; L.log_m = p->log_m[l]; L.log_t = log_s - L.log_m; L.tw_m = p->tw_m[l]; L.tw_s_lo = p->tw_s_lo[l]; L.tw_s_hi = p->tw_s_hi[l]; L.split = p->split[l];
+      const uint32_t lc = std::min(cols_for(L.log_m), L.log_t), tile = 1u << (L.log_m + lc);
+      const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
+      const size_t lds = (size_t)2 * 16 * tile;
+      const uint64_t blocks = (N >> log_s) << (L.log_t - lc);
+      Scope sc("ntt_pass");
+      hipLaunchKernelGGL(k_ntt_strided, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, scratch, L, lc, cur_len, cur_pre);
+      cur = scratch; cur_len = N; cur_pre = nullptr; log_s -= L.log_m;
+    }
+    const uint32_t lm = p->log_m[p->levels - 1], log_a = p->log_m[0], log_b = p->levels == 3 ? p->log_m[1] : 0;
+    const uint32_t lc = std::min(cols_for(lm), log_a), tile = 1u << (lm + lc);
+    const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
+    const size_t lds = (size_t)2 * 16 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc);
+    const uint64_t blocks = ((uint64_t)1 << log_b) << (log_a - lc);
+    Scope sc("ntt_pass");
+    hipLaunchKernelGGL(k_ntt_final, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, dst, lm, log_a, log_b, lc, p->tw_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
+  }
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+
+int finish_async() { if (g.profiling) resolve_spans(); return MI355_OK; }
+
+int with_host_io(void *data_host, size_t in_bytes, size_t out_bytes, size_t dev_bytes, const char *role, int (*body)(void *dev, void *ud), void *ud) {
+  void *dev; CHK(ws_get(role, dev_bytes, &dev));
+  HIPCHK(hipMemcpyAsync(dev, data_host, in_bytes, hipMemcpyHostToDevice, g.stream));
+  CHK(body(dev, ud));
+  HIPCHK(hipMemcpyAsync(data_host, dev, out_bytes, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  resolve_spans();
+  return MI355_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char *mi355_last_error(void) { return g_err.c_str(); }
+const char *mi355_version(void) { return "mi355zk 0.1.0 (gfx950; BN254 G1 MSM + Fr NTT)"; }
+
+int mi355_init(int device_id) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (g.inited) return g.device == device_id ? MI355_OK : fail(MI355_EBADARG, "already bound to another device (one device per process)");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); return fail(MI355_ENODEVICE, "no HIP device visible"); }
+  if (device_id < 0 || device_id >= count) return fail(MI355_EBADARG, "device_id out of range");
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipGetDeviceProperties(&g.prop, device_id));
+  if (strncmp(g.prop.gcnArchName, "gfx950", 6) != 0) return fail(MI355_ENODEVICE, std::string("device is ") + g.prop.gcnArchName + ", this library is built for gfx950 only");
+  HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
+  g.stream = g.own_stream; g.device = device_id;
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  g.inited = true;
+  return MI355_OK;
+}
+
+int mi355_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.inited) return MI355_OK;
+  hipStreamSynchronize(g.stream);
+  for (auto &kv : g.ws) if (kv.second.p) hipFree(kv.second.p);
+  g.ws.clear();
+  for (auto &kv : g.srs) if (kv.second.owned && kv.second.dev) hipFree(kv.second.dev);
+  g.srs.clear();
+  for (auto &kv : g.ntt_plans) { for (int i = 0; i < 3; i++) if (kv.second.tw_m[i]) hipFree(kv.second.tw_m[i]); for (int i = 0; i < 2; i++) { if (kv.second.tw_s_lo[i]) hipFree(kv.second.tw_s_lo[i]); if (kv.second.tw_s_hi[i]) hipFree(kv.second.tw_s_hi[i]); } }
+  g.ntt_plans.clear();
+  if (g.fixed_base_table) { hipFree(g.fixed_base_table); g.fixed_base_table = nullptr; }
+  if (g.own_stream) hipStreamDestroy(g.own_stream);
+  g.own_stream = g.stream = nullptr; g.inited = false; g.device = -1;
+  return MI355_OK;
+}
+
+int mi355_set_stream(void *hip_stream) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  HIPCHK(hipStreamSynchronize(g.stream));
+  g.stream = hip_stream ? (hipStream_t)hip_stream : g.own_stream;
+  return MI355_OK;
+}
+int mi355_synchronize(void) { std::lock_guard<std::mutex> lk(g.mu); CHK(need_init()); HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans(); return MI355_OK; }
+
+// ---- SRS
+int mi355_srs_register_host(const void *bases, uint64_t n, uint64_t *handle_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!bases || !handle_out || n == 0) return fail(MI355_EBADARG, "srs_register: null pointer or n == 0");
+  Srs s; s.n = n; s.owned = true;
+  HIPCHK(hipMalloc((void **)&s.dev, n * sizeof(g1_affine_t)));
+  hipError_t e = hipMemcpy(s.dev, bases, n * sizeof(g1_affine_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(s.dev); return fail(MI355_EHIP, std::string("srs upload: ") + hipGetErrorString(e)); }
+  *handle_out = g.next_handle++; g.srs[*handle_out] = s; return MI355_OK;
+}
+int mi355_srs_register_dev(const void *bases_dev, uint64_t n, int copy, uint64_t *handle_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!bases_dev || !handle_out || n == 0) return fail(MI355_EBADARG, "srs_register_dev: null pointer or n == 0");
+  Srs s; s.n = n;
+  if (copy) { s.owned = true; HIPCHK(hipMalloc((void **)&s.dev, n * sizeof(g1_affine_t))); HIPCHK(hipMemcpyAsync(s.dev, bases_dev, n * sizeof(g1_affine_t), hipMemcpyDeviceToDevice, g.stream)); HIPCHK(hipStreamSynchronize(g.stream)); }
+  else { s.owned = false; s.dev = (g1_affine_t *)bases_dev; }
+  *handle_out = g.next_handle++; g.srs[*handle_out] = s; return MI355_OK;
+}
+int mi355_srs_release(uint64_t handle) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  auto it = g.srs.find(handle);
+  if (it == g.srs.end()) return fail(MI355_EBADARG, "srs_release: unknown handle");
+  if (g.inited) hipStreamSynchronize(g.stream);
+  if (it->second.owned) hipFree(it->second.dev);
+  g.srs.erase(it); return MI355_OK;
+}
+int mi355_srs_len(uint64_t handle, uint64_t *n_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  auto it = g.srs.find(handle);
+  if (it == g.srs.end() || !n_out) return fail(MI355_EBADARG, "srs_len: unknown handle");
+  *n_out = it->second.n; return MI355_OK;
+}
+int mi355_srs_dev_ptr(uint64_t handle, void **dev_ptr_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  auto it = g.srs.find(handle);
+  if (it == g.srs.end() || !dev_ptr_out) return fail(MI355_EBADARG, "srs_dev_ptr: unknown handle");
+  *dev_ptr_out = it->second.dev; return MI355_OK;
+}
+
+// ---- MSM
+static int srs_slice(uint64_t handle, uint64_t off, uint64_t n, const g1_affine_t **out) {
+  auto it = g.srs.find(handle);
+  if (it == g.srs.end()) return fail(MI355_EBADARG, "msm: unknown SRS handle");
+  if (off > it->second.n || n > it->second.n - off) return fail(MI355_EBADARG, "msm: base_offset + n exceeds the registered basis (best_multiexp panics on length mismatch)");
+  *out = it->second.dev + off; return MI355_OK;
+}
+int mi355_msm_g1_dev(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!out_g1_host || (n && !scalars_dev)) return fail(MI355_EBADARG, "msm: null pointer");
+  const g1_affine_t *bases; CHK(srs_slice(srs_handle, base_offset, n, &bases));
+  return msm_dev_impl(bases, (const fe_t *)scalars_dev, n, out_g1_host);
+}
+int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *scalars_host, uint64_t n, void *out_g1_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!out_g1_host || (n && !scalars_host)) return fail(MI355_EBADARG, "msm: null pointer");
+  const g1_affine_t *bases; CHK(srs_slice(srs_handle, base_offset, n, &bases));
+  fe_t *sc = nullptr;
+  if (n) { CHK(ws_get("io.scalars", n * sizeof(fe_t), (void **)&sc)); HIPCHK(hipMemcpyAsync(sc, scalars_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
+  return msm_dev_impl(bases, sc, n, out_g1_host);
+}
+int mi355_msm_g1_adhoc_host(const void *bases_host, const void *scalars_host, uint64_t n, void *out_g1_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!out_g1_host || (n && (!scalars_host || !bases_host))) return fail(MI355_EBADARG, "msm: null pointer");
+  fe_t *sc = nullptr; g1_affine_t *bs = nullptr;
+  if (n) {
+    CHK(ws_get("io.scalars", n * sizeof(fe_t), (void **)&sc)); CHK(ws_get("io.bases", n * sizeof(g1_affine_t), (void **)&bs));
+    HIPCHK(hipMemcpyAsync(sc, scalars_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(bs, bases_host, n * sizeof(g1_affine_t), hipMemcpyHostToDevice, g.stream));
+  }
+  return msm_dev_impl(bs, sc, n, out_g1_host);
+}
+int mi355_g1_sum_host(const void *pts_host, uint64_t n, void *out_g1_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!out_g1_host || (n && !pts_host) || n > (1u << 20)) return fail(MI355_EBADARG, "g1_sum: bad argument");
+  g1_jac_t *dev; CHK(ws_get("io.g1sum", (n + 1) * sizeof(g1_jac_t), (void **)&dev));
+  if (n) HIPCHK(hipMemcpyAsync(dev + 1, pts_host, n * sizeof(g1_jac_t), hipMemcpyHostToDevice, g.stream));
+  hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(64), 0, g.stream, dev + 1, (uint32_t)n, dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_g1_host, dev, sizeof(g1_jac_t), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return MI355_OK;
+}
+int mi355_msm_set_window_bits(int c) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (c != 0 && (c < 2 || c > 24)) return fail(MI355_EBADARG, "window bits must be 0 (auto) or in [2, 24]");
+  g.force_c = c; return MI355_OK;
+}
+int mi355_msm_last_plan(int *c_out, int *windows_out, uint64_t *entries_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (c_out) *c_out = g.last_c; if (windows_out) *windows_out = g.last_w; if (entries_out) *entries_out = g.last_entries; return MI355_OK;
+}
+
+// ---- NTT
+static int check_ntt_args(const void *data, uint32_t log_n, const void *omega) {
+  if (!data || !omega) return fail(MI355_EBADARG, "ntt: null pointer");
+  if (log_n > 28) return fail(MI355_EBADARG, "ntt: log_n > 28");
+  return MI355_OK;
+}
+int mi355_ntt_fr_dev(void *data_dev, uint32_t log_n, const void *omega) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init()); CHK(check_ntt_args(data_dev, log_n, omega));
+  CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_n, (fe_t *)data_dev, log_n, omega, nullptr, nullptr));
+  return finish_async();
+}
+int mi355_intt_fr_dev(void *data_dev, uint32_t log_n, const void *omega_inv, const void *divisor) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init()); CHK(check_ntt_args(data_dev, log_n, omega_inv));
+  if (!divisor) return fail(MI355_EBADARG, "intt: null divisor");
+  fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], divisor, 32);
+  CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_n, (fe_t *)data_dev, log_n, omega_inv, nullptr, post));
+  return finish_async();
+}
+int mi355_coeff_to_extended_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init()); CHK(check_ntt_args(dst_dev, log_ext, extended_omega));
+  if (!coeffs_dev || !g_coset || !g_coset_inv || log_n > log_ext) return fail(MI355_EBADARG, "coeff_to_extended: bad argument");
+  fe_t pre[3]; pre[0] = Fr::one(); memcpy(&pre[1], g_coset, 32); memcpy(&pre[2], g_coset_inv, 32);
+  CHK(ntt_dev_impl((const fe_t *)coeffs_dev, 1ull << log_n, (fe_t *)dst_dev, log_ext, extended_omega, pre, nullptr));
+  return finish_async();
+}
+int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init()); CHK(check_ntt_args(data_dev, log_ext, extended_omega_inv));
+  if (!g_coset || !g_coset_inv || !extended_ifft_divisor) return fail(MI355_EBADARG, "extended_to_coeff: null pointer");
+  // post-scale table {d, d * g_coset_inv, d * g_coset}: three constant products formed on the host (setup, not data path)
+  fe_t d, gc, gci, post[3]; memcpy(&d, extended_ifft_divisor, 32); memcpy(&gc, g_coset, 32); memcpy(&gci, g_coset_inv, 32);
+  post[0] = d; post[1] = Fr::mul(d, gci); post[2] = Fr::mul(d, gc);
+  CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_ext, (fe_t *)data_dev, log_ext, extended_omega_inv, nullptr, post));
+  return finish_async();
+}
+
+struct NttHostArgs { uint32_t log_n; const void *omega; const void *divisor; };
+int mi355_ntt_fr_host(void *data_host, uint32_t log_n, const void *omega) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init()); CHK(check_ntt_args(data_host, log_n, omega));
+  NttHostArgs a{log_n, omega, nullptr};
+  const size_t bytes = sizeof(fe_t) << log_n;
+  return with_host_io(data_host, bytes, bytes, bytes, "io.ntt", [](void *dev, void *ud) { auto *a = (NttHostArgs *)ud; return ntt_dev_impl((const fe_t *)dev, 1ull << a->log_n, (fe_t *)dev, a->log_n, a->omega, nullptr, nullptr); }, &a);
+}
+int mi355_intt_fr_host(void *data_host, uint32_t log_n, const void *omega_inv, const void *divisor) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init()); CHK(check_ntt_args(data_host, log_n, omega_inv));
+  if (!divisor) return fail(MI355_EBADARG, "intt: null divisor");
+  NttHostArgs a{log_n, omega_inv, divisor};
+  const size_t bytes = sizeof(fe_t) << log_n;
+  return with_host_io(data_host, bytes, bytes, bytes, "io.ntt", [](void *dev, void *ud) {
+    auto *a = (NttHostArgs *)ud; fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], a->divisor, 32);
+    return ntt_dev_impl((const fe_t *)dev, 1ull << a->log_n, (fe_t *)dev, a->log_n, a->omega, nullptr, post); }, &a);
+}
+int mi355_coeff_to_extended_host(void *dst_host, const void *coeffs_host, uint32_t log_n, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega) {
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    CHK(need_init()); CHK(check_ntt_args(dst_host, log_ext, extended_omega));
+    if (!coeffs_host || !g_coset || !g_coset_inv || log_n > log_ext) return fail(MI355_EBADARG, "coeff_to_extended: bad argument");
+    void *src, *dst; CHK(ws_get("io.ntt_src", sizeof(fe_t) << log_n, &src)); CHK(ws_get("io.ntt", sizeof(fe_t) << log_ext, &dst));
+    HIPCHK(hipMemcpyAsync(src, coeffs_host, sizeof(fe_t) << log_n, hipMemcpyHostToDevice, g.stream));
+    fe_t pre[3]; pre[0] = Fr::one(); memcpy(&pre[1], g_coset, 32); memcpy(&pre[2], g_coset_inv, 32);
+    CHK(ntt_dev_impl((const fe_t *)src, 1ull << log_n, (fe_t *)dst, log_ext, extended_omega, pre, nullptr));
+    HIPCHK(hipMemcpyAsync(dst_host, dst, sizeof(fe_t) << log_ext, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans();
+  }
+  return MI355_OK;
+}
+int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
+  void *dev;
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    CHK(need_init()); CHK(check_ntt_args(data_host, log_ext, extended_omega_inv));
+    CHK(ws_get("io.ntt", sizeof(fe_t) << log_ext, &dev));
+    HIPCHK(hipMemcpyAsync(dev, data_host, sizeof(fe_t) << log_ext, hipMemcpyHostToDevice, g.stream));
+  }
+  CHK(mi355_extended_to_coeff_dev(dev, log_ext, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor));
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    HIPCHK(hipMemcpyAsync(data_host, dev, sizeof(fe_t) << log_ext, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans();
+  }
+  return MI355_OK;
+}
+
+// ---- synthetic SRS
+static int ensure_fixed_base_table() {
+  if (g.fixed_base_table) return MI355_OK;
+  HIPCHK(hipMalloc((void **)&g.fixed_base_table, 32 * 256 * sizeof(g1_affine_t)));
+  hipLaunchKernelGGL(k_fixed_base_table, dim3(1), dim3(256), 0, g.stream, g.fixed_base_table);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+int mi355_g1_fixed_base_mul_dev(void *points_dev, const void *scalars_dev, uint64_t n) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!points_dev || !scalars_dev) return fail(MI355_EBADARG, "fixed_base_mul: null pointer");
+  CHK(ensure_fixed_base_table());
+  hipLaunchKernelGGL(k_fixed_base_mul, dim3(ceil_div(n, 256)), dim3(256), 0, g.stream, g.fixed_base_table, (const fe_t *)scalars_dev, (g1_affine_t *)points_dev, n);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const void *tau, const void *omega) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!g_dev || !g_lagrange_dev || !tau || !omega || k > 28) return fail(MI355_EBADARG, "srs_setup: bad argument");
+  CHK(ensure_fixed_base_table());
+  const uint64_t n = 1ull << k;
+  fe_t *sc; CHK(ws_get("srs.scalars", 2 * n * sizeof(fe_t), (void **)&sc));
+  fe_t t, w; memcpy(&t, tau, 32); memcpy(&w, omega, 32);
+  // (tau^n - 1) / n: one-off constant, formed on the host with the same limb code
+  fe_t nn = Fr::zero(); nn.l[0] = (uint32_t)n; nn.l[1] = (uint32_t)(n >> 32);
+  const fe_t tn1_over_n = Fr::mul(Fr::sub(Fr::pow_u64(t, n), Fr::one()), Fr::inv(Fr::from_canonical(nn)));
+  hipLaunchKernelGGL(k_srs_scalars, dim3(ceil_div(n, 256)), dim3(256), 0, g.stream, sc, sc + n, t, w, tn1_over_n, n);
+  hipLaunchKernelGGL(k_fixed_base_mul, dim3(ceil_div(n, 256)), dim3(256), 0, g.stream, g.fixed_base_table, sc, (g1_affine_t *)g_dev, n);
+  hipLaunchKernelGGL(k_fixed_base_mul, dim3(ceil_div(n, 256)), dim3(256), 0, g.stream, g.fixed_base_table, sc + n, (g1_affine_t *)g_lagrange_dev, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return MI355_OK;
+}
+
+// ---- profiling
+int mi355_profile_enable(int on) { std::lock_guard<std::mutex> lk(g.mu); g.profiling = on != 0; return MI355_OK; }
+int mi355_profile_reset(void) { std::lock_guard<std::mutex> lk(g.mu); if (g.inited) resolve_spans(); g.prof.clear(); return MI355_OK; }
+int mi355_profile_get(const char *name, double *ms_out, uint64_t *launches_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!name) return fail(MI355_EBADARG, "profile_get: null name");
+  if (g.inited) resolve_spans();
+  auto it = g.prof.find(name);
+  if (ms_out) *ms_out = it == g.prof.end() ? 0.0 : it->second.ms;
+  if (launches_out) *launches_out = it == g.prof.end() ? 0 : it->second.launches;
+  return MI355_OK;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,269 @@
+// msm.cuh -- BN254 G1 multi-scalar multiplication (Pippenger / bucket method) for gfx950.
+// Stands in for halo2_proofs::arithmetic::best_multiexp and the ParamsKZG::commit / commit_lagrange wrappers
+// (SURVEY.md §8a a1/a2).  The result is a group element, so any correct schedule is bit-exact with the CPU
+// path after normalisation; what differs from the CPU reference is the schedule:
+//
+//   1 k_msm_digits      scalars (Montgomery) -> canonical -> signed c-bit digits d in [-2^(c-1), 2^(c-1)],
+//                       digit plane [w][i] (coalesced), per-(window,bucket) histogram (atomics)
+//   2 scan              exclusive prefix sum of the W * 2^(c-1) histogram -> bucket offsets
+//   3 k_msm_scatter     counting-sort scatter of point indices (sign in bit 31) into bucket order
+//   4 k_msm_accumulate  SEGMENTED bucket accumulation: thread t owns entries [t*L, (t+1)*L) of the sorted
+//                       list whatever bucket boundaries fall inside, keeps an XYZZ accumulator in registers,
+//                       gathers affine bases (64 B each) and does mixed additions.  Perfectly load-balanced
+//                       for any scalar distribution (witness columns are mostly 0/1/small values).
+//   5 k_msm_fixup       buckets that straddle thread boundaries: sum their partials
+//   6 k_msm_bucket_reduce / k_msm_window_reduce   sum_b (b+1) * B[w][b] by chunked running sums, then a
+//                       wavefront-shuffle + LDS tree per window
+//   7 k_msm_final       Horner over windows (c doublings each), normalise to (x, y, 1)
+//
+// Algorithmic HBM bytes: 96 B per (scalar, point) pair.  The kernel is VALU-integer bound
+// (~11 field multiplications x ~300 instructions per mixed addition), see DESIGN.md.
+#pragma once
+#include "fp_asm.cuh"
+
+namespace zk {
+
+#if defined(__HIPCC__)
+
+struct MsmPlan {
+  uint32_t n;        // pairs
+  uint32_t c;        // window bits
+  uint32_t windows;  // W = ceil(255 / c)
+  uint32_t nb;       // buckets per window = 2^(c-1)
+  uint32_t seg;      // entries per accumulate thread
+};
+
+__device__ __forceinline__ g1_affine_t load_affine(const g1_affine_t *p) {
+  g1_affine_t r; r.x = g_load(&p->x); r.y = g_load(&p->y); return r;
+}
+__device__ __forceinline__ g1_xyzz_t load_xyzz(const g1_xyzz_t *p) {
+  g1_xyzz_t r; r.x = g_load(&p->x); r.y = g_load(&p->y); r.zz = g_load(&p->zz); r.zzz = g_load(&p->zzz); return r;
+}
+__device__ __forceinline__ void store_xyzz(g1_xyzz_t *p, const g1_xyzz_t &v) {
+  g_store(&p->x, v.x); g_store(&p->y, v.y); g_store(&p->zz, v.zz); g_store(&p->zzz, v.zzz);
+}
+
+// ---- 1. digits + histogram
+__global__ void __launch_bounds__(256) k_msm_digits(const fe_t *__restrict__ scalars, int32_t *__restrict__ digits, uint32_t *__restrict__ hist, MsmPlan P) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t half = 1u << (P.c - 1), mask = (1u << P.c) - 1;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
+    fe_t one_c = Fr::zero(); one_c.l[0] = 1;
+    const fe_t k = fr_mul_ps(g_load(&scalars[i]), one_c);   // Montgomery -> canonical (= to_repr())
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < P.windows; w++) {
+      const uint32_t bit = w * P.c, word = bit >> 5, sh = bit & 31;
+      uint32_t raw = 0;
+      if (word < 8) { raw = k.l[word] >> sh; if (sh + P.c > 32 && word + 1 < 8) raw |= k.l[word + 1] << (32 - sh); }
+      raw = (raw & mask) + carry;
+      int32_t d;
+      if (raw > half) { d = (int32_t)raw - (int32_t)(1u << P.c); carry = 1; } else { d = (int32_t)raw; carry = 0; }
+      digits[(uint64_t)w * P.n + i] = d;
+      if (d != 0) atomicAdd(&hist[w * P.nb + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+    }
+  }
+}
+
+// ---- 2. exclusive scan (three small kernels; the array has W * 2^(c-1) + 1 entries)
+constexpr uint32_t SCAN_BLOCK = 1024, SCAN_ITEMS = 4;  // 4096 per workgroup
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds, uint32_t &total) {
+  // wave-level inclusive scan by shuffles, then across the 16 waves through LDS
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+  for (uint32_t o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+  if (lane == 63) lds[wave] = x;
+  __syncthreads();
+  if (wave == 0) { uint32_t s = lane < (blockDim.x >> 6) ? lds[lane] : 0; for (uint32_t o = 1; o < 16; o <<= 1) { uint32_t y = __shfl_up(s, o); if (lane >= o) s += y; } if (lane < 16) lds[16 + lane] = s; }
+  __syncthreads();
+  const uint32_t wave_off = wave ? lds[16 + wave - 1] : 0;
+  total = lds[16 + (blockDim.x >> 6) - 1];
+  __syncthreads();
+  return wave_off + x - v;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partial(const uint32_t *__restrict__ in, uint32_t *__restrict__ block_sums, uint32_t n) {
+  __shared__ uint32_t lds[32];
+  const uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+  for (uint32_t k = 0; k < SCAN_ITEMS; k++) if (base + k < n) s += in[base + k];
+  uint32_t total; block_exclusive_scan(s, lds, total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_block_sums(uint32_t *block_sums, uint32_t nblocks) {
+  __shared__ uint32_t lds[32];
+  __shared__ uint32_t running;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nblocks; base += SCAN_BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nblocks ? block_sums[i] : 0;
+    uint32_t total; const uint32_t ex = block_exclusive_scan(v, lds, total);
+    const uint32_t r = running;
+    if (i < nblocks) block_sums[i] = r + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) running = r + total;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const uint32_t *__restrict__ in, const uint32_t *__restrict__ block_sums, uint32_t *__restrict__ out_a, uint32_t *__restrict__ out_b, uint32_t n) {
+  __shared__ uint32_t lds[32];
+  const uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS], s = 0;
+  for (uint32_t k = 0; k < SCAN_ITEMS; k++) { v[k] = base + k < n ? in[base + k] : 0; s += v[k]; }
+  uint32_t total; uint32_t ex = block_exclusive_scan(s, lds, total) + block_sums[blockIdx.x];
+  for (uint32_t k = 0; k < SCAN_ITEMS; k++) if (base + k < n) { out_a[base + k] = ex; out_b[base + k] = ex; ex += v[k]; }
+}
+
+// ---- 3. scatter
+__global__ void __launch_bounds__(256) k_msm_scatter(const int32_t *__restrict__ digits, uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted, MsmPlan P) {
+  const uint64_t total = (uint64_t)P.n * P.windows, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int32_t d = digits[e];
+    if (d == 0) continue;
+    const uint32_t w = (uint32_t)(e / P.n), i = (uint32_t)(e - (uint64_t)w * P.n);
+    const uint32_t pos = atomicAdd(&cursor[w * P.nb + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+    sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+  }
+}
+
+// ---- 4. segmented accumulation
+// offsets[b] .. offsets[b+1] = entries of global bucket b (b = w * nb + bucket); offsets has nbuckets+1 entries.
+// bucket_sums must be zero-filled (all-zero XYZZ = identity) before launch.
+__global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
+                                                        uint32_t nbuckets, g1_xyzz_t *__restrict__ bucket_sums, g1_xyzz_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg) {
+  const uint32_t total = offsets[nbuckets];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t start64 = (uint64_t)t * seg;
+  if (start64 >= total) { if (start64 < (uint64_t)total + seg || true) { part_id[2 * t] = -1; part_id[2 * t + 1] = -1; } return; }
+  const uint32_t start = (uint32_t)start64, end = (uint32_t)min((uint64_t)total, start64 + seg);
+  // largest b with offsets[b] <= start  (then offsets[b+1] > start: the bucket that contains `start`)
+  uint32_t lo = 0, hi = nbuckets;  // invariant offsets[lo] <= start < offsets[hi]
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (offsets[mid] <= start) lo = mid; else hi = mid; }
+  uint32_t b = lo, b_end = offsets[b + 1];
+  int32_t id_first = -1, id_last = -1;
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (uint32_t pos = start; pos < end; pos++) {
+    if (pos >= b_end) {
+      // leave bucket b: it ends inside this thread's range
+      if (offsets[b] >= start) store_xyzz(&bucket_sums[b], acc);                        // began here too: sole owner
+      else { store_xyzz(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }          // began in an earlier thread
+      acc = g1_xyzz_identity();
+      do { b++; b_end = offsets[b + 1]; } while (pos >= b_end);
+    }
+    const uint32_t ent = sorted[pos];
+    g1_affine_t p = load_affine(&bases[ent & 0x7fffffffu]);
+    if (ent >> 31) p.y = Fq::neg(p.y);
+    g1_xyzz_madd_ps(acc, p);
+  }
+  // bucket b is still open at `end`
+  if (offsets[b] >= start && b_end <= end) store_xyzz(&bucket_sums[b], acc);
+  else if (offsets[b] < start) { store_xyzz(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }   // spans the whole segment or just its head
+  else { store_xyzz(&part[2 * (uint64_t)t + 1], acc); id_last = (int32_t)b; }                        // began here, continues in the next thread
+  part_id[2 * t] = id_first; part_id[2 * t + 1] = id_last;
+}
+
+// ---- 5. fix-up of buckets that straddle thread boundaries
+__global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz_t *__restrict__ bucket_sums,
+                                                   const g1_xyzz_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  const uint32_t s = offsets[b], e = offsets[b + 1];
+  if (e == s) return;
+  const uint32_t t0 = s / seg, t1 = (e - 1) / seg;
+  if (t0 == t1) return;  // sole owner wrote it
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (uint32_t t = t0; t <= t1; t++) {
+    if (part_id[2 * t] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz(&part[2 * (uint64_t)t]));
+    else if (part_id[2 * t + 1] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz(&part[2 * (uint64_t)t + 1]));
+  }
+  store_xyzz(&bucket_sums[b], acc);
+}
+
+// ---- 6a. chunked running sums: thread j of window w covers buckets [j*K, (j+1)*K) and emits
+//          T + (j*K) * S  where S = sum B_i, T = sum (i_local + 1) B_i
+__global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz_t *__restrict__ bucket_sums, g1_xyzz_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {
+  const uint32_t chunks_per_window = P.nb / chunk;
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= chunks_per_window * P.windows) return;
+  const uint32_t w = g / chunks_per_window, j = g - w * chunks_per_window;
+  const g1_xyzz_t *B = bucket_sums + (uint64_t)w * P.nb + (uint64_t)j * chunk;
+  g1_xyzz_t run = g1_xyzz_identity(), T = g1_xyzz_identity();
+  for (uint32_t i = chunk; i-- > 0;) { g1_xyzz_add_ps(run, load_xyzz(&B[i])); g1_xyzz_add_ps(T, run); }
+  if (j != 0) {
+    const uint32_t k = j * chunk;
+    g1_xyzz_t kS = g1_xyzz_identity();
+    for (int bit = 31 - __clz(k); bit >= 0; bit--) { kS = g1_xyzz_dbl_ps(kS); if ((k >> bit) & 1) g1_xyzz_add_ps(kS, run); }
+    g1_xyzz_add_ps(T, kS);
+  }
+  store_xyzz(&chunk_out[g], T);
+}
+// ---- 6b. per window: tree-sum of the chunk results (wavefront shuffles, then LDS across waves)
+__device__ __forceinline__ fe_t shfl_down_fe(const fe_t &v, uint32_t o) { fe_t r; for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], o); return r; }
+__device__ __forceinline__ g1_xyzz_t shfl_down_xyzz(const g1_xyzz_t &v, uint32_t o) {
+  g1_xyzz_t r; r.x = shfl_down_fe(v.x, o); r.y = shfl_down_fe(v.y, o); r.zz = shfl_down_fe(v.zz, o); r.zzz = shfl_down_fe(v.zzz, o); return r;
+}
+__global__ void __launch_bounds__(256) k_msm_window_reduce(const g1_xyzz_t *__restrict__ chunk_out, g1_xyzz_t *__restrict__ window_sums, uint32_t chunks_per_window) {
+  __shared__ g1_xyzz_t lds[4];
+  const uint32_t w = blockIdx.x;
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (uint32_t i = threadIdx.x; i < chunks_per_window; i += blockDim.x) g1_xyzz_add_ps(acc, load_xyzz(&chunk_out[(uint64_t)w * chunks_per_window + i]));
+  for (uint32_t o = 32; o >= 1; o >>= 1) { g1_xyzz_t other = shfl_down_xyzz(acc, o); g1_xyzz_add_ps(acc, other); }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz_add_ps(acc, lds[k]); store_xyzz(&window_sums[w], acc); }
+}
+// ---- 7. Horner over windows + normalisation.  One lane; 255 doublings are inherently serial.
+__global__ void k_msm_final(const g1_xyzz_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (uint32_t w = windows; w-- > 0;) {
+    for (uint32_t k = 0; k < c; k++) acc = g1_xyzz_dbl_ps(acc);
+    g1_xyzz_add_ps(acc, load_xyzz(&window_sums[w]));
+  }
+  *out = g1_xyzz_to_jac_normalised(acc);
+}
+// sum of n Jacobian points (fold of per-GPU partial results), normalised
+__global__ void k_g1_sum(const g1_jac_t *__restrict__ pts, uint32_t n, g1_jac_t *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (uint32_t i = 0; i < n; i++) { g1_jac_t p = pts[i]; g1_xyzz_add_ps(acc, g1_jac_to_xyzz(p)); }
+  *out = g1_xyzz_to_jac_normalised(acc);
+}
+
+// ---- synthetic SRS helpers (ParamsKZG::setup restated): fixed-base multiplication by 8-bit windows.
+// table[j][d] = d * 2^(8j) * G  for j < 32, d < 256 (affine; entry d = 0 is the identity (0,0)).
+__global__ void k_fixed_base_table(g1_affine_t *table) {
+  // one workgroup of 256 threads; thread d computes d * 2^(8j) G for every j by repeated doubling of its own point
+  const uint32_t d = threadIdx.x;
+  g1_affine_t G; G.x = Fq::one(); G.y = Fq::dbl(Fq::one());
+  g1_xyzz_t P = g1_xyzz_mul_small(g1_xyzz_from_affine(G), d);
+  for (uint32_t j = 0; j < 32; j++) {
+    table[j * 256 + d] = g1_xyzz_to_affine(P);
+    for (int k = 0; k < 8; k++) P = g1_xyzz_dbl_ps(P);
+  }
+}
+// points[i] = scalars[i] * G, affine.  One thread per point: 32 mixed additions + one inversion.
+__global__ void __launch_bounds__(256) k_fixed_base_mul(const g1_affine_t *__restrict__ table, const fe_t *__restrict__ scalars, g1_affine_t *__restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe_t one_c = Fr::zero(); one_c.l[0] = 1;
+  const fe_t k = fr_mul_ps(g_load(&scalars[i]), one_c);
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (uint32_t j = 0; j < 32; j++) {
+    const uint32_t d = (k.l[j >> 2] >> ((j & 3) * 8)) & 0xff;
+    if (d) g1_xyzz_madd_ps(acc, load_affine(&table[j * 256 + d]));
+  }
+  g1_affine_t r = g1_xyzz_to_affine(acc);
+  g_store(&out[i].x, r.x); g_store(&out[i].y, r.y);
+}
+// scalars for setup: g_scal[i] = tau^i ; gl_scal[i] = omega^i (tau^n - 1) / (n (tau - omega^i))
+__global__ void __launch_bounds__(256) k_srs_scalars(fe_t *__restrict__ g_scal, fe_t *__restrict__ gl_scal, fe_t tau, fe_t omega, fe_t tn1_over_n, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g_store(&g_scal[i], Fr::pow_u64(tau, i));
+  const fe_t wi = Fr::pow_u64(omega, i);
+  const fe_t d = Fr::inv(Fr::sub(tau, wi));
+  g_store(&gl_scal[i], fr_mul_ps(fr_mul_ps(wi, tn1_over_n), d));
+}
+#endif  // __HIPCC__
+
+}  // namespace zk

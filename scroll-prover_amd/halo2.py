@@ -1,0 +1,216 @@
+"""
+halo2.py -- host-side mirror of the halo2_proofs operator surface that scroll-prover reaches through
+`gen_halo2_chunk_proof` / `gen_batch_proof` / `gen_bundle_proof` [REF integration/src/prove.rs:37,67,96], implemented
+on libmi355zk.so.  Names, argument meaning and error behaviour follow halo2_proofs@e5ddf67 [EXT-recalled]:
+
+  best_multiexp(coeffs, bases)          src/arithmetic.rs   panics (here: AssertionError) on length mismatch
+  best_fft(a, omega, log_n)             src/arithmetic.rs   in place, natural -> natural
+  EvaluationDomain(j, k)                src/poly/domain.rs  lagrange_to_coeff, coeff_to_lagrange, coeff_to_extended,
+                                                            extended_to_coeff, constants omega/omega_inv/extended_omega/g_coset
+  ParamsKZG                             src/poly/kzg/commitment.rs  setup, commit, commit_lagrange, downsize, n, k
+
+Host arrays are numpy uint64: [n, 4] field elements (Montgomery LE limbs), [n, 8] G1Affine, [12] G1 (Jacobian).
+Device-resident operands are torch.uint8/uint64 CUDA tensors; they are passed by address (torch is plumbing only).
+The constants (omega, n^-1, ...) are computed with Python integers -- host set-up, exactly as EvaluationDomain::new does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, lib, ptr
+
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+P_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+FR_S = 28
+FR_ROOT_OF_UNITY = pow(7, (R_MOD - 1) >> FR_S, R_MOD)
+FR_ZETA = 0x30644E72E131A029048B6E193FD84104CC37A73FEC2BC5E9B8CA0B2D36636F23  # halo2curves bn256::Fr::ZETA [EXT-recalled]
+_M64 = (1 << 64) - 1
+
+
+def fr(x: int) -> np.ndarray:
+    """canonical integer -> 4 x u64 Montgomery limbs (the in-memory form of halo2curves Fr)."""
+    v = (x % R_MOD) * (1 << 256) % R_MOD
+    return np.array([(v >> (64 * i)) & _M64 for i in range(4)], dtype=np.uint64)
+
+
+def fr_to_int(limbs) -> int:
+    v = sum(int(l) << (64 * i) for i, l in enumerate(limbs))
+    return v * pow(1 << 256, -1, R_MOD) % R_MOD
+
+
+def _is_device(x) -> bool:
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+# ------------------------------------------------------------------------------------------ arithmetic.rs
+def best_multiexp(coeffs, bases) -> np.ndarray:
+    """sum_i coeffs[i] * bases[i] -> G1 (12 u64: normalised Jacobian).  bases: host [n,8] array or a ParamsKZG basis handle slice."""
+    n = int(coeffs.shape[0])
+    out = np.zeros(12, dtype=np.uint64)
+    if isinstance(bases, SrsSlice):
+        assert n == bases.n, "best_multiexp: coeffs.len() != bases.len()"
+        fn = lib().mi355_msm_g1_dev if _is_device(coeffs) else lib().mi355_msm_g1_host
+        check(fn(bases.handle, bases.offset, ptr(coeffs), n, ptr(out)))
+        return out
+    assert n == int(bases.shape[0]), "best_multiexp: coeffs.len() != bases.len()"
+    check(lib().mi355_msm_g1_adhoc_host(ptr(np.ascontiguousarray(bases)), ptr(np.ascontiguousarray(coeffs)), n, ptr(out)))
+    return out
+
+
+def best_fft(a, omega: np.ndarray, log_n: int) -> None:
+    """in place; a is a host [2^log_n, 4] uint64 array or a device tensor of 2^log_n * 32 bytes."""
+    if _is_device(a):
+        assert a.numel() * a.element_size() == 32 << log_n
+        check(lib().mi355_ntt_fr_dev(ptr(a), log_n, ptr(omega)))
+    else:
+        assert a.shape == (1 << log_n, 4) and a.dtype == np.uint64
+        check(lib().mi355_ntt_fr_host(ptr(a), log_n, ptr(omega)))
+
+
+def g1_sum(points: np.ndarray) -> np.ndarray:
+    """fold of per-GPU partial results: results.iter().fold(identity, |a, b| a + b)."""
+    points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros(12, dtype=np.uint64)
+    check(lib().mi355_g1_sum_host(ptr(points), points.shape[0], ptr(out)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ poly/domain.rs
+class EvaluationDomain:
+    """EvaluationDomain::new(j, k): n = 2^k, quotient_poly_degree = j - 1, extended_k minimal with 2^extended_k >= n * (j - 1)."""
+
+    def __init__(self, j: int, k: int):
+        self.k, self.n = k, 1 << k
+        self.quotient_poly_degree = j - 1
+        ext = k
+        while (1 << ext) < self.n * self.quotient_poly_degree:
+            ext += 1
+        assert ext <= FR_S, "extended_k exceeds the two-adicity of Fr"
+        self.extended_k = ext
+        ew = pow(FR_ROOT_OF_UNITY, 1 << (FR_S - ext), R_MOD)
+        w = pow(ew, 1 << (ext - k), R_MOD)
+        self._omega, self._extended_omega = w, ew
+        self.omega, self.omega_inv = fr(w), fr(pow(w, -1, R_MOD))
+        self.extended_omega, self.extended_omega_inv = fr(ew), fr(pow(ew, -1, R_MOD))
+        self.g_coset, self.g_coset_inv = fr(FR_ZETA), fr(FR_ZETA * FR_ZETA % R_MOD)
+        self.ifft_divisor = fr(pow(self.n, -1, R_MOD))
+        self.extended_ifft_divisor = fr(pow(1 << ext, -1, R_MOD))
+
+    def extended_len(self) -> int:
+        return 1 << self.extended_k
+
+    def coeff_to_lagrange(self, a):
+        best_fft(a, self.omega, self.k)
+        return a
+
+    def lagrange_to_coeff(self, a):
+        """ifft: best_fft(a, omega_inv, k) then a[i] *= n^-1."""
+        if _is_device(a):
+            check(lib().mi355_intt_fr_dev(ptr(a), self.k, ptr(self.omega_inv), ptr(self.ifft_divisor)))
+        else:
+            check(lib().mi355_intt_fr_host(ptr(a), self.k, ptr(self.omega_inv), ptr(self.ifft_divisor)))
+        return a
+
+    def coeff_to_extended(self, a, out=None):
+        """zero-pad to the extended domain, move into the coset g_coset * H, transform.  Returns a new array (host) or fills `out` (device)."""
+        if _is_device(a):
+            assert out is not None and _is_device(out)
+            check(lib().mi355_coeff_to_extended_dev(ptr(out), ptr(a), self.k, self.extended_k, ptr(self.g_coset), ptr(self.g_coset_inv), ptr(self.extended_omega)))
+            return out
+        dst = np.zeros((self.extended_len(), 4), dtype=np.uint64)
+        check(lib().mi355_coeff_to_extended_host(ptr(dst), ptr(np.ascontiguousarray(a)), self.k, self.extended_k, ptr(self.g_coset), ptr(self.g_coset_inv), ptr(self.extended_omega)))
+        return dst
+
+    def extended_to_coeff(self, a):
+        """inverse of coeff_to_extended, truncated to n * quotient_poly_degree coefficients (host) / in place (device, caller truncates)."""
+        if _is_device(a):
+            check(lib().mi355_extended_to_coeff_dev(ptr(a), self.extended_k, ptr(self.g_coset), ptr(self.g_coset_inv), ptr(self.extended_omega_inv), ptr(self.extended_ifft_divisor)))
+            return a
+        a = np.array(a, dtype=np.uint64, copy=True, order="C")
+        check(lib().mi355_extended_to_coeff_host(ptr(a), self.extended_k, ptr(self.g_coset), ptr(self.g_coset_inv), ptr(self.extended_omega_inv), ptr(self.extended_ifft_divisor)))
+        return a[: self.n * self.quotient_poly_degree]
+
+
+# ------------------------------------------------------------------------------------------ poly/kzg/commitment.rs
+class SrsSlice:
+    """&params.g[..n] / &params.g_lagrange[..n]: a registered, HBM-resident basis plus (offset, n)."""
+
+    def __init__(self, handle: int, offset: int, n: int):
+        self.handle, self.offset, self.n = handle, offset, n
+
+
+class ParamsKZG:
+    """ParamsKZG<Bn256> { k, n, g, g_lagrange } with both bases resident in HBM for the life of the object
+    (the reference keeps them in the process-wide params_map [REF bin/src/trace_prover.rs:35-43])."""
+
+    def __init__(self, k: int, g_handle: int, gl_handle: int, owner=None):
+        self.k, self.n = k, 1 << k
+        self._g, self._gl, self._owner = g_handle, gl_handle, owner
+
+    @classmethod
+    def from_host(cls, k: int, g: np.ndarray, g_lagrange: np.ndarray) -> "ParamsKZG":
+        """what `Prover::load_params_map` hands down, registered once."""
+        hs = []
+        for arr in (g, g_lagrange):
+            arr = np.ascontiguousarray(arr, dtype=np.uint64)
+            assert arr.shape == (1 << k, 8)
+            h = C.c_uint64()
+            check(lib().mi355_srs_register_host(ptr(arr), 1 << k, C.byref(h)))
+            hs.append(h.value)
+        return cls(k, hs[0], hs[1])
+
+    @classmethod
+    def setup(cls, k: int, tau: int) -> "ParamsKZG":
+        """ParamsKZG::setup(k, rng) with the toxic scalar given explicitly: g[i] = tau^i G, g_lagrange[i] = L_i(tau) G, built on the device."""
+        import torch
+        n = 1 << k
+        g = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
+        gl = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
+        w = pow(FR_ROOT_OF_UNITY, 1 << (FR_S - k), R_MOD)
+        check(lib().mi355_srs_setup_dev(ptr(g), ptr(gl), k, ptr(fr(tau)), ptr(fr(w))))
+        hs = []
+        for t in (g, gl):
+            h = C.c_uint64()
+            check(lib().mi355_srs_register_dev(ptr(t), n, 0, C.byref(h)))
+            hs.append(h.value)
+        return cls(k, hs[0], hs[1], owner=(g, gl))
+
+    def commit(self, poly_coeff) -> np.ndarray:
+        """commit(&self, poly: &Polynomial<_, Coeff>, _: Blind) = best_multiexp(poly, &self.g[..poly.len()])"""
+        n = poly_coeff.shape[0] if not _is_device(poly_coeff) else poly_coeff.numel() * poly_coeff.element_size() // 32
+        return best_multiexp(_as_scalars(poly_coeff, n), SrsSlice(self._g, 0, n))
+
+    def commit_lagrange(self, poly_lagrange) -> np.ndarray:
+        """commit_lagrange = best_multiexp(poly, &self.g_lagrange[..poly.len()])"""
+        n = poly_lagrange.shape[0] if not _is_device(poly_lagrange) else poly_lagrange.numel() * poly_lagrange.element_size() // 32
+        assert n == self.n, "commit_lagrange: polynomial must have exactly n evaluations"
+        return best_multiexp(_as_scalars(poly_lagrange, n), SrsSlice(self._gl, 0, n))
+
+    def g_slice(self, offset: int, n: int) -> SrsSlice:
+        return SrsSlice(self._g, offset, n)
+
+    def g_lagrange_slice(self, offset: int, n: int) -> SrsSlice:
+        return SrsSlice(self._gl, offset, n)
+
+    def release(self) -> None:
+        for h in (self._g, self._gl):
+            check(lib().mi355_srs_release(h))
+        self._owner = None
+
+
+class _Scalars:
+    """adapter giving device tensors the `.shape[0]` best_multiexp expects"""
+
+    def __init__(self, t, n):
+        self._t, self.shape = t, (n,)
+        self.is_cuda = True
+
+    def data_ptr(self):
+        return self._t.data_ptr()
+
+
+def _as_scalars(x, n):
+    return _Scalars(x, n) if _is_device(x) else np.ascontiguousarray(x, dtype=np.uint64)

@@ -1,0 +1,230 @@
+"""
+-m gpu parity tests: the HIP path (through the C-ABI, via the halo2 mirror) against the CPU oracle on the same
+seeded inputs -- bit-exact (raw Montgomery bytes for NTT, normalised affine for MSM).  Sizes are kept where the
+oracle finishes in seconds; the full BASELINE sizes are covered by size-independent properties in
+tests/test_gpu_properties.py.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+from oracle import cref, pyref
+from tests.gpu_common import R, affine_of, rand_fr, rand_points
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zk():
+    pkg = ge.load_package()
+    pkg.init(0)
+    yield pkg
+    pkg._capi.check(pkg._capi.lib().mi355_msm_set_window_bits(0))
+
+
+# ------------------------------------------------------------------------------------------------ NTT
+@pytest.mark.parametrize("k", list(range(0, 15)) + [16, 18, 19, 20])
+def test_best_fft_matches_oracle(zk, k):
+    h2 = zk.halo2
+    rng = np.random.default_rng(1000 + k)
+    n = 1 << k
+    a = rand_fr(rng, n)
+    w = h2.fr(pyref.omega(k))
+    want = cref.best_fft(a, w, k)
+    got = a.copy()
+    h2.best_fft(got, w, k)
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("k", [1, 5, 9, 13])
+def test_ntt_patterns(zk, k):
+    h2 = zk.halo2
+    n = 1 << k
+    w = h2.fr(pyref.omega(k))
+    one, zero = cref.fr_mont(1), cref.fr_mont(0)
+    delta = np.tile(zero, (n, 1)); delta[0] = one
+    a = delta.copy(); h2.best_fft(a, w, k)
+    assert (a == np.tile(one, (n, 1))).all()                       # NTT(delta_0) = all ones
+    a = np.tile(one, (n, 1)); h2.best_fft(a, w, k)
+    want = np.tile(zero, (n, 1)); want[0] = cref.fr_mont(n)
+    assert (a == want).all()                                       # NTT(all ones) = n * delta_0
+    a = np.tile(zero, (n, 1)); h2.best_fft(a, w, k)
+    assert (a == 0).all()
+    d1 = np.tile(zero, (n, 1)); d1[1] = one; h2.best_fft(d1, w, k)  # NTT(delta_1)[i] = omega^i (transpose-detecting)
+    assert (d1 == cref.best_fft(np.vstack([zero, one] + [zero] * (n - 2)), w, k)).all()
+
+
+@pytest.mark.parametrize("k", [3, 8, 12, 17])
+def test_domain_roundtrip_and_ifft(zk, k):
+    h2 = zk.halo2
+    rng = np.random.default_rng(2000 + k)
+    dom = h2.EvaluationDomain(4, k)
+    a = rand_fr(rng, 1 << k)
+    b = a.copy()
+    dom.coeff_to_lagrange(b)
+    c = b.copy()
+    dom.lagrange_to_coeff(c)
+    assert (c == a).all()
+    assert (c == cref.ifft(b, dom.omega_inv, k, dom.ifft_divisor)).all()
+    # KAT A1/A2 consistency: the domain constants the mirror derives equal the fixture's for k = 25/26 (host-only arithmetic)
+
+
+@pytest.mark.parametrize("k,j", [(4, 4), (7, 3), (10, 5), (13, 4)])
+def test_coset_extension_matches_oracle(zk, k, j):
+    h2 = zk.halo2
+    rng = np.random.default_rng(3000 + k)
+    dom = h2.EvaluationDomain(j, k)
+    coeffs = rand_fr(rng, 1 << k)
+    ext = dom.coeff_to_extended(coeffs)
+    want = cref.coeff_to_extended(coeffs, k, dom.extended_k, dom.g_coset, dom.g_coset_inv, dom.extended_omega)
+    assert ext.shape == want.shape and (ext == want).all()
+    back = dom.extended_to_coeff(ext)
+    wantb = cref.extended_to_coeff(want, dom.extended_k, dom.g_coset, dom.g_coset_inv, dom.extended_omega_inv, dom.extended_ifft_divisor)
+    assert (back == wantb[: back.shape[0]]).all()
+    assert (back[: 1 << k] == coeffs).all() and (back[1 << k:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ MSM
+@pytest.fixture(scope="module")
+def points(zk):
+    rng = np.random.default_rng(42)
+    return rand_points(rng, 2048)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 31, 32, 33, 100, 255, 256, 257, 1000, 2048])
+def test_best_multiexp_matches_oracle(zk, points, n):
+    h2 = zk.halo2
+    rng = np.random.default_rng(4000 + n)
+    sc = rand_fr(rng, n)
+    got = affine_of(h2.best_multiexp(sc, points[:n]))
+    want = cref.g1_to_affine(cref.best_multiexp(sc, points[:n]))
+    assert (got == want).all()
+    if n <= 33:
+        assert (got == cref.g1_to_affine(cref.msm_naive(sc, points[:n]))).all()
+
+
+@pytest.mark.parametrize("c", [2, 5, 8, 11, 13, 16])
+def test_msm_window_bits_do_not_change_the_result(zk, points, c):
+    h2 = zk.halo2
+    rng = np.random.default_rng(77)
+    n = 1500
+    sc = rand_fr(rng, n)
+    zk._capi.check(zk._capi.lib().mi355_msm_set_window_bits(c))
+    try:
+        got = affine_of(h2.best_multiexp(sc, points[:n]))
+    finally:
+        zk._capi.check(zk._capi.lib().mi355_msm_set_window_bits(0))
+    assert (got == cref.g1_to_affine(cref.best_multiexp(sc, points[:n]))).all()
+
+
+def test_msm_edge_cases(zk, points):
+    h2 = zk.halo2
+    rng = np.random.default_rng(5)
+    n = 512
+    pts = points[:n]
+    zero, one = cref.fr_mont(0), cref.fr_mont(1)
+
+    def gpu(sc, bases=pts):
+        return affine_of(h2.best_multiexp(np.ascontiguousarray(sc), np.ascontiguousarray(bases)))
+
+    def cpu(sc, bases=pts):
+        return cref.g1_to_affine(cref.best_multiexp(np.ascontiguousarray(sc), np.ascontiguousarray(bases)))
+
+    assert (gpu(np.tile(zero, (n, 1))) == 0).all()                                  # all-zero scalars -> identity
+    assert (gpu(np.tile(one, (n, 1))) == cpu(np.tile(one, (n, 1)))).all()            # all ones = sum of the points (one giant bucket)
+    e = np.tile(zero, (n, 1)); e[137] = one
+    assert (gpu(e) == pts[137]).all()                                               # unit vector
+    neg1 = np.tile(cref.fr_mont(R - 1), (n, 1))
+    assert (gpu(neg1) == cpu(neg1)).all()                                           # r - 1 everywhere (negative digits, top window)
+    sc = rand_fr(rng, n)
+    b2 = pts.copy(); b2[::3] = 0                                                    # identity bases contribute nothing
+    assert (gpu(sc, b2) == cpu(sc, b2)).all()
+    rep = np.tile(pts[5], (n, 1))                                                   # one point repeated: exercises P + P inside buckets
+    assert (gpu(sc, rep) == cpu(sc, rep)).all()
+    assert (gpu(np.tile(cref.fr_mont(7), (n, 1)), rep) == cpu(np.tile(cref.fr_mont(7), (n, 1)), rep)).all()
+    pm = pts.copy(); negp = pts[0].copy()
+    negy = cref.f_sub(cref.FQ, np.zeros(4, dtype=np.uint64), pts[0][4:]); negp[4:] = negy
+    pm[0::2] = pts[0]; pm[1::2] = negp                                              # P, -P, P, -P ... with equal scalars -> identity
+    assert (gpu(np.tile(cref.fr_mont(5), (n, 1)), pm) == 0).all()
+    assert (gpu(sc, pm) == cpu(sc, pm)).all()
+    # linearity: (s + t).P == s.P + t.P
+    t = rand_fr(rng, n)
+    st = np.stack([cref.f_add(cref.FR, sc[i], t[i]) for i in range(n)])
+    lhs = gpu(st)
+    rhs = cref.g1_to_affine(cref.g1_add(cref.best_multiexp(sc, pts), cref.best_multiexp(t, pts)))
+    assert (lhs == rhs).all()
+
+
+def test_msm_witness_like_distribution(zk, points):
+    """60 % zero, 20 % < 256, 10 % < 2^64, 10 % uniform: heavily skewed buckets."""
+    h2 = zk.halo2
+    rng = np.random.default_rng(6)
+    n = 2048
+    kind = rng.random(n)
+    vals = []
+    for i in range(n):
+        if kind[i] < 0.6: vals.append(0)
+        elif kind[i] < 0.8: vals.append(int(rng.integers(1, 256)))
+        elif kind[i] < 0.9: vals.append(int(rng.integers(0, 2**63)))
+        else: vals.append(int(rng.integers(0, 2**63)) ** 4 % R)
+    sc = np.stack([h2.fr(v) for v in vals])
+    got = affine_of(h2.best_multiexp(sc, points[:n]))
+    assert (got == cref.g1_to_affine(cref.best_multiexp(sc, points[:n]))).all()
+
+
+def test_g1_sum_and_errors(zk, points):
+    h2 = zk.halo2
+    G = cref.g1_generator()
+    parts = np.stack([cref.g1_mul(points[i], cref.fr_mont(i + 3)) for i in range(8)])   # non-normalised Jacobians
+    want = parts[0]
+    for p in parts[1:]:
+        want = cref.g1_add(want, p)
+    assert (affine_of(h2.g1_sum(parts)) == cref.g1_to_affine(want)).all()
+    assert (affine_of(h2.g1_sum(np.zeros((3, 12), dtype=np.uint64))) == 0).all()
+    with pytest.raises(AssertionError):            # best_multiexp asserts equal lengths
+        h2.best_multiexp(rand_fr(np.random.default_rng(0), 4), points[:5])
+    with pytest.raises(zk.Mi355Error):             # unknown SRS handle
+        h2.best_multiexp(rand_fr(np.random.default_rng(0), 4), h2.SrsSlice(987654, 0, 4))
+    _ = G
+
+
+def test_registered_srs_offsets(zk, points):
+    h2 = zk.halo2
+    params = h2.ParamsKZG.from_host(11, points, points[::-1].copy())
+    rng = np.random.default_rng(9)
+    sc = rand_fr(rng, 700)
+    got = affine_of(h2.best_multiexp(sc, params.g_slice(300, 700)))
+    assert (got == cref.g1_to_affine(cref.best_multiexp(sc, points[300:1000]))).all()
+    got = affine_of(h2.best_multiexp(sc, params.g_lagrange_slice(0, 700)))
+    assert (got == cref.g1_to_affine(cref.best_multiexp(sc, points[::-1][:700].copy()))).all()
+    with pytest.raises(zk.Mi355Error):
+        h2.best_multiexp(sc, params.g_slice(1500, 700))   # runs past the basis
+    params.release()
+
+
+def test_fixed_base_and_synthetic_srs(zk):
+    """ParamsKZG::setup restated on the device vs the oracle's setup; upstream test_commit_lagrange property."""
+    import torch
+    h2 = zk.halo2
+    k, n = 6, 64
+    tau = 0x1F2E3D4C5B6A79880123456789ABCDEF
+    params = h2.ParamsKZG.setup(k, tau)
+    g = params._owner[0].cpu().numpy().view(np.uint64).reshape(n, 8)
+    gl = params._owner[1].cpu().numpy().view(np.uint64).reshape(n, 8)
+    og, ogl, _, _ = cref.srs_setup(k, h2.fr(tau), h2.fr(pyref.omega(k)))
+    assert (g == og).all() and (gl == ogl).all()
+    rng = np.random.default_rng(10)
+    evals = rand_fr(rng, n)
+    dom = h2.EvaluationDomain(4, k)
+    coeffs = evals.copy(); dom.lagrange_to_coeff(coeffs)
+    c1 = affine_of(params.commit(coeffs)); c2 = affine_of(params.commit_lagrange(evals))
+    assert (c1 == c2).all()
+    p_tau = cref.eval_polynomial(coeffs, h2.fr(tau))
+    assert (c1 == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), p_tau))).all()
+    params.release()
+    _ = torch
