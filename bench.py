@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""
+bench.py -- the headline measurement of BASELINE.json: BN254 G1 MSM (G1-adds/s) + Fr NTT (butterflies/s) at k = 26
+on MI355X, one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input: ONE commitment = one G1 MSM over 2^k
+(scalar, point) pairs (ParamsKZG::commit / best_multiexp; create_proof issues 11-14 of these per compression-layer
+proof).  Inputs (scalars and the SRS basis) are resident in HBM when the timed region starts; the
+result (96 B) comes back to the host inside it, exactly as the C-ABI delivers it.
+N > 1: the 2^k pairs are sharded by point range: rank r owns 2^k / N points + scalars, computes its
+partial sum, the 96-byte partials are all-gathered with RCCL and folded on the device ("scaling": "strong").
+The NTT (fwd + inv, natural order, ifft divisor included) is timed in the same run as a secondary figure; it does
+not shard at k <= 26 (replicas only), so each rank runs its own copy.
+
+Synthetic data: basis g[i] = tau_r^i * G built on the device (ParamsKZG::setup restated, so every commitment can be
+checked in the field: commit(p) = p(tau) G); scalars uniform in [0, r) from a seeded generator.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+R_TOP = 0x30644E72E131A029
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def rand_scalars(n: int, seed: int, device) -> torch.Tensor:
+    """n field elements as [n,4] int64 limbs (Montgomery form of uniformly random elements), generated on the device."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    a = torch.randint(0, 256, (n * 32,), dtype=torch.uint8, device=device, generator=gen).view(torch.int64).view(n, 4)
+    top = a[:, 3] & ((1 << 62) - 1)
+    top = torch.where(top >= R_TOP, top >> 1, top)  # keep the 254-bit value below r
+    a[:, 3] = top
+    return a
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--logn", type=int, default=26, help="log2 of the MSM / NTT size (BASELINE metric: 26)")
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" == RCCL on ROCm
+
+    zk = ge.load_package()
+    lib, check, ptr, h2 = zk._capi.lib(), zk._capi.check, zk._capi.ptr, zk.halo2
+    zk.init(local_rank)
+    check(lib.mi355_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    check(lib.mi355_msm_set_window_bits(args.window_bits))
+
+    k = args.logn
+    n_total = 1 << k
+    assert n_total % world == 0
+    n = n_total // world                      # pairs owned by this rank (point-range shard)
+
+    # ---- synthetic inputs, resident in HBM
+    tau = 0x5343524F4C4C0001 + 7919 * rank    # seed ("SCROLL", 1), distinct per shard
+    shard_k = (n - 1).bit_length()
+    g = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    gl_scratch = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    w_shard = pow(h2.FR_ROOT_OF_UNITY, 1 << (h2.FR_S - shard_k), h2.R_MOD)
+    tau_m, w_m = h2.fr(tau), h2.fr(w_shard)
+    check(lib.mi355_srs_setup_dev(ptr(g), ptr(gl_scratch), shard_k, ptr(tau_m), ptr(w_m)))
+    del gl_scratch
+    handle = C.c_uint64()
+    check(lib.mi355_srs_register_dev(ptr(g), n, 0, C.byref(handle)))
+    scalars = rand_scalars(n, 0x5343524F4C4C0002 + rank, dev)
+    torch.cuda.synchronize()
+
+    out = np.zeros(12, dtype=np.uint64)
+    gathered = torch.empty(world * 96, dtype=torch.uint8, device=dev) if world > 1 else None
+    part_dev = torch.empty(96, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        check(lib.mi355_msm_g1_dev(handle.value, 0, ptr(scalars), n, ptr(out)))
+        if world == 1:
+            return out
+        part_dev.copy_(torch.from_numpy(out.view(np.uint8)), non_blocking=False)
+        dist.all_gather_into_tensor(gathered, part_dev)          # RCCL over xGMI: 96 B per rank
+        parts = gathered.cpu().numpy().view(np.uint64).reshape(world, 12)
+        return h2.g1_sum(parts)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        result = step()
+    check(lib.mi355_profile_reset())
+    check(lib.mi355_profile_enable(1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    check(lib.mi355_profile_enable(0))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    def prof(name):
+        ms, cnt = C.c_double(), C.c_uint64()
+        check(lib.mi355_profile_get(name.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    c_, w_, e_ = C.c_int(), C.c_int(), C.c_uint64()
+    check(lib.mi355_msm_last_plan(C.byref(c_), C.byref(w_), C.byref(e_)))
+    c, W = c_.value, w_.value
+    acc_ms, acc_cnt = prof("msm_accumulate")
+    phases = {p: prof(p)[0] / max(1, prof(p)[1]) for p in ("msm_digits", "msm_sort", "msm_accumulate", "msm_reduce", "msm_total")}
+
+    # ---- correctness of what was timed: commit(p) = p(tau) G checked in the field (rank-local shard, oracle = checker only)
+    verified = None
+    if rank == 0 and k <= 22 and world == 1:
+        from oracle import cref
+        sc_host = scalars.cpu().numpy().view(np.uint64)
+        p_tau = cref.eval_polynomial(sc_host, tau_m)
+        want = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), p_tau))
+        verified = bool((np.asarray(result)[:8] == want).all())
+
+    ms_per_step = dt / args.steps * 1e3
+    pairs_per_s = n_total * args.steps / dt
+    adds_per_msm = n_total * W + world * W * (1 << c)      # N*W bucket additions + 2 * 2^(c-1) running-sum additions per window (per shard)
+    value = adds_per_msm * args.steps / dt
+
+    # ---- secondary: NTT fwd + inv at 2^k on this rank (replica), device resident
+    ntt = None
+    if not args.no_ntt:
+        dom = h2.EvaluationDomain(2, k)
+        poly = rand_scalars(1 << k, 0x5343524F4C4C0003, dev)
+        orig = poly[:4096].clone()
+        check(lib.mi355_profile_reset()); check(lib.mi355_profile_enable(1))
+        dom.coeff_to_lagrange(poly); dom.lagrange_to_coeff(poly)  # warm-up + round trip check
+        torch.cuda.synchronize()
+        rt_ok = bool(torch.equal(poly[:4096], orig))
+        check(lib.mi355_profile_reset())
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        reps = max(1, args.steps)
+        for _ in range(reps):
+            dom.coeff_to_lagrange(poly); dom.lagrange_to_coeff(poly)
+        check(lib.mi355_synchronize()); torch.cuda.synchronize()
+        dt_ntt = (time.perf_counter() - t1) / (2 * reps)
+        check(lib.mi355_profile_enable(0))
+        pass_ms, pass_cnt = prof("ntt_pass")
+        bf = (1 << k) // 2 * k
+        ntt = {"log_n": k, "ms_per_transform": dt_ntt * 1e3, "butterflies_per_s": bf / dt_ntt, "roundtrip_ok": rt_ok,
+               "passes_per_transform": pass_cnt / (2 * reps),
+               "roofline": {"bound": "hbm", "achieved": 64.0 * (1 << k) / dt_ntt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": 64.0 * (1 << k) / dt_ntt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "note": "algorithmic bytes = 64*N per transform (SURVEY 8d); whole-transform time, all passes"}}
+        del poly
+
+    # ---- CPU baseline (rank 0, N = 1 only): the restated reference algorithm on a bounded sample of the same workload
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cref
+        cores = os.cpu_count() or 1
+        ks = min(k, 21)
+        ns = 1 << ks
+        sc_host = scalars[:ns].cpu().numpy().view(np.uint64)
+        g_host = g[: ns * 64].cpu().numpy().view(np.uint64).reshape(ns, 8)
+        t2 = time.perf_counter()
+        ref = cref.best_multiexp(sc_host, g_host, threads=cores)
+        dt_cpu = time.perf_counter() - t2
+        chunk = max(1, ns // cores)
+        c_cpu = int(np.ceil(np.log(chunk))) if chunk >= 32 else 3
+        seg = 256 // c_cpu + 1
+        adds_cpu = ns * seg + (ns // chunk) * seg * 2 * ((1 << c_cpu) - 1)
+        cpu = {"value": adds_cpu / dt_cpu, "unit": "G1-adds/s", "cores": cores, "kind": "port",
+               "sample": f"best_multiexp restatement (oracle/bn254_oracle.c, pthreads, c=ceil(ln(n/threads))={c_cpu}, {seg} segments) on the first 2^{ks} pairs of the same workload, {dt_cpu:.2f} s wall",
+               "pairs_per_s": ns / dt_cpu}
+        if ks == k:
+            verified = bool((np.asarray(result)[:8] == cref.g1_to_affine(ref)).all()) and (verified is not False)
+
+    if rank == 0:
+        acc_avg_ms = acc_ms / max(1, acc_cnt)
+        achieved = 96.0 * n / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"msm_accumulate_k{k}_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "BN254 MSM G1-adds/sec at k=%d" % k, "value": value, "unit": "G1-adds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32x8 (256-bit Montgomery integers, v_mad_u64_u32)", "data": "synthetic",
+            "config": {"workload": f"BN254 G1 Pippenger MSM, 2^{k} uniform random scalars x synthetic SRS points, inputs resident in HBM; "
+                                   f"point-range shards over {world} GPU(s), RCCL all-gather of 96-B partials",
+                       "log_n": k, "window_bits": c, "windows": W, "parallelism": f"point-range x{world}"},
+            "pairs_per_s": pairs_per_s, "g1_adds_per_msm": adds_per_msm, "verified_against_field_check": verified,
+            "msm_phase_ms": phases,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "kernel": "k_msm_accumulate", "avg_launch_ms": acc_avg_ms,
+                         "note": "algorithmic bytes = 96 B per (scalar, point) pair x pairs per launch (SURVEY 8d); the kernel is VALU-integer bound, see DESIGN.md"},
+            "cpu_baseline": cpu, "ntt": ntt,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

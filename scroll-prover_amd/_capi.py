@@ -103,4 +103,4 @@ def ptr(x) -> C.c_void_p:
     if hasattr(x, "data_ptr"):
         return C.c_void_p(x.data_ptr())
     assert x.flags["C_CONTIGUOUS"], "array must be C-contiguous"
-    return C.c_void_p(x.ctypes.data)
+    return x.ctypes.data_as(C.c_void_p)  # data_as keeps a reference to the array, so temporaries stay alive for the call
