@@ -112,6 +112,9 @@ int mi355_profile_reset(void);
 /* (c, windows, entries) chosen by the last MSM, for G1-adds accounting                                        */
 int mi355_msm_last_plan(int *c_out, int *windows_out, uint64_t *entries_out);
 
+/* test hook: copy `bytes` of the internal workspace buffer `role` (e.g. "msm.offsets", "msm.sorted") to the host   */
+int mi355_debug_ws_read(const char *role, uint64_t offset, void *dst_host, uint64_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

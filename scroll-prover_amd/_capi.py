@@ -41,6 +41,7 @@ SIGNATURES = {
     "mi355_profile_enable": (_int, [_int]),
     "mi355_profile_get": (_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "mi355_profile_reset": (_int, []),
+    "mi355_debug_ws_read": (_int, [C.c_char_p, _u64, _vp, _u64]),
     "mi355_msm_last_plan": (_int, [C.POINTER(_int), C.POINTER(_int), C.POINTER(_u64)]),
 }
 

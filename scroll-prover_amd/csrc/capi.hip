@@ -122,14 +122,30 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   while (chunk > 4 && (uint64_t)(P.nb / chunk) * P.windows < 16384) chunk >>= 1;
   const uint32_t chunks_per_window = P.nb / chunk, nchunks = chunks_per_window * P.windows;
 
-  int32_t *digits; uint32_t *hist, *offsets, *cursor, *sorted, *scan_sums; g1_xyzz_t *buckets, *part, *chunk_out, *window_sums; int32_t *part_id; g1_jac_t *out_dev;
-  CHK(ws_get("msm.digits", emax * 4, (void **)&digits));
+  // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest (<= 9)
+  SortPlan S; S.n = P.n; S.windows = P.windows; S.nb = P.nb;
+  { uint32_t kb = P.c - 1; uint32_t fb = kb < 10 ? kb : 10; if (kb - fb > 9) fb = kb - 9; S.fb = fb; S.cb_bits = kb - fb; }
+  S.regions = P.windows << S.cb_bits;
+  S.t1 = 16384;
+  { uint64_t t2 = emax / 8192; if (t2 < 4096) t2 = 4096; if (t2 > 65536) t2 = 65536; S.t2 = (uint32_t)t2; }
+  if (S.fb > 12 || (1u << S.cb_bits) > SORT_MAX_BINS) return fail(MI355_EBADARG, "msm: window bits out of range for the sorter");
+  const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions;
+
+  uint32_t *enc, *hist, *offsets, *cursor, *sorted, *scan_sums, *coarse_hist, *coarse_off, *coarse_cursor, *tile_start; uint64_t *pairs;
+  g1_xyzz_t *buckets, *part, *chunk_out, *window_sums; int32_t *part_id; g1_jac_t *out_dev;
+  CHK(ws_get("msm.digits", emax * 4, (void **)&enc));
+  CHK(ws_get("msm.pairs", emax * 8, (void **)&pairs));
   CHK(ws_get("msm.hist", ((size_t)nbuckets + 1) * 4, (void **)&hist));
   CHK(ws_get("msm.offsets", ((size_t)nbuckets + 1) * 4, (void **)&offsets));
   CHK(ws_get("msm.cursor", ((size_t)nbuckets + 1) * 4, (void **)&cursor));
+  CHK(ws_get("msm.coarse_hist", ((size_t)S.regions + 1) * 4, (void **)&coarse_hist));
+  CHK(ws_get("msm.coarse_off", ((size_t)S.regions + 1) * 4, (void **)&coarse_off));
+  CHK(ws_get("msm.coarse_cursor", ((size_t)S.regions + 1) * 4, (void **)&coarse_cursor));
+  CHK(ws_get("msm.tile_start", ((size_t)S.regions + 1) * 4, (void **)&tile_start));
   CHK(ws_get("msm.sorted", emax * 4, (void **)&sorted));
   const uint32_t scan_n = nbuckets + 1, scan_blocks = ceil_div(scan_n, SCAN_BLOCK * SCAN_ITEMS);
-  CHK(ws_get("msm.scan_sums", (size_t)scan_blocks * 4, (void **)&scan_sums));
+  const uint32_t cscan_n = S.regions + 1, cscan_blocks = ceil_div(cscan_n, SCAN_BLOCK * SCAN_ITEMS);
+  CHK(ws_get("msm.scan_sums", (size_t)(scan_blocks + cscan_blocks) * 4, (void **)&scan_sums));
   CHK(ws_get("msm.buckets", (size_t)nbuckets * sizeof(g1_xyzz_t), (void **)&buckets));
   CHK(ws_get("msm.part", (size_t)tn * 2 * sizeof(g1_xyzz_t), (void **)&part));
   CHK(ws_get("msm.part_id", (size_t)tn * 2 * 4, (void **)&part_id));
@@ -143,15 +159,23 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
     Scope total("msm_total");
     {
       Scope sc("msm_digits");
-      HIPCHK(hipMemsetAsync(hist, 0, ((size_t)nbuckets + 1) * 4, s));
-      hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream), dim3(256), 0, s, scalars, digits, hist, P);
+      hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream), dim3(256), 0, s, scalars, enc, P);
     }
     {
       Scope sc("msm_sort");
+      HIPCHK(hipMemsetAsync(coarse_hist, 0, ((size_t)S.regions + 1) * 4, s));
+      HIPCHK(hipMemsetAsync(hist, 0, ((size_t)nbuckets + 1) * 4, s));
+      hipLaunchKernelGGL(k_sort_l1_hist, dim3(tiles1 * P.windows), dim3(256), 0, s, enc, coarse_hist, S);
+      hipLaunchKernelGGL(k_scan_partial, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, cscan_n);
+      hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums + scan_blocks, cscan_blocks);
+      hipLaunchKernelGGL(k_scan_final, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, coarse_off, coarse_cursor, cscan_n);
+      hipLaunchKernelGGL(k_sort_l1_scatter, dim3(tiles1 * P.windows), dim3(256), 0, s, enc, coarse_cursor, pairs, S);
+      hipLaunchKernelGGL(k_sort_tile_prefix, dim3(1), dim3(SCAN_BLOCK), 0, s, coarse_off, tile_start, S);
+      hipLaunchKernelGGL(k_sort_l2_hist, dim3(l2_tiles_max), dim3(256), 0, s, pairs, coarse_off, tile_start, hist, S);
       hipLaunchKernelGGL(k_scan_partial, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, scan_n);
       hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums, scan_blocks);
       hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, offsets, cursor, scan_n);
-      hipLaunchKernelGGL(k_msm_scatter, dim3(grid_stream * 2), dim3(256), 0, s, digits, cursor, sorted, P);
+      hipLaunchKernelGGL(k_sort_l2_scatter, dim3(l2_tiles_max), dim3(256), 0, s, pairs, coarse_off, tile_start, cursor, sorted, S);
     }
     {
       Scope sc("msm_accumulate");
@@ -544,6 +568,17 @@ int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const voi
   hipLaunchKernelGGL(k_fixed_base_mul, dim3(ceil_div(n, 256)), dim3(256), 0, g.stream, g.fixed_base_table, sc + n, (g1_affine_t *)g_lagrange_dev, n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(g.stream));
+  return MI355_OK;
+}
+
+// ---- test hook: read back a workspace buffer ("msm.sorted", "msm.offsets", ...) after a call
+int mi355_debug_ws_read(const char *role, uint64_t offset, void *dst_host, uint64_t bytes) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  auto it = g.ws.find(role ? role : "");
+  if (it == g.ws.end() || !dst_host || offset + bytes > it->second.cap) return fail(MI355_EBADARG, "debug_ws_read: unknown role or range");
+  HIPCHK(hipStreamSynchronize(g.stream));
+  HIPCHK(hipMemcpy(dst_host, (const char *)it->second.p + offset, bytes, hipMemcpyDeviceToHost));
   return MI355_OK;
 }
 

@@ -43,8 +43,8 @@ __device__ __forceinline__ void store_xyzz(g1_xyzz_t *p, const g1_xyzz_t &v) {
   g_store(&p->x, v.x); g_store(&p->y, v.y); g_store(&p->zz, v.zz); g_store(&p->zzz, v.zzz);
 }
 
-// ---- 1. digits + histogram
-__global__ void __launch_bounds__(256) k_msm_digits(const fe_t *__restrict__ scalars, int32_t *__restrict__ digits, uint32_t *__restrict__ hist, MsmPlan P) {
+// ---- 1. digits.  Plane layout enc[w * n + i]: 0 for a zero digit, else |d| (1 .. 2^(c-1)) with bit 31 = sign.
+__global__ void __launch_bounds__(256) k_msm_digits(const fe_t *__restrict__ scalars, uint32_t *__restrict__ enc, MsmPlan P) {
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t half = 1u << (P.c - 1), mask = (1u << P.c) - 1;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
@@ -56,10 +56,9 @@ __global__ void __launch_bounds__(256) k_msm_digits(const fe_t *__restrict__ sca
       uint32_t raw = 0;
       if (word < 8) { raw = k.l[word] >> sh; if (sh + P.c > 32 && word + 1 < 8) raw |= k.l[word + 1] << (32 - sh); }
       raw = (raw & mask) + carry;
-      int32_t d;
-      if (raw > half) { d = (int32_t)raw - (int32_t)(1u << P.c); carry = 1; } else { d = (int32_t)raw; carry = 0; }
-      digits[(uint64_t)w * P.n + i] = d;
-      if (d != 0) atomicAdd(&hist[w * P.nb + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
+      uint32_t e;
+      if (raw > half) { e = (1u << P.c) - raw; if (e) e |= 0x80000000u; carry = 1; } else { e = raw; carry = 0; }   // raw == 2^c: digit 0, carry 1
+      enc[(uint64_t)w * P.n + i] = e;
     }
   }
 }
@@ -113,15 +112,104 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const uint32_t *__res
   for (uint32_t k = 0; k < SCAN_ITEMS; k++) if (base + k < n) { out_a[base + k] = ex; out_b[base + k] = ex; ex += v[k]; }
 }
 
-// ---- 3. scatter
-__global__ void __launch_bounds__(256) k_msm_scatter(const int32_t *__restrict__ digits, uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted, MsmPlan P) {
-  const uint64_t total = (uint64_t)P.n * P.windows, stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-    const int32_t d = digits[e];
-    if (d == 0) continue;
-    const uint32_t w = (uint32_t)(e / P.n), i = (uint32_t)(e - (uint64_t)w * P.n);
-    const uint32_t pos = atomicAdd(&cursor[w * P.nb + (uint32_t)(d < 0 ? -d : d) - 1], 1u);
-    sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+// ---- 3. two-level counting sort of the (window, bucket) keys, built for 19-22 bit keys and ~10^9 entries.
+// A global atomic per entry (histogram + cursor) costs ~120 ms at 2^26 x 13 windows; here every workgroup first
+// aggregates a tile in an LDS histogram and issues ONE global atomic per (tile, non-empty bin).
+//   level 1: tiles over the digit plane, bin = window * CB + (bucket >> fb)          (CB = 2^cb_bits coarse bins per window)
+//            -> pairs[] = (fine key << 32 | point index | sign), grouped by coarse region
+//   level 2: tiles inside each coarse region, bin = fine key (2^fb bins)             -> exact bucket offsets + sorted[]
+// Order inside a bucket is arbitrary (group addition commutes), so nothing needs to be stable.
+constexpr uint32_t SORT_MAX_BINS = 4096;
+struct SortPlan { uint32_t n, windows, nb, fb, cb_bits, t1, t2, regions; };
+
+__global__ void __launch_bounds__(256) k_sort_l1_hist(const uint32_t *__restrict__ enc, uint32_t *__restrict__ coarse_hist, SortPlan S) {
+  __shared__ uint32_t h[SORT_MAX_BINS];
+  const uint32_t CB = 1u << S.cb_bits, tiles1 = (S.n + S.t1 - 1) / S.t1;
+  const uint32_t w = blockIdx.x / tiles1, j = blockIdx.x - w * tiles1;
+  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  const uint32_t i0 = j * S.t1, i1 = min(S.n, i0 + S.t1);
+  const uint32_t *plane = enc + (uint64_t)w * S.n;
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) { const uint32_t e = plane[i]; if (e) atomicAdd(&h[((e & 0x7fffffffu) - 1) >> S.fb], 1u); }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) if (h[b]) atomicAdd(&coarse_hist[w * CB + b], h[b]);
+}
+__global__ void __launch_bounds__(256) k_sort_l1_scatter(const uint32_t *__restrict__ enc, uint32_t *__restrict__ coarse_cursor, uint64_t *__restrict__ pairs, SortPlan S) {
+  __shared__ uint32_t h[SORT_MAX_BINS];
+  __shared__ uint32_t base[SORT_MAX_BINS];
+  const uint32_t CB = 1u << S.cb_bits, tiles1 = (S.n + S.t1 - 1) / S.t1, fmask = (1u << S.fb) - 1;
+  const uint32_t w = blockIdx.x / tiles1, j = blockIdx.x - w * tiles1;
+  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  const uint32_t i0 = j * S.t1, i1 = min(S.n, i0 + S.t1);
+  const uint32_t *plane = enc + (uint64_t)w * S.n;
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) { const uint32_t e = plane[i]; if (e) atomicAdd(&h[((e & 0x7fffffffu) - 1) >> S.fb], 1u); }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) { const uint32_t cnt = h[b]; base[b] = cnt ? atomicAdd(&coarse_cursor[w * CB + b], cnt) : 0; h[b] = 0; }
+  __syncthreads();
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const uint32_t e = plane[i];
+    if (!e) continue;
+    const uint32_t bucket = (e & 0x7fffffffu) - 1, bin = bucket >> S.fb;
+    const uint32_t r = atomicAdd(&h[bin], 1u);
+    pairs[base[bin] + r] = ((uint64_t)(bucket & fmask) << 32) | (uint64_t)(i | (e & 0x80000000u));
+  }
+}
+// tile_start[r] = sum_{r' < r} ceil(size_r' / t2); one workgroup of SCAN_BLOCK threads, regions <= 8192
+__global__ void __launch_bounds__(SCAN_BLOCK) k_sort_tile_prefix(const uint32_t *__restrict__ coarse_off, uint32_t *__restrict__ tile_start, SortPlan S) {
+  __shared__ uint32_t lds[32];
+  __shared__ uint32_t running;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < S.regions; base += SCAN_BLOCK) {
+    const uint32_t r = base + threadIdx.x;
+    const uint32_t v = r < S.regions ? (coarse_off[r + 1] - coarse_off[r] + S.t2 - 1) / S.t2 : 0;
+    uint32_t total; const uint32_t ex = block_exclusive_scan(v, lds, total);
+    const uint32_t run = running;
+    if (r < S.regions) tile_start[r] = run + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) running = run + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tile_start[S.regions] = running;
+}
+__device__ __forceinline__ bool sort_l2_tile(const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start, const SortPlan &S, uint32_t &region, uint32_t &s, uint32_t &e) {
+  const uint32_t tile = blockIdx.x;
+  if (tile >= tile_start[S.regions]) return false;
+  uint32_t lo = 0, hi = S.regions;  // tile_start[lo] <= tile < tile_start[hi]
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tile_start[mid] <= tile) lo = mid; else hi = mid; }
+  region = lo;
+  s = coarse_off[lo] + (tile - tile_start[lo]) * S.t2;
+  e = min(coarse_off[lo + 1], s + S.t2);
+  return true;
+}
+__global__ void __launch_bounds__(256) k_sort_l2_hist(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ hist, SortPlan S) {
+  __shared__ uint32_t h[SORT_MAX_BINS];
+  uint32_t region, s, e;
+  if (!sort_l2_tile(coarse_off, tile_start, S, region, s, e)) return;
+  const uint32_t FB = 1u << S.fb;
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  for (uint32_t p = s + threadIdx.x; p < e; p += blockDim.x) atomicAdd(&h[(uint32_t)(pairs[p] >> 32)], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) if (h[b]) atomicAdd(&hist[(region << S.fb) + b], h[b]);
+}
+__global__ void __launch_bounds__(256) k_sort_l2_scatter(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted, SortPlan S) {
+  __shared__ uint32_t h[SORT_MAX_BINS];
+  __shared__ uint32_t base[SORT_MAX_BINS];
+  uint32_t region, s, e;
+  if (!sort_l2_tile(coarse_off, tile_start, S, region, s, e)) return;
+  const uint32_t FB = 1u << S.fb;
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  for (uint32_t p = s + threadIdx.x; p < e; p += blockDim.x) atomicAdd(&h[(uint32_t)(pairs[p] >> 32)], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) { const uint32_t cnt = h[b]; base[b] = cnt ? atomicAdd(&cursor[(region << S.fb) + b], cnt) : 0; h[b] = 0; }
+  __syncthreads();
+  for (uint32_t p = s + threadIdx.x; p < e; p += blockDim.x) {
+    const uint64_t pr = pairs[p];
+    const uint32_t fine = (uint32_t)(pr >> 32);
+    sorted[base[fine] + atomicAdd(&h[fine], 1u)] = (uint32_t)pr;
   }
 }
 
