@@ -98,17 +98,16 @@ def main() -> None:
     torch.cuda.synchronize()
 
     out = np.zeros(12, dtype=np.uint64)
-    gathered = torch.empty(world * 96, dtype=torch.uint8, device=dev) if world > 1 else None
-    part_dev = torch.empty(96, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def local_msm():
+        check(lib.mi355_msm_g1_dev(handle.value, 0, ptr(scalars), n, ptr(out)))
+        return out
 
     def step():
-        check(lib.mi355_msm_g1_dev(handle.value, 0, ptr(scalars), n, ptr(out)))
         if world == 1:
-            return out
-        part_dev.copy_(torch.from_numpy(out.view(np.uint8)), non_blocking=False)
-        dist.all_gather_into_tensor(gathered, part_dev)          # RCCL over xGMI: 96 B per rank
-        parts = gathered.cpu().numpy().view(np.uint64).reshape(world, 12)
-        return h2.g1_sum(parts)
+            return local_msm()
+        # RCCL over xGMI: one all_gather of 96 B per rank, then the fold on the device (scroll-prover_amd/distributed.py)
+        return zk.distributed.sharded_multiexp(local_msm, h2.g1_sum, dev)
 
     def barrier():
         if world > 1:

@@ -49,8 +49,11 @@ int mi355_init(int device_id);
 int mi355_shutdown(void);
 const char *mi355_last_error(void);
 const char *mi355_version(void);
-/* Launch all kernels on `hip_stream` (a hipStream_t, e.g. torch's current stream); NULL = the library's own.  */
+/* Launch all kernels on `hip_stream` (a hipStream_t, e.g. torch's current stream).  NULL selects the HIP null
+ * (legacy default) stream -- torch's default stream.  After mi355_init the library uses a private non-blocking
+ * stream; mi355_reset_stream() returns to it.                                                                 */
 int mi355_set_stream(void *hip_stream);
+int mi355_reset_stream(void);
 /* Block until everything queued by the library has finished.                                                  */
 int mi355_synchronize(void);
 

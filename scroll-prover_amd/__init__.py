@@ -13,3 +13,4 @@ but every compute call raises unless libmi355zk.so is present AND mi355_init() b
 from . import _capi  # noqa: F401
 from ._capi import Mi355Error, lib, init, shutdown  # noqa: F401
 from . import halo2  # noqa: F401
+from . import distributed  # noqa: F401

@@ -17,6 +17,7 @@ SIGNATURES = {
     "mi355_last_error": (C.c_char_p, []),
     "mi355_version": (C.c_char_p, []),
     "mi355_set_stream": (_int, [_vp]),
+    "mi355_reset_stream": (_int, []),
     "mi355_synchronize": (_int, []),
     "mi355_srs_register_host": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "mi355_srs_register_dev": (_int, [_vp, _u64, _int, C.POINTER(_u64)]),
@@ -87,6 +88,15 @@ def init(device_id: int = 0) -> None:
     global _initialised
     check(lib().mi355_init(device_id))
     _initialised = True
+    # device-resident operands come from torch: run the library on torch's current stream so that kernels are ordered
+    # with the tensor producers/consumers (the host-pointer ABI used by the Rust shim is synchronous and unaffected)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_device(device_id)
+            check(lib().mi355_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    except ImportError:  # pragma: no cover
+        pass
 
 
 def shutdown() -> None:

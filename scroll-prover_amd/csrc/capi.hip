@@ -344,7 +344,14 @@ int mi355_set_stream(void *hip_stream) {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   HIPCHK(hipStreamSynchronize(g.stream));
-  g.stream = hip_stream ? (hipStream_t)hip_stream : g.own_stream;
+  g.stream = (hipStream_t)hip_stream;   // NULL = the HIP null (legacy default) stream, which is torch's default stream
+  return MI355_OK;
+}
+int mi355_reset_stream(void) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  HIPCHK(hipStreamSynchronize(g.stream));
+  g.stream = g.own_stream;
   return MI355_OK;
 }
 int mi355_synchronize(void) { std::lock_guard<std::mutex> lk(g.mu); CHK(need_init()); HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans(); return MI355_OK; }

@@ -1,0 +1,43 @@
+"""
+distributed.py -- the multi-GPU leg of the MSM: one process per GPU, point-range shards, one tiny
+exchange.  best_multiexp on the CPU already splits the point range across threads and folds the partial sums with `+`
+[halo2_proofs arithmetic.rs, EXT-recalled]; here the threads are ranks, each owns bases[lo:hi] resident in its HBM, and
+the fold input is gathered with ONE all_gather of 96-byte partials (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  There is no elliptic-curve reduction op in RCCL, hence gather + local fold.
+
+Nothing here touches the data path: the compute callables are injected (the HIP path in production / bench.py, the CPU
+oracle in tests/test_multi_gpu_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, Tuple
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """point range [lo, hi) owned by `rank`: contiguous, sizes differ by at most one, covers [0, n) exactly."""
+    assert 0 <= rank < world and n >= 0
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allgather_partials(partial: np.ndarray, device=None) -> np.ndarray:
+    """every rank contributes one G1 (12 x u64 = 96 B); returns [world, 12] on every rank."""
+    import torch
+    import torch.distributed as dist
+    partial = np.ascontiguousarray(partial, dtype=np.uint64).reshape(12)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return partial.reshape(1, 12).copy()
+    world = dist.get_world_size()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    mine = torch.from_numpy(partial.view(np.uint8).copy()).to(dev)
+    out = torch.empty(world * 96, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, mine)
+    return out.cpu().numpy().view(np.uint64).reshape(world, 12).copy()
+
+
+def sharded_multiexp(local_msm: Callable[[], np.ndarray], fold: Callable[[np.ndarray], np.ndarray], device=None) -> np.ndarray:
+    """local_msm() -> this rank's partial sum over its own shard; fold([world,12]) -> their sum.  Same result on every rank."""
+    return fold(allgather_partials(local_msm(), device))

@@ -1,0 +1,50 @@
+"""CPU-only: the host side above the C-ABI (halo2 mirror constants, shard arithmetic) against the fixtures and the oracle."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from oracle import cref, pyref
+
+
+@pytest.fixture(scope="module")
+def zk():
+    return ge.load_package()
+
+
+@pytest.mark.parametrize("which,k", [("chunk_protocol", 25), ("batch_proof", 26)])
+def test_evaluation_domain_constants_match_reference_fixtures(zk, kat, which, k):
+    """EvaluationDomain::new derives omega from ROOT_OF_UNITY; the released protocol files store the same value (KAT A1/A2)."""
+    pr = kat[which] if which == "chunk_protocol" else kat[which]["protocol"]
+    dom = zk.halo2.EvaluationDomain(2, k)
+    assert dom.omega.tolist() == pr["domain"]["gen"]
+    assert dom.omega_inv.tolist() == pr["domain"]["gen_inv"]
+    assert dom.ifft_divisor.tolist() == pr["domain"]["n_inv"]
+
+
+def test_extended_domain_rule(zk):
+    h2 = zk.halo2
+    for j, k, want in [(2, 10, 10), (3, 10, 11), (4, 10, 12), (5, 10, 12), (6, 10, 13), (5, 26, 28)]:
+        dom = h2.EvaluationDomain(j, k)
+        assert dom.extended_k == want
+        assert pow(dom._extended_omega, 1 << dom.extended_k, h2.R_MOD) == 1 and pow(dom._extended_omega, 1 << (dom.extended_k - 1), h2.R_MOD) != 1
+        assert pow(dom._extended_omega, 1 << (dom.extended_k - k), h2.R_MOD) == dom._omega
+    with pytest.raises(AssertionError):
+        h2.EvaluationDomain(9, 26)      # would need 2^29 > two-adicity 28
+    assert (h2.fr(h2.FR_ZETA) == cref.fr_mont(pyref.FR_ZETA)).all()
+    for v in (0, 1, 7, h2.R_MOD - 1, 1 << 200):
+        assert (h2.fr(v) == cref.fr_mont(v)).all() and h2.fr_to_int(h2.fr(v)) == v % h2.R_MOD
+
+
+def test_shard_ranges(zk):
+    sr = zk.distributed.shard_range
+    for n in (0, 1, 7, 8, 1000, 1 << 26):
+        for world in (1, 2, 3, 4, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = sr(n, r, world)
+                assert 0 <= lo <= hi <= n
+                cover.append((lo, hi))
+            assert cover[0][0] == 0 and cover[-1][1] == n
+            assert all(cover[i][1] == cover[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in cover]
+            assert max(sizes) - min(sizes) <= 1
