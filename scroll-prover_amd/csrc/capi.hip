@@ -126,8 +126,9 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   SortPlan S; S.n = P.n; S.windows = P.windows; S.nb = P.nb;
   { uint32_t kb = P.c - 1; uint32_t fb = kb < 10 ? kb : 10; if (kb - fb > 9) fb = kb - 9; S.fb = fb; S.cb_bits = kb - fb; }
   S.regions = P.windows << S.cb_bits;
-  S.t1 = 16384;
-  { uint64_t t2 = emax / 8192; if (t2 < 4096) t2 = 4096; if (t2 > 65536) t2 = 65536; S.t2 = (uint32_t)t2; }
+  S.t1 = 16384;                               // level-1 tile: 1024 threads x 16 entries, staged in 128 KiB of LDS
+  const bool big_t2 = S.fb <= 10;             // level-2 tile: 32768 entries (128 KiB of indices) unless the fine table is large
+  S.t2 = big_t2 ? 32768 : 16384;
   if (S.fb > 12 || (1u << S.cb_bits) > SORT_MAX_BINS) return fail(MI355_EBADARG, "msm: window bits out of range for the sorter");
   const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions;
 
@@ -169,13 +170,20 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
       hipLaunchKernelGGL(k_scan_partial, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, cscan_n);
       hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums + scan_blocks, cscan_blocks);
       hipLaunchKernelGGL(k_scan_final, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, coarse_off, coarse_cursor, cscan_n);
-      hipLaunchKernelGGL(k_sort_l1_scatter, dim3(tiles1 * P.windows), dim3(256), 0, s, enc, coarse_cursor, pairs, S);
+      {
+        const uint32_t CBp = ((1u << S.cb_bits) + 1) & ~1u;
+        hipLaunchKernelGGL(k_sort_l1_scatter<16>, dim3(tiles1 * P.windows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
+      }
       hipLaunchKernelGGL(k_sort_tile_prefix, dim3(1), dim3(SCAN_BLOCK), 0, s, coarse_off, tile_start, S);
       hipLaunchKernelGGL(k_sort_l2_hist, dim3(l2_tiles_max), dim3(256), 0, s, pairs, coarse_off, tile_start, hist, S);
       hipLaunchKernelGGL(k_scan_partial, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, scan_n);
       hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums, scan_blocks);
       hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, offsets, cursor, scan_n);
-      hipLaunchKernelGGL(k_sort_l2_scatter, dim3(l2_tiles_max), dim3(256), 0, s, pairs, coarse_off, tile_start, cursor, sorted, S);
+      {
+        const size_t lds2 = (size_t)(3 * (1u << S.fb) + 32) * 4 + (size_t)S.t2 * 4;
+        if (big_t2) hipLaunchKernelGGL(k_sort_l2_scatter<32>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
+        else hipLaunchKernelGGL(k_sort_l2_scatter<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
+      }
     }
     {
       Scope sc("msm_accumulate");
@@ -320,6 +328,9 @@ int mi355_init(int device_id) {
   g.stream = g.own_stream; g.device = device_id;
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   g.inited = true;
   return MI355_OK;
 }

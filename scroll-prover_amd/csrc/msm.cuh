@@ -134,25 +134,50 @@ __global__ void __launch_bounds__(256) k_sort_l1_hist(const uint32_t *__restrict
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) if (h[b]) atomicAdd(&coarse_hist[w * CB + b], h[b]);
 }
-__global__ void __launch_bounds__(256) k_sort_l1_scatter(const uint32_t *__restrict__ enc, uint32_t *__restrict__ coarse_cursor, uint64_t *__restrict__ pairs, SortPlan S) {
-  __shared__ uint32_t h[SORT_MAX_BINS];
-  __shared__ uint32_t base[SORT_MAX_BINS];
-  const uint32_t CB = 1u << S.cb_bits, tiles1 = (S.n + S.t1 - 1) / S.t1, fmask = (1u << S.fb) - 1;
+// Per-tile bin bookkeeping shared by both scatter kernels (1024 threads): lstart[] = exclusive scan of the tile histogram,
+// gbase[] = start of this tile's run inside each global bin (ONE returning global atomic per non-empty bin).
+__device__ __forceinline__ uint32_t tile_bin_offsets(const uint32_t *h, uint32_t *lstart, uint32_t *gbase, uint32_t nbins, uint32_t *global_cursor, uint32_t *scratch32) {
+  const uint32_t bpt = (nbins + 1023) >> 10, b0 = threadIdx.x * bpt;   // bpt <= 4
+  uint32_t local[4], sum = 0;
+  for (uint32_t k = 0; k < 4; k++) { local[k] = (k < bpt && b0 + k < nbins) ? h[b0 + k] : 0; sum += local[k]; }
+  uint32_t total; uint32_t ex = block_exclusive_scan(sum, scratch32, total);
+  for (uint32_t k = 0; k < 4; k++) if (k < bpt && b0 + k < nbins) { lstart[b0 + k] = ex; gbase[b0 + k] = local[k] ? atomicAdd(&global_cursor[b0 + k], local[k]) : 0; ex += local[k]; }
+  return total;
+}
+// Level-1 scatter, LDS-staged: the tile is counting-sorted inside LDS first so that the global stores are coalesced runs
+// (the direct version wrote 8-byte records at random: 3.4x write amplification measured with WRITE_SIZE).
+// 1024 threads, tile = 1024 * EPT entries, dynamic LDS = 3 * CB * 4 + 128 + tile * 8 bytes.
+template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(const uint32_t *__restrict__ enc, uint32_t *__restrict__ coarse_cursor, uint64_t *__restrict__ pairs, SortPlan S) {
+  extern __shared__ uint32_t sm[];
+  const uint32_t CB = 1u << S.cb_bits, CBp = (CB + 1) & ~1u, fmask = (1u << S.fb) - 1;
+  uint32_t *h = sm, *lstart = sm + CBp, *gbase = sm + 2 * CBp, *scratch32 = sm + 3 * CBp;
+  uint64_t *stage = reinterpret_cast<uint64_t *>(sm + 3 * CBp + 32);
+  const uint32_t tiles1 = (S.n + S.t1 - 1) / S.t1;
   const uint32_t w = blockIdx.x / tiles1, j = blockIdx.x - w * tiles1;
-  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) h[b] = 0;
+  for (uint32_t b = threadIdx.x; b < CB; b += 1024) h[b] = 0;
   __syncthreads();
   const uint32_t i0 = j * S.t1, i1 = min(S.n, i0 + S.t1);
   const uint32_t *plane = enc + (uint64_t)w * S.n;
-  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) { const uint32_t e = plane[i]; if (e) atomicAdd(&h[((e & 0x7fffffffu) - 1) >> S.fb], 1u); }
+  uint32_t e[EPT], rank[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; k++) {
+    const uint32_t i = i0 + k * 1024 + threadIdx.x;
+    e[k] = i < i1 ? plane[i] : 0;
+    if (e[k]) rank[k] = atomicAdd(&h[((e[k] & 0x7fffffffu) - 1) >> S.fb], 1u);
+  }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) { const uint32_t cnt = h[b]; base[b] = cnt ? atomicAdd(&coarse_cursor[w * CB + b], cnt) : 0; h[b] = 0; }
+  const uint32_t total = tile_bin_offsets(h, lstart, gbase, CB, coarse_cursor + w * CB, scratch32);
   __syncthreads();
-  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-    const uint32_t e = plane[i];
-    if (!e) continue;
-    const uint32_t bucket = (e & 0x7fffffffu) - 1, bin = bucket >> S.fb;
-    const uint32_t r = atomicAdd(&h[bin], 1u);
-    pairs[base[bin] + r] = ((uint64_t)(bucket & fmask) << 32) | (uint64_t)(i | (e & 0x80000000u));
+#pragma unroll
+  for (int k = 0; k < EPT; k++) if (e[k]) {
+    const uint32_t bucket = (e[k] & 0x7fffffffu) - 1, i = i0 + k * 1024 + threadIdx.x;
+    stage[lstart[bucket >> S.fb] + rank[k]] = ((uint64_t)bucket << 32) | (uint64_t)(i | (e[k] & 0x80000000u));
+  }
+  __syncthreads();
+  for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
+    const uint64_t pr = stage[sidx];
+    const uint32_t bucket = (uint32_t)(pr >> 32), bin = bucket >> S.fb;
+    pairs[gbase[bin] + (sidx - lstart[bin])] = ((uint64_t)(bucket & fmask) << 32) | (uint64_t)(uint32_t)pr;
   }
 }
 // tile_start[r] = sum_{r' < r} ceil(size_r' / t2); one workgroup of SCAN_BLOCK threads, regions <= 8192
@@ -194,22 +219,33 @@ __global__ void __launch_bounds__(256) k_sort_l2_hist(const uint64_t *__restrict
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) if (h[b]) atomicAdd(&hist[(region << S.fb) + b], h[b]);
 }
-__global__ void __launch_bounds__(256) k_sort_l2_scatter(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted, SortPlan S) {
-  __shared__ uint32_t h[SORT_MAX_BINS];
-  __shared__ uint32_t base[SORT_MAX_BINS];
+// Level-2 scatter, LDS-staged (same idea): tile <= 1024 * EPT entries of one coarse region, 2^fb fine bins.
+// dynamic LDS = 3 * 2^fb * 4 + 128 + tile * 4 bytes.
+template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted, SortPlan S) {
+  extern __shared__ uint32_t sm[];
+  const uint32_t FB = 1u << S.fb;
+  uint32_t *h = sm, *lstart = sm + FB, *gbase = sm + 2 * FB, *scratch32 = sm + 3 * FB, *stage = sm + 3 * FB + 32;
   uint32_t region, s, e;
   if (!sort_l2_tile(coarse_off, tile_start, S, region, s, e)) return;
-  const uint32_t FB = 1u << S.fb;
-  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) h[b] = 0;
+  for (uint32_t b = threadIdx.x; b < FB; b += 1024) h[b] = 0;
   __syncthreads();
-  for (uint32_t p = s + threadIdx.x; p < e; p += blockDim.x) atomicAdd(&h[(uint32_t)(pairs[p] >> 32)], 1u);
+  uint32_t idx[EPT], fine[EPT], rank[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; k++) {
+    const uint32_t p = s + k * 1024 + threadIdx.x;
+    fine[k] = 0xffffffffu;
+    if (p < e) { const uint64_t pr = pairs[p]; idx[k] = (uint32_t)pr; fine[k] = (uint32_t)(pr >> 32); rank[k] = atomicAdd(&h[fine[k]], 1u); }
+  }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) { const uint32_t cnt = h[b]; base[b] = cnt ? atomicAdd(&cursor[(region << S.fb) + b], cnt) : 0; h[b] = 0; }
+  const uint32_t total = tile_bin_offsets(h, lstart, gbase, FB, cursor + (region << S.fb), scratch32);
   __syncthreads();
-  for (uint32_t p = s + threadIdx.x; p < e; p += blockDim.x) {
-    const uint64_t pr = pairs[p];
-    const uint32_t fine = (uint32_t)(pr >> 32);
-    sorted[base[fine] + atomicAdd(&h[fine], 1u)] = (uint32_t)pr;
+#pragma unroll
+  for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) stage[lstart[fine[k]] + rank[k]] = idx[k];
+  __syncthreads();
+  for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
+    uint32_t lo = 0, hi = FB;   // largest bin with lstart[bin] <= sidx
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lstart[mid] <= sidx) lo = mid; else hi = mid; }
+    sorted[gbase[lo] + (sidx - lstart[lo])] = stage[sidx];
   }
 }
 
