@@ -133,7 +133,7 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions;
 
   uint32_t *enc, *hist, *offsets, *cursor, *sorted, *scan_sums, *coarse_hist, *coarse_off, *coarse_cursor, *tile_start; uint64_t *pairs;
-  g1_xyzz_t *buckets, *part, *chunk_out, *window_sums; int32_t *part_id; g1_jac_t *out_dev;
+  g1_xyzz29_t *buckets, *part; g1_xyzz_t *chunk_out, *window_sums; int32_t *part_id; g1_jac_t *out_dev;
   CHK(ws_get("msm.digits", emax * 4, (void **)&enc));
   CHK(ws_get("msm.pairs", emax * 8, (void **)&pairs));
   CHK(ws_get("msm.hist", ((size_t)nbuckets + 1) * 4, (void **)&hist));
@@ -147,9 +147,12 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   const uint32_t scan_n = nbuckets + 1, scan_blocks = ceil_div(scan_n, SCAN_BLOCK * SCAN_ITEMS);
   const uint32_t cscan_n = S.regions + 1, cscan_blocks = ceil_div(cscan_n, SCAN_BLOCK * SCAN_ITEMS);
   CHK(ws_get("msm.scan_sums", (size_t)(scan_blocks + cscan_blocks) * 4, (void **)&scan_sums));
-  CHK(ws_get("msm.buckets", (size_t)nbuckets * sizeof(g1_xyzz_t), (void **)&buckets));
-  CHK(ws_get("msm.part", (size_t)tn * 2 * sizeof(g1_xyzz_t), (void **)&part));
+  CHK(ws_get("msm.buckets", (size_t)nbuckets * sizeof(g1_xyzz29_t), (void **)&buckets));
+  CHK(ws_get("msm.part", (size_t)tn * 2 * sizeof(g1_xyzz29_t), (void **)&part));
   CHK(ws_get("msm.part_id", (size_t)tn * 2 * 4, (void **)&part_id));
+  const uint32_t big_cap = tn / FIXUP_SERIAL_MAX + 2;
+  uint32_t *big_list; CHK(ws_get("msm.big_list", ((size_t)big_cap * 3 + 1) * 4, (void **)&big_list));
+  uint32_t *big_count = big_list + (size_t)big_cap * 3;
   CHK(ws_get("msm.chunk_out", (size_t)nchunks * sizeof(g1_xyzz_t), (void **)&chunk_out));
   CHK(ws_get("msm.window_sums", (size_t)P.windows * sizeof(g1_xyzz_t), (void **)&window_sums));
   CHK(ws_get("msm.out", sizeof(g1_jac_t), (void **)&out_dev));
@@ -187,12 +190,14 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
     }
     {
       Scope sc("msm_accumulate");
-      HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz_t), s));
+      HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
       hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg);
     }
     {
       Scope sc("msm_reduce");
-      hipLaunchKernelGGL(k_msm_fixup, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg);
+      HIPCHK(hipMemsetAsync(big_count, 0, 4, s));
+      hipLaunchKernelGGL(k_msm_fixup, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap);
+      hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
       hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, P, chunk);
       hipLaunchKernelGGL(k_msm_window_reduce, dim3(P.windows), dim3(256), 0, s, chunk_out, window_sums, chunks_per_window);
       hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, window_sums, P.windows, P.c, out_dev);

@@ -20,6 +20,7 @@
 // (~11 field multiplications x ~300 instructions per mixed addition), see DESIGN.md.
 #pragma once
 #include "fp_asm.cuh"
+#include "g1_29.cuh"
 
 namespace zk {
 
@@ -41,6 +42,23 @@ __device__ __forceinline__ g1_xyzz_t load_xyzz(const g1_xyzz_t *p) {
 }
 __device__ __forceinline__ void store_xyzz(g1_xyzz_t *p, const g1_xyzz_t &v) {
   g_store(&p->x, v.x); g_store(&p->y, v.y); g_store(&p->zz, v.zz); g_store(&p->zzz, v.zzz);
+}
+
+// raw 29-bit accumulator records (144 B = 9 x 16 B): what k_msm_accumulate flushes without any arithmetic
+__device__ __forceinline__ void store_xyzz29(g1_xyzz29_t *p, const g1_xyzz29_t &v) {
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(&v); uint4 *q = reinterpret_cast<uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ g1_xyzz_t load_xyzz29_as_sat(const g1_xyzz29_t *p) {
+  g1_xyzz29_t v; uint32_t *w = reinterpret_cast<uint32_t *>(&v); const uint4 *q = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { const uint4 a = q[i]; w[4 * i] = a.x; w[4 * i + 1] = a.y; w[4 * i + 2] = a.z; w[4 * i + 3] = a.w; }
+  return g1_xyzz29_to_sat(v);
+}
+__device__ __forceinline__ void store_sat_as_xyzz29(g1_xyzz29_t *p, const g1_xyzz_t &v) {
+  g1_xyzz29_t r; r.x = Fq29::from_sat(v.x); r.y = Fq29::from_sat(v.y); r.zz = Fq29::from_sat(v.zz); r.zzz = Fq29::from_sat(v.zzz);
+  store_xyzz29(p, r);
 }
 
 // ---- 1. digits.  Plane layout enc[w * n + i]: 0 for a zero digit, else |d| (1 .. 2^(c-1)) with bit 31 = sign.
@@ -253,65 +271,97 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
 // offsets[b] .. offsets[b+1] = entries of global bucket b (b = w * nb + bucket); offsets has nbuckets+1 entries.
 // bucket_sums must be zero-filled (all-zero XYZZ = identity) before launch.
 __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
-                                                        uint32_t nbuckets, g1_xyzz_t *__restrict__ bucket_sums, g1_xyzz_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg) {
+                                                        uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg) {
   const uint32_t total = offsets[nbuckets];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t start64 = (uint64_t)t * seg;
-  if (start64 >= total) { if (start64 < (uint64_t)total + seg || true) { part_id[2 * t] = -1; part_id[2 * t + 1] = -1; } return; }
+  if (start64 >= total) { part_id[2 * t] = -1; part_id[2 * t + 1] = -1; return; }
   const uint32_t start = (uint32_t)start64, end = (uint32_t)min((uint64_t)total, start64 + seg);
   // largest b with offsets[b] <= start  (then offsets[b+1] > start: the bucket that contains `start`)
   uint32_t lo = 0, hi = nbuckets;  // invariant offsets[lo] <= start < offsets[hi]
   while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (offsets[mid] <= start) lo = mid; else hi = mid; }
   uint32_t b = lo, b_end = offsets[b + 1];
   int32_t id_first = -1, id_last = -1;
-  g1_xyzz_t acc = g1_xyzz_identity();
+  // the accumulator lives in the 9 x 29-bit unsaturated field (g1_29.cuh): one v_mad_u64_u32 per limb product, no carry chain;
+  // it is converted to the saturated XYZZ record only when a bucket is flushed
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  // software pipeline: the gather of entry pos+1 (index, then 64-byte base) is issued before the ~10 field multiplications
+  // of entry pos, so the ~2 us random-access latency overlaps arithmetic instead of stalling one of only 4 waves per SIMD
+  uint32_t ent = sorted[start];
+  g1_affine_t p = load_affine(&bases[ent & 0x7fffffffu]);
   for (uint32_t pos = start; pos < end; pos++) {
+    uint32_t ent_next = 0; g1_affine_t p_next = p;
+    if (pos + 1 < end) { ent_next = sorted[pos + 1]; p_next = load_affine(&bases[ent_next & 0x7fffffffu]); }
     if (pos >= b_end) {
       // leave bucket b: it ends inside this thread's range
-      if (offsets[b] >= start) store_xyzz(&bucket_sums[b], acc);                        // began here too: sole owner
-      else { store_xyzz(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }          // began in an earlier thread
-      acc = g1_xyzz_identity();
+      if (offsets[b] >= start) store_xyzz29(&bucket_sums[b], acc);                        // began here too: sole owner
+      else { store_xyzz29(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }          // began in an earlier thread
+      acc = g1_xyzz29_identity();
       do { b++; b_end = offsets[b + 1]; } while (pos >= b_end);
     }
-    const uint32_t ent = sorted[pos];
-    g1_affine_t p = load_affine(&bases[ent & 0x7fffffffu]);
-    if (ent >> 31) p.y = Fq::neg(p.y);
-    g1_xyzz_madd_ps(acc, p);
+    g1_xyzz29_madd(acc, p, (ent >> 31) != 0);
+    ent = ent_next; p = p_next;
   }
   // bucket b is still open at `end`
-  if (offsets[b] >= start && b_end <= end) store_xyzz(&bucket_sums[b], acc);
-  else if (offsets[b] < start) { store_xyzz(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }   // spans the whole segment or just its head
-  else { store_xyzz(&part[2 * (uint64_t)t + 1], acc); id_last = (int32_t)b; }                        // began here, continues in the next thread
+  if (offsets[b] >= start && b_end <= end) store_xyzz29(&bucket_sums[b], acc);
+  else if (offsets[b] < start) { store_xyzz29(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }   // spans the whole segment or just its head
+  else { store_xyzz29(&part[2 * (uint64_t)t + 1], acc); id_last = (int32_t)b; }                        // began here, continues in the next thread
   part_id[2 * t] = id_first; part_id[2 * t + 1] = id_last;
 }
 
-// ---- 5. fix-up of buckets that straddle thread boundaries
-__global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz_t *__restrict__ bucket_sums,
-                                                   const g1_xyzz_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg) {
+// ---- 5. fix-up of buckets that straddle thread boundaries.  Small spans are summed by one lane; a bucket that spans more than
+//         FIXUP_SERIAL_MAX accumulate-threads (skewed scalars: zeros/ones/small values, or the short top window) is queued and
+//         reduced by a whole workgroup (wavefront-shuffle tree + LDS) in k_msm_fixup_big.
+__device__ __forceinline__ fe_t shfl_down_fe(const fe_t &v, uint32_t o) { fe_t r; for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], o); return r; }
+__device__ __forceinline__ g1_xyzz_t shfl_down_xyzz(const g1_xyzz_t &v, uint32_t o) {
+  g1_xyzz_t r; r.x = shfl_down_fe(v.x, o); r.y = shfl_down_fe(v.y, o); r.zz = shfl_down_fe(v.zz, o); r.zzz = shfl_down_fe(v.zzz, o); return r;
+}
+constexpr uint32_t FIXUP_SERIAL_MAX = 32;
+__device__ __forceinline__ void fixup_take(g1_xyzz_t &acc, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t t, uint32_t b) {
+  if (part_id[2 * t] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz29_as_sat(&part[2 * (uint64_t)t]));
+  else if (part_id[2 * t + 1] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz29_as_sat(&part[2 * (uint64_t)t + 1]));
+}
+__global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
+                                                   const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg,
+                                                   uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   const uint32_t s = offsets[b], e = offsets[b + 1];
   if (e == s) return;
   const uint32_t t0 = s / seg, t1 = (e - 1) / seg;
   if (t0 == t1) return;  // sole owner wrote it
-  g1_xyzz_t acc = g1_xyzz_identity();
-  for (uint32_t t = t0; t <= t1; t++) {
-    if (part_id[2 * t] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz(&part[2 * (uint64_t)t]));
-    else if (part_id[2 * t + 1] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz(&part[2 * (uint64_t)t + 1]));
+  if (t1 - t0 > FIXUP_SERIAL_MAX) {
+    const uint32_t idx = atomicAdd(big_count, 1u);
+    if (idx < big_cap) { big_list[3 * idx] = b; big_list[3 * idx + 1] = t0; big_list[3 * idx + 2] = t1; }
+    return;
   }
-  store_xyzz(&bucket_sums[b], acc);
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (uint32_t t = t0; t <= t1; t++) fixup_take(acc, part, part_id, t, b);
+  store_sat_as_xyzz29(&bucket_sums[b], acc);
+}
+__global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyzz29_t *__restrict__ bucket_sums, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id,
+                                                       const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count) {
+  __shared__ g1_xyzz_t lds[4];
+  if (blockIdx.x >= *big_count) return;
+  const uint32_t b = big_list[3 * blockIdx.x], t0 = big_list[3 * blockIdx.x + 1], t1 = big_list[3 * blockIdx.x + 2];
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) fixup_take(acc, part, part_id, t, b);
+  for (uint32_t o = 32; o >= 1; o >>= 1) { g1_xyzz_t other = shfl_down_xyzz(acc, o); g1_xyzz_add_ps(acc, other); }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz_add_ps(acc, lds[k]); store_sat_as_xyzz29(&bucket_sums[b], acc); }
 }
 
 // ---- 6a. chunked running sums: thread j of window w covers buckets [j*K, (j+1)*K) and emits
 //          T + (j*K) * S  where S = sum B_i, T = sum (i_local + 1) B_i
-__global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz_t *__restrict__ bucket_sums, g1_xyzz_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {
+__global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {
   const uint32_t chunks_per_window = P.nb / chunk;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= chunks_per_window * P.windows) return;
   const uint32_t w = g / chunks_per_window, j = g - w * chunks_per_window;
-  const g1_xyzz_t *B = bucket_sums + (uint64_t)w * P.nb + (uint64_t)j * chunk;
+  const g1_xyzz29_t *B = bucket_sums + (uint64_t)w * P.nb + (uint64_t)j * chunk;
   g1_xyzz_t run = g1_xyzz_identity(), T = g1_xyzz_identity();
-  for (uint32_t i = chunk; i-- > 0;) { g1_xyzz_add_ps(run, load_xyzz(&B[i])); g1_xyzz_add_ps(T, run); }
+  for (uint32_t i = chunk; i-- > 0;) { g1_xyzz_add_ps(run, load_xyzz29_as_sat(&B[i])); g1_xyzz_add_ps(T, run); }
   if (j != 0) {
     const uint32_t k = j * chunk;
     g1_xyzz_t kS = g1_xyzz_identity();
@@ -321,10 +371,6 @@ __global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz_t *__re
   store_xyzz(&chunk_out[g], T);
 }
 // ---- 6b. per window: tree-sum of the chunk results (wavefront shuffles, then LDS across waves)
-__device__ __forceinline__ fe_t shfl_down_fe(const fe_t &v, uint32_t o) { fe_t r; for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], o); return r; }
-__device__ __forceinline__ g1_xyzz_t shfl_down_xyzz(const g1_xyzz_t &v, uint32_t o) {
-  g1_xyzz_t r; r.x = shfl_down_fe(v.x, o); r.y = shfl_down_fe(v.y, o); r.zz = shfl_down_fe(v.zz, o); r.zzz = shfl_down_fe(v.zzz, o); return r;
-}
 __global__ void __launch_bounds__(256) k_msm_window_reduce(const g1_xyzz_t *__restrict__ chunk_out, g1_xyzz_t *__restrict__ window_sums, uint32_t chunks_per_window) {
   __shared__ g1_xyzz_t lds[4];
   const uint32_t w = blockIdx.x;

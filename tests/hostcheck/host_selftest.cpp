@@ -4,6 +4,8 @@
 // never linked into libmi355zk.so.
 #include "../../scroll-prover_amd/csrc/g1.cuh"
 #include "../../scroll-prover_amd/csrc/fp_asm.cuh"
+#include "../../scroll-prover_amd/csrc/fp29.cuh"
+#include "../../scroll-prover_amd/csrc/g1_29.cuh"
 #include <string.h>
 using namespace zk;
 
@@ -41,3 +43,42 @@ extern "C" void hs_jac_to_xyzz(void *out, const void *p) { *(g1_xyzz_t *)out = g
 extern "C" void hs_xyzz_mul_small(void *out, const void *p, uint32_t k) { *(g1_xyzz_t *)out = g1_xyzz_mul_small(*(const g1_xyzz_t *)p, k); }
 extern "C" void hs_xyzz_madd_ps(void *acc_xyzz, const void *affine) { g1_xyzz_madd_ps(*(g1_xyzz_t *)acc_xyzz, *(const g1_affine_t *)affine); }
 extern "C" void hs_xyzz_add_ps(void *acc_xyzz, const void *q) { g1_xyzz_add_ps(*(g1_xyzz_t *)acc_xyzz, *(const g1_xyzz_t *)q); }
+
+// ---- 29-bit unsaturated arithmetic (fp29.cuh): every op takes/returns saturated ABI elements so the test can use the oracle
+template <class F29> static void op29(int op, fe_t *o, const fe_t *a, const fe_t *b) {
+  fe29_t x = F29::from_sat(*a), y = F29::from_sat(*b), r;
+  switch (op) {
+    case 0: r = F29::mul(x, y); break;                                  // a*b
+    case 1: r = F29::sqr(x); break;                                     // a^2
+    case 2: r = F29::mul(F29::add(x, y), y); break;                     // (a+b)*b   loose operand
+    case 3: r = F29::sub4(x, F29::mul(y, F29::one())); break;           // a - b     (b made tight first)
+    case 4: r = F29::sub8(F29::mul(x, F29::one()), F29::dbl(F29::mul(y, F29::one()))); break;   // a - 2b
+    case 5: r = F29::sub16(x, F29::sub8(F29::mul(y, F29::one()), F29::dbl(F29::mul(x, F29::one())))); break;  // a - (b - 2a) = 3a - b
+    case 6: { fe29_t xt = F29::mul(x, F29::one()), yt = F29::mul(y, F29::one()); r = F29::sqr(F29::sub16(xt, F29::sub4(yt, xt))); } break;  // (2a - b)^2, chained lazy values (from_sat output is < 2^259 and may only feed mul or the minuend)
+    default: r = x;
+  }
+  *o = F29::to_sat(r);
+}
+extern "C" void hs_f29_op(int which, int op, void *o, const void *a, const void *b) {
+  if (which) op29<Fr29>(op, (fe_t *)o, (const fe_t *)a, (const fe_t *)b); else op29<Fq29>(op, (fe_t *)o, (const fe_t *)a, (const fe_t *)b);
+}
+extern "C" int hs_f29_is_zero(int which, const void *a, const void *b) {   // is (a - b) == 0 through the tight zero test
+  const fe_t *x = (const fe_t *)a, *y = (const fe_t *)b;
+  if (which) { fe29_t d = Fr29::sub4(Fr29::from_sat(*x), Fr29::mul(Fr29::from_sat(*y), Fr29::one())); return Fr29::is_zero_tight(Fr29::mul(d, Fr29::one())); }
+  fe29_t d = Fq29::sub4(Fq29::from_sat(*x), Fq29::mul(Fq29::from_sat(*y), Fq29::one())); return Fq29::is_zero_tight(Fq29::mul(d, Fq29::one()));
+}
+
+// bucket-style accumulation with the 29-bit accumulator: out = sum_i (+-) pts[i] (sign bit = bit 0 of signs[i]), flushed to the saturated XYZZ record
+extern "C" void hs_bucket_sum29(void *out_xyzz, const void *pts, const uint8_t *signs, uint64_t n) {
+  const g1_affine_t *p = (const g1_affine_t *)pts;
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  for (uint64_t i = 0; i < n; i++) g1_xyzz29_madd(acc, p[i], signs[i] & 1);
+  *(g1_xyzz_t *)out_xyzz = g1_xyzz29_to_sat(acc);
+}
+
+// reduce_small on k*p + delta inputs given as plain 9-limb integers (limbs < 2^29): returns 1 when the result is tight, < 2p and congruent
+extern "C" void hs_f29_reduce_small(int which, uint32_t *out9, const uint32_t *in9) {
+  fe29_t v; for (int i = 0; i < 9; i++) v.l[i] = in9[i];
+  fe29_t r = which ? Fr29::reduce_small(v) : Fq29::reduce_small(v);
+  for (int i = 0; i < 9; i++) out9[i] = r.l[i];
+}

@@ -104,3 +104,76 @@ def test_xyzz_special_cases(hs):
     # Jacobian (non-normalised) -> XYZZ
     j = cref.g1_mul(_pt(G), cref.fr_mont(777)); x = np.zeros(16, dtype=np.uint64)
     hs.hs_jac_to_xyzz(p_(x), p_(j)); assert aff(x) == pyref.g1_mul(G, 777)
+
+
+def test_unsaturated_29bit_arithmetic(hs):
+    """fp29.cuh (9 x 29-bit limbs, R' = 2^261): conversions from/to the ABI form, lazy add/sub chains, mul/sqr, zero test."""
+    rng = random.Random(29)
+    for w, m in ((cref.FQ, P), (cref.FR, R)):
+        edge = [0, 1, 2, m - 1, m - 2, (1 << 253) % m, (1 << 29) - 1, 1 << 29, (1 << 232), (1 << 232) - 1]
+        vals = edge + [rng.randrange(m) for _ in range(200)]
+        mont = cref.f_from_canonical_vec(w, np.array([pyref.to_limbs(v) for v in vals], dtype=np.uint64))
+
+        def o29(op, a, b):
+            out = np.zeros(4, dtype=np.uint64); hs.hs_f29_op(w, op, p_(out), p_(np.ascontiguousarray(a)), p_(np.ascontiguousarray(b))); return out
+
+        for i in range(len(vals)):
+            a, b = mont[i], mont[(i * 5 + 1) % len(vals)]
+            va, vb = vals[i], vals[(i * 5 + 1) % len(vals)]
+            c = lambda x: cref.limbs_to_int(cref.f_to_canonical_vec(w, x[None])[0])
+            assert (o29(0, a, b) == cref.f_mul(w, a, b)).all()
+            assert (o29(1, a, b) == cref.f_mul(w, a, a)).all()
+            assert c(o29(2, a, b)) == (va + vb) * vb % m
+            assert c(o29(3, a, b)) == (va - vb) % m
+            assert c(o29(4, a, b)) == (va - 2 * vb) % m
+            assert c(o29(5, a, b)) == (3 * va - vb) % m
+            assert c(o29(6, a, b)) == (2 * va - vb) ** 2 % m
+            assert o29(7, a, b).tolist() == a.tolist()          # from_sat / to_sat round trip
+            assert bool(hs.hs_f29_is_zero(w, p_(np.ascontiguousarray(a)), p_(np.ascontiguousarray(a)))) is True
+            assert bool(hs.hs_f29_is_zero(w, p_(np.ascontiguousarray(a)), p_(np.ascontiguousarray(b)))) is (va == vb)
+
+
+def test_xyzz29_bucket_accumulator(hs):
+    """g1_29.cuh: long chains of mixed additions with lazy values, negation, identity bases, P+P and P+(-P) inside a bucket."""
+    rng = random.Random(31)
+    G = pyref.G1_GEN
+    pool = [pyref.g1_mul(G, rng.randrange(1, R)) for _ in range(12)]
+
+    def run(seq):  # seq of (point or None, sign)
+        pts = np.stack([_pt(p) if p is not None else np.zeros(8, dtype=np.uint64) for p, _ in seq])
+        signs = (C.c_uint8 * len(seq))(*[s for _, s in seq])
+        out = np.zeros(16, dtype=np.uint64)
+        hs.hs_bucket_sum29(p_(out), p_(pts), signs, C.c_uint64(len(seq)))
+        jac = np.zeros(12, dtype=np.uint64); hs.hs_xyzz_to_jac(p_(jac), p_(out))
+        got = pyref.g1_jacobian_from_limbs(jac[:4], jac[4:8], jac[8:])
+        want = None
+        for p, s in seq:
+            want = pyref.g1_add(want, pyref.g1_neg(p) if s else p)
+        assert got == want, seq
+
+    for trial in range(30):
+        n = rng.randrange(1, 40)
+        run([(rng.choice(pool), rng.randrange(2)) for _ in range(n)])
+    A, B = pool[0], pool[1]
+    run([(A, 0), (A, 0)])                          # doubling branch
+    run([(A, 1), (A, 1), (B, 0)])                  # doubling of a negated point, then a normal add
+    run([(A, 0), (A, 1)])                          # annihilation
+    run([(A, 0), (A, 1), (B, 1), (None, 0), (B, 1)])   # identity -> re-init -> identity base -> doubling
+    run([(A, 0), (B, 0), (pyref.g1_add(A, B), 1)])  # sum hits the negative of the accumulator
+    run([(A, 0), (B, 0), (pyref.g1_add(A, B), 0)])  # sum equals the accumulator: doubling with non-trivial ZZ
+    run([(None, 0), (None, 1)])
+    run([(A, 0)] * 64)                              # 64 P by repeated additions (one doubling, then ordinary adds)
+
+
+def test_reduce_small_boundaries(hs):
+    """quotient estimate of Fp29::reduce_small: exact multiples of p, one below/above, and random values below 64p."""
+    rng = random.Random(64)
+    M = (1 << 29) - 1
+    for w, m in ((0, P), (1, R)):
+        vals = [k * m + d for k in range(64) for d in (0, 1, m - 1, m // 2) if k * m + d < 64 * m] + [rng.randrange(64 * m) for _ in range(3000)]
+        for v in vals:
+            inp = (C.c_uint32 * 9)(*[(v >> (29 * i)) & M if i < 8 else v >> 232 for i in range(9)])
+            out = (C.c_uint32 * 9)()
+            hs.hs_f29_reduce_small(w, out, inp)
+            got = sum(int(out[i]) << (29 * i) for i in range(9))
+            assert got % m == v % m and got < 2 * m and all(out[i] <= M for i in range(8)), (w, v // m)

@@ -8,6 +8,7 @@
 #include <vector>
 #include "../scroll-prover_amd/csrc/g1.cuh"
 #include "../scroll-prover_amd/csrc/fp_asm.cuh"
+#include "../scroll-prover_amd/csrc/fp29.cuh"
 using namespace zk;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -75,6 +76,16 @@ template <int VARIANT> __global__ void k_fqmul(fe_t *io) {
   }
   io[2 * t] = a; io[2 * t + 1] = b;
 }
+template <int VARIANT> __global__ void k_fq29mul(fe_t *io) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  fe29_t a = Fq29::from_sat(io[2 * t]), b = Fq29::from_sat(io[2 * t + 1]);
+  for (int i = 0; i < MULS; i += 2) {
+    if (VARIANT == 0) { a = Fq29::mul(a, b); b = Fq29::mul(b, a); }
+    if (VARIANT == 1) { a = Fq29::sqr(a); a = Fq29::mul(a, b); }
+    if (VARIANT == 2) { a = Fq29::mul(Fq29::sub4(a, b), b); b = Fq29::mul(Fq29::add(b, a), a); }   // with lazy add/sub in the chain
+  }
+  io[2 * t] = Fq29::to_sat(a); io[2 * t + 1] = Fq29::to_sat(b);
+}
 // XYZZ mixed-add chain: the real MSM inner loop without memory traffic
 template <int VARIANT> __global__ void k_madd(g1_xyzz_t *accs, const g1_affine_t *pts, int npts, int iters) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,6 +142,17 @@ int main() {
   { float ms = time_kernel([&] { hipLaunchKernelGGL(k_fqmul<V>, dim3(blocks), dim3(threads), 0, 0, d2); });                                \
     double muls = lanes * MULS; printf("%-24s %8.3f ms  %8.2f G fieldmul/s  ~%6.0f cyc/wave-mul/SIMD @2.4GHz\n", name, ms, muls / ms * 1e-6, ms * 1e-3 * ghz * 1e9 * simds / (muls / 64.0)); }
   RUN_MUL(0, "Fq::mul (C++ CIOS)") RUN_MUL(1, "fq_mul_ps (asm FIPS)") RUN_MUL(2, "fq_sqr_ps+mul_ps")
+#define RUN_MUL29(V, name)                                                                                                              \
+  { float ms = time_kernel([&] { hipLaunchKernelGGL(k_fq29mul<V>, dim3(blocks), dim3(threads), 0, 0, d2); });                              \
+    double muls = lanes * MULS; printf("%-24s %8.3f ms  %8.2f G fieldmul/s  ~%6.0f cyc/wave-mul/SIMD @2.4GHz\n", name, ms, muls / ms * 1e-6, ms * 1e-3 * ghz * 1e9 * simds / (muls / 64.0)); }
+  {
+    CK(hipMemcpy(d1, h.data(), nfe * 32, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fq29mul<0>, dim3(blocks), dim3(threads), 0, 0, d1); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(r1.data(), d1, nfe * 32, hipMemcpyDeviceToHost));
+    size_t bad29 = 0; for (size_t i = 0; i < nfe; i++) if (memcmp(&r0[i], &r1[i], 32)) bad29++;
+    printf("Fq29::mul chain vs Fq::mul chain mismatches (inputs must be < p for equality; random inputs here are < 2^253): %zu of %zu\n", bad29, nfe);
+  }
+  RUN_MUL29(0, "Fq29::mul (9x29)") RUN_MUL29(1, "Fq29 sqr+mul") RUN_MUL29(2, "Fq29 mul + lazy add/sub")
   // occupancy sensitivity: fewer blocks
   for (int bpc : {1, 2, 4}) {
     int b2 = prop.multiProcessorCount * bpc;
