@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355zk.so")
 SOURCES = ["capi.hip"]
-HEADERS = ["fp.cuh", "fp_asm.cuh", "fp_asm_gen.inc", "g1.cuh", "msm.cuh", "ntt.cuh", os.path.join("..", "..", "include", "mi355zk.h")]
+HEADERS = ["fp.cuh", "fp_asm.cuh", "fp_asm_gen.inc", "fp29.cuh", "g1.cuh", "g1_29.cuh", "msm.cuh", "ntt.cuh", "ntt29.cuh", os.path.join("..", "..", "include", "mi355zk.h")]
 
 
 def needs_build() -> bool:

@@ -4,6 +4,7 @@
 // compute entry point returns MI355_ENODEVICE.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -15,6 +16,7 @@
 #include "../../include/mi355zk.h"
 #include "msm.cuh"
 #include "ntt.cuh"
+#include "ntt29.cuh"
 
 using namespace zk;
 
@@ -41,6 +43,9 @@ struct NttPlan {
   fe_t *tw_m[3] = {nullptr, nullptr, nullptr};
   fe_t *tw_s_lo[2] = {nullptr, nullptr}, *tw_s_hi[2] = {nullptr, nullptr};
   uint32_t split[2] = {0, 0};
+  // the same tables as w * 2^261 mod r in 29-bit limbs (SoA) for the unsaturated kernels (ntt29.cuh)
+  Tw29 tw29_m[3] = {}, tw29_s_lo[2] = {}, tw29_s_hi[2] = {};
+  std::vector<void *> owned;
 };
 struct Prof { double ms = 0; uint64_t launches = 0; };
 
@@ -56,6 +61,7 @@ struct Ctx {
   std::map<std::string, NttPlan> ntt_plans;  // key = log_n | omega bytes
   g1_affine_t *fixed_base_table = nullptr;
   int force_c = 0;
+  bool ntt29 = true;   // unsaturated 29-bit NTT kernels (MI355_NTT_SAT=1 selects the saturated 8x32 ones for A/B runs)
   bool profiling = false;
   std::map<std::string, Prof> prof;
   int last_c = 0, last_w = 0; uint64_t last_entries = 0;
@@ -222,6 +228,17 @@ int pow_table(fe_t **out, const fe_t &base, uint64_t step, uint32_t count) {
   return MI355_OK;
 }
 
+int pow_table29(NttPlan &p, Tw29 *out, const fe_t &base, uint64_t step, uint32_t count) {
+  uint4 *lo, *hi; uint32_t *top;
+  HIPCHK(hipMalloc((void **)&lo, (size_t)count * 16)); p.owned.push_back(lo);
+  HIPCHK(hipMalloc((void **)&hi, (size_t)count * 16)); p.owned.push_back(hi);
+  HIPCHK(hipMalloc((void **)&top, (size_t)count * 4)); p.owned.push_back(top);
+  hipLaunchKernelGGL(k_pow_table29, dim3(ceil_div(count, 256)), dim3(256), 0, g.stream, lo, hi, top, base, step, count);
+  HIPCHK(hipGetLastError());
+  out->lo = lo; out->hi = hi; out->top = top;
+  return MI355_OK;
+}
+
 int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
   const std::string key = plan_key(log_n, omega);
   auto it = g.ntt_plans.find(key);
@@ -236,10 +253,13 @@ int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
   for (uint32_t l = 0; l < p.levels; l++) {
     const uint32_t lm = p.log_m[l];
     if (lm >= 1) CHK(pow_table(&p.tw_m[l], w, N >> lm, std::max(1u, 1u << (lm - 1))));
+    CHK(pow_table29(p, &p.tw29_m[l], w, N >> lm, std::max(1u, (1u << lm) >> 1)));
     if (l + 1 < p.levels) {
       p.split[l] = (log_s + 1) / 2;
       CHK(pow_table(&p.tw_s_lo[l], w, N >> log_s, 1u << p.split[l]));
       CHK(pow_table(&p.tw_s_hi[l], w, (N >> log_s) << p.split[l], 1u << (log_s - p.split[l])));
+      CHK(pow_table29(p, &p.tw29_s_lo[l], w, N >> log_s, 1u << p.split[l]));
+      CHK(pow_table29(p, &p.tw29_s_hi[l], w, (N >> log_s) << p.split[l], 1u << (log_s - p.split[l])));
     }
     log_s -= lm;
   }
@@ -273,7 +293,8 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
     const size_t lds = (size_t)2 * 16 * (tile + 1);
     Scope sc("ntt_pass");
-    hipLaunchKernelGGL(k_ntt_final, dim3(1), dim3(threads), lds, s, src, dst, lm, 0u, 0u, 0u, p->tw_m[0], src_len, pre3, post3);
+    if (g.ntt29) hipLaunchKernelGGL(k_ntt29_final, dim3(1), dim3(threads), (size_t)36 * (tile + 1), s, src, dst, lm, 0u, 0u, 0u, p->tw29_m[0], src_len, pre3, post3);
+    else hipLaunchKernelGGL(k_ntt_final, dim3(1), dim3(threads), lds, s, src, dst, lm, 0u, 0u, 0u, p->tw_m[0], src_len, pre3, post3);
   } else {
     fe_t *scratch; CHK(ws_get("ntt.scratch", N * sizeof(fe_t), (void **)&scratch));
     uint32_t log_s = log_n;
@@ -285,6 +306,10 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
       const size_t lds = (size_t)2 * 16 * tile;
       const uint64_t blocks = (N >> log_s) << (L.log_t - lc);
       Scope sc("ntt_pass");
+      if (g.ntt29) {
+        Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l];
+        hipLaunchKernelGGL(k_ntt29_strided, dim3((uint32_t)blocks), dim3(threads), (size_t)36 * tile, s, cur, scratch, L9, lc, cur_len, cur_pre);
+      } else
       hipLaunchKernelGGL(k_ntt_strided, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, scratch, L, lc, cur_len, cur_pre);
       cur = scratch; cur_len = N; cur_pre = nullptr; log_s -= L.log_m;
     }
@@ -294,7 +319,8 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     const size_t lds = (size_t)2 * 16 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc);
     const uint64_t blocks = ((uint64_t)1 << log_b) << (log_a - lc);
     Scope sc("ntt_pass");
-    hipLaunchKernelGGL(k_ntt_final, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, dst, lm, log_a, log_b, lc, p->tw_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
+    if (g.ntt29) hipLaunchKernelGGL(k_ntt29_final, dim3((uint32_t)blocks), dim3(threads), (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), s, cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
+    else hipLaunchKernelGGL(k_ntt_final, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, dst, lm, log_a, log_b, lc, p->tw_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
   }
   HIPCHK(hipGetLastError());
   return MI355_OK;
@@ -336,6 +362,9 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
   g.inited = true;
   return MI355_OK;
 }
@@ -348,7 +377,7 @@ int mi355_shutdown(void) {
   g.ws.clear();
   for (auto &kv : g.srs) if (kv.second.owned && kv.second.dev) hipFree(kv.second.dev);
   g.srs.clear();
-  for (auto &kv : g.ntt_plans) { for (int i = 0; i < 3; i++) if (kv.second.tw_m[i]) hipFree(kv.second.tw_m[i]); for (int i = 0; i < 2; i++) { if (kv.second.tw_s_lo[i]) hipFree(kv.second.tw_s_lo[i]); if (kv.second.tw_s_hi[i]) hipFree(kv.second.tw_s_hi[i]); } }
+  for (auto &kv : g.ntt_plans) { for (void *q : kv.second.owned) hipFree(q); for (int i = 0; i < 3; i++) if (kv.second.tw_m[i]) hipFree(kv.second.tw_m[i]); for (int i = 0; i < 2; i++) { if (kv.second.tw_s_lo[i]) hipFree(kv.second.tw_s_lo[i]); if (kv.second.tw_s_hi[i]) hipFree(kv.second.tw_s_hi[i]); } }
   g.ntt_plans.clear();
   if (g.fixed_base_table) { hipFree(g.fixed_base_table); g.fixed_base_table = nullptr; }
   if (g.own_stream) hipStreamDestroy(g.own_stream);

@@ -1,0 +1,139 @@
+// ntt29.cuh -- the NTT passes of ntt.cuh on the 9 x 29-bit unsaturated field (fp29.cuh).
+//
+// Same decomposition, tiling and global access pattern as ntt.cuh (strided passes + digit-reversing final pass); what
+// changes is the arithmetic inside the tile: one v_mad_u64_u32 per limb product and lazy additions.
+//   * data stay in the ABI domain (x * 2^256): they are only re-sliced (from_sat_plain) on load; twiddles are kept as
+//     w * 2^261 mod r (canonical, SoA tables), so Montgomery products with R' = 2^261 land back in the x * 2^256 domain
+//   * butterfly (DIF): sum = carry(u + v), dif = (u - v + 64 r) * w  -- no branch for w = 1 (table entry 0 is the unit)
+//   * value growth: a sum doubles the bound; after stages 5 and 10 of a tile the sums are brought back below 2r with
+//     reduce_small (no multiplication); differences come out of a multiplication (< 1.6 r).  Bounds: start < 1.2 r,
+//     <= 38.4 r before a reduction, 64 r is the limit of sub64 / reduce_small.
+//   * elements leave a pass through a multiplication (inter-level twiddle, or the ifft / coset factor) or reduce_small,
+//     then one conditional subtraction: everything written to HBM is canonical, so results stay bit-exact.
+// LDS: 36 B per element as two 16-byte planes + one 4-byte plane (4096-element tile = 144 KiB of the 160 KiB).
+#pragma once
+#include "fp29.cuh"
+#include "fp_asm.cuh"
+#include "ntt.cuh"
+
+namespace zk {
+
+struct Tw29 { const uint4 *lo; const uint4 *hi; const uint32_t *top; };   // entry i: limbs 0-3, 4-7, 8 of w^i * 2^261 mod r
+struct Ntt29Level { uint32_t log_m, log_t, split; Tw29 tw_m, tw_s_lo, tw_s_hi; };
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ fe29_t tw29_load(const Tw29 &T, uint32_t i) {
+  const uint4 a = T.lo[i], b = T.hi[i]; fe29_t r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = T.top[i]; return r;
+}
+struct Lds29 { uint4 *lo; uint4 *hi; uint32_t *top; };
+__device__ __forceinline__ Lds29 lds29_carve(uint4 *base, uint32_t elems) { Lds29 L; L.lo = base; L.hi = base + elems; L.top = reinterpret_cast<uint32_t *>(base + 2 * elems); return L; }
+__device__ __forceinline__ fe29_t lds29_get(const Lds29 &L, uint32_t i) {
+  const uint4 a = L.lo[i], b = L.hi[i]; fe29_t r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = L.top[i]; return r;
+}
+__device__ __forceinline__ void lds29_put(const Lds29 &L, uint32_t i, const fe29_t &v) {
+  L.lo[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]); L.hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]); L.top[i] = v.l[8];
+}
+// u - v + 64 r, limb-wise, no carry: v limbs <= 2^30 - 2, value(v) < 63.9 r; result limbs < 2^31.4 (multiplication operand only)
+__device__ __forceinline__ fe29_t fr29_sub64(const fe29_t &u, const fe29_t &v) {
+  constexpr uint32_t c[9] = {0x40000040u, 0x43eb27deu, 0x5709143cu, 0x54243cdau, 0x4174a0cdu, 0x56d03029u, 0x49b85043u, 0x57098cffu, 0xc19139au};
+  fe29_t r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = u.l[i] + c[i] - v.l[i];
+  return r;
+}
+// canonical ABI element from a tight value (< 2r, exact limbs)
+__device__ __forceinline__ fe_t fr29_finish(const fe29_t &t) { return Fr29::to_sat_plain(Fr29::cond_sub_p(t)); }
+
+__device__ __forceinline__ void lds_dif29(const Lds29 &L, uint32_t log_m, uint32_t log_c, uint32_t sm, uint32_t sc, const Tw29 &tw_m, bool col_fast) {
+  const uint32_t M = 1u << log_m, C = 1u << log_c, nbf = (M >> 1) << log_c;
+  for (uint32_t s = 0; s < log_m; s++) {
+    const uint32_t log_h = log_m - 1 - s, h = 1u << log_h;
+    const bool reduce_now = (s == 4 || s == 9);
+    for (uint32_t b = threadIdx.x; b < nbf; b += blockDim.x) {
+      uint32_t c, j;
+      if (col_fast) { c = b & (C - 1); j = b >> log_c; } else { j = b & ((M >> 1) - 1); c = b >> (log_m - 1); }
+      const uint32_t jl = j & (h - 1), i0 = ((j >> log_h) << (log_h + 1)) | jl;
+      const uint32_t e0 = i0 * sm + c * sc, e1 = e0 + h * sm;
+      const fe29_t u = lds29_get(L, e0), v = lds29_get(L, e1);
+      fe29_t sum = Fr29::carry(Fr29::add(u, v));
+      if (reduce_now) sum = Fr29::reduce_small(Fr29::normalise(sum));
+      const fe29_t dif = Fr29::mul(fr29_sub64(u, v), tw29_load(tw_m, jl << s));
+      lds29_put(L, e0, sum); lds29_put(L, e1, dif);
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ fe29_t load_input29(const fe_t *__restrict__ src, uint64_t gi, uint64_t src_len, const fe_t *__restrict__ pre3) {
+  if (gi >= src_len) return Fr29::zero();
+  fe29_t v = Fr29::from_sat_plain(g_load(&src[gi]));
+  if (pre3) { const uint32_t r3 = (uint32_t)(gi % 3); if (r3) v = Fr29::mul(v, Fr29::from_sat(g_load(&pre3[r3]))); }   // factor (c_sat << 5) = c * 2^261 < 2^259: output < 1.3 r
+  return v;
+}
+
+__global__ void __launch_bounds__(1024) k_ntt29_strided(const fe_t *__restrict__ src, fe_t *__restrict__ dst, Ntt29Level L, uint32_t log_c,
+                                                        uint64_t src_len, const fe_t *__restrict__ pre3) {
+  extern __shared__ uint4 lds[];
+  const uint32_t M = 1u << L.log_m, C = 1u << log_c, tile = M << log_c;
+  const Lds29 S = lds29_carve(lds, tile);
+  const uint32_t cb_per_sub = 1u << (L.log_t - log_c);
+  const uint64_t sub = blockIdx.x >> (L.log_t - log_c);
+  const uint32_t cb = blockIdx.x & (cb_per_sub - 1);
+  const uint64_t base = (sub << (L.log_m + L.log_t)) + ((uint64_t)cb << log_c);
+  for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+    const uint32_t c = e & (C - 1), m = e >> log_c;
+    lds29_put(S, e, load_input29(src, base + ((uint64_t)m << L.log_t) + c, src_len, pre3));
+  }
+  __syncthreads();
+  lds_dif29(S, L.log_m, log_c, C, 1, L.tw_m, true);
+  const uint32_t smask = (1u << L.split) - 1;
+  for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+    const uint32_t c = e & (C - 1), k = e >> log_c;
+    const fe29_t v = lds29_get(S, (bitrev32(k, L.log_m) << log_c) + c);
+    const uint32_t ex = ((cb << log_c) + c) * k;     // inter-level twiddle w_S^(col * k); entry 0 of both tables is the unit
+    const fe29_t w = Fr29::mul(tw29_load(L.tw_s_lo, ex & smask), tw29_load(L.tw_s_hi, ex >> L.split));
+    g_store(&dst[base + ((uint64_t)k << L.log_t) + c], fr29_finish(Fr29::mul(v, w)));
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_ntt29_final(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint32_t log_m, uint32_t log_a, uint32_t log_b,
+                                                      uint32_t log_c, Tw29 tw_m, uint64_t src_len, const fe_t *__restrict__ pre3, const fe_t *__restrict__ post3) {
+  extern __shared__ uint4 lds[];
+  const uint32_t M = 1u << log_m, C = 1u << log_c, seg = M + 1, tile = M << log_c;
+  const Lds29 S = lds29_carve(lds, seg << log_c);
+  const uint32_t k2 = blockIdx.x & ((1u << log_b) - 1);
+  const uint32_t k1_0 = (blockIdx.x >> log_b) << log_c;
+  for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+    const uint32_t m = e & (M - 1), c = e >> log_m;
+    const uint64_t q = ((uint64_t)(k1_0 + c) << log_b) + k2;
+    lds29_put(S, c * seg + m, load_input29(src, (q << log_m) + m, src_len, pre3));
+  }
+  __syncthreads();
+  lds_dif29(S, log_m, log_c, 1, seg, tw_m, false);
+  const uint32_t log_stride = log_a + log_b;  // N / M
+  fe29_t post0 = Fr29::zero(), post1 = post0, post2 = post0;   // named (not an array): runtime-indexed arrays go to scratch
+  if (post3) { post0 = Fr29::reduce_small(Fr29::from_sat(g_load(&post3[0]))); post1 = Fr29::reduce_small(Fr29::from_sat(g_load(&post3[1]))); post2 = Fr29::reduce_small(Fr29::from_sat(g_load(&post3[2]))); }   // c * 2^261, tight
+  for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+    const uint32_t c = e & (C - 1), k = e >> log_c;
+    const fe29_t v = lds29_get(S, c * seg + bitrev32(k, log_m));
+    const uint64_t oi = (uint64_t)(k1_0 + c) + ((uint64_t)k2 << log_a) + ((uint64_t)k << log_stride);
+    fe29_t t;
+    if (post3) { const uint32_t r3 = (uint32_t)(oi % 3); t = Fr29::mul(v, r3 == 0 ? post0 : (r3 == 1 ? post1 : post2)); }
+    else t = Fr29::reduce_small(Fr29::normalise(v));
+    g_store(&dst[oi], fr29_finish(t));
+  }
+}
+
+// SoA twiddle table: entry i = (base^step)^i * 2^261 mod r, canonical 29-bit limbs
+__global__ void k_pow_table29(uint4 *lo, uint4 *hi, uint32_t *top, fe_t base, uint64_t step, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const fe_t b = step == 1 ? base : Fr::pow_u64(base, step);
+  fe_t m32; { constexpr uint32_t c[8] = {0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u, 0x819caa80u, 0x5301fa84u, 0x563d4475u, 0xdc83629u}; for (int k = 0; k < 8; k++) m32.l[k] = c[k]; }   // 32 in Montgomery form
+  const fe29_t w = Fr29::from_sat_plain(fr_mul_ps(Fr::pow_u64(b, i), m32));   // (w * 2^256) * 32 = w * 2^261 mod r, canonical
+  lo[i] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]); hi[i] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]); top[i] = w.l[8];
+}
+#endif  // __HIPCC__
+
+}  // namespace zk
