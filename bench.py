@@ -58,6 +58,8 @@ def main() -> None:
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--proxy-chunk-proof", action="store_true", help="also replay the layer-2 (k=25) call mix of one chunk proof on synthetic data (SURVEY 3.3): 11 MSM + NTT mix")
+    ap.add_argument("--host-api", action="store_true", help="also time the host-pointer entry point (scalars cross PCIe) -- never the headline value")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -65,16 +67,23 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  MI355_BENCH_SHARE_GPU=1 (test only) lets several ranks share the visible GPUs and moves the
+    # collective to gloo, so the N > 1 control flow can be exercised on a one-GPU box; the driver never sets it.
+    share = os.environ.get("MI355_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" == RCCL on ROCm
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" == RCCL on ROCm
 
     zk = ge.load_package()
     lib, check, ptr, h2 = zk._capi.lib(), zk._capi.check, zk._capi.ptr, zk.halo2
-    zk.init(local_rank)
+    zk.init(dev_index)
     check(lib.mi355_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     check(lib.mi355_msm_set_window_bits(args.window_bits))
 
@@ -107,7 +116,7 @@ def main() -> None:
         if world == 1:
             return local_msm()
         # RCCL over xGMI: one all_gather of 96 B per rank, then the fold on the device (scroll-prover_amd/distributed.py)
-        return zk.distributed.sharded_multiexp(local_msm, h2.g1_sum, dev)
+        return zk.distributed.sharded_multiexp(local_msm, h2.g1_sum, "cpu" if share else dev)
 
     def barrier():
         if world > 1:
@@ -126,7 +135,7 @@ def main() -> None:
     dt = time.perf_counter() - t0
     check(lib.mi355_profile_enable(0))
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -149,6 +158,22 @@ def main() -> None:
         p_tau = cref.eval_polynomial(sc_host, tau_m)
         want = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), p_tau))
         verified = bool((np.asarray(result)[:8] == want).all())
+
+    # N > 1: every rank evaluates its shard polynomial at its own tau in the field (oracle = checker only, outside the timed
+    # region), the 32-byte evaluations are gathered, and rank 0 checks  result == (sum_r p_r(tau_r)) * G
+    if world > 1 and k <= 26:
+        from oracle import cref
+        e_r = cref.eval_polynomial(scalars.cpu().numpy().view(np.uint64), tau_m)
+        mine = torch.from_numpy(e_r.view(np.uint8).copy()).to("cpu" if share else dev)
+        allv = torch.empty(world * 32, dtype=torch.uint8, device=mine.device)
+        dist.all_gather_into_tensor(allv, mine)
+        if rank == 0:
+            ev = allv.cpu().numpy().view(np.uint64).reshape(world, 4)
+            tot = ev[0]
+            for r_ in range(1, world):
+                tot = cref.f_add(cref.FR, tot, ev[r_])
+            want = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), tot))
+            verified = bool((np.asarray(result)[:8] == want).all())
 
     ms_per_step = dt / args.steps * 1e3
     pairs_per_s = n_total * args.steps / dt
@@ -181,6 +206,35 @@ def main() -> None:
                             "frac": 64.0 * (1 << k) / dt_ntt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "note": "algorithmic bytes = 64*N per transform (SURVEY 8d); whole-transform time, all passes"}}
         del poly
+
+    extra = {}
+    if args.host_api and world == 1:
+        sc_host = scalars.cpu().numpy().view(np.uint64)
+        check(lib.mi355_msm_g1_host(handle.value, 0, ptr(sc_host), n, ptr(out)))   # warm-up (allocates the staging buffer)
+        t3 = time.perf_counter()
+        for _ in range(3):
+            check(lib.mi355_msm_g1_host(handle.value, 0, ptr(sc_host), n, ptr(out)))
+        extra["host_api_ms_per_commit_pcie_inclusive"] = (time.perf_counter() - t3) / 3 * 1e3
+        del sc_host
+    if args.proxy_chunk_proof and world == 1:
+        # layer-2 compression circuit, k = 25 (SURVEY 3.3 / BASELINE.md): 11 commitments (1+1+3 witness, 4 quotient pieces, 2 SHPLONK),
+        # 5 witness polys -> coefficient form (iNTT) and 4 coset extensions each, one extended inverse; synthetic data, device resident
+        kk = min(25, k)
+        domp = h2.EvaluationDomain(5, kk)
+        polys = [rand_scalars(1 << kk, 900 + i, dev) for i in range(5)]
+        ext = torch.empty((1 << domp.extended_k, 4), dtype=torch.int64, device=dev)
+        hh = C.c_uint64(); check(lib.mi355_srs_register_dev(ptr(g), 1 << kk, 0, C.byref(hh)))
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        for i in range(11):
+            check(lib.mi355_msm_g1_dev(hh.value, 0, ptr(polys[i % 5]), 1 << kk, ptr(out)))
+        for pl in polys:
+            domp.lagrange_to_coeff(pl)
+            domp.coeff_to_extended(pl, out=ext)
+        domp.extended_to_coeff(ext)
+        check(lib.mi355_synchronize()); torch.cuda.synchronize()
+        extra["proxy_chunk_proof_layer2_ms"] = (time.perf_counter() - t4) * 1e3
+        extra["proxy_chunk_proof_note"] = "11 MSM(2^%d) + 5 iNTT(2^%d) + 5 coeff_to_extended(2^%d->2^%d) + 1 extended_to_coeff; synthetic; excludes witness synthesis, evaluate_h, transcript (CPU side of create_proof)" % (kk, kk, kk, domp.extended_k)
+        check(lib.mi355_srs_release(hh.value)); del polys, ext
 
     # ---- CPU baseline (rank 0, N = 1 only): the restated reference algorithm on a bounded sample of the same workload
     cpu = None
@@ -229,6 +283,7 @@ def main() -> None:
                          "note": "algorithmic bytes = 96 B per (scalar, point) pair x pairs per launch (SURVEY 8d); the kernel is VALU-integer bound, see DESIGN.md"},
             "cpu_baseline": cpu, "ntt": ntt,
         }
+        line.update(extra)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -61,6 +61,7 @@ struct Ctx {
   std::map<std::string, NttPlan> ntt_plans;  // key = log_n | omega bytes
   g1_affine_t *fixed_base_table = nullptr;
   int force_c = 0;
+  uint32_t ntt_tile_log = 12;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
   bool ntt29 = true;   // unsaturated 29-bit NTT kernels (MI355_NTT_SAT=1 selects the saturated 8x32 ones for A/B runs)
   bool profiling = false;
   std::map<std::string, Prof> prof;
@@ -267,7 +268,7 @@ int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
   return MI355_OK;
 }
 
-uint32_t cols_for(uint32_t log_m) { uint32_t lc = 3; while (lc > 0 && log_m + lc > 12) lc--; return lc; }
+uint32_t cols_for(uint32_t log_m) { uint32_t lc = 3; while (lc > 0 && log_m + lc > g.ntt_tile_log) lc--; return lc; }
 
 // dst[2^log_n] = NTT_omega( pre3-scaled, zero-padded src[src_len] ), then optional post3 scaling.  src may equal dst.
 int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, const void *omega, const fe_t *pre3_host, const fe_t *post3_host) {
@@ -365,6 +366,7 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
+  { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
   g.inited = true;
   return MI355_OK;
 }

@@ -228,3 +228,23 @@ def test_fixed_base_and_synthetic_srs(zk):
     assert (c1 == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), p_tau))).all()
     params.release()
     _ = torch
+
+
+def test_giant_buckets_take_the_parallel_fixup(zk):
+    """all-equal scalars put every point of a window into ONE bucket (spanning thousands of accumulate threads): the queued,
+    workgroup-parallel fix-up (k_msm_fixup_big) must give the same answer as n * P arithmetic in the oracle."""
+    import torch
+    h2 = zk.halo2
+    k = 17
+    params = h2.ParamsKZG.setup(k, 0xABCDEF0123)
+    n = 1 << k
+    for val in (1, 2**40 + 3, pyref.R_MOD - 1):
+        sc = np.tile(h2.fr(val), (n, 1))
+        got = affine_of(params.commit(sc))
+        # sum_i val * tau^i G = val * (tau^n - 1)/(tau - 1) G
+        tau = 0xABCDEF0123
+        s = val * (pow(tau, n, R) - 1) * pow(tau - 1, -1, R) % R
+        want = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), h2.fr(s)))
+        assert (got == want).all()
+    params.release()
+    _ = torch
