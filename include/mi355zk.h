@@ -63,6 +63,13 @@ int mi355_synchronize(void);
 int mi355_srs_register_host(const void *bases_affine_host, uint64_t n, uint64_t *handle_out);
 int mi355_srs_register_dev(const void *bases_affine_dev, uint64_t n, int copy, uint64_t *handle_out);
 int mi355_srs_release(uint64_t handle);
+/* Optional, once per basis: build T[w][i] = 2^(c w) * P_i (w < W = ceil(255 / c), affine, W * n * 64 B of HBM) so that all
+ * windows of an MSM on this basis share ONE bucket set: no per-window Horner (255 serial doublings), W x fewer bucket
+ * reductions.  c = 0 picks the window for MSMs of n_hint points (0 = the whole basis).  MSMs on the handle then use the
+ * table whenever it is the cheaper schedule for their length.  The SRS is fixed for the life of the prover (params_map
+ * [REF bin/src/trace_prover.rs:35-43]), so this is registration-time work, like the reference's own g_lagrange set-up. */
+int mi355_srs_precompute(uint64_t handle, uint64_t n_hint, int c);
+int mi355_srs_pre_dev_ptr(uint64_t handle, void **dev_ptr_out, int *c_out, int *windows_out);
 int mi355_srs_len(uint64_t handle, uint64_t *n_out);
 /* device pointer of the resident basis (n x 64 B), for tests and chained device-side work                     */
 int mi355_srs_dev_ptr(uint64_t handle, void **dev_ptr_out);

@@ -22,6 +22,8 @@ SIGNATURES = {
     "mi355_srs_register_host": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "mi355_srs_register_dev": (_int, [_vp, _u64, _int, C.POINTER(_u64)]),
     "mi355_srs_release": (_int, [_u64]),
+    "mi355_srs_precompute": (_int, [_u64, _u64, _int]),
+    "mi355_srs_pre_dev_ptr": (_int, [_u64, C.POINTER(_vp), C.POINTER(_int), C.POINTER(_int)]),
     "mi355_srs_len": (_int, [_u64, C.POINTER(_u64)]),
     "mi355_srs_dev_ptr": (_int, [_u64, C.POINTER(_vp)]),
     "mi355_msm_g1_host": (_int, [_u64, _u64, _vp, _u64, _vp]),

@@ -36,7 +36,7 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
   } while (0)
 #define CHK(expr) do { int _r = (expr); if (_r != MI355_OK) return _r; } while (0)
 
-struct Srs { g1_affine_t *dev = nullptr; uint64_t n = 0; bool owned = false; };
+struct Srs { g1_affine_t *dev = nullptr; uint64_t n = 0; bool owned = false; g1_affine_t *pre = nullptr; int pre_c = 0, pre_w = 0; };
 struct Buf { void *p = nullptr; size_t cap = 0; };
 struct NttPlan {
   uint32_t log_n = 0, levels = 0, log_m[3] = {0, 0, 0};
@@ -111,28 +111,38 @@ int choose_c(uint64_t n) {
   return best_c;
 }
 
-int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void *out_host) {
+struct PreTable { const g1_affine_t *table = nullptr; uint64_t row_stride = 0; int c = 0, w = 0; };   // table already offset to the slice start
+
+double msm_cost(uint64_t n, int c, bool shared) { const double W = (255 + c - 1) / c, nb = (double)(1ull << (c - 1)); return shared ? W * (double)n + 4.2 * nb : W * ((double)n + 4.2 * nb); }
+
+int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void *out_host, const PreTable *pre = nullptr) {
   g1_jac_t result; memset(&result, 0, sizeof result);
   if (n == 0) { memcpy(out_host, &result, sizeof result); return MI355_OK; }
   if (n >= (1ull << 31)) return fail(MI355_EBADARG, "msm: n must be < 2^31");
-  MsmPlan P; P.n = (uint32_t)n; P.c = (uint32_t)choose_c(n); P.windows = (255 + P.c - 1) / P.c; P.nb = 1u << (P.c - 1);
+  MsmPlan P; P.n = (uint32_t)n; P.c = (uint32_t)choose_c(n);
+  // precomputed rows 2^(c w) P available and cheaper than the per-window schedule at this n -> all windows share one bucket set
+  const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)P.c, false) && n * (uint64_t)pre->w < (1ull << 31);
+  if (shared) { P.c = (uint32_t)pre->c; bases = pre->table; }
+  P.windows = (255 + P.c - 1) / P.c; P.nb = 1u << (P.c - 1);
   const uint64_t emax = n * P.windows;
   if (emax >= (1ull << 32)) return fail(MI355_EBADARG, "msm: n * windows must be < 2^32");
   const uint64_t want_threads = (uint64_t)g.prop.multiProcessorCount * 256 * 16;   // ~16 segments per lane slot
   uint64_t seg = (emax + want_threads - 1) / want_threads; if (seg < 16) seg = 16; if (seg > 4096) seg = 4096;
   P.seg = (uint32_t)seg;
-  const uint32_t nbuckets = P.windows * P.nb;
+  const uint32_t nbuckets = shared ? P.nb : P.windows * P.nb;
+  const uint32_t red_windows = shared ? 1 : P.windows;   // bucket sets to reduce
   const uint32_t acc_threads = ceil_div(emax, seg), acc_blocks = ceil_div(acc_threads, 256);
   const uint32_t tn = acc_blocks * 256;
   uint32_t chunk = 64; while (chunk > P.nb) chunk >>= 1;
   // keep at least ~8k reduce threads busy when buckets are few, at most ~512k
-  while (chunk > 4 && (uint64_t)(P.nb / chunk) * P.windows < 16384) chunk >>= 1;
-  const uint32_t chunks_per_window = P.nb / chunk, nchunks = chunks_per_window * P.windows;
+  while (chunk > 4 && (uint64_t)(P.nb / chunk) * red_windows < 16384) chunk >>= 1;
+  const uint32_t chunks_per_window = P.nb / chunk, nchunks = chunks_per_window * red_windows;
 
   // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest (<= 9)
   SortPlan S; S.n = P.n; S.windows = P.windows; S.nb = P.nb;
   { uint32_t kb = P.c - 1; uint32_t fb = kb < 10 ? kb : 10; if (kb - fb > 9) fb = kb - 9; S.fb = fb; S.cb_bits = kb - fb; }
-  S.regions = P.windows << S.cb_bits;
+  S.shared = shared ? 1 : 0;
+  S.regions = shared ? (1u << S.cb_bits) : (P.windows << S.cb_bits);
   S.t1 = 16384;                               // level-1 tile: 1024 threads x 16 entries, staged in 128 KiB of LDS
   const bool big_t2 = S.fb <= 10;             // level-2 tile: 32768 entries (128 KiB of indices) unless the fine table is large
   S.t2 = big_t2 ? 32768 : 16384;
@@ -198,16 +208,16 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
     {
       Scope sc("msm_accumulate");
       HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
-      hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg);
+      hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, P.n, shared ? pre->row_stride : (uint64_t)0);
     }
     {
       Scope sc("msm_reduce");
       HIPCHK(hipMemsetAsync(big_count, 0, 4, s));
       hipLaunchKernelGGL(k_msm_fixup, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap);
       hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
-      hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, P, chunk);
-      hipLaunchKernelGGL(k_msm_window_reduce, dim3(P.windows), dim3(256), 0, s, chunk_out, window_sums, chunks_per_window);
-      hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, window_sums, P.windows, P.c, out_dev);
+      { MsmPlan PR = P; PR.windows = red_windows; hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk); }
+      hipLaunchKernelGGL(k_msm_window_reduce, dim3(red_windows), dim3(256), 0, s, chunk_out, window_sums, chunks_per_window);
+      hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, window_sums, red_windows, shared ? 0u : P.c, out_dev);
     }
   }
   HIPCHK(hipGetLastError());
@@ -377,7 +387,7 @@ int mi355_shutdown(void) {
   hipStreamSynchronize(g.stream);
   for (auto &kv : g.ws) if (kv.second.p) hipFree(kv.second.p);
   g.ws.clear();
-  for (auto &kv : g.srs) if (kv.second.owned && kv.second.dev) hipFree(kv.second.dev);
+  for (auto &kv : g.srs) { if (kv.second.owned && kv.second.dev) hipFree(kv.second.dev); if (kv.second.pre) hipFree(kv.second.pre); }
   g.srs.clear();
   for (auto &kv : g.ntt_plans) { for (void *q : kv.second.owned) hipFree(q); for (int i = 0; i < 3; i++) if (kv.second.tw_m[i]) hipFree(kv.second.tw_m[i]); for (int i = 0; i < 2; i++) { if (kv.second.tw_s_lo[i]) hipFree(kv.second.tw_s_lo[i]); if (kv.second.tw_s_hi[i]) hipFree(kv.second.tw_s_hi[i]); } }
   g.ntt_plans.clear();
@@ -429,7 +439,35 @@ int mi355_srs_release(uint64_t handle) {
   if (it == g.srs.end()) return fail(MI355_EBADARG, "srs_release: unknown handle");
   if (g.inited) hipStreamSynchronize(g.stream);
   if (it->second.owned) hipFree(it->second.dev);
+  if (it->second.pre) hipFree(it->second.pre);
   g.srs.erase(it); return MI355_OK;
+}
+int mi355_srs_precompute(uint64_t handle, uint64_t n_hint, int c) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  auto it = g.srs.find(handle);
+  if (it == g.srs.end()) return fail(MI355_EBADARG, "srs_precompute: unknown handle");
+  Srs &sr = it->second;
+  if (n_hint == 0 || n_hint > sr.n) n_hint = sr.n;
+  if (c == 0) {   // best shared-bucket window for n_hint, within the sorter's key range (c - 1 <= 21 bits)
+    double best = 1e300;
+    for (int cc = 4; cc <= 22; cc++) { const double co = msm_cost(n_hint, cc, true); if (co < best) { best = co; c = cc; } }
+  }
+  if (c < 2 || c > 22) return fail(MI355_EBADARG, "srs_precompute: window bits must be in [2, 22]");
+  const int W = (255 + c - 1) / c;
+  if (sr.pre) { HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipFree(sr.pre)); sr.pre = nullptr; }
+  HIPCHK(hipMalloc((void **)&sr.pre, (size_t)W * sr.n * sizeof(g1_affine_t)));
+  hipLaunchKernelGGL(k_srs_precompute, dim3(ceil_div(sr.n, 256)), dim3(256), 0, g.stream, sr.dev, sr.pre, sr.n, (uint32_t)W, (uint32_t)c);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(g.stream));
+  sr.pre_c = c; sr.pre_w = W;
+  return MI355_OK;
+}
+int mi355_srs_pre_dev_ptr(uint64_t handle, void **dev_ptr_out, int *c_out, int *windows_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  auto it = g.srs.find(handle);
+  if (it == g.srs.end() || !dev_ptr_out) return fail(MI355_EBADARG, "srs_pre_dev_ptr: unknown handle");
+  *dev_ptr_out = it->second.pre; if (c_out) *c_out = it->second.pre_c; if (windows_out) *windows_out = it->second.pre_w; return MI355_OK;
 }
 int mi355_srs_len(uint64_t handle, uint64_t *n_out) {
   std::lock_guard<std::mutex> lk(g.mu);
@@ -445,27 +483,29 @@ int mi355_srs_dev_ptr(uint64_t handle, void **dev_ptr_out) {
 }
 
 // ---- MSM
-static int srs_slice(uint64_t handle, uint64_t off, uint64_t n, const g1_affine_t **out) {
+static int srs_slice(uint64_t handle, uint64_t off, uint64_t n, const g1_affine_t **out, PreTable *pre) {
   auto it = g.srs.find(handle);
   if (it == g.srs.end()) return fail(MI355_EBADARG, "msm: unknown SRS handle");
   if (off > it->second.n || n > it->second.n - off) return fail(MI355_EBADARG, "msm: base_offset + n exceeds the registered basis (best_multiexp panics on length mismatch)");
-  *out = it->second.dev + off; return MI355_OK;
+  *out = it->second.dev + off;
+  if (it->second.pre) { pre->table = it->second.pre + off; pre->row_stride = it->second.n; pre->c = it->second.pre_c; pre->w = it->second.pre_w; }
+  return MI355_OK;
 }
 int mi355_msm_g1_dev(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_host) {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_host || (n && !scalars_dev)) return fail(MI355_EBADARG, "msm: null pointer");
-  const g1_affine_t *bases; CHK(srs_slice(srs_handle, base_offset, n, &bases));
-  return msm_dev_impl(bases, (const fe_t *)scalars_dev, n, out_g1_host);
+  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
+  return msm_dev_impl(bases, (const fe_t *)scalars_dev, n, out_g1_host, &pre);
 }
 int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *scalars_host, uint64_t n, void *out_g1_host) {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_host || (n && !scalars_host)) return fail(MI355_EBADARG, "msm: null pointer");
-  const g1_affine_t *bases; CHK(srs_slice(srs_handle, base_offset, n, &bases));
+  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
   fe_t *sc = nullptr;
   if (n) { CHK(ws_get("io.scalars", n * sizeof(fe_t), (void **)&sc)); HIPCHK(hipMemcpyAsync(sc, scalars_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
-  return msm_dev_impl(bases, sc, n, out_g1_host);
+  return msm_dev_impl(bases, sc, n, out_g1_host, &pre);
 }
 int mi355_msm_g1_adhoc_host(const void *bases_host, const void *scalars_host, uint64_t n, void *out_g1_host) {
   std::lock_guard<std::mutex> lk(g.mu);

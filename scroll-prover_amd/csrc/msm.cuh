@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const uint32_t *__res
 //   level 2: tiles inside each coarse region, bin = fine key (2^fb bins)             -> exact bucket offsets + sorted[]
 // Order inside a bucket is arbitrary (group addition commutes), so nothing needs to be stable.
 constexpr uint32_t SORT_MAX_BINS = 4096;
-struct SortPlan { uint32_t n, windows, nb, fb, cb_bits, t1, t2, regions; };
+struct SortPlan { uint32_t n, windows, nb, fb, cb_bits, t1, t2, regions, shared; };   // shared = 1: all windows feed ONE bucket set (precomputed 2^(cw) P tables)
 
 __global__ void __launch_bounds__(256) k_sort_l1_hist(const uint32_t *__restrict__ enc, uint32_t *__restrict__ coarse_hist, SortPlan S) {
   __shared__ uint32_t h[SORT_MAX_BINS];
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_sort_l1_hist(const uint32_t *__restrict
   const uint32_t *plane = enc + (uint64_t)w * S.n;
   for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) { const uint32_t e = plane[i]; if (e) atomicAdd(&h[((e & 0x7fffffffu) - 1) >> S.fb], 1u); }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) if (h[b]) atomicAdd(&coarse_hist[w * CB + b], h[b]);
+  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) if (h[b]) atomicAdd(&coarse_hist[(S.shared ? 0 : w * CB) + b], h[b]);
 }
 // Per-tile bin bookkeeping shared by both scatter kernels (1024 threads): lstart[] = exclusive scan of the tile histogram,
 // gbase[] = start of this tile's run inside each global bin (ONE returning global atomic per non-empty bin).
@@ -184,12 +184,13 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(con
     if (e[k]) rank[k] = atomicAdd(&h[((e[k] & 0x7fffffffu) - 1) >> S.fb], 1u);
   }
   __syncthreads();
-  const uint32_t total = tile_bin_offsets(h, lstart, gbase, CB, coarse_cursor + w * CB, scratch32);
+  const uint32_t total = tile_bin_offsets(h, lstart, gbase, CB, coarse_cursor + (S.shared ? 0 : w * CB), scratch32);
+  const uint32_t idx_base = S.shared ? w * S.n : 0;   // shared buckets: the payload names (window, point) = row w of the precomputed table
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < EPT; k++) if (e[k]) {
     const uint32_t bucket = (e[k] & 0x7fffffffu) - 1, i = i0 + k * 1024 + threadIdx.x;
-    stage[lstart[bucket >> S.fb] + rank[k]] = ((uint64_t)bucket << 32) | (uint64_t)(i | (e[k] & 0x80000000u));
+    stage[lstart[bucket >> S.fb] + rank[k]] = ((uint64_t)bucket << 32) | (uint64_t)((idx_base + i) | (e[k] & 0x80000000u));
   }
   __syncthreads();
   for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
@@ -271,7 +272,8 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
 // offsets[b] .. offsets[b+1] = entries of global bucket b (b = w * nb + bucket); offsets has nbuckets+1 entries.
 // bucket_sums must be zero-filled (all-zero XYZZ = identity) before launch.
 __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
-                                                        uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg) {
+                                                        uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg,
+                                                        uint32_t n, uint64_t row_stride) {
   const uint32_t total = offsets[nbuckets];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t start64 = (uint64_t)t * seg;
@@ -287,11 +289,18 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__res
   g1_xyzz29_t acc = g1_xyzz29_identity();
   // software pipeline: the gather of entry pos+1 (index, then 64-byte base) is issued before the ~10 field multiplications
   // of entry pos, so the ~2 us random-access latency overlaps arithmetic instead of stalling one of only 4 waves per SIMD
+  // row_stride != 0: entry index = w * n + i names row w of the precomputed table T[w][.] = 2^(c w) P (rows row_stride points apart)
+  auto base_of = [&](uint32_t e) -> const g1_affine_t * {
+    const uint32_t gi = e & 0x7fffffffu;
+    if (row_stride == 0) return &bases[gi];
+    const uint32_t w = gi / n;
+    return &bases[(uint64_t)w * row_stride + (gi - w * n)];
+  };
   uint32_t ent = sorted[start];
-  g1_affine_t p = load_affine(&bases[ent & 0x7fffffffu]);
+  g1_affine_t p = load_affine(base_of(ent));
   for (uint32_t pos = start; pos < end; pos++) {
     uint32_t ent_next = 0; g1_affine_t p_next = p;
-    if (pos + 1 < end) { ent_next = sorted[pos + 1]; p_next = load_affine(&bases[ent_next & 0x7fffffffu]); }
+    if (pos + 1 < end) { ent_next = sorted[pos + 1]; p_next = load_affine(base_of(ent_next)); }
     if (pos >= b_end) {
       // leave bucket b: it ends inside this thread's range
       if (offsets[b] >= start) store_xyzz29(&bucket_sums[b], acc);                        // began here too: sole owner
@@ -397,6 +406,31 @@ __global__ void k_g1_sum(const g1_jac_t *__restrict__ pts, uint32_t n, g1_jac_t 
   g1_xyzz_t acc = g1_xyzz_identity();
   for (uint32_t i = 0; i < n; i++) { g1_jac_t p = pts[i]; g1_xyzz_add_ps(acc, g1_jac_to_xyzz(p)); }
   *out = g1_xyzz_to_jac_normalised(acc);
+}
+
+// ---- window precomputation for a registered basis: T[w][i] = 2^(c w) * P_i, affine, w < W (row 0 = the basis itself).
+// One thread per point: c doublings, one inversion per row.  One-off cost at registration (about 6.4 k field multiplications per point).
+__device__ __forceinline__ fe_t fq_inv_ps(const fe_t &a) {
+  fe_t acc = Fq::one();
+  uint32_t e[8]; for (int i = 0; i < 8; i++) e[i] = FqP::mod(i); e[0] -= 2;
+  for (int i = 255; i >= 0; i--) { acc = fq_sqr_ps(acc); if ((e[i >> 5] >> (i & 31)) & 1) acc = fq_mul_ps(acc, a); }
+  return acc;
+}
+__global__ void __launch_bounds__(256) k_srs_precompute(const g1_affine_t *__restrict__ base, g1_affine_t *__restrict__ table, uint64_t n, uint32_t W, uint32_t c) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_affine_t P = load_affine(&base[i]);
+  g_store(&table[i].x, P.x); g_store(&table[i].y, P.y);
+  for (uint32_t w = 1; w < W; w++) {
+    if (!g1_affine_is_identity(P)) {
+      g1_xyzz_t acc = g1_xyzz_dbl_affine_ps(P);
+      for (uint32_t k = 1; k < c; k++) acc = g1_xyzz_dbl_ps(acc);
+      // BN254 G1 has prime order and no 2-torsion: doubling a non-identity point never gives the identity
+      const fe_t inv = fq_inv_ps(fq_mul_ps(acc.zz, acc.zzz));
+      P.x = fq_mul_ps(acc.x, fq_mul_ps(inv, acc.zzz)); P.y = fq_mul_ps(acc.y, fq_mul_ps(inv, acc.zz));
+    }
+    g_store(&table[w * n + i].x, P.x); g_store(&table[w * n + i].y, P.y);
+  }
 }
 
 // ---- synthetic SRS helpers (ParamsKZG::setup restated): fixed-base multiplication by 8-bit windows.

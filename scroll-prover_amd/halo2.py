@@ -189,6 +189,13 @@ class ParamsKZG:
         assert n == self.n, "commit_lagrange: polynomial must have exactly n evaluations"
         return best_multiexp(_as_scalars(poly_lagrange, n), SrsSlice(self._gl, 0, n))
 
+    def precompute(self, n_hint: int = 0, c: int = 0, lagrange: bool = True, coeff: bool = True) -> None:
+        """registration-time window tables 2^(c w) * P for the two bases (mi355_srs_precompute): W x the HBM, fewer windows, no Horner tail."""
+        if coeff:
+            check(lib().mi355_srs_precompute(self._g, n_hint, c))
+        if lagrange:
+            check(lib().mi355_srs_precompute(self._gl, n_hint, c))
+
     def g_slice(self, offset: int, n: int) -> SrsSlice:
         return SrsSlice(self._g, offset, n)
 
