@@ -61,6 +61,9 @@ struct Ctx {
   std::map<std::string, NttPlan> ntt_plans;  // key = log_n | omega bytes
   g1_affine_t *fixed_base_table = nullptr;
   int force_c = 0;
+  uint32_t sort_t2 = 8192;      // MI355_SORT_T2 = 8192 | 16384 | 32768
+  uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
+  uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
   uint32_t ntt_tile_log = 12;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
   bool ntt29 = true;   // unsaturated 29-bit NTT kernels (MI355_NTT_SAT=1 selects the saturated 8x32 ones for A/B runs)
   bool profiling = false;
@@ -140,12 +143,12 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
 
   // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest (<= 9)
   SortPlan S; S.n = P.n; S.windows = P.windows; S.nb = P.nb;
-  { uint32_t kb = P.c - 1; uint32_t fb = kb < 10 ? kb : 10; if (kb - fb > 9) fb = kb - 9; S.fb = fb; S.cb_bits = kb - fb; }
+  { uint32_t kb = P.c - 1; uint32_t fb = kb < 11 ? kb : 11; if (kb - fb > 10) fb = kb - 10; S.fb = fb; S.cb_bits = kb - fb; }
   S.shared = shared ? 1 : 0;
   S.regions = shared ? (1u << S.cb_bits) : (P.windows << S.cb_bits);
-  S.t1 = 16384;                               // level-1 tile: 1024 threads x 16 entries, staged in 128 KiB of LDS
-  const bool big_t2 = S.fb <= 10;             // level-2 tile: 32768 entries (128 KiB of indices) unless the fine table is large
-  S.t2 = big_t2 ? 32768 : 16384;
+  S.t1 = g.sort_t1;                           // level-1 tile: 1024 threads x 8 or 16 entries (64 / 128 KiB of LDS staging)
+  const bool big_t2 = S.fb <= 11 && g.sort_t2 == 32768;   // level-2 tile: 32768 entries (128 KiB of indices) unless the fine table is large
+  S.t2 = big_t2 ? 32768 : g.sort_t2 == 8192 ? 8192 : 16384;
   if (S.fb > 12 || (1u << S.cb_bits) > SORT_MAX_BINS) return fail(MI355_EBADARG, "msm: window bits out of range for the sorter");
   const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions;
 
@@ -192,7 +195,8 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
       hipLaunchKernelGGL(k_scan_final, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, coarse_off, coarse_cursor, cscan_n);
       {
         const uint32_t CBp = ((1u << S.cb_bits) + 1) & ~1u;
-        hipLaunchKernelGGL(k_sort_l1_scatter<16>, dim3(tiles1 * P.windows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
+        if (S.t1 == 16384) hipLaunchKernelGGL(k_sort_l1_scatter<16>, dim3(tiles1 * P.windows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
+        else hipLaunchKernelGGL(k_sort_l1_scatter<8>, dim3(tiles1 * P.windows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
       }
       hipLaunchKernelGGL(k_sort_tile_prefix, dim3(1), dim3(SCAN_BLOCK), 0, s, coarse_off, tile_start, S);
       hipLaunchKernelGGL(k_sort_l2_hist, dim3(l2_tiles_max), dim3(256), 0, s, pairs, coarse_off, tile_start, hist, S);
@@ -201,14 +205,15 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
       hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, offsets, cursor, scan_n);
       {
         const size_t lds2 = (size_t)(3 * (1u << S.fb) + 32) * 4 + (size_t)S.t2 * 4;
-        if (big_t2) hipLaunchKernelGGL(k_sort_l2_scatter<32>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
+        if (S.t2 == 8192) hipLaunchKernelGGL(k_sort_l2_scatter<8>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
+        else if (big_t2) hipLaunchKernelGGL(k_sort_l2_scatter<32>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
         else hipLaunchKernelGGL(k_sort_l2_scatter<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
       }
     }
     {
       Scope sc("msm_accumulate");
       HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
-      hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, P.n, shared ? pre->row_stride : (uint64_t)0);
+      hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, P.n, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask);
     }
     {
       Scope sc("msm_reduce");
@@ -371,11 +376,16 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
+  { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
+  { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384 || v == 32768) g.sort_t2 = (uint32_t)v; } }
+  { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
   g.inited = true;
   return MI355_OK;

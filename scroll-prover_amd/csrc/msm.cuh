@@ -273,7 +273,7 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
 // bucket_sums must be zero-filled (all-zero XYZZ = identity) before launch.
 __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
                                                         uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg,
-                                                        uint32_t n, uint64_t row_stride) {
+                                                        uint32_t n, uint64_t row_stride, uint32_t gather_mask) {
   const uint32_t total = offsets[nbuckets];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t start64 = (uint64_t)t * seg;
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__res
   // of entry pos, so the ~2 us random-access latency overlaps arithmetic instead of stalling one of only 4 waves per SIMD
   // row_stride != 0: entry index = w * n + i names row w of the precomputed table T[w][.] = 2^(c w) P (rows row_stride points apart)
   auto base_of = [&](uint32_t e) -> const g1_affine_t * {
-    const uint32_t gi = e & 0x7fffffffu;
+    const uint32_t gi = e & gather_mask;   // gather_mask = 0x7fffffff (index bits); smaller only in timing experiments
     if (row_stride == 0) return &bases[gi];
     const uint32_t w = gi / n;
     return &bases[(uint64_t)w * row_stride + (gi - w * n)];
