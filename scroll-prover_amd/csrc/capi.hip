@@ -64,7 +64,8 @@ struct Ctx {
   uint32_t sort_t2 = 8192;      // MI355_SORT_T2 = 8192 | 16384 | 32768
   uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
-  uint32_t ntt_tile_log = 12;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
+  uint32_t ntt_radix_log = 2;   // MI355_NTT_RADIX_LOG
+  uint32_t ntt_tile_log = 11;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
   bool ntt29 = true;   // unsaturated 29-bit NTT kernels (MI355_NTT_SAT=1 selects the saturated 8x32 ones for A/B runs)
   bool profiling = false;
   std::map<std::string, Prof> prof;
@@ -101,22 +102,23 @@ void resolve_spans() {
 // ------------------------------------------------------------------------------------------------ MSM
 uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// measured on MI355X, in units of one bucket addition (~0.077 ns at 13 G adds/s): sort ~0.18 per entry, bucket reduction ~8.2 per bucket
+// (the reduction kernels are latency-bound serial chains, far from the ALU rate)
+double msm_cost(uint64_t n, int c, bool shared) { const double W = (255 + c - 1) / c, nb = (double)(1ull << (c - 1)); return 1.18 * W * (double)n + 8.2 * nb * (shared ? 1.0 : W); }
+
 int choose_c(uint64_t n) {
   if (g.force_c) return g.force_c;
-  // cost model: n*W mixed additions + ~3 full additions per bucket (running sums + fix-up), full add ~1.4x mixed
   double best = 1e300; int best_c = 8;
   for (int c = 4; c <= 22; c++) {
     const double W = (255 + c - 1) / c, nb = (double)(1ull << (c - 1));
-    if (W * nb * sizeof(g1_xyzz_t) > 6.0e9) continue;
-    const double cost = W * ((double)n + 4.2 * nb);
+    if (W * nb * sizeof(g1_xyzz29_t) > 6.0e9) continue;
+    const double cost = msm_cost(n, c, false);
     if (cost < best) { best = cost; best_c = c; }
   }
   return best_c;
 }
 
 struct PreTable { const g1_affine_t *table = nullptr; uint64_t row_stride = 0; int c = 0, w = 0; };   // table already offset to the slice start
-
-double msm_cost(uint64_t n, int c, bool shared) { const double W = (255 + c - 1) / c, nb = (double)(1ull << (c - 1)); return shared ? W * (double)n + 4.2 * nb : W * ((double)n + 4.2 * nb); }
 
 int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void *out_host, const PreTable *pre = nullptr) {
   g1_jac_t result; memset(&result, 0, sizeof result);
@@ -136,9 +138,10 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   const uint32_t red_windows = shared ? 1 : P.windows;   // bucket sets to reduce
   const uint32_t acc_threads = ceil_div(emax, seg), acc_blocks = ceil_div(acc_threads, 256);
   const uint32_t tn = acc_blocks * 256;
+  // running-sum chunk per reduce thread: every thread is one serial chain of 2*chunk additions plus a ~(c-1)-bit scalar multiple, so the
+  // chain is kept short (the kernel is latency-bound) as long as there are enough buckets to give the GPU ~256k chains
   uint32_t chunk = 64; while (chunk > P.nb) chunk >>= 1;
-  // keep at least ~8k reduce threads busy when buckets are few, at most ~512k
-  while (chunk > 4 && (uint64_t)(P.nb / chunk) * red_windows < 16384) chunk >>= 1;
+  while (chunk > 8 && (uint64_t)(P.nb / chunk) * red_windows < 262144) chunk >>= 1;
   const uint32_t chunks_per_window = P.nb / chunk, nchunks = chunks_per_window * red_windows;
 
   // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest (<= 9)
@@ -174,6 +177,9 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   uint32_t *big_list; CHK(ws_get("msm.big_list", ((size_t)big_cap * 3 + 1) * 4, (void **)&big_list));
   uint32_t *big_count = big_list + (size_t)big_cap * 3;
   CHK(ws_get("msm.chunk_out", (size_t)nchunks * sizeof(g1_xyzz_t), (void **)&chunk_out));
+  g1_xyzz_t *tree_a, *tree_b;
+  { const size_t lvl = (size_t)ceil_div(chunks_per_window, 256 * TREE_PER_THREAD) * red_windows + 1;
+    CHK(ws_get("msm.tree_a", lvl * sizeof(g1_xyzz_t), (void **)&tree_a)); CHK(ws_get("msm.tree_b", lvl * sizeof(g1_xyzz_t), (void **)&tree_b)); }
   CHK(ws_get("msm.window_sums", (size_t)P.windows * sizeof(g1_xyzz_t), (void **)&window_sums));
   CHK(ws_get("msm.out", sizeof(g1_jac_t), (void **)&out_dev));
 
@@ -221,7 +227,17 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
       hipLaunchKernelGGL(k_msm_fixup, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap);
       hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
       { MsmPlan PR = P; PR.windows = red_windows; hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk); }
-      hipLaunchKernelGGL(k_msm_window_reduce, dim3(red_windows), dim3(256), 0, s, chunk_out, window_sums, chunks_per_window);
+      {
+        // tree-sum the chunk results per window, ping-ponging inside chunk_out's spare half
+        const g1_xyzz_t *cur = chunk_out; uint32_t cnt = chunks_per_window; g1_xyzz_t *bufs[2] = {tree_a, tree_b}; int which = 0;
+        while (true) {
+          const uint32_t outn = ceil_div(cnt, 256 * TREE_PER_THREAD);
+          g1_xyzz_t *dst = outn == 1 ? window_sums : bufs[which];
+          hipLaunchKernelGGL(k_msm_tree_sum, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
+          if (outn == 1) break;
+          cur = dst; cnt = outn; which ^= 1;
+        }
+      }
       hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, window_sums, red_windows, shared ? 0u : P.c, out_dev);
     }
   }
@@ -283,6 +299,14 @@ int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
   return MI355_OK;
 }
 
+// radix-2^R register rounds: R = g.ntt_radix_log (1..3); one work item per 2^R elements
+#define NTT29_LAUNCH(KERN, BLOCKS, TILE, LDS, ...)                                                                                          \
+  do {                                                                                                                                     \
+    if (g.ntt_radix_log == 3) hipLaunchKernelGGL(KERN<3>, dim3(BLOCKS), dim3(std::max(64u, std::min(512u, (TILE) / 8))), LDS, s, __VA_ARGS__);       \
+    else if (g.ntt_radix_log == 2) hipLaunchKernelGGL(KERN<2>, dim3(BLOCKS), dim3(std::max(64u, std::min(1024u, (TILE) / 4))), LDS, s, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERN<1>, dim3(BLOCKS), dim3(std::max(64u, std::min(1024u, (TILE) / 2))), LDS, s, __VA_ARGS__);                            \
+  } while (0)
+
 uint32_t cols_for(uint32_t log_m) { uint32_t lc = 3; while (lc > 0 && log_m + lc > g.ntt_tile_log) lc--; return lc; }
 
 // dst[2^log_n] = NTT_omega( pre3-scaled, zero-padded src[src_len] ), then optional post3 scaling.  src may equal dst.
@@ -309,7 +333,7 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
     const size_t lds = (size_t)2 * 16 * (tile + 1);
     Scope sc("ntt_pass");
-    if (g.ntt29) hipLaunchKernelGGL(k_ntt29_final, dim3(1), dim3(threads), (size_t)36 * (tile + 1), s, src, dst, lm, 0u, 0u, 0u, p->tw29_m[0], src_len, pre3, post3);
+    if (g.ntt29) NTT29_LAUNCH(k_ntt29_final, 1u, tile, (size_t)36 * (tile + 1), src, dst, lm, 0u, 0u, 0u, p->tw29_m[0], src_len, pre3, post3);
     else hipLaunchKernelGGL(k_ntt_final, dim3(1), dim3(threads), lds, s, src, dst, lm, 0u, 0u, 0u, p->tw_m[0], src_len, pre3, post3);
   } else {
     fe_t *scratch; CHK(ws_get("ntt.scratch", N * sizeof(fe_t), (void **)&scratch));
@@ -324,7 +348,7 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
       Scope sc("ntt_pass");
       if (g.ntt29) {
         Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l];
-        hipLaunchKernelGGL(k_ntt29_strided, dim3((uint32_t)blocks), dim3(threads), (size_t)36 * tile, s, cur, scratch, L9, lc, cur_len, cur_pre);
+        NTT29_LAUNCH(k_ntt29_strided, (uint32_t)blocks, tile, (size_t)36 * tile, cur, scratch, L9, lc, cur_len, cur_pre);
       } else
       hipLaunchKernelGGL(k_ntt_strided, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, scratch, L, lc, cur_len, cur_pre);
       cur = scratch; cur_len = N; cur_pre = nullptr; log_s -= L.log_m;
@@ -335,7 +359,7 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     const size_t lds = (size_t)2 * 16 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc);
     const uint64_t blocks = ((uint64_t)1 << log_b) << (log_a - lc);
     Scope sc("ntt_pass");
-    if (g.ntt29) hipLaunchKernelGGL(k_ntt29_final, dim3((uint32_t)blocks), dim3(threads), (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), s, cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
+    if (g.ntt29) NTT29_LAUNCH(k_ntt29_final, (uint32_t)blocks, tile, (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
     else hipLaunchKernelGGL(k_ntt_final, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, dst, lm, log_a, log_b, lc, p->tw_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
   }
   HIPCHK(hipGetLastError());
@@ -380,12 +404,17 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384 || v == 32768) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
+  { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
   g.inited = true;
   return MI355_OK;

@@ -380,15 +380,19 @@ __global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz29_t *__
   store_xyzz(&chunk_out[g], T);
 }
 // ---- 6b. per window: tree-sum of the chunk results (wavefront shuffles, then LDS across waves)
-__global__ void __launch_bounds__(256) k_msm_window_reduce(const g1_xyzz_t *__restrict__ chunk_out, g1_xyzz_t *__restrict__ window_sums, uint32_t chunks_per_window) {
+// ---- 6b. per window: tree-sum of the chunk results.  grid = (blocks, windows); a block folds up to 256 * TREE_PER_THREAD inputs
+//          (wavefront shuffles, then LDS across the 4 waves) into one output; launched repeatedly until one value per window is left.
+constexpr uint32_t TREE_PER_THREAD = 4;
+__global__ void __launch_bounds__(256) k_msm_tree_sum(const g1_xyzz_t *__restrict__ in, uint32_t in_per_window, g1_xyzz_t *__restrict__ out, uint32_t out_per_window) {
   __shared__ g1_xyzz_t lds[4];
-  const uint32_t w = blockIdx.x;
+  const uint32_t w = blockIdx.y, first = blockIdx.x * 256 * TREE_PER_THREAD;
+  const g1_xyzz_t *src = in + (uint64_t)w * in_per_window;
   g1_xyzz_t acc = g1_xyzz_identity();
-  for (uint32_t i = threadIdx.x; i < chunks_per_window; i += blockDim.x) g1_xyzz_add_ps(acc, load_xyzz(&chunk_out[(uint64_t)w * chunks_per_window + i]));
+  for (uint32_t k = 0; k < TREE_PER_THREAD; k++) { const uint32_t i = first + k * 256 + threadIdx.x; if (i < in_per_window) g1_xyzz_add_ps(acc, load_xyzz(&src[i])); }
   for (uint32_t o = 32; o >= 1; o >>= 1) { g1_xyzz_t other = shfl_down_xyzz(acc, o); g1_xyzz_add_ps(acc, other); }
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz_add_ps(acc, lds[k]); store_xyzz(&window_sums[w], acc); }
+  if (threadIdx.x == 0) { for (uint32_t k = 1; k < 4; k++) g1_xyzz_add_ps(acc, lds[k]); store_xyzz(&out[(uint64_t)w * out_per_window + blockIdx.x], acc); }
 }
 // ---- 7. Horner over windows + normalisation.  One lane; 255 doublings are inherently serial.
 __global__ void k_msm_final(const g1_xyzz_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out) {

@@ -46,23 +46,48 @@ __device__ __forceinline__ fe29_t fr29_sub64(const fe29_t &u, const fe29_t &v) {
 // canonical ABI element from a tight value (< 2r, exact limbs)
 __device__ __forceinline__ fe_t fr29_finish(const fe29_t &t) { return Fr29::to_sat_plain(Fr29::cond_sub_p(t)); }
 
-__device__ __forceinline__ void lds_dif29(const Lds29 &L, uint32_t log_m, uint32_t log_c, uint32_t sm, uint32_t sc, const Tw29 &tw_m, bool col_fast) {
-  const uint32_t M = 1u << log_m, C = 1u << log_c, nbf = (M >> 1) << log_c;
-  for (uint32_t s = 0; s < log_m; s++) {
-    const uint32_t log_h = log_m - 1 - s, h = 1u << log_h;
-    const bool reduce_now = (s == 4 || s == 9);
-    for (uint32_t b = threadIdx.x; b < nbf; b += blockDim.x) {
-      uint32_t c, j;
-      if (col_fast) { c = b & (C - 1); j = b >> log_c; } else { j = b & ((M >> 1) - 1); c = b >> (log_m - 1); }
-      const uint32_t jl = j & (h - 1), i0 = ((j >> log_h) << (log_h + 1)) | jl;
-      const uint32_t e0 = i0 * sm + c * sc, e1 = e0 + h * sm;
-      const fe29_t u = lds29_get(L, e0), v = lds29_get(L, e1);
-      fe29_t sum = Fr29::carry(Fr29::add(u, v));
-      if (reduce_now) sum = Fr29::reduce_small(Fr29::normalise(sum));
-      const fe29_t dif = Fr29::mul(fr29_sub64(u, v), tw29_load(tw_m, jl << s));
-      lds29_put(L, e0, sum); lds29_put(L, e1, dif);
+// One round = R consecutive radix-2 DIF stages done in registers: a work item owns the 2^R elements that differ only in the
+// R index bits those stages pair up, so the tile makes one LDS round trip and one barrier per R stages (3 per 9-stage tile
+// instead of 9) and each lane carries 2^(R-1) independent multiplications per stage (ILP instead of occupancy).
+template <int R> __device__ __forceinline__ void lds_dif29_round(const Lds29 &L, uint32_t log_m, uint32_t log_c, uint32_t sm, uint32_t sc,
+                                                                const Tw29 &tw_m, bool col_fast, uint32_t s0) {
+  constexpr uint32_t Q = 1u << R;
+  const uint32_t M = 1u << log_m, C = 1u << log_c, b_lo = log_m - s0 - R, items = (M >> R) << log_c;
+  for (uint32_t g = threadIdx.x; g < items; g += blockDim.x) {
+    uint32_t c, rest;
+    if (col_fast) { c = g & (C - 1); rest = g >> log_c; } else { rest = g & ((M >> R) - 1); c = g >> (log_m - R); }
+    const uint32_t low = rest & ((1u << b_lo) - 1), base = ((rest >> b_lo) << (b_lo + R)) | low;
+    fe29_t x[Q];
+#pragma unroll
+    for (uint32_t q = 0; q < Q; q++) x[q] = lds29_get(L, (base | (q << b_lo)) * sm + c * sc);
+#pragma unroll
+    for (int t = 0; t < R; t++) {
+      const uint32_t stage = s0 + t, bit = R - 1 - t;
+      const bool reduce_now = (stage == 4 || stage == 9);
+#pragma unroll
+      for (uint32_t q0 = 0; q0 < Q; q0++) {
+        if (q0 & (1u << bit)) continue;
+        const uint32_t q1 = q0 | (1u << bit);
+        const uint32_t jl = low | ((q0 & ((1u << bit) - 1)) << b_lo);      // index bits below the paired bit
+        const fe29_t u = x[q0], v = x[q1];
+        fe29_t sum = Fr29::carry(Fr29::add(u, v));
+        if (reduce_now) sum = Fr29::reduce_small(Fr29::normalise(sum));
+        x[q1] = Fr29::mul(fr29_sub64(u, v), tw29_load(tw_m, jl << stage));
+        x[q0] = sum;
+      }
     }
-    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < Q; q++) lds29_put(L, (base | (q << b_lo)) * sm + c * sc, x[q]);
+  }
+  __syncthreads();
+}
+template <int RMAX> __device__ __forceinline__ void lds_dif29(const Lds29 &L, uint32_t log_m, uint32_t log_c, uint32_t sm, uint32_t sc, const Tw29 &tw_m, bool col_fast) {
+  uint32_t s = 0;
+  while (s < log_m) {
+    const uint32_t left = log_m - s;
+    if (RMAX >= 3 && left >= 3 && left != 4) { lds_dif29_round<3>(L, log_m, log_c, sm, sc, tw_m, col_fast, s); s += 3; }
+    else if (RMAX >= 2 && left >= 2) { lds_dif29_round<2>(L, log_m, log_c, sm, sc, tw_m, col_fast, s); s += 2; }
+    else { lds_dif29_round<1>(L, log_m, log_c, sm, sc, tw_m, col_fast, s); s += 1; }
   }
 }
 __device__ __forceinline__ fe29_t load_input29(const fe_t *__restrict__ src, uint64_t gi, uint64_t src_len, const fe_t *__restrict__ pre3) {
@@ -72,7 +97,7 @@ __device__ __forceinline__ fe29_t load_input29(const fe_t *__restrict__ src, uin
   return v;
 }
 
-__global__ void __launch_bounds__(1024) k_ntt29_strided(const fe_t *__restrict__ src, fe_t *__restrict__ dst, Ntt29Level L, uint32_t log_c,
+template <int RMAX> __global__ void __launch_bounds__(RMAX == 3 ? 512 : 1024) k_ntt29_strided(const fe_t *__restrict__ src, fe_t *__restrict__ dst, Ntt29Level L, uint32_t log_c,
                                                         uint64_t src_len, const fe_t *__restrict__ pre3) {
   extern __shared__ uint4 lds[];
   const uint32_t M = 1u << L.log_m, C = 1u << log_c, tile = M << log_c;
@@ -86,7 +111,7 @@ __global__ void __launch_bounds__(1024) k_ntt29_strided(const fe_t *__restrict__
     lds29_put(S, e, load_input29(src, base + ((uint64_t)m << L.log_t) + c, src_len, pre3));
   }
   __syncthreads();
-  lds_dif29(S, L.log_m, log_c, C, 1, L.tw_m, true);
+  lds_dif29<RMAX>(S, L.log_m, log_c, C, 1, L.tw_m, true);
   const uint32_t smask = (1u << L.split) - 1;
   for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
     const uint32_t c = e & (C - 1), k = e >> log_c;
@@ -97,7 +122,7 @@ __global__ void __launch_bounds__(1024) k_ntt29_strided(const fe_t *__restrict__
   }
 }
 
-__global__ void __launch_bounds__(1024) k_ntt29_final(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint32_t log_m, uint32_t log_a, uint32_t log_b,
+template <int RMAX> __global__ void __launch_bounds__(RMAX == 3 ? 512 : 1024) k_ntt29_final(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint32_t log_m, uint32_t log_a, uint32_t log_b,
                                                       uint32_t log_c, Tw29 tw_m, uint64_t src_len, const fe_t *__restrict__ pre3, const fe_t *__restrict__ post3) {
   extern __shared__ uint4 lds[];
   const uint32_t M = 1u << log_m, C = 1u << log_c, seg = M + 1, tile = M << log_c;
@@ -110,7 +135,7 @@ __global__ void __launch_bounds__(1024) k_ntt29_final(const fe_t *__restrict__ s
     lds29_put(S, c * seg + m, load_input29(src, (q << log_m) + m, src_len, pre3));
   }
   __syncthreads();
-  lds_dif29(S, log_m, log_c, 1, seg, tw_m, false);
+  lds_dif29<RMAX>(S, log_m, log_c, 1, seg, tw_m, false);
   const uint32_t log_stride = log_a + log_b;  // N / M
   fe29_t post0 = Fr29::zero(), post1 = post0, post2 = post0;   // named (not an array): runtime-indexed arrays go to scratch
   if (post3) { post0 = Fr29::reduce_small(Fr29::from_sat(g_load(&post3[0]))); post1 = Fr29::reduce_small(Fr29::from_sat(g_load(&post3[1]))); post2 = Fr29::reduce_small(Fr29::from_sat(g_load(&post3[2]))); }   // c * 2^261, tight
