@@ -214,6 +214,15 @@ def main() -> None:
                "roofline": {"bound": "hbm", "achieved": 64.0 * (1 << k) / dt_ntt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": 64.0 * (1 << k) / dt_ntt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "note": "algorithmic bytes = 64*N per transform (SURVEY 8d); whole-transform time, all passes"}}
+        # eval_polynomial (step 9 of create_proof): streaming, 1 multiplication per 32-byte coefficient -> the HBM-bound kernel of the path
+        pt = h2.fr(0x1234567890ABCDEF)
+        h2.eval_polynomial(poly, pt)
+        torch.cuda.synchronize(); t5 = time.perf_counter()
+        for _ in range(5):
+            h2.eval_polynomial(poly, pt)
+        dt_ev = (time.perf_counter() - t5) / 5
+        ntt["eval_polynomial"] = {"log_n": k, "ms": dt_ev * 1e3, "roofline": {"bound": "hbm", "achieved": 32.0 * (1 << k) / dt_ev / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": 32.0 * (1 << k) / dt_ev / 1e9 / HBM_PEAK_GBS, "note": "algorithmic bytes = 32 B per coefficient, host wall time incl. the 32-byte result copy"}}
         del poly
 
     extra = {}

@@ -107,6 +107,11 @@ int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *
 int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv,
                                 const void *extended_omega_inv, const void *extended_ifft_divisor);
 
+/* ---- halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i  (the evaluations written to the
+ *      transcript in step 9 of create_proof); out_fr_host receives 32 B.  First widening into SURVEY 8f-3.   */
+int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host);
+int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *point, void *out_fr_host);
+
 /* ---- synthetic SRS: ParamsKZG::setup(k, rng) restated on the device [poly/kzg/commitment.rs]:
  *      g[i] = tau^i G,  g_lagrange[i] = L_i(tau) G.  Writes n = 2^k affine points per basis to device memory.   */
 int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const void *tau, const void *omega);

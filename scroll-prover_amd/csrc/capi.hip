@@ -668,6 +668,39 @@ int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *
   return MI355_OK;
 }
 
+// ---- eval_polynomial
+int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!out_fr_host || !point || (n && !poly_dev)) return fail(MI355_EBADARG, "eval_polynomial: null pointer");
+  fe_t res = Fr::zero();
+  if (n == 0) { memcpy(out_fr_host, &res, 32); return MI355_OK; }
+  fe_t x; memcpy(&x, point, 32);
+  const uint32_t blocks = ceil_div(n, (uint64_t)EVAL_RUN * 256);
+  fe_t *partial; CHK(ws_get("eval.partial", ((size_t)blocks + 1) * sizeof(fe_t), (void **)&partial));
+  {
+    Scope sc("eval_poly");
+    hipLaunchKernelGGL(k_eval_poly_partial, dim3(blocks), dim3(256), 0, g.stream, (const fe_t *)poly_dev, n, x, partial);
+    hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, g.stream, partial, (uint64_t)blocks, partial + blocks);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&res, partial + blocks, sizeof res, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  resolve_spans();
+  memcpy(out_fr_host, &res, 32);
+  return MI355_OK;
+}
+int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *point, void *out_fr_host) {
+  void *dev = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    CHK(need_init());
+    if (n && !poly_host) return fail(MI355_EBADARG, "eval_polynomial: null pointer");
+    if (n) { CHK(ws_get("io.ntt", n * sizeof(fe_t), &dev)); HIPCHK(hipMemcpyAsync(dev, poly_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
+  }
+  return mi355_eval_polynomial_dev(dev, n, point, out_fr_host);
+}
+
 // ---- synthetic SRS
 static int ensure_fixed_base_table() {
   if (g.fixed_base_table) return MI355_OK;

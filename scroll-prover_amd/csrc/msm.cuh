@@ -3,18 +3,18 @@
 // (SURVEY.md §8a a1/a2).  The result is a group element, so any correct schedule is bit-exact with the CPU
 // path after normalisation; what differs from the CPU reference is the schedule:
 //
-//   1 k_msm_digits      scalars (Montgomery) -> canonical -> signed c-bit digits d in [-2^(c-1), 2^(c-1)],
-//                       digit plane [w][i] (coalesced), per-(window,bucket) histogram (atomics)
-//   2 scan              exclusive prefix sum of the W * 2^(c-1) histogram -> bucket offsets
-//   3 k_msm_scatter     counting-sort scatter of point indices (sign in bit 31) into bucket order
-//   4 k_msm_accumulate  SEGMENTED bucket accumulation: thread t owns entries [t*L, (t+1)*L) of the sorted
-//                       list whatever bucket boundaries fall inside, keeps an XYZZ accumulator in registers,
-//                       gathers affine bases (64 B each) and does mixed additions.  Perfectly load-balanced
-//                       for any scalar distribution (witness columns are mostly 0/1/small values).
-//   5 k_msm_fixup       buckets that straddle thread boundaries: sum their partials
-//   6 k_msm_bucket_reduce / k_msm_window_reduce   sum_b (b+1) * B[w][b] by chunked running sums, then a
-//                       wavefront-shuffle + LDS tree per window
-//   7 k_msm_final       Horner over windows (c doublings each), normalise to (x, y, 1)
+//   0 k_srs_precompute  (optional, once per basis) T[w][i] = 2^(c w) P_i: all windows then share ONE bucket set
+//   1 k_msm_digits      scalars (Montgomery) -> canonical -> signed c-bit digits d in [-2^(c-1), 2^(c-1)], digit plane [w][i]
+//   2 k_sort_l1_* / k_sort_l2_*   two-level counting sort of (window, bucket) keys: LDS histograms + LDS-staged coalesced
+//                       stores, one global atomic per (tile, non-empty bin); exclusive scans give the bucket offsets
+//   3 k_msm_accumulate  SEGMENTED bucket accumulation: thread t owns entries [t*L, (t+1)*L) of the sorted list whatever
+//                       bucket boundaries fall inside, keeps a 9x29-bit XYZZ accumulator in registers, gathers affine
+//                       bases (64 B each) and does mixed additions.  Perfectly load-balanced for any scalar
+//                       distribution (witness columns are mostly 0/1/small values).
+//   4 k_msm_fixup(_big) buckets that straddle thread boundaries: sum their partials (one lane, or a workgroup for giant ones)
+//   5 k_msm_bucket_reduce / k_msm_tree_sum   sum_b (b+1) * B[b] by short chunked running sums, then multi-block
+//                       wavefront-shuffle + LDS trees
+//   6 k_msm_final       Horner over windows (none with window tables), normalise to (x, y, 1)
 //
 // Algorithmic HBM bytes: 96 B per (scalar, point) pair.  The kernel is VALU-integer bound
 // (~11 field multiplications x ~300 instructions per mixed addition), see DESIGN.md.

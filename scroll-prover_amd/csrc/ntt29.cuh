@@ -150,6 +150,69 @@ template <int RMAX> __global__ void __launch_bounds__(RMAX == 3 ? 512 : 1024) k_
   }
 }
 
+// ---- eval_polynomial (halo2_proofs::arithmetic::eval_polynomial, step 9 of create_proof: evaluations at x * omega^rot):
+// p(x) = sum_i c_i x^i as a streaming reduction: each thread runs Horner over a contiguous run of EVAL_RUN coefficients
+// (one multiplication per 32-byte coefficient read: the one kernel of the path that is close to HBM-bound), scales by
+// x^(start of run), then the block sums its values (wavefront shuffles + LDS) into one partial per block.
+constexpr uint32_t EVAL_RUN = 64;   // coefficients per thread; a block covers 256 * EVAL_RUN consecutive coefficients
+__device__ __forceinline__ fe29_t shfl_down_fe29(const fe29_t &v, uint32_t o) { fe29_t r; for (int i = 0; i < 9; i++) r.l[i] = __shfl_down(v.l[i], o); return r; }
+__device__ __forceinline__ fe29_t fr29_pow_u64(const fe29_t &x, uint64_t e) {
+  fe29_t r = Fr29::one(), sq = x;
+  while (e) { if (e & 1) r = Fr29::mul(r, sq); e >>= 1; if (e) sq = Fr29::sqr(sq); }
+  return r;
+}
+// Thread t of a block takes the coefficients base + t + 256 k (k < EVAL_RUN): loads are coalesced (consecutive lanes, consecutive
+// 32-byte coefficients) and every thread runs Horner in the SAME y = x^256, so the per-coefficient cost is one multiplication;
+// the thread-specific factor x^t and the block factor x^base (computed once per block, broadcast through LDS) are applied at the end.
+__global__ void __launch_bounds__(256) k_eval_poly_partial(const fe_t *__restrict__ poly, uint64_t n, fe_t x_sat, fe_t *__restrict__ partial) {
+  __shared__ uint32_t lds[5][9];
+  const uint64_t base = (uint64_t)blockIdx.x * 256 * EVAL_RUN;
+  const fe29_t x = Fr29::reduce_small(Fr29::from_sat(x_sat));          // x * 2^261, tight
+  if (threadIdx.x < 64) {                                               // wave 0: x^base for the whole block (all lanes compute the same value)
+    const fe29_t xb = fr29_pow_u64(x, base);
+    if (threadIdx.x == 0) for (int k = 0; k < 9; k++) lds[4][k] = xb.l[k];
+  }
+  fe29_t y = x;
+#pragma unroll
+  for (int i = 0; i < 8; i++) y = Fr29::sqr(y);                        // x^256
+  fe29_t acc = Fr29::zero();
+  bool any = false;
+  for (int k = EVAL_RUN - 1; k >= 0; k--) {
+    const uint64_t i = base + threadIdx.x + 256ull * (uint32_t)k;
+    if (any) acc = Fr29::mul(acc, y);                                  // tight, < 1.3 r
+    if (i < n) {
+      const fe29_t c = Fr29::from_sat_plain(g_load(&poly[i]));         // ABI domain (c * 2^256); products with x-powers keep it
+      for (int q = 0; q < 9; q++) acc.l[q] += c.l[q];                  // lazy add: limbs < 2^30, value < 2.3 r
+      any = true;
+    }
+  }
+  acc = Fr29::mul(acc, fr29_pow_u64(x, threadIdx.x));                  // * x^t (<= 8 squarings + multiplications)
+  __syncthreads();
+  { fe29_t xb; for (int k = 0; k < 9; k++) xb.l[k] = lds[4][k]; acc = Fr29::mul(acc, xb); }   // * x^base, tight
+  for (uint32_t o = 32; o >= 1; o >>= 1) {
+    const fe29_t other = shfl_down_fe29(acc, o);
+    acc = Fr29::carry(Fr29::add(acc, other));
+    if (o == 4) acc = Fr29::reduce_small(Fr29::normalise(acc));         // after 4 doublings: < 16 * 1.3 r -> < 2 r
+  }
+  acc = Fr29::reduce_small(Fr29::normalise(acc));                       // < 8 * 2 r -> < 2 r
+  if ((threadIdx.x & 63) == 0) for (int k = 0; k < 9; k++) lds[threadIdx.x >> 6][k] = acc.l[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t w = 1; w < 4; w++) { fe29_t o; for (int k = 0; k < 9; k++) o.l[k] = lds[w][k]; acc = Fr29::carry(Fr29::add(acc, o)); }
+    g_store(&partial[blockIdx.x], fr29_finish(Fr29::reduce_small(Fr29::normalise(acc))));   // canonical, ABI domain
+  }
+}
+// sum of m canonical field elements (the per-block partials) by one workgroup
+__global__ void __launch_bounds__(256) k_fr_sum(const fe_t *__restrict__ in, uint64_t m, fe_t *__restrict__ out) {
+  __shared__ fe_t lds[4];
+  fe_t acc = Fr::zero();
+  for (uint64_t i = threadIdx.x; i < m; i += blockDim.x) acc = Fr::add(acc, g_load(&in[i]));
+  for (uint32_t o = 32; o >= 1; o >>= 1) { fe_t other; for (int k = 0; k < 8; k++) other.l[k] = __shfl_down(acc.l[k], o); acc = Fr::add(acc, other); }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (uint32_t w = 1; w < 4; w++) acc = Fr::add(acc, lds[w]); g_store(out, acc); }
+}
+
 // SoA twiddle table: entry i = (base^step)^i * 2^261 mod r, canonical 29-bit limbs
 __global__ void k_pow_table29(uint4 *lo, uint4 *hi, uint32_t *top, fe_t base, uint64_t step, uint32_t count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -70,6 +70,18 @@ def best_fft(a, omega: np.ndarray, log_n: int) -> None:
         check(lib().mi355_ntt_fr_host(ptr(a), log_n, ptr(omega)))
 
 
+def eval_polynomial(poly, point: np.ndarray) -> np.ndarray:
+    """halo2_proofs::arithmetic::eval_polynomial: sum_i poly[i] * point^i -> Fr (4 x u64 Montgomery limbs)."""
+    out = np.zeros(4, dtype=np.uint64)
+    if _is_device(poly):
+        n = poly.numel() * poly.element_size() // 32
+        check(lib().mi355_eval_polynomial_dev(ptr(poly), n, ptr(point), ptr(out)))
+    else:
+        poly = np.ascontiguousarray(poly, dtype=np.uint64)
+        check(lib().mi355_eval_polynomial_host(ptr(poly), poly.shape[0], ptr(point), ptr(out)))
+    return out
+
+
 def g1_sum(points: np.ndarray) -> np.ndarray:
     """fold of per-GPU partial results: results.iter().fold(identity, |a, b| a + b)."""
     points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)

@@ -286,3 +286,15 @@ def test_precomputed_window_tables_and_shared_bucket_msm(zk, points, c):
         got = affine_of(h2.best_multiexp(sc, params.g_lagrange_slice(0, n)))
         assert (got == cref.g1_to_affine(cref.best_multiexp(sc, pts[::-1].copy()))).all()
     params.release()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 255, 4096, 4097, 100003, 1 << 20])
+def test_eval_polynomial_matches_oracle(zk, n):
+    h2 = zk.halo2
+    rng = np.random.default_rng(500 + n)
+    poly = rand_fr(rng, n) if n else np.zeros((0, 4), dtype=np.uint64)
+    for x in (0, 1, 0x1234567, R - 1, pyref.omega(20)):
+        pt = h2.fr(x)
+        got = h2.eval_polynomial(poly, pt)
+        want = cref.eval_polynomial(poly, pt) if n else cref.fr_mont(0)
+        assert (got == want).all(), (n, x)
