@@ -220,6 +220,44 @@ class ParamsKZG:
         self._owner = None
 
 
+# ------------------------------------------------------------------------------------------ params files (SerdeFormat::RawBytes)
+def params_file_size(k: int) -> int:
+    """`u32 LE k | g[2^k] x 64 B | g_lagrange[2^k] x 64 B | g2 128 B | s_g2 128 B` [EXT-recalled ParamsKZG::write_custom, RawBytes];
+    params26 = 8 589 934 852 bytes (SURVEY 6).  `prover::load_params` rejects any other length."""
+    return 4 + 2 * (1 << k) * 64 + 256
+
+
+def write_params(path: str, k: int, g: np.ndarray, g_lagrange: np.ndarray, g2: bytes = bytes(128), s_g2: bytes = bytes(128)) -> None:
+    g = np.ascontiguousarray(g, dtype=np.uint64); g_lagrange = np.ascontiguousarray(g_lagrange, dtype=np.uint64)
+    assert g.shape == (1 << k, 8) and g_lagrange.shape == (1 << k, 8) and len(g2) == 128 and len(s_g2) == 128
+    with open(path, "wb") as f:
+        f.write(int(k).to_bytes(4, "little")); f.write(g.tobytes()); f.write(g_lagrange.tobytes()); f.write(g2); f.write(s_g2)
+
+
+def read_params(path: str):
+    """-> (k, g [n,8], g_lagrange [n,8], g2 bytes, s_g2 bytes); memory-mapped so a params26 file is not copied twice."""
+    import os
+    size = os.path.getsize(path)
+    with open(path, "rb") as f:
+        k = int.from_bytes(f.read(4), "little")
+    if not (0 < k <= FR_S) or size != params_file_size(k):
+        raise ValueError(f"{path}: not a RawBytes params file (k={k}, {size} bytes, expected {params_file_size(k) if 0 < k <= FR_S else 'n/a'})")
+    n = 1 << k
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    g = mm[4: 4 + n * 64].view(np.uint64).reshape(n, 8)
+    gl = mm[4 + n * 64: 4 + 2 * n * 64].view(np.uint64).reshape(n, 8)
+    tail = bytes(mm[4 + 2 * n * 64:])
+    return k, g, gl, tail[:128], tail[128:]
+
+
+def params_from_file(path: str) -> "ParamsKZG":
+    """Prover::load_params [REF bin/src/trace_prover.rs:35-36] for one degree: parse the file and register both bases in HBM."""
+    k, g, gl, g2, s_g2 = read_params(path)
+    p = ParamsKZG.from_host(k, np.ascontiguousarray(g), np.ascontiguousarray(gl))
+    p.g2, p.s_g2 = g2, s_g2
+    return p
+
+
 class _Scalars:
     """adapter giving device tensors the `.shape[0]` best_multiexp expects"""
 

@@ -298,3 +298,52 @@ def test_eval_polynomial_matches_oracle(zk, n):
         got = h2.eval_polynomial(poly, pt)
         want = cref.eval_polynomial(poly, pt) if n else cref.fr_mont(0)
         assert (got == want).all(), (n, x)
+
+
+def test_concurrent_callers_are_serialised_correctly(zk, points):
+    """SURVEY 8b threading: rayon workers may issue commits concurrently -> entry points must be re-entrant."""
+    import threading
+    h2 = zk.halo2
+    rng = np.random.default_rng(99)
+    jobs = []
+    for t in range(6):
+        n = 200 + 37 * t
+        sc = rand_fr(rng, n)
+        k = 6 + t
+        a = rand_fr(rng, 1 << k)
+        jobs.append((sc, points[:n], a, k))
+    out = [None] * len(jobs)
+
+    def work(i):
+        sc, pts, a, k = jobs[i]
+        res = []
+        for _ in range(3):
+            m = affine_of(h2.best_multiexp(sc, pts))
+            b = a.copy(); h2.best_fft(b, h2.fr(pyref.omega(k)), k)
+            res.append((m, b))
+        out[i] = res
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in th: t.start()
+    for t in th: t.join()
+    for i, (sc, pts, a, k) in enumerate(jobs):
+        want_m = cref.g1_to_affine(cref.best_multiexp(sc, pts)); want_f = cref.best_fft(a, h2.fr(pyref.omega(k)), k)
+        for m, b in out[i]:
+            assert (m == want_m).all() and (b == want_f).all()
+
+
+def test_error_paths_do_not_crash(zk, points):
+    lib, capi = zk._capi.lib(), zk._capi
+    out = np.zeros(12, dtype=np.uint64); sc = rand_fr(np.random.default_rng(1), 8)
+    assert lib.mi355_msm_g1_host(424242, 0, capi.ptr(sc), 8, capi.ptr(out)) == capi.EBADARG and b"handle" in lib.mi355_last_error()
+    assert lib.mi355_msm_g1_adhoc_host(None, capi.ptr(sc), 8, capi.ptr(out)) == capi.EBADARG
+    assert lib.mi355_ntt_fr_host(capi.ptr(sc), 29, capi.ptr(sc[0])) == capi.EBADARG            # beyond the two-adicity of Fr
+    assert lib.mi355_ntt_fr_host(None, 3, capi.ptr(sc[0])) == capi.EBADARG
+    assert lib.mi355_msm_set_window_bits(40) == capi.EBADARG
+    assert lib.mi355_srs_release(424242) == capi.EBADARG
+    assert lib.mi355_srs_precompute(424242, 0, 0) == capi.EBADARG
+    # n == 0: identity / no-op, as best_multiexp on empty slices
+    assert lib.mi355_msm_g1_adhoc_host(capi.ptr(points[:1]), capi.ptr(sc), 0, capi.ptr(out)) == capi.OK and (out == 0).all()
+    # a working call still works afterwards
+    got = affine_of(zk.halo2.best_multiexp(sc, points[:8]))
+    assert (got == cref.g1_to_affine(cref.best_multiexp(sc, points[:8]))).all()

@@ -48,3 +48,20 @@ def test_shard_ranges(zk):
             assert all(cover[i][1] == cover[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in cover]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_params_file_format_roundtrip(zk, tmp_path):
+    """SerdeFormat::RawBytes layout of params{k} (SURVEY 8a-0) and the exact-length rule of prover::load_params."""
+    h2 = zk.halo2
+    assert h2.params_file_size(26) == 8589934852 and h2.params_file_size(20) == 134217988   # the sizes behind [REF params-sha256sum:1-5]
+    k = 3
+    g, gl, _, _ = cref.srs_setup(k, cref.fr_mont(0xABCDEF), cref.fr_mont(pyref.omega(k)))
+    path = str(tmp_path / "params3")
+    g2, s_g2 = bytes(range(128)), bytes(range(128, 256))
+    h2.write_params(path, k, g, gl, g2, s_g2)
+    k2, a, b, c, d = h2.read_params(path)
+    assert k2 == k and (a == g).all() and (b == gl).all() and c == g2 and d == s_g2
+    with open(path, "ab") as f:
+        f.write(b"\\0")
+    with pytest.raises(ValueError):
+        h2.read_params(path)
