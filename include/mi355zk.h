@@ -107,6 +107,11 @@ int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *
 int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv,
                                 const void *extended_omega_inv, const void *extended_ifft_divisor);
 
+/* distribute_powers: a[i] *= factor^i (in place), and the general coset transform dst = best_fft(coeffs[i] * coset_factor^i, omega):
+ * what `coeff_to_extended_part(poly, g_coset * extended_omega^j)` of the scroll fork does per quotient part [EXT-recalled domain.rs]. */
+int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *factor);
+int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, const void *coset_factor, const void *omega);
+
 /* ---- halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i  (the evaluations written to the
  *      transcript in step 9 of create_proof); out_fr_host receives 32 B.  First widening into SURVEY 8f-3.   */
 int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host);

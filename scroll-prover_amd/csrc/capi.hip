@@ -668,6 +668,28 @@ int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *
   return MI355_OK;
 }
 
+// ---- distribute_powers / coset NTT
+int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *factor) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!factor || (n && !data_dev)) return fail(MI355_EBADARG, "distribute_powers: null pointer");
+  if (n == 0) return MI355_OK;
+  fe_t f; memcpy(&f, factor, 32);
+  hipLaunchKernelGGL(k_distribute_powers, dim3(ceil_div(n, (uint64_t)EVAL_RUN * 256)), dim3(256), 0, g.stream, (fe_t *)data_dev, n, f);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, const void *coset_factor, const void *omega) {
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    CHK(need_init()); CHK(check_ntt_args(dst_dev, log_n, omega));
+    if (!coeffs_dev || !coset_factor) return fail(MI355_EBADARG, "coset_ntt: null pointer");
+    if (dst_dev != coeffs_dev) HIPCHK(hipMemcpyAsync(dst_dev, coeffs_dev, sizeof(fe_t) << log_n, hipMemcpyDeviceToDevice, g.stream));
+  }
+  CHK(mi355_distribute_powers_fr_dev(dst_dev, 1ull << log_n, coset_factor));
+  return mi355_ntt_fr_dev(dst_dev, log_n, omega);
+}
+
 // ---- eval_polynomial
 int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host) {
   std::lock_guard<std::mutex> lk(g.mu);

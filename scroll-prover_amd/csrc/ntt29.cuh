@@ -202,6 +202,27 @@ __global__ void __launch_bounds__(256) k_eval_poly_partial(const fe_t *__restric
     g_store(&partial[blockIdx.x], fr29_finish(Fr29::reduce_small(Fr29::normalise(acc))));   // canonical, ABI domain
   }
 }
+// a[i] *= f^i  (halo2_proofs distribute_powers: the coset shift of coeff_to_extended_part / general coset FFTs).
+// Same tiling as k_eval_poly_partial: thread t walks i = base + t + 256 k with a running power stepped by f^256.
+__global__ void __launch_bounds__(256) k_distribute_powers(fe_t *__restrict__ a, uint64_t n, fe_t f_sat) {
+  __shared__ uint32_t lds[9];
+  const uint64_t base = (uint64_t)blockIdx.x * 256 * EVAL_RUN;
+  const fe29_t f = Fr29::reduce_small(Fr29::from_sat(f_sat));
+  if (threadIdx.x < 64) { const fe29_t fb = fr29_pow_u64(f, base); if (threadIdx.x == 0) for (int k = 0; k < 9; k++) lds[k] = fb.l[k]; }
+  fe29_t y = f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) y = Fr29::sqr(y);                        // f^256
+  fe29_t pw = fr29_pow_u64(f, threadIdx.x);
+  __syncthreads();
+  { fe29_t fb; for (int k = 0; k < 9; k++) fb.l[k] = lds[k]; pw = Fr29::mul(pw, fb); }   // f^(base + t), tight
+  for (uint32_t k = 0; k < EVAL_RUN; k++) {
+    const uint64_t i = base + threadIdx.x + 256ull * k;
+    if (i >= n) break;
+    g_store(&a[i], fr29_finish(Fr29::mul(Fr29::from_sat_plain(g_load(&a[i])), pw)));
+    pw = Fr29::mul(pw, y);
+  }
+}
+
 // sum of m canonical field elements (the per-block partials) by one workgroup
 __global__ void __launch_bounds__(256) k_fr_sum(const fe_t *__restrict__ in, uint64_t m, fe_t *__restrict__ out) {
   __shared__ fe_t lds[4];

@@ -136,6 +136,13 @@ class EvaluationDomain:
         check(lib().mi355_coeff_to_extended_host(ptr(dst), ptr(np.ascontiguousarray(a)), self.k, self.extended_k, ptr(self.g_coset), ptr(self.g_coset_inv), ptr(self.extended_omega)))
         return dst
 
+    def coeff_to_extended_part(self, a, part: int, out):
+        """scroll-fork style: evaluations of the 2^k coefficients on the coset (g_coset * extended_omega^part) * H  (device tensors)."""
+        assert _is_device(a) and _is_device(out)
+        factor = fr(FR_ZETA * pow(self._extended_omega, part, R_MOD) % R_MOD)
+        check(lib().mi355_coset_ntt_fr_dev(ptr(out), ptr(a), self.k, ptr(factor), ptr(self.omega)))
+        return out
+
     def extended_to_coeff(self, a):
         """inverse of coeff_to_extended, truncated to n * quotient_poly_degree coefficients (host) / in place (device, caller truncates)."""
         if _is_device(a):

@@ -347,3 +347,29 @@ def test_error_paths_do_not_crash(zk, points):
     # a working call still works afterwards
     got = affine_of(zk.halo2.best_multiexp(sc, points[:8]))
     assert (got == cref.g1_to_affine(cref.best_multiexp(sc, points[:8]))).all()
+
+
+@pytest.mark.parametrize("k", [3, 9, 14, 17])
+def test_coset_parts_equal_the_extended_domain(zk, k):
+    """distribute_powers + NTT on the coset (zeta * w_ext^j) H must reproduce the interleaved rows of coeff_to_extended:
+    ext[q * j_stride ...]: evaluation at zeta * w_ext^(j + Q i) for the i-th point of part j (w_ext^Q = w)."""
+    import torch
+    h2 = zk.halo2
+    rng = np.random.default_rng(800 + k)
+    dom = h2.EvaluationDomain(5, k)            # extended_k = k + 2, Q = 4 parts
+    Q = 1 << (dom.extended_k - k)
+    coeffs = rand_fr(rng, 1 << k)
+    ext = dom.coeff_to_extended(coeffs)         # oracle-checked elsewhere
+    cd = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    out = torch.empty_like(cd)
+    for j in range(Q):
+        dom.coeff_to_extended_part(cd, j, out)
+        got = out.cpu().numpy().view(np.uint64)
+        assert (got == ext[j::Q]).all(), j
+    # distribute_powers alone against the oracle
+    f = 0x9876543210FEDCBA
+    d = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    zk._capi.check(zk._capi.lib().mi355_distribute_powers_fr_dev(zk._capi.ptr(d), 1 << k, zk._capi.ptr(h2.fr(f))))
+    got = d.cpu().numpy().view(np.uint64)
+    pw = np.stack([h2.fr(pow(f, i, R)) for i in range(min(1 << k, 600))])
+    assert (got[: pw.shape[0]] == cref.f_mul_vec(cref.FR, coeffs[: pw.shape[0]], pw)).all()
