@@ -303,7 +303,7 @@ int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
 #define NTT29_LAUNCH(KERN, BLOCKS, TILE, LDS, ...)                                                                                          \
   do {                                                                                                                                     \
     if (g.ntt_radix_log == 3) hipLaunchKernelGGL(KERN<3>, dim3(BLOCKS), dim3(std::max(64u, std::min(512u, (TILE) / 8))), LDS, s, __VA_ARGS__);       \
-    else if (g.ntt_radix_log == 2) hipLaunchKernelGGL(KERN<2>, dim3(BLOCKS), dim3(std::max(64u, std::min(1024u, (TILE) / 4))), LDS, s, __VA_ARGS__); \
+    else if (g.ntt_radix_log == 2) hipLaunchKernelGGL(KERN<2>, dim3(BLOCKS), dim3(std::max(64u, std::min(512u, (TILE) / 4))), LDS, s, __VA_ARGS__);  \
     else hipLaunchKernelGGL(KERN<1>, dim3(BLOCKS), dim3(std::max(64u, std::min(1024u, (TILE) / 2))), LDS, s, __VA_ARGS__);                            \
   } while (0)
 

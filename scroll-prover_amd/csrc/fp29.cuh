@@ -68,6 +68,36 @@ template <class P> struct Fp29 {
     r.l[8] = (uint32_t)acc;
     return r;
   }
+  // same product with TWO independent column accumulators (even / odd terms): halves the dependent v_mad_u64_u32 chain
+  // at the price of one 64-bit add per column; pays when few waves share a SIMD (experiment, see tools/microbench.hip)
+  ZK_HD static fe29_t mul2(const fe29_t &a, const fe29_t &b) {
+    uint64_t acc = 0; uint32_t m[9]; fe29_t r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      uint64_t e = acc, o = 0;
+#pragma unroll
+      for (int i = 0; i <= k; i++) { if (i & 1) o += (uint64_t)a.l[i] * b.l[k - i]; else e += (uint64_t)a.l[i] * b.l[k - i]; }
+#pragma unroll
+      for (int i = 0; i < k; i++) { if (i & 1) e += (uint64_t)m[i] * P::mod(k - i); else o += (uint64_t)m[i] * P::mod(k - i); }
+      acc = e + o;
+      m[k] = ((uint32_t)acc * P::INV) & M29;
+      acc += (uint64_t)m[k] * P::mod(0);
+      acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+      uint64_t e = acc, o = 0;
+#pragma unroll
+      for (int i = k - 8; i < 9; i++) { if (i & 1) o += (uint64_t)a.l[i] * b.l[k - i]; else e += (uint64_t)a.l[i] * b.l[k - i]; }
+#pragma unroll
+      for (int i = k - 8; i < 9; i++) { if (i & 1) e += (uint64_t)m[i] * P::mod(k - i); else o += (uint64_t)m[i] * P::mod(k - i); }
+      acc = e + o;
+      r.l[k - 9] = (uint32_t)acc & M29;
+      acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+  }
   ZK_HD static fe29_t sqr(const fe29_t &a) {
     uint64_t acc = 0; uint32_t m[9]; fe29_t r;
     uint32_t a2[9];

@@ -57,6 +57,19 @@ template <int R> __device__ __forceinline__ void lds_dif29_round(const Lds29 &L,
     uint32_t c, rest;
     if (col_fast) { c = g & (C - 1); rest = g >> log_c; } else { rest = g & ((M >> R) - 1); c = g >> (log_m - R); }
     const uint32_t low = rest & ((1u << b_lo) - 1), base = ((rest >> b_lo) << (b_lo + R)) | low;
+    // all twiddles of the round are fetched first (L1/L2 hits, but ~500 cycles each): R * 2^(R-1) independent loads in flight
+    // while the LDS reads and the first multiplications run
+    fe29_t tw[R][Q / 2];
+#pragma unroll
+    for (int t = 0; t < R; t++) {
+      const uint32_t stage = s0 + t, bit = R - 1 - t;
+      uint32_t n = 0;
+#pragma unroll
+      for (uint32_t q0 = 0; q0 < Q; q0++) {
+        if (q0 & (1u << bit)) continue;
+        tw[t][n++] = tw29_load(tw_m, (low | ((q0 & ((1u << bit) - 1)) << b_lo)) << stage);
+      }
+    }
     fe29_t x[Q];
 #pragma unroll
     for (uint32_t q = 0; q < Q; q++) x[q] = lds29_get(L, (base | (q << b_lo)) * sm + c * sc);
@@ -64,15 +77,15 @@ template <int R> __device__ __forceinline__ void lds_dif29_round(const Lds29 &L,
     for (int t = 0; t < R; t++) {
       const uint32_t stage = s0 + t, bit = R - 1 - t;
       const bool reduce_now = (stage == 4 || stage == 9);
+      uint32_t n = 0;
 #pragma unroll
       for (uint32_t q0 = 0; q0 < Q; q0++) {
         if (q0 & (1u << bit)) continue;
         const uint32_t q1 = q0 | (1u << bit);
-        const uint32_t jl = low | ((q0 & ((1u << bit) - 1)) << b_lo);      // index bits below the paired bit
         const fe29_t u = x[q0], v = x[q1];
         fe29_t sum = Fr29::carry(Fr29::add(u, v));
         if (reduce_now) sum = Fr29::reduce_small(Fr29::normalise(sum));
-        x[q1] = Fr29::mul(fr29_sub64(u, v), tw29_load(tw_m, jl << stage));
+        x[q1] = Fr29::mul(fr29_sub64(u, v), tw[t][n++]);
         x[q0] = sum;
       }
     }
@@ -97,7 +110,7 @@ __device__ __forceinline__ fe29_t load_input29(const fe_t *__restrict__ src, uin
   return v;
 }
 
-template <int RMAX> __global__ void __launch_bounds__(RMAX == 3 ? 512 : 1024) k_ntt29_strided(const fe_t *__restrict__ src, fe_t *__restrict__ dst, Ntt29Level L, uint32_t log_c,
+template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_ntt29_strided(const fe_t *__restrict__ src, fe_t *__restrict__ dst, Ntt29Level L, uint32_t log_c,
                                                         uint64_t src_len, const fe_t *__restrict__ pre3) {
   extern __shared__ uint4 lds[];
   const uint32_t M = 1u << L.log_m, C = 1u << log_c, tile = M << log_c;
@@ -122,7 +135,7 @@ template <int RMAX> __global__ void __launch_bounds__(RMAX == 3 ? 512 : 1024) k_
   }
 }
 
-template <int RMAX> __global__ void __launch_bounds__(RMAX == 3 ? 512 : 1024) k_ntt29_final(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint32_t log_m, uint32_t log_a, uint32_t log_b,
+template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_ntt29_final(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint32_t log_m, uint32_t log_a, uint32_t log_b,
                                                       uint32_t log_c, Tw29 tw_m, uint64_t src_len, const fe_t *__restrict__ pre3, const fe_t *__restrict__ post3) {
   extern __shared__ uint4 lds[];
   const uint32_t M = 1u << log_m, C = 1u << log_c, seg = M + 1, tile = M << log_c;

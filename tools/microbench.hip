@@ -83,6 +83,7 @@ template <int VARIANT> __global__ void k_fq29mul(fe_t *io) {
     if (VARIANT == 0) { a = Fq29::mul(a, b); b = Fq29::mul(b, a); }
     if (VARIANT == 1) { a = Fq29::sqr(a); a = Fq29::mul(a, b); }
     if (VARIANT == 2) { a = Fq29::mul(Fq29::sub4(a, b), b); b = Fq29::mul(Fq29::add(b, a), a); }   // with lazy add/sub in the chain
+    if (VARIANT == 3) { a = Fq29::mul2(a, b); b = Fq29::mul2(b, a); }
   }
   io[2 * t] = Fq29::to_sat(a); io[2 * t + 1] = Fq29::to_sat(b);
 }
@@ -163,7 +164,13 @@ int main() {
     size_t bad29 = 0; for (size_t i = 0; i < nfe; i++) if (memcmp(&r0[i], &r1[i], 32)) bad29++;
     printf("Fq29::mul chain vs Fq::mul chain mismatches (inputs must be < p for equality; random inputs here are < 2^253): %zu of %zu\n", bad29, nfe);
   }
-  RUN_MUL29(0, "Fq29::mul (9x29)") RUN_MUL29(1, "Fq29 sqr+mul") RUN_MUL29(2, "Fq29 mul + lazy add/sub")
+  RUN_MUL29(0, "Fq29::mul (9x29)") RUN_MUL29(1, "Fq29 sqr+mul") RUN_MUL29(2, "Fq29 mul + lazy add/sub") RUN_MUL29(3, "Fq29::mul2 (dual acc)")
+  for (int bpc : {1, 2, 4}) {
+    int b2 = prop.multiProcessorCount * bpc;
+    float m0 = time_kernel([&] { hipLaunchKernelGGL(k_fq29mul<0>, dim3(b2), dim3(threads), 0, 0, d2); });
+    float m3 = time_kernel([&] { hipLaunchKernelGGL(k_fq29mul<3>, dim3(b2), dim3(threads), 0, 0, d2); });
+    printf("Fq29 %d waves/SIMD: mul %8.2f G/s   mul2 %8.2f G/s\n", bpc, (double)b2 * threads * MULS / m0 * 1e-6, (double)b2 * threads * MULS / m3 * 1e-6);
+  }
   // occupancy sensitivity: fewer blocks
   for (int bpc : {1, 2, 4}) {
     int b2 = prop.multiProcessorCount * bpc;
