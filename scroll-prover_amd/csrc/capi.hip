@@ -63,6 +63,7 @@ struct Ctx {
   int force_c = 0;
   uint32_t sort_t2 = 8192;      // MI355_SORT_T2 = 8192 | 16384 | 32768
   uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
+  uint32_t seg_factor = 16;
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
   uint32_t ntt_radix_log = 2;   // MI355_NTT_RADIX_LOG
   uint32_t ntt_tile_log = 11;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
@@ -131,7 +132,7 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   P.windows = (255 + P.c - 1) / P.c; P.nb = 1u << (P.c - 1);
   const uint64_t emax = n * P.windows;
   if (emax >= (1ull << 32)) return fail(MI355_EBADARG, "msm: n * windows must be < 2^32");
-  const uint64_t want_threads = (uint64_t)g.prop.multiProcessorCount * 256 * 16;   // ~16 segments per lane slot
+  const uint64_t want_threads = (uint64_t)g.prop.multiProcessorCount * 256 * g.seg_factor;   // segments per lane slot (MI355_SEG_FACTOR)
   uint64_t seg = (emax + want_threads - 1) / want_threads; if (seg < 16) seg = 16; if (seg > 4096) seg = 4096;
   P.seg = (uint32_t)seg;
   const uint32_t nbuckets = shared ? P.nb : P.windows * P.nb;
@@ -189,13 +190,12 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
     Scope total("msm_total");
     {
       Scope sc("msm_digits");
-      hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream), dim3(256), 0, s, scalars, enc, P);
+      HIPCHK(hipMemsetAsync(coarse_hist, 0, ((size_t)S.regions + 1) * 4, s));
+      hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream), dim3(256), (size_t)S.regions * 4, s, scalars, enc, P, coarse_hist, S.fb, S.cb_bits, S.shared);
     }
     {
       Scope sc("msm_sort");
-      HIPCHK(hipMemsetAsync(coarse_hist, 0, ((size_t)S.regions + 1) * 4, s));
       HIPCHK(hipMemsetAsync(hist, 0, ((size_t)nbuckets + 1) * 4, s));
-      hipLaunchKernelGGL(k_sort_l1_hist, dim3(tiles1 * P.windows), dim3(256), 0, s, enc, coarse_hist, S);
       hipLaunchKernelGGL(k_scan_partial, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, cscan_n);
       hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums + scan_blocks, cscan_blocks);
       hipLaunchKernelGGL(k_scan_final, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, coarse_off, coarse_cursor, cscan_n);
@@ -412,6 +412,7 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
+  { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384 || v == 32768) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
   { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }

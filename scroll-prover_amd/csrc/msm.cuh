@@ -62,7 +62,14 @@ __device__ __forceinline__ void store_sat_as_xyzz29(g1_xyzz29_t *p, const g1_xyz
 }
 
 // ---- 1. digits.  Plane layout enc[w * n + i]: 0 for a zero digit, else |d| (1 .. 2^(c-1)) with bit 31 = sign.
-__global__ void __launch_bounds__(256) k_msm_digits(const fe_t *__restrict__ scalars, uint32_t *__restrict__ enc, MsmPlan P) {
+__global__ void __launch_bounds__(256) k_msm_digits(const fe_t *__restrict__ scalars, uint32_t *__restrict__ enc, MsmPlan P,
+                                                     uint32_t *__restrict__ coarse_hist, uint32_t fb, uint32_t cb_bits, uint32_t shared) {
+  // the level-1 (coarse) histogram of the sorter is taken here, while the digits are in registers: LDS counters per block,
+  // one global atomic per non-empty bin at the end (dynamic LDS = regions * 4 bytes)
+  extern __shared__ uint32_t hist_lds[];
+  const uint32_t CB = 1u << cb_bits, regions = shared ? CB : P.windows * CB;
+  for (uint32_t b = threadIdx.x; b < regions; b += blockDim.x) hist_lds[b] = 0;
+  __syncthreads();
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t half = 1u << (P.c - 1), mask = (1u << P.c) - 1;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
@@ -77,8 +84,11 @@ __global__ void __launch_bounds__(256) k_msm_digits(const fe_t *__restrict__ sca
       uint32_t e;
       if (raw > half) { e = (1u << P.c) - raw; if (e) e |= 0x80000000u; carry = 1; } else { e = raw; carry = 0; }   // raw == 2^c: digit 0, carry 1
       enc[(uint64_t)w * P.n + i] = e;
+      if (e) atomicAdd(&hist_lds[(shared ? 0 : w * CB) + (((e & 0x7fffffffu) - 1) >> fb)], 1u);
     }
   }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < regions; b += blockDim.x) if (hist_lds[b]) atomicAdd(&coarse_hist[b], hist_lds[b]);
 }
 
 // ---- 2. exclusive scan (three small kernels; the array has W * 2^(c-1) + 1 entries)
@@ -133,25 +143,14 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const uint32_t *__res
 // ---- 3. two-level counting sort of the (window, bucket) keys, built for 19-22 bit keys and ~10^9 entries.
 // A global atomic per entry (histogram + cursor) costs ~120 ms at 2^26 x 13 windows; here every workgroup first
 // aggregates a tile in an LDS histogram and issues ONE global atomic per (tile, non-empty bin).
-//   level 1: tiles over the digit plane, bin = window * CB + (bucket >> fb)          (CB = 2^cb_bits coarse bins per window)
+//   level 1: tiles over the digit plane, bin = window * CB + (bucket >> fb)          (CB = 2^cb_bits coarse bins per window;
+//            its histogram is taken by k_msm_digits while the digits are in registers)
 //            -> pairs[] = (fine key << 32 | point index | sign), grouped by coarse region
 //   level 2: tiles inside each coarse region, bin = fine key (2^fb bins)             -> exact bucket offsets + sorted[]
 // Order inside a bucket is arbitrary (group addition commutes), so nothing needs to be stable.
 constexpr uint32_t SORT_MAX_BINS = 4096;
 struct SortPlan { uint32_t n, windows, nb, fb, cb_bits, t1, t2, regions, shared; };   // shared = 1: all windows feed ONE bucket set (precomputed 2^(cw) P tables)
 
-__global__ void __launch_bounds__(256) k_sort_l1_hist(const uint32_t *__restrict__ enc, uint32_t *__restrict__ coarse_hist, SortPlan S) {
-  __shared__ uint32_t h[SORT_MAX_BINS];
-  const uint32_t CB = 1u << S.cb_bits, tiles1 = (S.n + S.t1 - 1) / S.t1;
-  const uint32_t w = blockIdx.x / tiles1, j = blockIdx.x - w * tiles1;
-  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) h[b] = 0;
-  __syncthreads();
-  const uint32_t i0 = j * S.t1, i1 = min(S.n, i0 + S.t1);
-  const uint32_t *plane = enc + (uint64_t)w * S.n;
-  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) { const uint32_t e = plane[i]; if (e) atomicAdd(&h[((e & 0x7fffffffu) - 1) >> S.fb], 1u); }
-  __syncthreads();
-  for (uint32_t b = threadIdx.x; b < CB; b += blockDim.x) if (h[b]) atomicAdd(&coarse_hist[(S.shared ? 0 : w * CB) + b], h[b]);
-}
 // Per-tile bin bookkeeping shared by both scatter kernels (1024 threads): lstart[] = exclusive scan of the tile histogram,
 // gbase[] = start of this tile's run inside each global bin (ONE returning global atomic per non-empty bin).
 __device__ __forceinline__ uint32_t tile_bin_offsets(const uint32_t *h, uint32_t *lstart, uint32_t *gbase, uint32_t nbins, uint32_t *global_cursor, uint32_t *scratch32) {

@@ -124,3 +124,26 @@ def test_extended_domain_2_22_to_2_24(zk):
         assert (ext[i].cpu().numpy().view(np.uint64) == cref.eval_polynomial(ch, cref.fr_mont(x))).all()
     dom.extended_to_coeff(ext)
     assert torch.equal(ext[: 1 << k], coeffs) and int(ext[1 << k:].abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("k", [18, 22, 26])
+def test_ntt_extreme_inputs_stress_lazy_bounds(zk, k):
+    """worst case for the lazy 29-bit sums: every input r - 1 (and every input 1): NTT(c * ones) = c * n * delta_0, all passes at full tile depth."""
+    h2 = zk.halo2
+    n = 1 << k
+    dom = h2.EvaluationDomain(2, k)
+    for c in (R - 1, 1, (R - 1) // 2):
+        row = torch.from_numpy(h2.fr(c).view(np.int64)).cuda()
+        a = row.repeat(n, 1).contiguous()
+        dom.coeff_to_lagrange(a)
+        assert (a[0].cpu().numpy().view(np.uint64) == h2.fr(c * n % R)).all()
+        assert int((a[1:] != 0).sum().item()) == 0
+        # alternating +c, -c: energy lands on bin n/2
+        b = row.repeat(n, 1).contiguous()
+        neg = torch.from_numpy(h2.fr(R - c).view(np.int64)).cuda()
+        b[1::2] = neg
+        dom.coeff_to_lagrange(b)
+        assert (b[n // 2].cpu().numpy().view(np.uint64) == h2.fr(c * n % R)).all()
+        assert int((b[: n // 2] != 0).sum().item()) == 0 and int((b[n // 2 + 1:] != 0).sum().item()) == 0
+        del a, b
+    torch.cuda.empty_cache()
