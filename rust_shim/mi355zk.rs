@@ -22,6 +22,7 @@ extern "C" {
     pub fn mi355_last_error() -> *const c_char;
     pub fn mi355_srs_register_host(bases_affine_host: *const c_void, n: u64, handle_out: *mut u64) -> c_int;
     pub fn mi355_srs_release(handle: u64) -> c_int;
+    pub fn mi355_srs_precompute(handle: u64, n_hint: u64, c: c_int) -> c_int;
     pub fn mi355_msm_g1_host(srs: u64, base_offset: u64, scalars_host: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_msm_g1_adhoc_host(bases: *const c_void, scalars: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_ntt_fr_host(data_host: *mut c_void, log_n: u32, omega: *const c_void) -> c_int;
@@ -69,6 +70,8 @@ fn srs_handle(bases: &[G1Affine]) -> Option<(u64, u64)> {
     let mut h = 0u64;
     let rc = unsafe { mi355_srs_register_host(bases.as_ptr() as *const c_void, l as u64, &mut h) };
     if rc != MI355_OK { return None; }
+    // registration-time window tables (W x the basis in HBM; MI355_SRS_PRECOMPUTE=0 disables): all windows share one bucket set
+    if std::env::var("MI355_SRS_PRECOMPUTE").map(|v| v != "0").unwrap_or(true) { unsafe { let _ = mi355_srs_precompute(h, 0, 0); } }
     map.insert((p, l), h);
     Some((h, 0))
 }
