@@ -68,6 +68,36 @@ template <class P> struct Fp29 {
     r.l[8] = (uint32_t)acc;
     return r;
   }
+  // (a*b - c*d) * R'^-1 + p  in ONE Montgomery reduction (lazy reduction of a difference of products): the column accumulator is signed.
+  // Limb bounds: all four operands <= 2^29 + 8 so that 9 + 9 + 9 products stay below 2^63.  Value: (ab - cd)/R' must lie in (-p, 6p).
+  // Result: limbs <= 2^30 - 2 (no carry needed), value = (ab - cd)/R' + p + [0, p).
+  ZK_HD static fe29_t mul_sub(const fe29_t &a, const fe29_t &b, const fe29_t &c, const fe29_t &d) {
+    int64_t acc = 0; uint32_t m[9]; fe29_t r;
+    int32_t nc[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) nc[i] = -(int32_t)c.l[i];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) { acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[k - i]; acc += (int64_t)nc[i] * (int32_t)d.l[k - i]; }
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (int64_t)(int32_t)m[i] * (int32_t)P::mod(k - i);
+      m[k] = ((uint32_t)acc * P::INV) & M29;
+      acc += (int64_t)(int32_t)m[k] * (int32_t)P::mod(0);
+      acc >>= 29;   // exact: the low 29 bits are zero
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+      for (int i = k - 8; i < 9; i++) { acc += (int64_t)(int32_t)a.l[i] * (int32_t)b.l[k - i]; acc += (int64_t)nc[i] * (int32_t)d.l[k - i]; }
+#pragma unroll
+      for (int i = k - 8; i < 9; i++) acc += (int64_t)(int32_t)m[i] * (int32_t)P::mod(k - i);
+      r.l[k - 9] = ((uint32_t)acc & M29) + P::mod(k - 9);
+      acc >>= 29;   // arithmetic shift: floor division keeps the limbs in [0, 2^29)
+    }
+    r.l[8] = (uint32_t)((int32_t)acc + (int32_t)P::mod(8));
+    return r;
+  }
   // same product with TWO independent column accumulators (even / odd terms): halves the dependent v_mad_u64_u32 chain
   // at the price of one 64-bit add per column; pays when few waves share a SIMD (experiment, see tools/microbench.hip)
   ZK_HD static fe29_t mul2(const fe29_t &a, const fe29_t &b) {

@@ -2,7 +2,7 @@
 // time is entirely field multiplications.  Same formulas and exceptional cases as g1.cuh (madd-2008-s / mdbl-2008-s); what
 // changes is the bookkeeping of lazy values.  Invariants of an accumulator between additions (p = Fq modulus):
 //     x   limbs <= 2^29 + 8, value < 14 p          zz, zzz   tight (mul outputs), value < 1.1 p
-//     y   limbs <= 2^29 + 8, value < 6.1 p         identity  <=> all limbs of zz are 0
+//     y   limbs <= 2^30 - 2, value < 6.1 p         identity  <=> all limbs of zz are 0
 // Bases arrive in the ABI form (8 x 32, R = 2^256) and are re-sliced on the fly (from_sat: value < 2^259, limbs < 2^29:
 // only ever used as a multiplication operand).  Bounds of every intermediate are written next to it.
 #pragma once
@@ -40,7 +40,7 @@ ZK_HD g1_xyzz29_t g1_xyzz29_dbl_affine(const fe29_t &xt, const fe29_t &yt) {
 }
 
 // acc += (+-) q, q in the ABI form.  madd-2008-s.
-ZK_HD void g1_xyzz29_madd(g1_xyzz29_t &acc, const g1_affine_t &q, bool negate) {
+template <bool FUSED_Y3 = true> ZK_HD void g1_xyzz29_madd(g1_xyzz29_t &acc, const g1_affine_t &q, bool negate) {
   if (g1_affine_is_identity(q)) return;
   const fe29_t x2 = Fq29::from_sat(q.x);
   fe29_t y2 = Fq29::from_sat(q.y);
@@ -66,7 +66,9 @@ ZK_HD void g1_xyzz29_madd(g1_xyzz29_t &acc, const g1_affine_t &q, bool negate) {
   const fe29_t PPP = Fq29::mul(Pd, PP);                                        // < 1.4 p
   const fe29_t Q = Fq29::mul(acc.x, PP);                                       // < 1.3 p
   const fe29_t X3 = Fq29::sub8(Fq29::sub4(Fq29::sqr(Rd), PPP), Fq29::dbl(Q)); // (1.6 + 4) p + 8 p = 13.6 p
-  const fe29_t Y3 = Fq29::sub4(Fq29::mul(Rd, Fq29::sub16(Q, X3)), Fq29::mul(acc.y, PPP));   // < 2.1 p + 4 p
+  // Y3 = Rd (Q - X3) - Y1 PPP: both products under ONE Montgomery reduction (signed column accumulator): (1.02 - 0.05 .. ) p + p + [0, p) < 3.1 p
+  const fe29_t Y3 = FUSED_Y3 ? Fq29::mul_sub(Rd, Fq29::sub16(Q, X3), acc.y, PPP)
+                             : Fq29::sub4(Fq29::mul(Rd, Fq29::sub16(Q, X3)), Fq29::mul(acc.y, PPP));   // unfused form: < 2.1 p + 4 p
   acc.x = X3; acc.y = Y3; acc.zz = ZZ3; acc.zzz = Fq29::mul(acc.zzz, PPP);
 }
 

@@ -55,6 +55,7 @@ template <class F29> static void op29(int op, fe_t *o, const fe_t *a, const fe_t
     case 4: r = F29::sub8(F29::mul(x, F29::one()), F29::dbl(F29::mul(y, F29::one()))); break;   // a - 2b
     case 5: r = F29::sub16(x, F29::sub8(F29::mul(y, F29::one()), F29::dbl(F29::mul(x, F29::one())))); break;  // a - (b - 2a) = 3a - b
     case 6: { fe29_t xt = F29::mul(x, F29::one()), yt = F29::mul(y, F29::one()); r = F29::sqr(F29::sub16(xt, F29::sub4(yt, xt))); } break;  // (2a - b)^2, chained lazy values (from_sat output is < 2^259 and may only feed mul or the minuend)
+    case 8: { fe29_t xt = F29::mul(x, F29::one()), yt = F29::mul(y, F29::one()); r = F29::mul_sub(F29::sub16(xt, yt), F29::sub8(yt, F29::dbl(xt)), F29::sub4(yt, xt), xt); } break;  // (a-b)(b-2a) - (b-a)a
     default: r = x;
   }
   *o = F29::to_sat(r);

@@ -129,6 +129,7 @@ def test_unsaturated_29bit_arithmetic(hs):
             assert c(o29(5, a, b)) == (3 * va - vb) % m
             assert c(o29(6, a, b)) == (2 * va - vb) ** 2 % m
             assert o29(7, a, b).tolist() == a.tolist()          # from_sat / to_sat round trip
+            assert c(o29(8, a, b)) == ((va - vb) * (vb - 2 * va) - (vb - va) * va) % m    # fused difference of products (signed lazy reduction)
             assert bool(hs.hs_f29_is_zero(w, p_(np.ascontiguousarray(a)), p_(np.ascontiguousarray(a)))) is True
             assert bool(hs.hs_f29_is_zero(w, p_(np.ascontiguousarray(a)), p_(np.ascontiguousarray(b)))) is (va == vb)
 

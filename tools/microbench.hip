@@ -89,12 +89,12 @@ template <int VARIANT> __global__ void k_fq29mul(fe_t *io) {
 }
 // madd chain on the 29-bit accumulator, to see the ALU ceiling of k_msm_accumulate at its real occupancy
 #include "../scroll-prover_amd/csrc/g1_29.cuh"
-__global__ void __launch_bounds__(256) k_madd29(g1_xyzz_t *accs, const g1_affine_t *pts, int npts, int iters) {
+template <bool FUSED> __global__ void __launch_bounds__(256) k_madd29(g1_xyzz_t *accs, const g1_affine_t *pts, int npts, int iters) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   g1_xyzz29_t acc = g1_xyzz29_identity();
   for (int i = 0; i < iters; i++) {
     g1_affine_t p = pts[(t * 31 + i) % npts];
-    g1_xyzz29_madd(acc, p, (i & 1) != 0);
+    g1_xyzz29_madd<FUSED>(acc, p, (i & 1) != 0);
   }
   accs[t] = g1_xyzz29_to_sat(acc);
 }
@@ -192,8 +192,9 @@ int main() {
     printf("g1_xyzz_madd_ps vs g1_xyzz_madd mismatches: %zu of %zu\n", badm, (size_t)lanes);
     for (int bpc : {1, 2, 3, 4, 8}) {
       int b2 = prop.multiProcessorCount * bpc;
-      float ms = time_kernel([&] { hipLaunchKernelGGL(k_madd29, dim3(b2), dim3(threads), 0, 0, da, dp, npts, iters); });
-      printf("xyzz29 madd chain %d waves/SIMD: %8.3f ms  %8.2f G madd/s\n", bpc, ms, (double)b2 * threads * iters / ms * 1e-6);
+      float ms = time_kernel([&] { hipLaunchKernelGGL(k_madd29<true>, dim3(b2), dim3(threads), 0, 0, da, dp, npts, iters); });
+      float ms0 = time_kernel([&] { hipLaunchKernelGGL(k_madd29<false>, dim3(b2), dim3(threads), 0, 0, da, dp, npts, iters); });
+      printf("xyzz29 madd chain %d waves/SIMD: fused-Y3 %8.2f G madd/s   unfused %8.2f G madd/s\n", bpc, (double)b2 * threads * iters / ms * 1e-6, (double)b2 * threads * iters / ms0 * 1e-6);
     }
     for (int v = 0; v < 2; v++) {
       float ms = time_kernel([&] { if (v == 0) hipLaunchKernelGGL(k_madd<0>, dim3(blocks), dim3(threads), 0, 0, da, dp, npts, iters); else hipLaunchKernelGGL(k_madd<1>, dim3(blocks), dim3(threads), 0, 0, db, dp, npts, iters); });
