@@ -63,6 +63,7 @@ struct Ctx {
   int force_c = 0;
   uint32_t sort_t2 = 8192;      // MI355_SORT_T2 = 8192 | 16384 | 32768
   uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
+  uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): bit 0 nontemporal gathers, bit 1 prefetched bucket ends -- neither measurably helps
   uint32_t seg_factor = 16;
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
   uint32_t ntt_radix_log = 2;   // MI355_NTT_RADIX_LOG
@@ -219,7 +220,9 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
     {
       Scope sc("msm_accumulate");
       HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
-      hipLaunchKernelGGL(k_msm_accumulate, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, P.n, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask);
+#define ACC_LAUNCH(V) hipLaunchKernelGGL(k_msm_accumulate<V>, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, P.n, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask)
+      switch (g.acc_variant) { case 0: ACC_LAUNCH(0); break; case 1: ACC_LAUNCH(1); break; case 2: ACC_LAUNCH(2); break; default: ACC_LAUNCH(3); break; }
+#undef ACC_LAUNCH
     }
     {
       Scope sc("msm_reduce");
@@ -412,6 +415,7 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
+  { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 3; }
   { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384 || v == 32768) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }

@@ -37,6 +37,14 @@ struct MsmPlan {
 __device__ __forceinline__ g1_affine_t load_affine(const g1_affine_t *p) {
   g1_affine_t r; r.x = g_load(&p->x); r.y = g_load(&p->y); return r;
 }
+// streaming variant for the bucket gathers: every 64-byte base of the (48 GiB) table is used once per MSM, so it should not
+// displace the index / offset streams from the caches
+__device__ __forceinline__ g1_affine_t load_affine_nt(const g1_affine_t *p) {
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(p); g1_affine_t r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { r.x.l[i] = __builtin_nontemporal_load(q + i); r.y.l[i] = __builtin_nontemporal_load(q + 8 + i); }
+  return r;
+}
 __device__ __forceinline__ g1_xyzz_t load_xyzz(const g1_xyzz_t *p) {
   g1_xyzz_t r; r.x = g_load(&p->x); r.y = g_load(&p->y); r.zz = g_load(&p->zz); r.zzz = g_load(&p->zzz); return r;
 }
@@ -270,7 +278,7 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
 // ---- 4. segmented accumulation
 // offsets[b] .. offsets[b+1] = entries of global bucket b (b = w * nb + bucket); offsets has nbuckets+1 entries.
 // bucket_sums must be zero-filled (all-zero XYZZ = identity) before launch.
-__global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
+template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
                                                         uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg,
                                                         uint32_t n, uint64_t row_stride, uint32_t gather_mask) {
   const uint32_t total = offsets[nbuckets];
@@ -281,13 +289,12 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__res
   // largest b with offsets[b] <= start  (then offsets[b+1] > start: the bucket that contains `start`)
   uint32_t lo = 0, hi = nbuckets;  // invariant offsets[lo] <= start < offsets[hi]
   while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (offsets[mid] <= start) lo = mid; else hi = mid; }
-  uint32_t b = lo, b_end = offsets[b + 1];
+  uint32_t b = lo, b_start = offsets[b], b_end = offsets[b + 1];
+  uint32_t next_end = (b + 2 <= nbuckets) ? offsets[b + 2] : b_end;   // end of bucket b+1, fetched one bucket ahead so that a crossing does not stall on a load
   int32_t id_first = -1, id_last = -1;
   // the accumulator lives in the 9 x 29-bit unsaturated field (g1_29.cuh): one v_mad_u64_u32 per limb product, no carry chain;
-  // it is converted to the saturated XYZZ record only when a bucket is flushed
+  // it is flushed as a raw 144-byte record
   g1_xyzz29_t acc = g1_xyzz29_identity();
-  // software pipeline: the gather of entry pos+1 (index, then 64-byte base) is issued before the ~10 field multiplications
-  // of entry pos, so the ~2 us random-access latency overlaps arithmetic instead of stalling one of only 4 waves per SIMD
   // row_stride != 0: entry index = w * n + i names row w of the precomputed table T[w][.] = 2^(c w) P (rows row_stride points apart)
   auto base_of = [&](uint32_t e) -> const g1_affine_t * {
     const uint32_t gi = e & gather_mask;   // gather_mask = 0x7fffffff (index bits); smaller only in timing experiments
@@ -295,24 +302,32 @@ __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__res
     const uint32_t w = gi / n;
     return &bases[(uint64_t)w * row_stride + (gi - w * n)];
   };
+  auto gather = [&](uint32_t e) -> g1_affine_t { return (VARIANT & 1) ? load_affine_nt(base_of(e)) : load_affine(base_of(e)); };
+  // software pipeline: the gather of entry pos+1 (index, then 64-byte base) is issued before the ~10 field multiplications of entry pos
   uint32_t ent = sorted[start];
-  g1_affine_t p = load_affine(base_of(ent));
+  g1_affine_t p = gather(ent);
   for (uint32_t pos = start; pos < end; pos++) {
     uint32_t ent_next = 0; g1_affine_t p_next = p;
-    if (pos + 1 < end) { ent_next = sorted[pos + 1]; p_next = load_affine(base_of(ent_next)); }
+    if (pos + 1 < end) { ent_next = sorted[pos + 1]; p_next = gather(ent_next); }
     if (pos >= b_end) {
       // leave bucket b: it ends inside this thread's range
-      if (offsets[b] >= start) store_xyzz29(&bucket_sums[b], acc);                        // began here too: sole owner
+      if (b_start >= start) store_xyzz29(&bucket_sums[b], acc);                           // began here too: sole owner
       else { store_xyzz29(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }          // began in an earlier thread
       acc = g1_xyzz29_identity();
-      do { b++; b_end = offsets[b + 1]; } while (pos >= b_end);
+      if (VARIANT & 2) {
+        b++; b_start = b_end; b_end = next_end;
+        while (pos >= b_end) { b++; b_start = b_end; b_end = offsets[b + 1]; }            // empty buckets (rare with uniform digits)
+        next_end = (b + 2 <= nbuckets) ? offsets[b + 2] : b_end;
+      } else {
+        do { b++; b_start = b_end; b_end = offsets[b + 1]; } while (pos >= b_end);
+      }
     }
     g1_xyzz29_madd(acc, p, (ent >> 31) != 0);
     ent = ent_next; p = p_next;
   }
   // bucket b is still open at `end`
-  if (offsets[b] >= start && b_end <= end) store_xyzz29(&bucket_sums[b], acc);
-  else if (offsets[b] < start) { store_xyzz29(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }   // spans the whole segment or just its head
+  if (b_start >= start && b_end <= end) store_xyzz29(&bucket_sums[b], acc);
+  else if (b_start < start) { store_xyzz29(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }   // spans the whole segment or just its head
   else { store_xyzz29(&part[2 * (uint64_t)t + 1], acc); id_last = (int32_t)b; }                        // began here, continues in the next thread
   part_id[2 * t] = id_first; part_id[2 * t + 1] = id_last;
 }
