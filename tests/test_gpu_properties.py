@@ -89,7 +89,7 @@ def test_commit_coeff_equals_commit_lagrange_2_20(zk):
     params.release()
 
 
-@pytest.mark.parametrize("k", [22, 24, 26])
+@pytest.mark.parametrize("k", [22, 24, 26, 28])   # 28 = the extended domain of k = 26 with 4 quotient chunks: the two-adicity limit of Fr
 def test_ntt_roundtrip_and_evaluation_semantics(zk, k):
     h2 = zk.halo2
     n = 1 << k
@@ -100,7 +100,7 @@ def test_ntt_roundtrip_and_evaluation_semantics(zk, k):
     # a'[i] == a(omega^i) for a few i (Horner in the oracle over the original coefficients)
     coeffs = orig.cpu().numpy().view(np.uint64)
     w = pyref.omega(k)
-    for i in (0, 1, 12345, n // 2 + 3, n - 1):
+    for i in ((0, 1, 12345, n // 2 + 3, n - 1) if k <= 26 else (1, n - 1)):
         want = cref.eval_polynomial(coeffs, cref.fr_mont(pow(w, i, R)))
         assert (a[i].cpu().numpy().view(np.uint64) == want).all(), f"evaluation at omega^{i}"
     dom.lagrange_to_coeff(a)
