@@ -112,6 +112,12 @@ int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_
 int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *factor);
 int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, const void *coset_factor, const void *omega);
 
+/* element-wise operations on device-resident vectors of Fr (op 0: a + b, 1: a - b, 2: a * b; dst may alias a or b) and
+ * data[i] *= table[i mod period] (period a power of two <= 4096; EvaluationDomain::divide_by_vanishing_poly multiplies the extended
+ * evaluations by the inverted t_evaluations, whose period is 2^(extended_k - k)).  The pointwise glue of SURVEY 8f-1.            */
+int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_dev, uint64_t n);
+int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_host, uint32_t period);
+
 /* ---- halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i  (the evaluations written to the
  *      transcript in step 9 of create_proof); out_fr_host receives 32 B.  First widening into SURVEY 8f-3.   */
 int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host);

@@ -695,6 +695,29 @@ int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n
   return mi355_ntt_fr_dev(dst_dev, log_n, omega);
 }
 
+// ---- element-wise vector operations on resident polynomials
+int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_dev, uint64_t n) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (op < 0 || op > 2 || (n && (!dst_dev || !a_dev || !b_dev))) return fail(MI355_EBADARG, "fr_vec_op: bad argument");
+  if (n == 0) return MI355_OK;
+  hipLaunchKernelGGL(k_fr_vec_op, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, op, (fe_t *)dst_dev, (const fe_t *)a_dev, (const fe_t *)b_dev, n);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_host, uint32_t period) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!table_host || period == 0 || (period & (period - 1)) || period > 4096 || (n && !data_dev)) return fail(MI355_EBADARG, "fr_vec_mul_periodic: period must be a power of two <= 4096");
+  if (n == 0) return MI355_OK;
+  fe_t *tab; CHK(ws_get("vec.table", (size_t)period * sizeof(fe_t), (void **)&tab));
+  HIPCHK(hipMemcpyAsync(tab, table_host, (size_t)period * sizeof(fe_t), hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  hipLaunchKernelGGL(k_fr_vec_mul_periodic, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, (fe_t *)data_dev, n, tab, period - 1);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+
 // ---- eval_polynomial
 int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host) {
   std::lock_guard<std::mutex> lk(g.mu);

@@ -236,6 +236,24 @@ __global__ void __launch_bounds__(256) k_distribute_powers(fe_t *__restrict__ a,
   }
 }
 
+// element-wise vector operations on device-resident polynomials (the pointwise steps between the transforms of the quotient
+// construction): op 0 add, 1 sub, 2 mul; and data[i] *= table[i mod period] (division by the vanishing polynomial on
+// the extended coset: halo2's t_evaluations have period 2^(extended_k - k)).  Streaming, 16 B/lane accesses, grid-stride.
+__global__ void __launch_bounds__(256) k_fr_vec_op(int op, fe_t *__restrict__ dst, const fe_t *__restrict__ a, const fe_t *__restrict__ b, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const fe_t x = g_load(&a[i]), y = g_load(&b[i]);
+    fe_t r;
+    if (op == 0) r = Fr::add(x, y);
+    else if (op == 1) r = Fr::sub(x, y);
+    else r = fr29_finish(Fr29::mul(Fr29::from_sat_plain(x), Fr29::from_sat(y)));   // (x 2^256)(y 2^261) / 2^261
+    g_store(&dst[i], r);
+  }
+}
+__global__ void __launch_bounds__(256) k_fr_vec_mul_periodic(fe_t *__restrict__ data, uint64_t n, const fe_t *__restrict__ table, uint32_t period_mask) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    g_store(&data[i], fr29_finish(Fr29::mul(Fr29::from_sat_plain(g_load(&data[i])), Fr29::from_sat(g_load(&table[i & period_mask])))));
+}
+
 // sum of m canonical field elements (the per-block partials) by one workgroup
 __global__ void __launch_bounds__(256) k_fr_sum(const fe_t *__restrict__ in, uint64_t m, fe_t *__restrict__ out) {
   __shared__ fe_t lds[4];

@@ -82,6 +82,13 @@ def eval_polynomial(poly, point: np.ndarray) -> np.ndarray:
     return out
 
 
+def fr_vec_op(op: str, dst, a, b):
+    """element-wise add / sub / mul of device-resident Fr vectors (pointwise steps of the quotient construction)."""
+    n = a.numel() * a.element_size() // 32
+    check(lib().mi355_fr_vec_op_dev({"add": 0, "sub": 1, "mul": 2}[op], ptr(dst), ptr(a), ptr(b), n))
+    return dst
+
+
 def g1_sum(points: np.ndarray) -> np.ndarray:
     """fold of per-GPU partial results: results.iter().fold(identity, |a, b| a + b)."""
     points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
@@ -108,6 +115,9 @@ class EvaluationDomain:
         self.omega, self.omega_inv = fr(w), fr(pow(w, -1, R_MOD))
         self.extended_omega, self.extended_omega_inv = fr(ew), fr(pow(ew, -1, R_MOD))
         self.g_coset, self.g_coset_inv = fr(FR_ZETA), fr(FR_ZETA * FR_ZETA % R_MOD)
+        # t_evaluations: (zeta * extended_omega^i)^n - 1 for i < 2^(extended_k - k) (it is periodic), stored inverted as halo2 does
+        q = 1 << (ext - k)
+        self.t_evaluations_inv = np.stack([fr(pow((pow(FR_ZETA, self.n, R_MOD) * pow(ew, i * self.n, R_MOD) - 1) % R_MOD, -1, R_MOD)) for i in range(q)])
         self.ifft_divisor = fr(pow(self.n, -1, R_MOD))
         self.extended_ifft_divisor = fr(pow(1 << ext, -1, R_MOD))
 
@@ -142,6 +152,13 @@ class EvaluationDomain:
         factor = fr(FR_ZETA * pow(self._extended_omega, part, R_MOD) % R_MOD)
         check(lib().mi355_coset_ntt_fr_dev(ptr(out), ptr(a), self.k, ptr(factor), ptr(self.omega)))
         return out
+
+    def divide_by_vanishing_poly(self, a):
+        """EvaluationDomain::divide_by_vanishing_poly on extended-coset evaluations (device tensor, in place): a[i] *= t_evaluations[i % len]^-1."""
+        assert _is_device(a)
+        n = a.numel() * a.element_size() // 32
+        check(lib().mi355_fr_vec_mul_periodic_dev(ptr(a), n, ptr(self.t_evaluations_inv), self.t_evaluations_inv.shape[0]))
+        return a
 
     def extended_to_coeff(self, a):
         """inverse of coeff_to_extended, truncated to n * quotient_poly_degree coefficients (host) / in place (device, caller truncates)."""

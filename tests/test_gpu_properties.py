@@ -147,3 +147,38 @@ def test_ntt_extreme_inputs_stress_lazy_bounds(zk, k):
         assert int((b[: n // 2] != 0).sum().item()) == 0 and int((b[n // 2 + 1:] != 0).sum().item()) == 0
         del a, b
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("k", [10, 18])
+def test_quotient_pipeline_replay_device_resident(zk, k):
+    """Steps 6-8 of create_proof replayed on device-resident data for the toy gate a*b - c = 0:
+    Lagrange -> coeff (iNTT), coeff -> extended coset (x3), pointwise a*b - c, divide by the vanishing polynomial, extended -> coeff,
+    commit the quotient; then check the polynomial identity a(x) b(x) - c(x) = t(x) (x^n - 1) at a random x (eval_polynomial on the
+    device, the identity itself in Python integers) and commit(t) = t(tau) G.  Couples NTT, coset conventions, vector ops, eval and MSM."""
+    h2 = zk.halo2
+    n = 1 << k
+    dom = h2.EvaluationDomain(3, k)            # quotient degree 2 -> extended_k = k + 1
+    assert dom.extended_k == k + 1
+    a_l, b_l = dev_scalars(n, 71), dev_scalars(n, 72)
+    c_l = torch.empty_like(a_l)
+    h2.fr_vec_op("mul", c_l, a_l, b_l)         # c = a * b on H, so the gate vanishes on H
+    polys = []
+    for p in (a_l, b_l, c_l):
+        dom.lagrange_to_coeff(p); polys.append(p)
+    exts = []
+    for p in polys:
+        e = torch.empty((dom.extended_len(), 4), dtype=torch.int64, device="cuda"); dom.coeff_to_extended(p, out=e); exts.append(e)
+    h = exts[0]
+    h2.fr_vec_op("mul", h, exts[0], exts[1]); h2.fr_vec_op("sub", h, h, exts[2])
+    dom.divide_by_vanishing_poly(h)
+    dom.extended_to_coeff(h)                    # quotient t, degree <= n - 2
+    assert int((h[n:] != 0).sum().item()) == 0, "quotient must have degree < n for this gate"
+    x = 0x0123456789ABCDEF0FEDCBA987654321 % R
+    xm = h2.fr(x)
+    ev = [h2.fr_to_int(h2.eval_polynomial(p, xm)) for p in polys]
+    t_x = h2.fr_to_int(h2.eval_polynomial(h[:n].contiguous(), xm))
+    assert (ev[0] * ev[1] - ev[2]) % R == t_x * (pow(x, n, R) - 1) % R
+    params = h2.ParamsKZG.setup(k, TAU + 5)
+    got = affine_of(params.commit(h[:n].contiguous()))
+    assert (got == field_commit(h[:n].contiguous(), TAU + 5)).all()
+    params.release()
