@@ -244,6 +244,42 @@ class ParamsKZG:
         self._owner = None
 
 
+# ------------------------------------------------------------------------------------------ wire codec of G1 (proof / .vkey bytes)
+def g1_to_bytes(g1) -> bytes:
+    """compressed encoding written to transcripts and .vkey files [EXT-recalled halo2curves derive/curve.rs; pinned by fixture KAT A4]:
+    32 bytes little-endian x, bit 254 = parity of canonical y, identity = 32 zero bytes.  Accepts G1Affine (8 limbs) or a normalised
+    G1 (12 limbs) as returned by best_multiexp.  Host-side (the transcript lives on the host, as in the reference)."""
+    v = [int(t) for t in g1]
+    if len(v) == 12:
+        assert v[8:] == [0, 0, 0, 0] or sum(l << (64 * i) for i, l in enumerate(v[8:])) == (1 << 256) % P_MOD, "normalise first"
+        if v[8:] == [0, 0, 0, 0]:
+            return bytes(32)
+    rinv = pow(1 << 256, -1, P_MOD)
+    x = sum(l << (64 * i) for i, l in enumerate(v[0:4])) * rinv % P_MOD
+    y = sum(l << (64 * i) for i, l in enumerate(v[4:8])) * rinv % P_MOD
+    if x == 0 and y == 0:
+        return bytes(32)
+    return (x | ((y & 1) << 254)).to_bytes(32, "little")
+
+
+def g1_from_bytes(b: bytes) -> np.ndarray:
+    """inverse of g1_to_bytes -> G1Affine limbs (Montgomery); raises ValueError for x not on the curve (y^2 = x^3 + 3, p = 3 mod 4)."""
+    v = int.from_bytes(b, "little")
+    sign, x = (v >> 254) & 1, v & ((1 << 254) - 1)
+    if x == 0 and sign == 0:
+        return np.zeros(8, dtype=np.uint64)
+    if x >= P_MOD:
+        raise ValueError("x out of range")
+    y2 = (x * x * x + 3) % P_MOD
+    y = pow(y2, (P_MOD + 1) // 4, P_MOD)
+    if y * y % P_MOD != y2:
+        raise ValueError("not on the curve")
+    if (y & 1) != sign:
+        y = P_MOD - y
+    m = lambda t: [((t << 256) % P_MOD >> (64 * i)) & _M64 for i in range(4)]
+    return np.array(m(x) + m(y), dtype=np.uint64)
+
+
 # ------------------------------------------------------------------------------------------ params files (SerdeFormat::RawBytes)
 def params_file_size(k: int) -> int:
     """`u32 LE k | g[2^k] x 64 B | g_lagrange[2^k] x 64 B | g2 128 B | s_g2 128 B` [EXT-recalled ParamsKZG::write_custom, RawBytes];

@@ -65,3 +65,23 @@ def test_params_file_format_roundtrip(zk, tmp_path):
         f.write(b"\\0")
     with pytest.raises(ValueError):
         h2.read_params(path)
+
+
+@pytest.mark.parametrize("vk,proto,npts", [("vk_chunk", "chunk_protocol", 7), ("vk_batch_agg", "batch_proof", 9)])
+def test_g1_wire_codec_against_released_vkeys(zk, kat, vk, proto, npts):
+    """the host mirror's compressed-point codec on the reference's own .vkey bytes and protocol points (KAT A4), and on proof words (A5/A6)."""
+    h2 = zk.halo2
+    raw = bytes.fromhex(kat[vk])
+    pr = kat[proto] if proto == "chunk_protocol" else kat[proto]["protocol"]
+    for i in range(npts):
+        word = raw[8 + 32 * i: 40 + 32 * i]
+        pt = np.array(pr["preprocessed"][i]["x"] + pr["preprocessed"][i]["y"], dtype=np.uint64)
+        assert (h2.g1_from_bytes(word) == pt).all() and h2.g1_to_bytes(pt) == word
+        assert (h2.g1_from_bytes(word) == cref.g1_decompress(word)).all()
+    proof = bytes.fromhex(kat["chunk_proof"]["proof"])
+    for i in list(range(9)) + [26, 27]:
+        w = proof[32 * i: 32 * i + 32]
+        assert h2.g1_to_bytes(h2.g1_from_bytes(w)) == w and cref.g1_is_on_curve(h2.g1_from_bytes(w))
+    assert h2.g1_to_bytes(np.zeros(12, dtype=np.uint64)) == bytes(32) and (h2.g1_from_bytes(bytes(32)) == 0).all()
+    with pytest.raises(ValueError):
+        h2.g1_from_bytes((4).to_bytes(32, "little"))      # x = 4: 4^3 + 3 = 67 is not a square mod p
