@@ -36,6 +36,9 @@ import __graft_entry__ as ge  # noqa: E402
 
 R_TOP = 0x30644E72E131A029
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# ALU-side ceiling of the dominant kernel: the 29-bit XYZZ mixed-addition chain of tools/microbench.hip at this kernel's occupancy
+# (3 waves/SIMD, operands cache-resident), profiles/r01_microbench_final.log.  Reported next to the HBM roofline, never instead of it.
+MADD_CHAIN_PEAK = 15.9e9
 
 
 def rand_scalars(n: int, seed: int, device) -> torch.Tensor:
@@ -336,6 +339,9 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "k_msm_accumulate", "avg_launch_ms": acc_avg_ms,
+                         "alu": {"achieved": (n * W / (acc_avg_ms * 1e-3)) if acc_avg_ms > 0 else None, "peak": MADD_CHAIN_PEAK, "unit": "G1 mixed additions/s",
+                                 "frac": (n * W / (acc_avg_ms * 1e-3) / MADD_CHAIN_PEAK) if acc_avg_ms > 0 else None,
+                                 "source": "profiles/r01_microbench_final.log (xyzz29 madd chain, 3 waves/SIMD)"},
                          "note": "algorithmic bytes = 96 B per (scalar, point) pair x pairs per launch (SURVEY 8d); the kernel is VALU-integer bound, see DESIGN.md"},
             "cpu_baseline": cpu, "ntt": ntt,
         }
