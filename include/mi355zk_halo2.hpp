@@ -1,0 +1,160 @@
+// mi355zk_halo2.hpp -- C++ host-side mirror of the halo2_proofs operator surface on top of the C-ABI (include/mi355zk.h).
+//
+// The reference's host language is Rust; no Rust toolchain exists in this repository's container, so next to
+// the Rust binding that a maintainer adds (rust_shim/mi355zk.rs) this header gives compiled-code callers the same names, argument
+// meaning and error behaviour as the functions scroll-prover reaches through gen_halo2_chunk_proof / gen_batch_proof
+// [REF integration/src/prove.rs:37,67,96] in halo2_proofs@e5ddf67 [EXT-recalled]:
+//
+//   best_multiexp(coeffs, bases) -> G1           src/arithmetic.rs     (length mismatch: the Rust code panics; here std::invalid_argument)
+//   best_fft(a, omega, log_n)                    src/arithmetic.rs     in place, natural order in and out
+//   eval_polynomial(poly, point)                 src/arithmetic.rs
+//   EvaluationDomain::new(j, k) + lagrange_to_coeff / coeff_to_lagrange / coeff_to_extended / extended_to_coeff / get_omega ...
+//   ParamsKZG { k, n, g, g_lagrange } + commit / commit_lagrange (bases registered once, resident in HBM)
+//
+// Header-only; link with -lmi355zk.  Types are the in-memory forms of halo2curves::bn256 (4 x u64 LE Montgomery limbs).
+// Host arithmetic here is limited to the domain constants (omega, n^-1, ...), exactly what EvaluationDomain::new computes;
+// it reuses the product's own limb code (scroll-prover_amd/csrc/fp.cuh compiles for the host).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mi355zk.h"
+#include "../scroll-prover_amd/csrc/fp.cuh"
+
+namespace mi355zk {
+namespace halo2 {
+
+using Fr = std::array<uint64_t, 4>;
+using G1Affine = std::array<uint64_t, 8>;   // {x, y}, identity (0, 0)
+using G1 = std::array<uint64_t, 12>;        // Jacobian {x, y, z}; results come back normalised (z = R or the all-zero identity)
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error("mi355zk error " + std::to_string(c) + ": " + m), code(c) {}
+};
+inline void check(int rc) { if (rc != MI355_OK) throw Error(rc, mi355_last_error()); }
+inline void init(int device_id = 0) { check(mi355_init(device_id)); }
+
+// ---- helpers on Fr (host, for constants only)
+namespace detail {
+inline zk::fe_t to_fe(const Fr &a) { zk::fe_t r; std::memcpy(&r, a.data(), 32); return r; }
+inline Fr from_fe(const zk::fe_t &a) { Fr r; std::memcpy(r.data(), &a, 32); return r; }
+inline Fr fr_from_u64(uint64_t v) { zk::fe_t c = zk::Fr::zero(); c.l[0] = (uint32_t)v; c.l[1] = (uint32_t)(v >> 32); return from_fe(zk::Fr::from_canonical(c)); }
+inline Fr fr_mul(const Fr &a, const Fr &b) { return from_fe(zk::Fr::mul(to_fe(a), to_fe(b))); }
+inline Fr fr_inv(const Fr &a) { return from_fe(zk::Fr::inv(to_fe(a))); }
+inline Fr fr_pow(const Fr &a, uint64_t e) { return from_fe(zk::Fr::pow_u64(to_fe(a), e)); }
+// halo2curves bn256::Fr::ROOT_OF_UNITY = 7^((r-1)/2^28) and ZETA (cube root of unity), canonical values [EXT-recalled src/bn256/fr.rs];
+// both are re-derived / checked in tests/test_oracle_golden.py
+inline Fr root_of_unity() {
+  zk::fe_t c; const uint32_t w[8] = {0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du, 0x3dd31f74u, 0x98865ea9u, 0x166d18b7u, 0x03ddb9f5u};
+  for (int i = 0; i < 8; i++) c.l[i] = w[i];
+  return from_fe(zk::Fr::from_canonical(c));
+}
+inline Fr zeta() {
+  zk::fe_t c; const uint32_t w[8] = {0x36636f23u, 0xb8ca0b2du, 0xec2bc5e9u, 0xcc37a73fu, 0x3fd84104u, 0x048b6e19u, 0xe131a029u, 0x30644e72u};
+  for (int i = 0; i < 8; i++) c.l[i] = w[i];
+  return from_fe(zk::Fr::from_canonical(c));
+}
+}  // namespace detail
+
+constexpr uint32_t FR_S = 28;
+
+// ------------------------------------------------------------------------------------------------ arithmetic.rs
+inline G1 best_multiexp(const std::vector<Fr> &coeffs, const std::vector<G1Affine> &bases) {
+  if (coeffs.size() != bases.size()) throw std::invalid_argument("best_multiexp: coeffs.len() != bases.len()");
+  G1 out;
+  check(mi355_msm_g1_adhoc_host(bases.data(), coeffs.data(), coeffs.size(), out.data()));
+  return out;
+}
+inline void best_fft(std::vector<Fr> &a, const Fr &omega, uint32_t log_n) {
+  if (a.size() != (size_t(1) << log_n)) throw std::invalid_argument("best_fft: a.len() != 1 << log_n");
+  check(mi355_ntt_fr_host(a.data(), log_n, omega.data()));
+}
+inline Fr eval_polynomial(const std::vector<Fr> &poly, const Fr &point) {
+  Fr out;
+  check(mi355_eval_polynomial_host(poly.data(), poly.size(), point.data(), out.data()));
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------ poly/domain.rs
+class EvaluationDomain {
+ public:
+  uint32_t k, extended_k, quotient_poly_degree;
+  uint64_t n;
+  Fr omega, omega_inv, extended_omega, extended_omega_inv, g_coset, g_coset_inv, ifft_divisor, extended_ifft_divisor;
+
+  // EvaluationDomain::new(j, k): n = 2^k, quotient_poly_degree = j - 1, extended_k minimal with 2^extended_k >= n * (j - 1)
+  EvaluationDomain(uint32_t j, uint32_t k_) : k(k_), quotient_poly_degree(j - 1), n(uint64_t(1) << k_) {
+    extended_k = k;
+    while ((uint64_t(1) << extended_k) < n * quotient_poly_degree) extended_k++;
+    if (extended_k > FR_S) throw std::invalid_argument("EvaluationDomain: extended_k exceeds the two-adicity of Fr");
+    extended_omega = detail::root_of_unity();
+    for (uint32_t i = extended_k; i < FR_S; i++) extended_omega = detail::fr_mul(extended_omega, extended_omega);
+    omega = extended_omega;
+    for (uint32_t i = k; i < extended_k; i++) omega = detail::fr_mul(omega, omega);
+    omega_inv = detail::fr_inv(omega); extended_omega_inv = detail::fr_inv(extended_omega);
+    g_coset = detail::zeta(); g_coset_inv = detail::fr_mul(g_coset, g_coset);
+    ifft_divisor = detail::fr_inv(detail::fr_from_u64(n));
+    extended_ifft_divisor = detail::fr_inv(detail::fr_from_u64(uint64_t(1) << extended_k));
+  }
+  uint64_t extended_len() const { return uint64_t(1) << extended_k; }
+  const Fr &get_omega() const { return omega; }
+  const Fr &get_extended_omega() const { return extended_omega; }
+
+  void coeff_to_lagrange(std::vector<Fr> &a) const { best_fft(a, omega, k); }
+  // ifft: best_fft(a, omega_inv, k) then a[i] *= n^-1
+  void lagrange_to_coeff(std::vector<Fr> &a) const {
+    if (a.size() != n) throw std::invalid_argument("lagrange_to_coeff: wrong length");
+    check(mi355_intt_fr_host(a.data(), k, omega_inv.data(), ifft_divisor.data()));
+  }
+  std::vector<Fr> coeff_to_extended(const std::vector<Fr> &a) const {
+    if (a.size() != n) throw std::invalid_argument("coeff_to_extended: wrong length");
+    std::vector<Fr> out(extended_len());
+    check(mi355_coeff_to_extended_host(out.data(), a.data(), k, extended_k, g_coset.data(), g_coset_inv.data(), extended_omega.data()));
+    return out;
+  }
+  // inverse transform, truncated to n * quotient_poly_degree coefficients as halo2 does
+  std::vector<Fr> extended_to_coeff(std::vector<Fr> a) const {
+    if (a.size() != extended_len()) throw std::invalid_argument("extended_to_coeff: wrong length");
+    check(mi355_extended_to_coeff_host(a.data(), extended_k, g_coset.data(), g_coset_inv.data(), extended_omega_inv.data(), extended_ifft_divisor.data()));
+    a.resize(n * quotient_poly_degree);
+    return a;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ poly/kzg/commitment.rs
+class ParamsKZG {
+ public:
+  uint32_t k;
+  uint64_t n;
+  // what Prover::load_params hands down: both bases are registered once and stay resident (params_map outlives every prover)
+  ParamsKZG(uint32_t k_, const std::vector<G1Affine> &g, const std::vector<G1Affine> &g_lagrange, bool window_tables = false) : k(k_), n(uint64_t(1) << k_) {
+    if (g.size() != n || g_lagrange.size() != n) throw std::invalid_argument("ParamsKZG: bases must have 2^k points");
+    check(mi355_srs_register_host(g.data(), n, &g_));
+    check(mi355_srs_register_host(g_lagrange.data(), n, &gl_));
+    if (window_tables) { check(mi355_srs_precompute(g_, 0, 0)); check(mi355_srs_precompute(gl_, 0, 0)); }
+  }
+  ParamsKZG(const ParamsKZG &) = delete;
+  ParamsKZG &operator=(const ParamsKZG &) = delete;
+  ~ParamsKZG() { if (g_) mi355_srs_release(g_); if (gl_) mi355_srs_release(gl_); }
+
+  // commit(poly: Coeff) = best_multiexp(poly, &g[..poly.len()]);  commit_lagrange(poly) = best_multiexp(poly, &g_lagrange[..n])
+  G1 commit(const std::vector<Fr> &poly) const {
+    if (poly.size() > n) throw std::invalid_argument("commit: polynomial longer than the basis");
+    G1 out; check(mi355_msm_g1_host(g_, 0, poly.data(), poly.size(), out.data())); return out;
+  }
+  G1 commit_lagrange(const std::vector<Fr> &poly) const {
+    if (poly.size() != n) throw std::invalid_argument("commit_lagrange: polynomial must have exactly n evaluations");
+    G1 out; check(mi355_msm_g1_host(gl_, 0, poly.data(), poly.size(), out.data())); return out;
+  }
+
+ private:
+  uint64_t g_ = 0, gl_ = 0;
+};
+
+}  // namespace halo2
+}  // namespace mi355zk

@@ -1,0 +1,87 @@
+// test_halo2_mirror.cpp -- exercises include/mi355zk_halo2.hpp (the C++ mirror of the halo2_proofs operator surface) the way the
+// upstream crates test theirs: results against the CPU oracle (oracle/liboracle_bn254.so -- the checker), domain constants against
+// the reference's released protocol file (KAT A1).  `--host-only` runs the part that needs no GPU.  Exit code 0 = all checks passed.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+
+#include "mi355zk_halo2.hpp"
+
+using namespace mi355zk::halo2;
+
+extern "C" {   // oracle (TEST INFRASTRUCTURE): see oracle/bn254_oracle.c
+void orc_best_multiexp(void *out, const void *coeffs, const void *bases, uint64_t n, int threads);
+void orc_g1_to_affine(void *o, const void *p);
+void orc_g1_mul(void *o, const void *p, const void *scalar_mont);
+void orc_g1_generator(void *o);
+void orc_best_fft(void *a, const void *omega, uint32_t log_n, int threads);
+void orc_ifft(void *a, const void *omega_inv, uint32_t log_n, const void *divisor, int threads);
+void orc_eval_polynomial(void *out, const void *poly, uint64_t n, const void *point);
+void orc_coeff_to_extended(void *dst, const void *coeffs, uint32_t k, uint32_t ext_k, const void *g, const void *gi, const void *ew, int threads);
+}
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond); failures++; } } while (0)
+
+static Fr rand_fr(std::mt19937_64 &g) { Fr r{g(), g(), g(), g() & ((uint64_t(1) << 60) - 1)}; return r; }
+
+int main(int argc, char **argv) {
+  const bool host_only = argc > 1 && std::strcmp(argv[1], "--host-only") == 0;
+  // --- EvaluationDomain::new against [REF release-v0.13.1/chunk.protocol] domain {k: 25, gen, gen_inv, n_inv}
+  EvaluationDomain d25(2, 25);
+  const Fr gen{13338605924273364442ull, 11440449704248451096ull, 16859609365912477452ull, 3421252324365184758ull};
+  const Fr gen_inv{2738242980467392064ull, 8765460162850139420ull, 6637814084492473216ull, 1260493707339115276ull};
+  const Fr n_inv{0, 0, 0, 549755813888ull};
+  EXPECT(d25.omega == gen); EXPECT(d25.omega_inv == gen_inv); EXPECT(d25.ifft_divisor == n_inv);
+  EXPECT(EvaluationDomain(5, 26).extended_k == 28); EXPECT(EvaluationDomain(4, 10).extended_k == 12); EXPECT(EvaluationDomain(3, 10).extended_k == 11);
+  bool threw = false; try { EvaluationDomain bad(9, 26); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
+  threw = false; try { best_multiexp(std::vector<Fr>(3), std::vector<G1Affine>(4)); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
+  if (host_only) {
+    // without a GPU every compute entry point must fail loudly (no CPU fallback)
+    threw = false; try { init(0); } catch (const Error &e) { threw = e.code == MI355_ENODEVICE; } 
+    if (!threw) { std::printf("note: a GPU is visible; host-only run skips the no-device check\n"); }
+    std::printf(failures ? "FAILED (%d)\n" : "host-only checks passed\n", failures);
+    return failures ? 1 : 0;
+  }
+  init(0);
+  std::mt19937_64 rng(20240924);
+  // --- best_multiexp / ParamsKZG::commit against the oracle
+  const uint32_t k = 10; const uint64_t n = 1 << k;
+  G1Affine G; orc_g1_generator(G.data());
+  std::vector<G1Affine> bases(n); std::vector<Fr> sc(n);
+  for (uint64_t i = 0; i < n; i++) { Fr s = rand_fr(rng); G1 j; orc_g1_mul(j.data(), G.data(), s.data()); orc_g1_to_affine(bases[i].data(), j.data()); sc[i] = rand_fr(rng); }
+  G1 want_j; orc_best_multiexp(want_j.data(), sc.data(), bases.data(), n, 4);
+  G1Affine want; orc_g1_to_affine(want.data(), want_j.data());
+  G1 got = best_multiexp(sc, bases);
+  EXPECT(std::memcmp(got.data(), want.data(), 64) == 0);
+  {
+    std::vector<G1Affine> rev(bases.rbegin(), bases.rend());
+    ParamsKZG params(k, bases, rev, /*window_tables=*/true);
+    G1 c1 = params.commit(sc);
+    EXPECT(std::memcmp(c1.data(), want.data(), 64) == 0);
+    G1 c2 = params.commit_lagrange(sc);
+    G1 w2; orc_best_multiexp(w2.data(), sc.data(), rev.data(), n, 4); G1Affine w2a; orc_g1_to_affine(w2a.data(), w2.data());
+    EXPECT(std::memcmp(c2.data(), w2a.data(), 64) == 0);
+    threw = false; try { params.commit_lagrange(std::vector<Fr>(n - 1)); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
+  }
+  // --- best_fft / EvaluationDomain against the oracle (raw Montgomery bytes)
+  EvaluationDomain dom(4, k);
+  std::vector<Fr> a(n); for (auto &x : a) x = rand_fr(rng);
+  std::vector<Fr> f = a, wf = a;
+  dom.coeff_to_lagrange(f); orc_best_fft(wf.data(), dom.omega.data(), k, 4);
+  EXPECT(f == wf);
+  std::vector<Fr> back = f; dom.lagrange_to_coeff(back); EXPECT(back == a);
+  std::vector<Fr> ext = dom.coeff_to_extended(a), wext(dom.extended_len());
+  orc_coeff_to_extended(wext.data(), a.data(), k, dom.extended_k, dom.g_coset.data(), dom.g_coset_inv.data(), dom.extended_omega.data(), 4);
+  EXPECT(ext == wext);
+  std::vector<Fr> coeffs = dom.extended_to_coeff(ext);
+  EXPECT(coeffs.size() == n * 3); EXPECT(std::equal(a.begin(), a.end(), coeffs.begin()));
+  for (size_t i = n; i < coeffs.size(); i++) EXPECT((coeffs[i] == Fr{0, 0, 0, 0}));
+  // --- eval_polynomial
+  Fr x = rand_fr(rng), ev = eval_polynomial(a, x), wev; orc_eval_polynomial(wev.data(), a.data(), n, x.data());
+  EXPECT(ev == wev);
+  EXPECT(f[5] == eval_polynomial(a, mi355zk::halo2::detail::fr_pow(dom.omega, 5)));   // a'[i] = a(omega^i)
+  std::printf(failures ? "FAILED (%d)\n" : "all checks passed\n", failures);
+  return failures ? 1 : 0;
+}
