@@ -84,6 +84,9 @@ int mi355_msm_g1_adhoc_host(const void *bases_affine_host, const void *scalars_h
 /* sum of `n` G1 (Jacobian, any representative) points: the fold `results.iter().fold(identity, |a, b| a + b)` of
  * best_multiexp, used to combine per-GPU partial sums after the RCCL all-gather.                  */
 int mi355_g1_sum_host(const void *g1_points_host, uint64_t n, void *out_g1_host);
+/* normalise = 0: subsequent MSM results are SOME Jacobian representative of the sum (as best_multiexp's C::Curve is) instead of the
+ * normalised one; saves the serial field inversion (~0.4 ms) where the result is folded again anyway (per-GPU partial sums).      */
+int mi355_msm_set_normalise(int on);
 /* tuning: window bits c for subsequent MSMs (0 = automatic from n)                                             */
 int mi355_msm_set_window_bits(int c);
 

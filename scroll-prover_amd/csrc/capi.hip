@@ -63,6 +63,7 @@ struct Ctx {
   int force_c = 0;
   uint32_t sort_t2 = 8192;      // MI355_SORT_T2 = 8192 | 16384 | 32768
   uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
+  bool normalise = true;        // mi355_msm_set_normalise(0): MSM results come back as an un-normalised Jacobian representative
   uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): bit 0 nontemporal gathers, bit 1 prefetched bucket ends -- neither measurably helps
   uint32_t seg_factor = 16;
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
@@ -241,7 +242,7 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
           cur = dst; cnt = outn; which ^= 1;
         }
       }
-      hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, window_sums, red_windows, shared ? 0u : P.c, out_dev);
+      hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, window_sums, red_windows, shared ? 0u : P.c, out_dev, g.normalise ? 1 : 0);
     }
   }
   HIPCHK(hipGetLastError());
@@ -580,6 +581,7 @@ int mi355_msm_set_window_bits(int c) {
   if (c != 0 && (c < 2 || c > 24)) return fail(MI355_EBADARG, "window bits must be 0 (auto) or in [2, 24]");
   g.force_c = c; return MI355_OK;
 }
+int mi355_msm_set_normalise(int on) { std::lock_guard<std::mutex> lk(g.mu); g.normalise = on != 0; return MI355_OK; }
 int mi355_msm_last_plan(int *c_out, int *windows_out, uint64_t *entries_out) {
   std::lock_guard<std::mutex> lk(g.mu);
   if (c_out) *c_out = g.last_c; if (windows_out) *windows_out = g.last_w; if (entries_out) *entries_out = g.last_entries; return MI355_OK;

@@ -409,14 +409,20 @@ __global__ void __launch_bounds__(256) k_msm_tree_sum(const g1_xyzz_t *__restric
   if (threadIdx.x == 0) { for (uint32_t k = 1; k < 4; k++) g1_xyzz_add_ps(acc, lds[k]); store_xyzz(&out[(uint64_t)w * out_per_window + blockIdx.x], acc); }
 }
 // ---- 7. Horner over windows + normalisation.  One lane; 255 doublings are inherently serial.
-__global__ void k_msm_final(const g1_xyzz_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out) {
+__global__ void k_msm_final(const g1_xyzz_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   g1_xyzz_t acc = g1_xyzz_identity();
   for (uint32_t w = windows; w-- > 0;) {
     for (uint32_t k = 0; k < c; k++) acc = g1_xyzz_dbl_ps(acc);
     g1_xyzz_add_ps(acc, load_xyzz(&window_sums[w]));
   }
-  *out = g1_xyzz_to_jac_normalised(acc);
+  if (normalise) { *out = g1_xyzz_to_jac_normalised(acc); return; }
+  // un-normalised Jacobian representative (X ZZ^2, Y ZZZ^2, ZZZ): skips the ~380 serial multiplications of the inversion; used for the
+  // per-GPU partial sums, which are folded (and normalised once) by k_g1_sum
+  g1_jac_t r;
+  if (g1_xyzz_is_identity(acc)) { r.x = Fq::zero(); r.y = Fq::zero(); r.z = Fq::zero(); }
+  else { r.x = fq_mul_ps(acc.x, fq_sqr_ps(acc.zz)); r.y = fq_mul_ps(acc.y, fq_sqr_ps(acc.zzz)); r.z = acc.zzz; }
+  *out = r;
 }
 // sum of n Jacobian points (fold of per-GPU partial results), normalised
 __global__ void k_g1_sum(const g1_jac_t *__restrict__ pts, uint32_t n, g1_jac_t *__restrict__ out) {

@@ -23,6 +23,9 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_BUFFERS = {}   # (world, device) -> (send, recv, pinned host copy): the exchange is 96 B per rank, so allocation would dominate it
+
+
 def allgather_partials(partial: np.ndarray, device=None) -> np.ndarray:
     """every rank contributes one G1 (12 x u64 = 96 B); returns [world, 12] on every rank."""
     import torch
@@ -32,8 +35,11 @@ def allgather_partials(partial: np.ndarray, device=None) -> np.ndarray:
         return partial.reshape(1, 12).copy()
     world = dist.get_world_size()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    mine = torch.from_numpy(partial.view(np.uint8).copy()).to(dev)
-    out = torch.empty(world * 96, dtype=torch.uint8, device=dev)
+    key = (world, str(dev))
+    if key not in _BUFFERS:
+        _BUFFERS[key] = (torch.empty(96, dtype=torch.uint8, device=dev), torch.empty(world * 96, dtype=torch.uint8, device=dev))
+    mine, out = _BUFFERS[key]
+    mine.copy_(torch.from_numpy(partial.view(np.uint8)))
     dist.all_gather_into_tensor(out, mine)
     return out.cpu().numpy().view(np.uint64).reshape(world, 12).copy()
 

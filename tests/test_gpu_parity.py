@@ -373,3 +373,25 @@ def test_coset_parts_equal_the_extended_domain(zk, k):
     got = d.cpu().numpy().view(np.uint64)
     pw = np.stack([h2.fr(pow(f, i, R)) for i in range(min(1 << k, 600))])
     assert (got[: pw.shape[0]] == cref.f_mul_vec(cref.FR, coeffs[: pw.shape[0]], pw)).all()
+
+
+def test_unnormalised_partials_fold_to_the_same_point(zk, points):
+    """mi355_msm_set_normalise(0): per-GPU partial sums as arbitrary Jacobian representatives, folded by g1_sum (the multi-GPU path)."""
+    h2 = zk.halo2
+    lib, check = zk._capi.lib(), zk._capi.check
+    rng = np.random.default_rng(2024)
+    n = 1536
+    sc = rand_fr(rng, n)
+    check(lib.mi355_msm_set_normalise(0))
+    try:
+        parts = np.stack([h2.best_multiexp(sc[lo:hi], points[lo:hi]) for lo, hi in ((0, 500), (500, 1100), (1100, n))])
+        zero_part = h2.best_multiexp(np.tile(cref.fr_mont(0), (4, 1)), points[:4])
+    finally:
+        check(lib.mi355_msm_set_normalise(1))
+    one_q = np.array(pyref.to_limbs(pyref.MONT_R % pyref.P_MOD), dtype=np.uint64)
+    assert not all((p[8:] == one_q).all() for p in parts), "partials should not be normalised in this mode"
+    assert (zero_part[8:] == 0).all()
+    for p, (lo, hi) in zip(parts, ((0, 500), (500, 1100), (1100, n))):
+        assert (cref.g1_to_affine(p) == cref.g1_to_affine(cref.best_multiexp(sc[lo:hi], points[lo:hi]))).all()
+    total = affine_of(h2.g1_sum(np.vstack([parts, zero_part[None]])))
+    assert (total == cref.g1_to_affine(cref.best_multiexp(sc, points[:n]))).all()
