@@ -79,6 +79,12 @@ int mi355_srs_dev_ptr(uint64_t handle, void **dev_ptr_out);
  *      out_g1 receives 96 B (normalised Jacobian, see above) in host memory.                                  */
 int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *scalars_host, uint64_t n, void *out_g1_host);
 int mi355_msm_g1_dev(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_host);
+/* `batch` commitments over the SAME basis slice in one pass (e.g. all advice columns of a phase: create_proof commits them one
+ * after the other): scalars_dev is a host array of `batch` device pointers (n x 32 B each), out receives
+ * batch x 96 B.  Results are identical to `batch` separate calls; the fixed per-call costs are paid once.                          */
+int mi355_msm_g1_batch_dev(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_dev, uint32_t batch, uint64_t n, void *out_g1_host);
+/* the same with `batch` host pointers (what the Rust loop over advice columns holds)                                              */
+int mi355_msm_g1_batch_host(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_host, uint32_t batch, uint64_t n, void *out_g1_host);
 /* ad-hoc bases (best_multiexp with bases that are not a registered SRS)                                        */
 int mi355_msm_g1_adhoc_host(const void *bases_affine_host, const void *scalars_host, uint64_t n, void *out_g1_host);
 /* sum of `n` G1 (Jacobian, any representative) points: the fold `results.iter().fold(identity, |a, b| a + b)` of

@@ -151,6 +151,21 @@ class ParamsKZG {
     if (poly.size() != n) throw std::invalid_argument("commit_lagrange: polynomial must have exactly n evaluations");
     G1 out; check(mi355_msm_g1_host(gl_, 0, poly.data(), poly.size(), out.data())); return out;
   }
+  // the per-column loop of create_proof (advice / lookup / permutation commitments of one phase) as one call: equal-length polynomials,
+  // results in input order, identical to calling commit / commit_lagrange on each
+  std::vector<G1> commit_many(const std::vector<const std::vector<Fr> *> &polys, bool lagrange = false) const {
+    std::vector<G1> out(polys.size());
+    if (polys.empty()) return out;
+    const size_t len = polys[0]->size();
+    std::vector<const void *> p(polys.size());
+    for (size_t m = 0; m < polys.size(); m++) {
+      if (polys[m]->size() != len) throw std::invalid_argument("commit_many: polynomials must have equal length");
+      p[m] = polys[m]->data();
+    }
+    if (len > n || (lagrange && len != n)) throw std::invalid_argument("commit_many: polynomial length does not fit the basis");
+    check(mi355_msm_g1_batch_host(lagrange ? gl_ : g_, 0, p.data(), (uint32_t)polys.size(), len, out.data()));
+    return out;
+  }
 
  private:
   uint64_t g_ = 0, gl_ = 0;

@@ -24,6 +24,7 @@ extern "C" {
     pub fn mi355_srs_release(handle: u64) -> c_int;
     pub fn mi355_srs_precompute(handle: u64, n_hint: u64, c: c_int) -> c_int;
     pub fn mi355_msm_g1_host(srs: u64, base_offset: u64, scalars_host: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
+    pub fn mi355_msm_g1_batch_host(srs: u64, base_offset: u64, scalars_host: *const *const c_void, batch: u32, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_msm_g1_adhoc_host(bases: *const c_void, scalars: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_ntt_fr_host(data_host: *mut c_void, log_n: u32, omega: *const c_void) -> c_int;
     pub fn mi355_intt_fr_host(data_host: *mut c_void, log_n: u32, omega_inv: *const c_void, divisor: *const c_void) -> c_int;
@@ -91,6 +92,23 @@ pub fn multiexp_g1(coeffs: &[Fr], bases: &[G1Affine]) -> Option<G1> {
         }
     };
     if rc == MI355_OK { Some(unsafe { out.assume_init() }) } else { None }
+}
+
+/// One call for the `polys.iter().map(|p| params.commit_lagrange(p, blind))` loops of create_proof (advice / instance / lookup /
+/// permutation columns of one phase): equal-length polynomials over one registered basis.  The blinding term is added by the caller as
+/// in the reference.  None -> caller runs the original per-polynomial loop.
+pub fn multiexp_g1_many(polys: &[&[Fr]], bases: &[G1Affine]) -> Option<Vec<G1>> {
+    if polys.is_empty() { return Some(vec![]); }
+    let n = polys[0].len();
+    assert!(polys.iter().all(|p| p.len() == n) && n <= bases.len());
+    if !available() || (n as u64) < (1u64 << min_log("MI355_MSM_MIN_LOGN", 14)) { return None; }
+    let (h, off) = srs_handle(&bases[..n])?;
+    let ptrs: Vec<*const c_void> = polys.iter().map(|p| p.as_ptr() as *const c_void).collect();
+    let mut out: Vec<G1> = Vec::with_capacity(polys.len());
+    let rc = unsafe { mi355_msm_g1_batch_host(h, off, ptrs.as_ptr(), polys.len() as u32, n as u64, out.as_mut_ptr() as *mut c_void) };
+    if rc != MI355_OK { return None; }
+    unsafe { out.set_len(polys.len()); }
+    Some(out)
 }
 
 /// Replacement body of `best_fft` for G = Scalar = Fr (the G = curve-point instantiation keeps the CPU code).

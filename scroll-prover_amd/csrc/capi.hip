@@ -123,22 +123,45 @@ int choose_c(uint64_t n) {
 
 struct PreTable { const g1_affine_t *table = nullptr; uint64_t row_stride = 0; int c = 0, w = 0; };   // table already offset to the slice start
 
+int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre);
+
 int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void *out_host, const PreTable *pre = nullptr) {
-  g1_jac_t result; memset(&result, 0, sizeof result);
-  if (n == 0) { memcpy(out_host, &result, sizeof result); return MI355_OK; }
+  return msm_batch_impl(bases, &scalars, 1, n, out_host, pre);
+}
+
+// M commitments over the same basis slice in one pass: (polynomial m, window w) is window m * W + w of one big bucket problem, so the
+// per-call fixed costs (launches, the latency-bound reduction tail) are paid once per batch.  out_host: M x 96 B.
+int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre) {
+  if (M == 0) return MI355_OK;
+  if (n == 0) { memset(out_host, 0, (size_t)M * sizeof(g1_jac_t)); return MI355_OK; }
   if (n >= (1ull << 31)) return fail(MI355_EBADARG, "msm: n must be < 2^31");
-  MsmPlan P; P.n = (uint32_t)n; P.c = (uint32_t)choose_c(n);
+  const g1_affine_t *bases0 = bases;
+  MsmPlan P; P.n = (uint32_t)n; P.batch = M; P.c = (uint32_t)choose_c(n);
   // precomputed rows 2^(c w) P available and cheaper than the per-window schedule at this n -> all windows share one bucket set
   const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)P.c, false) && n * (uint64_t)pre->w < (1ull << 31);
   if (shared) { P.c = (uint32_t)pre->c; bases = pre->table; }
   P.windows = (255 + P.c - 1) / P.c; P.nb = 1u << (P.c - 1);
-  const uint64_t emax = n * P.windows;
+  const uint64_t emax = (uint64_t)M * n * P.windows;
+  {
+    // a batch that would overflow the 32-bit entry index, the coarse histogram's LDS or a sensible workspace (16 B per entry) is
+    // processed as two half batches
+    const uint32_t kb = P.c - 1, cbits = kb <= 11 ? 0 : (kb - 11 > 10 ? 10 : kb - 11);
+    const uint64_t regions = (uint64_t)M * (shared ? 1 : P.windows) << cbits, bk = (uint64_t)M * (shared ? 1 : P.windows) << kb;
+    if (M > 1 && (emax > (1ull << 29) || regions * 4 > 48 * 1024 || bk >= (1ull << 28))) {
+      const uint32_t h = M / 2;
+      int rc = msm_batch_impl(bases0, polys_host, h, n, out_host, pre);
+      if (rc != MI355_OK) return rc;
+      return msm_batch_impl(bases0, polys_host + h, M - h, n, (char *)out_host + (size_t)h * sizeof(g1_jac_t), pre);
+    }
+  }
   if (emax >= (1ull << 32)) return fail(MI355_EBADARG, "msm: n * windows must be < 2^32");
   const uint64_t want_threads = (uint64_t)g.prop.multiProcessorCount * 256 * g.seg_factor;   // segments per lane slot (MI355_SEG_FACTOR)
   uint64_t seg = (emax + want_threads - 1) / want_threads; if (seg < 16) seg = 16; if (seg > 4096) seg = 4096;
   P.seg = (uint32_t)seg;
-  const uint32_t nbuckets = shared ? P.nb : P.windows * P.nb;
-  const uint32_t red_windows = shared ? 1 : P.windows;   // bucket sets to reduce
+  const uint32_t red_wpp = shared ? 1 : P.windows;        // bucket sets per polynomial
+  const uint32_t red_windows = M * red_wpp;               // bucket sets to reduce
+  if ((uint64_t)red_windows * P.nb >= (1ull << 31)) return fail(MI355_EBADARG, "msm: too many buckets (split the batch)");
+  const uint32_t nbuckets = red_windows * P.nb;
   const uint32_t acc_threads = ceil_div(emax, seg), acc_blocks = ceil_div(acc_threads, 256);
   const uint32_t tn = acc_blocks * 256;
   // running-sum chunk per reduce thread: every thread is one serial chain of 2*chunk additions plus a ~(c-1)-bit scalar multiple, so the
@@ -148,15 +171,17 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   const uint32_t chunks_per_window = P.nb / chunk, nchunks = chunks_per_window * red_windows;
 
   // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest (<= 9)
-  SortPlan S; S.n = P.n; S.windows = P.windows; S.nb = P.nb;
+  SortPlan S; S.n = P.n; S.windows = M * P.windows; S.wpp = P.windows; S.nb = P.nb;
   { uint32_t kb = P.c - 1; uint32_t fb = kb < 11 ? kb : 11; if (kb - fb > 10) fb = kb - 10; S.fb = fb; S.cb_bits = kb - fb; }
   S.shared = shared ? 1 : 0;
-  S.regions = shared ? (1u << S.cb_bits) : (P.windows << S.cb_bits);
+  S.regions = red_windows << S.cb_bits;
+  if ((size_t)S.regions * 4 > 48 * 1024) return fail(MI355_EBADARG, "msm: batch too large for the coarse histogram (split the batch)");
   S.t1 = g.sort_t1;                           // level-1 tile: 1024 threads x 8 or 16 entries (64 / 128 KiB of LDS staging)
   const bool big_t2 = S.fb <= 11 && g.sort_t2 == 32768;   // level-2 tile: 32768 entries (128 KiB of indices) unless the fine table is large
   S.t2 = big_t2 ? 32768 : g.sort_t2 == 8192 ? 8192 : 16384;
   if (S.fb > 12 || (1u << S.cb_bits) > SORT_MAX_BINS) return fail(MI355_EBADARG, "msm: window bits out of range for the sorter");
   const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions;
+  const uint32_t vwindows = M * P.windows;   // (polynomial, window) pairs
 
   uint32_t *enc, *hist, *offsets, *cursor, *sorted, *scan_sums, *coarse_hist, *coarse_off, *coarse_cursor, *tile_start; uint64_t *pairs;
   g1_xyzz29_t *buckets, *part; g1_xyzz_t *chunk_out, *window_sums; int32_t *part_id; g1_jac_t *out_dev;
@@ -183,8 +208,10 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   g1_xyzz_t *tree_a, *tree_b;
   { const size_t lvl = (size_t)ceil_div(chunks_per_window, 256 * TREE_PER_THREAD) * red_windows + 1;
     CHK(ws_get("msm.tree_a", lvl * sizeof(g1_xyzz_t), (void **)&tree_a)); CHK(ws_get("msm.tree_b", lvl * sizeof(g1_xyzz_t), (void **)&tree_b)); }
-  CHK(ws_get("msm.window_sums", (size_t)P.windows * sizeof(g1_xyzz_t), (void **)&window_sums));
-  CHK(ws_get("msm.out", sizeof(g1_jac_t), (void **)&out_dev));
+  CHK(ws_get("msm.window_sums", (size_t)red_windows * sizeof(g1_xyzz_t), (void **)&window_sums));
+  CHK(ws_get("msm.out", (size_t)M * sizeof(g1_jac_t), (void **)&out_dev));
+  const fe_t **polys_dev; CHK(ws_get("msm.polys", (size_t)M * sizeof(void *), (void **)&polys_dev));
+  HIPCHK(hipMemcpyAsync(polys_dev, polys_host, (size_t)M * sizeof(void *), hipMemcpyHostToDevice, g.stream));
 
   hipStream_t s = g.stream;
   const int grid_stream = g.prop.multiProcessorCount * 8;
@@ -193,7 +220,7 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
     {
       Scope sc("msm_digits");
       HIPCHK(hipMemsetAsync(coarse_hist, 0, ((size_t)S.regions + 1) * 4, s));
-      hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream), dim3(256), (size_t)S.regions * 4, s, scalars, enc, P, coarse_hist, S.fb, S.cb_bits, S.shared);
+      hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream / M > 0 ? grid_stream / M : 1, M), dim3(256), (size_t)S.regions * 4, s, polys_dev, enc, P, coarse_hist, S.fb, S.cb_bits, S.shared);
     }
     {
       Scope sc("msm_sort");
@@ -203,8 +230,8 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
       hipLaunchKernelGGL(k_scan_final, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, coarse_off, coarse_cursor, cscan_n);
       {
         const uint32_t CBp = ((1u << S.cb_bits) + 1) & ~1u;
-        if (S.t1 == 16384) hipLaunchKernelGGL(k_sort_l1_scatter<16>, dim3(tiles1 * P.windows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
-        else hipLaunchKernelGGL(k_sort_l1_scatter<8>, dim3(tiles1 * P.windows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
+        if (S.t1 == 16384) hipLaunchKernelGGL(k_sort_l1_scatter<16>, dim3(tiles1 * vwindows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
+        else hipLaunchKernelGGL(k_sort_l1_scatter<8>, dim3(tiles1 * vwindows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
       }
       hipLaunchKernelGGL(k_sort_tile_prefix, dim3(1), dim3(SCAN_BLOCK), 0, s, coarse_off, tile_start, S);
       hipLaunchKernelGGL(k_sort_l2_hist, dim3(l2_tiles_max), dim3(256), 0, s, pairs, coarse_off, tile_start, hist, S);
@@ -242,14 +269,13 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
           cur = dst; cnt = outn; which ^= 1;
         }
       }
-      hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, s, window_sums, red_windows, shared ? 0u : P.c, out_dev, g.normalise ? 1 : 0);
+      hipLaunchKernelGGL(k_msm_final, dim3(M), dim3(64), 0, s, window_sums, red_wpp, shared ? 0u : P.c, out_dev, g.normalise ? 1 : 0);
     }
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(&result, out_dev, sizeof result, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(out_host, out_dev, (size_t)M * sizeof(g1_jac_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   resolve_spans();
-  memcpy(out_host, &result, sizeof result);
   g.last_c = (int)P.c; g.last_w = (int)P.windows; g.last_entries = emax;
   return MI355_OK;
 }
@@ -551,6 +577,35 @@ int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *sca
   fe_t *sc = nullptr;
   if (n) { CHK(ws_get("io.scalars", n * sizeof(fe_t), (void **)&sc)); HIPCHK(hipMemcpyAsync(sc, scalars_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
   return msm_dev_impl(bases, sc, n, out_g1_host, &pre);
+}
+int mi355_msm_g1_batch_dev(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_dev, uint32_t batch, uint64_t n, void *out_g1_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!out_g1_host || (batch && !scalars_dev)) return fail(MI355_EBADARG, "msm_batch: null pointer");
+  for (uint32_t m = 0; m < batch; m++) if (n && !scalars_dev[m]) return fail(MI355_EBADARG, "msm_batch: null polynomial pointer");
+  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
+  return msm_batch_impl(bases, (const fe_t *const *)scalars_dev, batch, n, out_g1_host, &pre);
+}
+int mi355_msm_g1_batch_host(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_host, uint32_t batch, uint64_t n, void *out_g1_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!out_g1_host || (batch && !scalars_host)) return fail(MI355_EBADARG, "msm_batch: null pointer");
+  for (uint32_t m = 0; m < batch; m++) if (n && !scalars_host[m]) return fail(MI355_EBADARG, "msm_batch: null polynomial pointer");
+  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
+  if (batch == 0 || n == 0) return msm_batch_impl(bases, nullptr, batch, n, out_g1_host, &pre);
+  // staged in groups of at most 4 GiB of scalars
+  const uint32_t group_max = (uint32_t)std::max<uint64_t>(1, (4ull << 30) / (n * sizeof(fe_t)));
+  for (uint32_t m0 = 0; m0 < batch; m0 += group_max) {
+    const uint32_t mg = std::min(group_max, batch - m0);
+    fe_t *sc; CHK(ws_get("io.scalars", (size_t)mg * n * sizeof(fe_t), (void **)&sc));
+    std::vector<const fe_t *> ptrs(mg);
+    for (uint32_t m = 0; m < mg; m++) {
+      ptrs[m] = sc + (size_t)m * n;
+      HIPCHK(hipMemcpyAsync(sc + (size_t)m * n, scalars_host[m0 + m], n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream));
+    }
+    CHK(msm_batch_impl(bases, ptrs.data(), mg, n, (char *)out_g1_host + (size_t)m0 * sizeof(g1_jac_t), &pre));
+  }
+  return MI355_OK;
 }
 int mi355_msm_g1_adhoc_host(const void *bases_host, const void *scalars_host, uint64_t n, void *out_g1_host) {
   std::lock_guard<std::mutex> lk(g.mu);

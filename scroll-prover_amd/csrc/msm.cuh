@@ -32,6 +32,7 @@ struct MsmPlan {
   uint32_t windows;  // W = ceil(255 / c)
   uint32_t nb;       // buckets per window = 2^(c-1)
   uint32_t seg;      // entries per accumulate thread
+  uint32_t batch;    // M polynomials committed in one pass (same basis); (polynomial m, window w) acts as window index m * W + w
 };
 
 __device__ __forceinline__ g1_affine_t load_affine(const g1_affine_t *p) {
@@ -70,19 +71,19 @@ __device__ __forceinline__ void store_sat_as_xyzz29(g1_xyzz29_t *p, const g1_xyz
 }
 
 // ---- 1. digits.  Plane layout enc[w * n + i]: 0 for a zero digit, else |d| (1 .. 2^(c-1)) with bit 31 = sign.
-__global__ void __launch_bounds__(256) k_msm_digits(const fe_t *__restrict__ scalars, uint32_t *__restrict__ enc, MsmPlan P,
+__global__ void __launch_bounds__(256) k_msm_digits(const fe_t *const *__restrict__ polys, uint32_t *__restrict__ enc, MsmPlan P,
                                                      uint32_t *__restrict__ coarse_hist, uint32_t fb, uint32_t cb_bits, uint32_t shared) {
   // the level-1 (coarse) histogram of the sorter is taken here, while the digits are in registers: LDS counters per block,
   // one global atomic per non-empty bin at the end (dynamic LDS = regions * 4 bytes)
   extern __shared__ uint32_t hist_lds[];
-  const uint32_t CB = 1u << cb_bits, regions = shared ? CB : P.windows * CB;
+  const uint32_t CB = 1u << cb_bits, per_poly = (shared ? 1u : P.windows) * CB, regions = P.batch * per_poly;
   for (uint32_t b = threadIdx.x; b < regions; b += blockDim.x) hist_lds[b] = 0;
   __syncthreads();
-  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t stride = gridDim.x * blockDim.x, m = blockIdx.y;   // grid.y = batch
   const uint32_t half = 1u << (P.c - 1), mask = (1u << P.c) - 1;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
     fe_t one_c = Fr::zero(); one_c.l[0] = 1;
-    const fe_t k = fr_mul_ps(g_load(&scalars[i]), one_c);   // Montgomery -> canonical (= to_repr())
+    const fe_t k = fr_mul_ps(g_load(&polys[m][i]), one_c);   // Montgomery -> canonical (= to_repr())
     uint32_t carry = 0;
     for (uint32_t w = 0; w < P.windows; w++) {
       const uint32_t bit = w * P.c, word = bit >> 5, sh = bit & 31;
@@ -91,8 +92,8 @@ __global__ void __launch_bounds__(256) k_msm_digits(const fe_t *__restrict__ sca
       raw = (raw & mask) + carry;
       uint32_t e;
       if (raw > half) { e = (1u << P.c) - raw; if (e) e |= 0x80000000u; carry = 1; } else { e = raw; carry = 0; }   // raw == 2^c: digit 0, carry 1
-      enc[(uint64_t)w * P.n + i] = e;
-      if (e) atomicAdd(&hist_lds[(shared ? 0 : w * CB) + (((e & 0x7fffffffu) - 1) >> fb)], 1u);
+      enc[((uint64_t)m * P.windows + w) * P.n + i] = e;
+      if (e) atomicAdd(&hist_lds[m * per_poly + (shared ? 0 : w * CB) + (((e & 0x7fffffffu) - 1) >> fb)], 1u);
     }
   }
   __syncthreads();
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const uint32_t *__res
 //   level 2: tiles inside each coarse region, bin = fine key (2^fb bins)             -> exact bucket offsets + sorted[]
 // Order inside a bucket is arbitrary (group addition commutes), so nothing needs to be stable.
 constexpr uint32_t SORT_MAX_BINS = 4096;
-struct SortPlan { uint32_t n, windows, nb, fb, cb_bits, t1, t2, regions, shared; };   // shared = 1: all windows feed ONE bucket set (precomputed 2^(cw) P tables)
+struct SortPlan { uint32_t n, windows /* batch * W */, wpp /* W */, nb, fb, cb_bits, t1, t2, regions, shared; };   // shared = 1: all windows feed ONE bucket set (precomputed 2^(cw) P tables)
 
 // Per-tile bin bookkeeping shared by both scatter kernels (1024 threads): lstart[] = exclusive scan of the tile histogram,
 // gbase[] = start of this tile's run inside each global bin (ONE returning global atomic per non-empty bin).
@@ -191,8 +192,10 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(con
     if (e[k]) rank[k] = atomicAdd(&h[((e[k] & 0x7fffffffu) - 1) >> S.fb], 1u);
   }
   __syncthreads();
-  const uint32_t total = tile_bin_offsets(h, lstart, gbase, CB, coarse_cursor + (S.shared ? 0 : w * CB), scratch32);
-  const uint32_t idx_base = S.shared ? w * S.n : 0;   // shared buckets: the payload names (window, point) = row w of the precomputed table
+  // w = m * W + w_in: polynomial m of the batch, window w_in.  shared buckets: one bucket set per polynomial, payload names row w_in of the table
+  const uint32_t m_poly = w / S.wpp, w_in = w - m_poly * S.wpp;
+  const uint32_t total = tile_bin_offsets(h, lstart, gbase, CB, coarse_cursor + (S.shared ? m_poly * CB : w * CB), scratch32);
+  const uint32_t idx_base = S.shared ? w_in * S.n : 0;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < EPT; k++) if (e[k]) {
@@ -410,7 +413,8 @@ __global__ void __launch_bounds__(256) k_msm_tree_sum(const g1_xyzz_t *__restric
 }
 // ---- 7. Horner over windows + normalisation.  One lane; 255 doublings are inherently serial.
 __global__ void k_msm_final(const g1_xyzz_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (threadIdx.x != 0) return;
+  window_sums += (uint64_t)blockIdx.x * windows; out += blockIdx.x;      // one block per polynomial of the batch
   g1_xyzz_t acc = g1_xyzz_identity();
   for (uint32_t w = windows; w-- > 0;) {
     for (uint32_t k = 0; k < c; k++) acc = g1_xyzz_dbl_ps(acc);

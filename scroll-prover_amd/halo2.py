@@ -232,6 +232,30 @@ class ParamsKZG:
         if lagrange:
             check(lib().mi355_srs_precompute(self._gl, n_hint, c))
 
+    def commit_many(self, polys, lagrange: bool = False) -> np.ndarray:
+        """commit / commit_lagrange for a list of polynomials of equal length (all device tensors or all host arrays) in ONE pass
+        (mi355_msm_g1_batch_dev / _host): [M, 12].  create_proof commits the advice columns of a phase one after the other
+        [EXT halo2_proofs src/plonk/prover.rs, SURVEY 3.2 step 2]; this is that loop as one call."""
+        out = np.zeros((len(polys), 12), dtype=np.uint64)
+        if len(polys) == 0:
+            return out
+        dev = _is_device(polys[0])
+        assert all(_is_device(p) == dev for p in polys), "commit_many: mix of host and device polynomials"
+        if dev:
+            n = polys[0].numel() * polys[0].element_size() // 32
+            assert all(p.numel() * p.element_size() // 32 == n for p in polys), "commit_many: polynomials must have equal length"
+            arr = (C.c_void_p * len(polys))(*[p.data_ptr() for p in polys])
+            fn = lib().mi355_msm_g1_batch_dev
+        else:
+            polys = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
+            n = polys[0].shape[0]
+            assert all(p.shape == (n, 4) for p in polys), "commit_many: polynomials must have equal length"
+            arr = (C.c_void_p * len(polys))(*[p.ctypes.data for p in polys])
+            fn = lib().mi355_msm_g1_batch_host
+        assert n <= self.n and (not lagrange or n == self.n)
+        check(fn(self._gl if lagrange else self._g, 0, arr, len(polys), n, ptr(out)))
+        return out
+
     def g_slice(self, offset: int, n: int) -> SrsSlice:
         return SrsSlice(self._g, offset, n)
 

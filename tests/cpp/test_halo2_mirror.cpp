@@ -64,6 +64,17 @@ int main(int argc, char **argv) {
     G1 w2; orc_best_multiexp(w2.data(), sc.data(), rev.data(), n, 4); G1Affine w2a; orc_g1_to_affine(w2a.data(), w2.data());
     EXPECT(std::memcmp(c2.data(), w2a.data(), 64) == 0);
     threw = false; try { params.commit_lagrange(std::vector<Fr>(n - 1)); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
+    // commit_many == the loop of commits (three columns, one of them all-zero)
+    std::vector<Fr> col2(n), col3(n, Fr{0, 0, 0, 0});
+    for (auto &x : col2) x = rand_fr(rng);
+    std::vector<G1> many = params.commit_many({&sc, &col2, &col3});
+    EXPECT(many.size() == 3 && many[0] == c1 && many[1] == params.commit(col2) && many[2] == (G1{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}));
+    std::vector<G1> many_l = params.commit_many({&col2, &sc}, /*lagrange=*/true);
+    EXPECT(many_l[1] == c2 && many_l[0] == params.commit_lagrange(col2));
+    G1 wj; orc_best_multiexp(wj.data(), col2.data(), bases.data(), n, 4); G1Affine wa; orc_g1_to_affine(wa.data(), wj.data());
+    EXPECT(std::memcmp(many[1].data(), wa.data(), 64) == 0);
+    std::vector<Fr> shorter(n - 1);
+    threw = false; try { params.commit_many({&sc, &shorter}); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
   }
   // --- best_fft / EvaluationDomain against the oracle (raw Montgomery bytes)
   EvaluationDomain dom(4, k);

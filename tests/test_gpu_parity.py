@@ -395,3 +395,62 @@ def test_unnormalised_partials_fold_to_the_same_point(zk, points):
         assert (cref.g1_to_affine(p) == cref.g1_to_affine(cref.best_multiexp(sc[lo:hi], points[lo:hi]))).all()
     total = affine_of(h2.g1_sum(np.vstack([parts, zero_part[None]])))
     assert (total == cref.g1_to_affine(cref.best_multiexp(sc, points[:n]))).all()
+
+
+@pytest.mark.parametrize("pre_c", [None, 0, 6])
+def test_batched_commitments_equal_separate_commitments(zk, points, pre_c):
+    """mi355_msm_g1_batch_dev (ParamsKZG.commit_many): M polynomials over one basis in one pass == M x best_multiexp,
+    with per-window buckets (no tables) and with the shared-bucket schedule (window tables)."""
+    import torch
+    h2 = zk.halo2
+    n = 1000
+    pts = points[:1024].copy(); pts[11] = 0
+    params = h2.ParamsKZG.from_host(10, pts, pts[::-1].copy())
+    if pre_c is not None:
+        params.precompute(c=pre_c)
+    rng = np.random.default_rng(9100 + (pre_c or 0))
+    for M in (1, 2, 5, 16):
+        polys = [rand_fr(rng, n) for _ in range(M)]
+        if M >= 5:
+            polys[2] = np.tile(cref.fr_mont(0), (n, 1))             # a zero column: the identity in the middle of the batch
+            polys[3] = np.tile(cref.fr_mont(R - 1), (n, 1))
+            polys[4][:, :] = 0; polys[4][17] = cref.fr_mont(5)      # a single non-zero coefficient
+        dev = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
+        got = params.commit_many(dev)
+        assert got.shape == (M, 12)
+        for m in range(M):
+            want = cref.g1_to_affine(cref.best_multiexp(polys[m], pts[:n]))
+            assert (affine_of(got[m]) == want).all(), (M, m)
+            assert (got[m] == params.commit(dev[m])).all()
+        assert (params.commit_many(polys) == got).all()                 # host pointers: mi355_msm_g1_batch_host
+        gl = params.commit_many([torch.from_numpy(np.vstack([p, p[:24]]).view(np.int64)).cuda() for p in polys], lagrange=True)
+        for m in range(M):
+            want = cref.g1_to_affine(cref.best_multiexp(np.vstack([polys[m], polys[m][:24]]), pts[::-1].copy()))
+            assert (affine_of(gl[m]) == want).all()
+    params.release()
+
+
+def test_batched_commitments_split_oversized_batches(zk, points):
+    """a batch whose coarse histogram would not fit is processed as half batches; results keep their order."""
+    import torch
+    h2 = zk.halo2
+    lib, check = zk._capi.lib(), zk._capi.check
+    n, M = 300, 53
+    params = h2.ParamsKZG.from_host(9, points[:512], points[:512])
+    rng = np.random.default_rng(9200)
+    polys = [rand_fr(rng, n, full=False) for _ in range(M)]
+    dev = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
+    check(lib.mi355_msm_set_window_bits(16))          # 16 windows x 16 coarse bins per polynomial -> 53 x 256 regions > the LDS budget
+    try:
+        got = params.commit_many(dev)
+    finally:
+        check(lib.mi355_msm_set_window_bits(0))
+    for m in range(M):
+        assert (affine_of(got[m]) == cref.g1_to_affine(cref.best_multiexp(polys[m], points[:n]))).all(), m
+    # error behaviour: null polynomial pointer, null output
+    arr = (C.c_void_p * 2)(dev[0].data_ptr(), None)
+    out = np.zeros((2, 12), dtype=np.uint64)
+    assert lib.mi355_msm_g1_batch_dev(params._g, 0, arr, 2, n, zk._capi.ptr(out)) == zk._capi.EBADARG
+    assert lib.mi355_msm_g1_batch_dev(params._g, 0, arr, 0, n, zk._capi.ptr(out)) == 0
+    assert lib.mi355_msm_g1_batch_dev(params._g, 500, arr, 1, n, zk._capi.ptr(out)) == zk._capi.EBADARG   # slice past the basis
+    params.release()
