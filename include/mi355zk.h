@@ -126,6 +126,12 @@ int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n
  * evaluations by the inverted t_evaluations, whose period is 2^(extended_k - k)).  The pointwise glue of SURVEY 8f-1.            */
 int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_dev, uint64_t n);
 int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_host, uint32_t period);
+/* the multiplicative scans of the permutation / lookup arguments [EXT-recalled halo2_proofs src/plonk/permutation/prover.rs,
+ * src/plonk/lookup/prover.rs]: data[i] = data[i]^-1 with zeros left zero (ff::BatchInvert), and the grand product
+ * dst[0] = 1, dst[i] = prod_{j<i} src[j] (dst may alias src; total_out_host, optional, receives prod_{j<n} src[j] and makes the
+ * call synchronous).  Asynchronous on the library stream otherwise.                                                               */
+int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n);
+int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host);
 
 /* ---- halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i  (the evaluations written to the
  *      transcript in step 9 of create_proof); out_fr_host receives 32 B.  First widening into SURVEY 8f-3.   */
@@ -137,6 +143,20 @@ int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *po
 int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const void *tau, const void *omega);
 /* points[i] = scalars[i] * G (fixed-base, batch-normalised); building block of the above                      */
 int mi355_g1_fixed_base_mul_dev(void *points_affine_dev, const void *scalars_dev, uint64_t n);
+
+/* ---- best_fft::<Fr, G1> -- the same DFT over G1 points, a'[i] = sum_j omega^(ij) a[j] -- and its one caller, g_to_lagrange, which
+ * ParamsKZG::downsize(k) [REF integration/tests/integration.rs:17-22] and ParamsKZG::setup run to rebuild g_lagrange from
+ * g[..2^k]: g_lagrange = n^-1 * DFT_{omega^-1}(g) [EXT-recalled halo2_proofs src/arithmetic.rs g_to_lagrange].
+ * Points: 96-byte Jacobian in place (any representative in, normalised z = R / all-zero identity out); g_to_lagrange takes and
+ * returns 64-byte affine points (input and output may be the same buffer).                                                        */
+int mi355_g1_fft_dev(void *points_jac_dev, uint32_t log_n, const void *omega);
+int mi355_g1_fft_host(void *points_jac_host, uint32_t log_n, const void *omega);
+int mi355_g_to_lagrange_dev(const void *g_affine_dev, void *g_lagrange_affine_dev, uint32_t log_n, const void *omega_inv, const void *n_inv);
+/* downsize on handles: a NEW library-owned basis g_lagrange' = g_to_lagrange(g[..2^k]) from a registered coefficient basis
+ * (omega_inv = omega_k^-1, n_inv = 2^-k, Montgomery); mi355_srs_read_host copies points of any registered basis back, which is
+ * how the Rust ParamsKZG refills its g_lagrange Vec after downsize.                                                                */
+int mi355_srs_downsize(uint64_t g_handle, uint32_t k, const void *omega_inv, const void *n_inv, uint64_t *g_lagrange_handle_out);
+int mi355_srs_read_host(uint64_t handle, uint64_t offset, uint64_t n, void *out_affine_host);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the kernels of the most recent MSM / NTT call.       */
 int mi355_profile_enable(int on);

@@ -74,6 +74,11 @@ inline void best_fft(std::vector<Fr> &a, const Fr &omega, uint32_t log_n) {
   if (a.size() != (size_t(1) << log_n)) throw std::invalid_argument("best_fft: a.len() != 1 << log_n");
   check(mi355_ntt_fr_host(a.data(), log_n, omega.data()));
 }
+// best_fft::<Fr, G1>: the same transform over curve points (Jacobian, in place); its caller in halo2 is g_to_lagrange
+inline void best_fft(std::vector<G1> &a, const Fr &omega, uint32_t log_n) {
+  if (a.size() != (size_t(1) << log_n)) throw std::invalid_argument("best_fft: a.len() != 1 << log_n");
+  check(mi355_g1_fft_host(a.data(), log_n, omega.data()));
+}
 inline Fr eval_polynomial(const std::vector<Fr> &poly, const Fr &point) {
   Fr out;
   check(mi355_eval_polynomial_host(poly.data(), poly.size(), point.data(), out.data()));
@@ -151,6 +156,21 @@ class ParamsKZG {
     if (poly.size() != n) throw std::invalid_argument("commit_lagrange: polynomial must have exactly n evaluations");
     G1 out; check(mi355_msm_g1_host(gl_, 0, poly.data(), poly.size(), out.data())); return out;
   }
+  // ParamsKZG::downsize(k): g.truncate(2^k); g_lagrange = g_to_lagrange(g, k) -- an inverse DFT over G1 points, run on the device
+  void downsize(uint32_t new_k) {
+    if (new_k > k) throw std::invalid_argument("downsize: k must not exceed the current degree");
+    if (new_k == k) return;
+    Fr w = detail::root_of_unity();
+    for (uint32_t i = new_k; i < FR_S; i++) w = detail::fr_mul(w, w);
+    const Fr w_inv = detail::fr_inv(w), n_inv = detail::fr_inv(detail::fr_from_u64(uint64_t(1) << new_k));
+    uint64_t h = 0;
+    check(mi355_srs_downsize(g_, new_k, w_inv.data(), n_inv.data(), &h));
+    mi355_srs_release(gl_); gl_ = h; k = new_k; n = uint64_t(1) << new_k;
+  }
+  // the bases as ParamsKZG::write serialises them (first n points)
+  std::vector<G1Affine> get_g() const { std::vector<G1Affine> v(n); check(mi355_srs_read_host(g_, 0, n, v.data())); return v; }
+  std::vector<G1Affine> get_g_lagrange() const { std::vector<G1Affine> v(n); check(mi355_srs_read_host(gl_, 0, n, v.data())); return v; }
+
   // the per-column loop of create_proof (advice / lookup / permutation commitments of one phase) as one call: equal-length polynomials,
   // results in input order, identical to calling commit / commit_lagrange on each
   std::vector<G1> commit_many(const std::vector<const std::vector<Fr> *> &polys, bool lagrange = false) const {

@@ -338,6 +338,59 @@ void orc_best_fft(fe *a, const fe *omega, uint32_t log_n, int num_threads) {
   free(tw);
 }
 
+/* best_fft with G = G1 (FftGroup: group_scale = point * scalar, group_add / group_sub) [EXT-recalled src/arithmetic.rs], serial layers:
+ * the transform g_to_lagrange / ParamsKZG::downsize run over the SRS points.  Jacobian in place. */
+static void g1j_mul_mont(g1j *o, const g1j *p, const fe *s_mont) {
+  /* double-and-add on a Jacobian base, top bit first */
+  fe k; fe_to_canonical(&k, s_mont, &FR);
+  g1j acc; g1j_set_identity(&acc);
+  for (int i = 255; i >= 0; i--) { g1j_double(&acc, &acc); if ((k.l[i >> 6] >> (i & 63)) & 1) g1j_add(&acc, &acc, p); }
+  *o = acc;
+}
+void orc_best_fft_g1(g1j *a, const fe *omega, uint32_t log_n) {
+  uint64_t n = 1ULL << log_n;
+  for (uint64_t k = 0; k < n; k++) { uint64_t rk = bitreverse(k, log_n); if (k < rk) { g1j t = a[rk]; a[rk] = a[k]; a[k] = t; } }
+  if (n == 1) return;
+  fe *tw = (fe *)malloc((n / 2) * sizeof(fe)); fe w = FR.r;
+  for (uint64_t i = 0; i < n / 2; i++) { tw[i] = w; fe_mul(&w, &w, omega, &FR); }
+  uint64_t chunk = 2, twiddle_chunk = n / 2;
+  for (uint32_t s = 0; s < log_n; s++) {
+    uint64_t half = chunk / 2;
+    for (uint64_t g = 0; g < n / 2; g++) {
+      uint64_t blk = g / half, i = g % half; g1j *x = &a[blk * chunk + i], *y = x + half, t, nt;
+      if (i == 0) t = *y; else g1j_mul_mont(&t, y, &tw[i * twiddle_chunk]);
+      nt = t; fe_neg(&nt.y, &t.y, &FQ);
+      g1j_add(y, x, &nt); g1j_add(x, x, &t);
+    }
+    chunk *= 2; twiddle_chunk /= 2;
+  }
+  free(tw);
+}
+/* g_to_lagrange(g_projective, k) [EXT-recalled src/arithmetic.rs]: best_fft(g, omega_inv, k); every point *= n^-1; batch_normalize */
+void orc_g_to_lagrange(g1a *out, const g1a *g, uint32_t k, const fe *omega_inv, const fe *n_inv) {
+  uint64_t n = 1ULL << k; g1j *a = (g1j *)malloc(n * sizeof(g1j));
+  for (uint64_t i = 0; i < n; i++) { g1j_set_identity(&a[i]); g1j_add_affine(&a[i], &a[i], &g[i]); }
+  orc_best_fft_g1(a, omega_inv, k);
+  for (uint64_t i = 0; i < n; i++) { g1j t; g1j_mul_mont(&t, &a[i], n_inv); g1j_to_affine(&out[i], &t); }
+  free(a);
+}
+
+/* ff::BatchInvert (Montgomery's trick, zeros skipped and left zero) [EXT-recalled ff batch.rs BatchInverter::invert_with_external_scratch],
+ * as used on `modified_values` by the permutation / lookup provers before the grand product */
+void orc_batch_invert(fe *a, uint64_t n) {
+  fe *scratch = (fe *)malloc((n ? n : 1) * sizeof(fe)); fe acc = FR.r;
+  for (uint64_t i = 0; i < n; i++) { scratch[i] = acc; if (!fe_is_zero(&a[i])) fe_mul(&acc, &acc, &a[i], &FR); }
+  fe_inv(&acc, &acc, &FR);
+  for (uint64_t i = n; i-- > 0;) { if (fe_is_zero(&a[i])) continue; fe t; fe_mul(&t, &acc, &a[i], &FR); fe_mul(&a[i], &acc, &scratch[i], &FR); acc = t; }
+  free(scratch);
+}
+/* the grand-product column: z[0] = 1, z[i + 1] = z[i] * v[i] [EXT-recalled halo2_proofs src/plonk/permutation/prover.rs]; returns z[n] in *total */
+void orc_prefix_product(fe *z, const fe *v, uint64_t n, fe *total) {
+  fe acc = FR.r;
+  for (uint64_t i = 0; i < n; i++) { fe t; fe_mul(&t, &acc, &v[i], &FR); z[i] = acc; acc = t; }
+  if (total) *total = acc;
+}
+
 /* EvaluationDomain pieces [EXT-recalled halo2_proofs src/poly/domain.rs] */
 /* ifft: best_fft(a, omega_inv, log_n) then a[i] *= divisor (= n^-1) */
 void orc_ifft(fe *a, const fe *omega_inv, uint32_t log_n, const fe *divisor, int num_threads) {

@@ -166,6 +166,27 @@ def best_fft(a, omega, log_n: int, threads: int | None = None):
     lib().orc_best_fft(_p(a), _p(np.ascontiguousarray(omega)), C.c_uint32(log_n), C.c_int(threads)); return a
 
 
+def best_fft_g1(points_jac, omega, log_n: int):
+    """best_fft over G1 (Jacobian [n,12]), on a copy."""
+    a = np.array(points_jac, dtype=np.uint64, copy=True, order="C"); assert a.shape == (1 << log_n, 12)
+    lib().orc_best_fft_g1(_p(a), _p(np.ascontiguousarray(omega)), C.c_uint32(log_n)); return a
+
+
+def g_to_lagrange(g_affine, k: int, omega_inv, n_inv):
+    g = np.ascontiguousarray(g_affine, dtype=np.uint64); assert g.shape == (1 << k, 8)
+    out = np.zeros_like(g)
+    lib().orc_g_to_lagrange(_p(out), _p(g), C.c_uint32(k), _p(np.ascontiguousarray(omega_inv)), _p(np.ascontiguousarray(n_inv))); return out
+
+
+def batch_invert(a):
+    a = np.array(a, dtype=np.uint64, copy=True, order="C"); lib().orc_batch_invert(_p(a), C.c_uint64(a.shape[0])); return a
+
+
+def prefix_product(v):
+    v = np.ascontiguousarray(v, dtype=np.uint64); z = np.zeros_like(v); t = _fe()
+    lib().orc_prefix_product(_p(z), _p(v), C.c_uint64(v.shape[0]), _p(t)); return z, t
+
+
 def ifft(a, omega_inv, log_n: int, divisor, threads: int | None = None):
     threads = threads or os.cpu_count() or 1
     a = np.array(a, dtype=np.uint64, copy=True, order="C")

@@ -46,6 +46,13 @@ SIGNATURES = {
     "mi355_coset_ntt_fr_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
     "mi355_fr_vec_op_dev": (_int, [_int, _vp, _vp, _vp, _u64]),
     "mi355_fr_vec_mul_periodic_dev": (_int, [_vp, _u64, _vp, _u32]),
+    "mi355_g1_fft_dev": (_int, [_vp, _u32, _vp]),
+    "mi355_g1_fft_host": (_int, [_vp, _u32, _vp]),
+    "mi355_g_to_lagrange_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
+    "mi355_srs_downsize": (_int, [_u64, _u32, _vp, _vp, C.POINTER(_u64)]),
+    "mi355_srs_read_host": (_int, [_u64, _u64, _u64, _vp]),
+    "mi355_fr_batch_invert_dev": (_int, [_vp, _u64]),
+    "mi355_fr_prefix_product_dev": (_int, [_vp, _vp, _u64, _vp]),
     "mi355_eval_polynomial_dev": (_int, [_vp, _u64, _vp, _vp]),
     "mi355_eval_polynomial_host": (_int, [_vp, _u64, _vp, _vp]),
     "mi355_srs_setup_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),

@@ -17,6 +17,8 @@
 #include "msm.cuh"
 #include "ntt.cuh"
 #include "ntt29.cuh"
+#include "g1fft.cuh"
+#include "frscan.cuh"
 
 using namespace zk;
 
@@ -398,6 +400,39 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
 
 int finish_async() { if (g.profiling) resolve_spans(); return MI355_OK; }
 
+// DFT over G1 points (g1fft.cuh).  in: n x (96 B Jacobian | 64 B affine), out likewise (may alias in); scale: optional Fr (Montgomery).
+int g1fft_impl(const void *in, int in_jac, void *out, int out_jac, uint32_t log_n, const void *omega, const void *scale_host) {
+  const uint32_t n = 1u << log_n, half = std::max(1u, n / 2);
+  g1_xyzz_t *work; fe_t *tw, *scale = nullptr;
+  CHK(ws_get("g1fft.work", (size_t)n * sizeof(g1_xyzz_t), (void **)&work));
+  CHK(ws_get("g1fft.tw", (size_t)half * sizeof(fe_t), (void **)&tw));
+  hipStream_t s = g.stream;
+  fe_t w; memcpy(&w, omega, 32);
+  Scope total("g1_fft");
+  hipLaunchKernelGGL(k_pow_table, dim3(ceil_div(half, 256)), dim3(256), 0, s, tw, w, (uint64_t)1, half);
+  if (scale_host) { CHK(ws_get("g1fft.scale", sizeof(fe_t), (void **)&scale)); HIPCHK(hipMemcpyAsync(scale, scale_host, sizeof(fe_t), hipMemcpyHostToDevice, s)); }
+  if (in_jac) hipLaunchKernelGGL(k_g1fft_load<1>, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, work, log_n);
+  else hipLaunchKernelGGL(k_g1fft_load<0>, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, work, log_n);
+  for (uint32_t st = 0; st < log_n; st++) hipLaunchKernelGGL(k_g1fft_stage, dim3(ceil_div(n / 2, 256)), dim3(256), 0, s, work, tw, log_n, st);
+  if (out_jac) hipLaunchKernelGGL(k_g1fft_store<1>, dim3(ceil_div(n, 256)), dim3(256), 0, s, work, out, log_n, scale);
+  else hipLaunchKernelGGL(k_g1fft_store<0>, dim3(ceil_div(n, 256)), dim3(256), 0, s, work, out, log_n, scale);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+
+// data[i] <- data[i]^-1 (zeros kept): tile products -> (recursively) their inverses -> per-tile completion
+int batch_invert_impl(fe_t *data, uint64_t n, int level) {
+  const uint32_t tiles = (uint32_t)ceil_div(n, FRSCAN_TILE);
+  hipStream_t s = g.stream;
+  if (tiles <= 32) { hipLaunchKernelGGL(k_fr_batch_invert<0>, dim3(tiles), dim3(FRSCAN_THREADS), 0, s, data, n, (fe_t *)nullptr); return MI355_OK; }
+  fe_t *tile_prod; const std::string role = "frscan.inv_tiles" + std::to_string(level);
+  CHK(ws_get(role.c_str(), (size_t)tiles * sizeof(fe_t), (void **)&tile_prod));
+  hipLaunchKernelGGL(k_fr_batch_invert<1>, dim3(tiles), dim3(FRSCAN_THREADS), 0, s, data, n, tile_prod);
+  CHK(batch_invert_impl(tile_prod, tiles, level + 1));
+  hipLaunchKernelGGL(k_fr_batch_invert<2>, dim3(tiles), dim3(FRSCAN_THREADS), 0, s, data, n, tile_prod);
+  return MI355_OK;
+}
+
 int with_host_io(void *data_host, size_t in_bytes, size_t out_bytes, size_t dev_bytes, const char *role, int (*body)(void *dev, void *ud), void *ud) {
   void *dev; CHK(ws_get(role, dev_bytes, &dev));
   HIPCHK(hipMemcpyAsync(dev, data_host, in_bytes, hipMemcpyHostToDevice, g.stream));
@@ -440,6 +475,8 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_fr_prefix_product<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_fr_prefix_product<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 3; }
@@ -699,6 +736,50 @@ int mi355_intt_fr_host(void *data_host, uint32_t log_n, const void *omega_inv, c
     auto *a = (NttHostArgs *)ud; fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], a->divisor, 32);
     return ntt_dev_impl((const fe_t *)dev, 1ull << a->log_n, (fe_t *)dev, a->log_n, a->omega, nullptr, post); }, &a);
 }
+// ---- DFT over G1 points (best_fft::<Fr, G1>, g_to_lagrange)
+int mi355_g1_fft_dev(void *points_jac_dev, uint32_t log_n, const void *omega) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init()); CHK(check_ntt_args(points_jac_dev, log_n, omega));
+  CHK(g1fft_impl(points_jac_dev, 1, points_jac_dev, 1, log_n, omega, nullptr));
+  return finish_async();
+}
+int mi355_g1_fft_host(void *points_jac_host, uint32_t log_n, const void *omega) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init()); CHK(check_ntt_args(points_jac_host, log_n, omega));
+  NttHostArgs a{log_n, omega, nullptr};
+  const size_t bytes = sizeof(g1_jac_t) << log_n;
+  return with_host_io(points_jac_host, bytes, bytes, bytes, "io.g1fft", [](void *dev, void *ud) { auto *a = (NttHostArgs *)ud; return g1fft_impl(dev, 1, dev, 1, a->log_n, a->omega, nullptr); }, &a);
+}
+int mi355_g_to_lagrange_dev(const void *g_affine_dev, void *g_lagrange_affine_dev, uint32_t log_n, const void *omega_inv, const void *n_inv) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init()); CHK(check_ntt_args(g_affine_dev, log_n, omega_inv));
+  if (!g_lagrange_affine_dev || !n_inv) return fail(MI355_EBADARG, "g_to_lagrange: null pointer");
+  CHK(g1fft_impl(g_affine_dev, 0, g_lagrange_affine_dev, 0, log_n, omega_inv, n_inv));
+  return finish_async();
+}
+int mi355_srs_downsize(uint64_t g_handle, uint32_t k, const void *omega_inv, const void *n_inv, uint64_t *g_lagrange_handle_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  auto it = g.srs.find(g_handle);
+  if (it == g.srs.end()) return fail(MI355_EBADARG, "srs_downsize: unknown handle");
+  if (!omega_inv || !n_inv || !g_lagrange_handle_out || k > 28 || (1ull << k) > it->second.n) return fail(MI355_EBADARG, "srs_downsize: bad argument (2^k must not exceed the registered basis)");
+  Srs s; s.n = 1ull << k; s.owned = true;
+  HIPCHK(hipMalloc((void **)&s.dev, s.n * sizeof(g1_affine_t)));
+  int rc = g1fft_impl(it->second.dev, 0, s.dev, 0, k, omega_inv, n_inv);
+  if (rc == MI355_OK) rc = finish_async();
+  if (rc == MI355_OK && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MI355_EHIP, "srs_downsize: stream synchronize failed");
+  if (rc != MI355_OK) { (void)hipFree(s.dev); return rc; }
+  *g_lagrange_handle_out = g.next_handle++; g.srs[*g_lagrange_handle_out] = s; return MI355_OK;
+}
+int mi355_srs_read_host(uint64_t handle, uint64_t offset, uint64_t n, void *out_affine_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  auto it = g.srs.find(handle);
+  if (it == g.srs.end() || (n && !out_affine_host)) return fail(MI355_EBADARG, "srs_read_host: unknown handle or null pointer");
+  if (offset > it->second.n || n > it->second.n - offset) return fail(MI355_EBADARG, "srs_read_host: range exceeds the registered basis");
+  if (n) { HIPCHK(hipMemcpyAsync(out_affine_host, it->second.dev + offset, n * sizeof(g1_affine_t), hipMemcpyDeviceToHost, g.stream)); HIPCHK(hipStreamSynchronize(g.stream)); }
+  return MI355_OK;
+}
 int mi355_coeff_to_extended_host(void *dst_host, const void *coeffs_host, uint32_t log_n, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega) {
   {
     std::lock_guard<std::mutex> lk(g.mu);
@@ -760,6 +841,35 @@ int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_
   if (n == 0) return MI355_OK;
   hipLaunchKernelGGL(k_fr_vec_op, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, op, (fe_t *)dst_dev, (const fe_t *)a_dev, (const fe_t *)b_dev, n);
   HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (n && !data_dev) return fail(MI355_EBADARG, "fr_batch_invert: null pointer");
+  if (n >= (1ull << 40)) return fail(MI355_EBADARG, "fr_batch_invert: n too large");
+  if (n == 0) return MI355_OK;
+  CHK(batch_invert_impl((fe_t *)data_dev, n, 0));
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (n && (!dst_dev || !src_dev)) return fail(MI355_EBADARG, "fr_prefix_product: null pointer");
+  if (n >= (1ull << 40)) return fail(MI355_EBADARG, "fr_prefix_product: n too large");
+  const uint32_t tiles = (uint32_t)ceil_div(n, FRSCAN_TILE);
+  fe_t *tile_prod, *tile_prefix, *total;
+  CHK(ws_get("frscan.tile_prod", ((size_t)tiles + 1) * sizeof(fe_t), (void **)&tile_prod));
+  CHK(ws_get("frscan.tile_prefix", ((size_t)tiles + 1) * sizeof(fe_t), (void **)&tile_prefix));
+  CHK(ws_get("frscan.total", sizeof(fe_t), (void **)&total));
+  const size_t lds = (size_t)(FRSCAN_THREADS * 65 + 2 * FRSCAN_THREADS * 9) * 4;
+  hipStream_t s = g.stream;
+  if (tiles) hipLaunchKernelGGL(k_fr_prefix_product<0>, dim3(tiles), dim3(FRSCAN_THREADS), lds, s, (const fe_t *)src_dev, (fe_t *)dst_dev, n, tile_prod, (const fe_t *)tile_prefix);
+  hipLaunchKernelGGL(k_fr_scan_tile_products, dim3(1), dim3(FRSCAN_THREADS), 0, s, (const fe_t *)tile_prod, tile_prefix, tiles, total);
+  if (tiles) hipLaunchKernelGGL(k_fr_prefix_product<1>, dim3(tiles), dim3(FRSCAN_THREADS), lds, s, (const fe_t *)src_dev, (fe_t *)dst_dev, n, tile_prod, (const fe_t *)tile_prefix);
+  HIPCHK(hipGetLastError());
+  if (total_out_host) { HIPCHK(hipMemcpyAsync(total_out_host, total, sizeof(fe_t), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
   return MI355_OK;
 }
 int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_host, uint32_t period) {

@@ -1,0 +1,160 @@
+// frscan.cuh -- multiplicative scans over device-resident Fr vectors: the grand products and the batch inversion of the permutation and
+// lookup arguments of create_proof [EXT-recalled halo2_proofs src/plonk/permutation/prover.rs,
+// src/plonk/lookup/prover.rs: `modified_values.batch_invert()`, then z[0] = 1, z[i + 1] = z[i] * modified_values[i]].
+//
+//   k_fr_batch_invert     data[i] = data[i]^-1, zeros stay zero (ff::BatchInvert semantics).  A thread multiplies its 8 (strided,
+//                         coalesced) elements, the 256 thread products are scanned from both ends through LDS; the products of the
+//                         2048-element tiles are themselves batch-inverted (recursion on the host side), so the whole vector costs a
+//                         handful of Fermat inversions.
+//   k_fr_prefix_product   dst[i] = prod_{j < i} src[j]  (dst[0] = 1): tile products -> scan of the tile products -> tile-local rescan
+//                         with the carried-in prefix.  Order matters here, so tiles go through LDS to turn coalesced 16-byte-per-lane
+//                         global accesses into 8 consecutive elements per thread (chunk stride 65 dwords: conflict-free).
+// Both are streaming kernels (one read + one write of the vector, plus one re-read for the prefix product) with ~5 multiplications
+// per element; Montgomery form in, Montgomery form out, fully reduced.
+#pragma once
+#include "fp_asm.cuh"
+
+namespace zk {
+#ifdef __HIPCC__
+
+constexpr uint32_t FRSCAN_THREADS = 256, FRSCAN_EPT = 8, FRSCAN_TILE = FRSCAN_THREADS * FRSCAN_EPT;
+
+__device__ __forceinline__ void lds_put(uint32_t *p, const fe_t &v) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) p[k] = v.l[k];
+}
+__device__ __forceinline__ fe_t lds_get(const uint32_t *p) {
+  fe_t v;
+#pragma unroll
+  for (int k = 0; k < 8; k++) v.l[k] = p[k];
+  return v;
+}
+
+// exclusive multiplicative scan of one value per thread across the workgroup (Hillis-Steele through LDS, 9 dwords per slot).
+// buf: 2 * 256 * 9 dwords.  Returns prod_{t' < t} x_t'; total = product of all 256 values.  REVERSE scans from the other end.
+template <bool REVERSE> __device__ fe_t block_exclusive_mul_scan(const fe_t &x, uint32_t *buf, fe_t &total) {
+  const uint32_t t = REVERSE ? FRSCAN_THREADS - 1 - threadIdx.x : threadIdx.x;
+  uint32_t *cur = buf, *nxt = buf + FRSCAN_THREADS * 9;
+  lds_put(cur + t * 9, x);
+  __syncthreads();
+  fe_t v = x;
+  for (uint32_t o = 1; o < FRSCAN_THREADS; o <<= 1) {
+    if (t >= o) v = fr_mul_ps(lds_get(cur + (t - o) * 9), v);
+    lds_put(nxt + t * 9, v);
+    __syncthreads();
+    uint32_t *tmp = cur; cur = nxt; nxt = tmp;
+  }
+  total = lds_get(cur + (FRSCAN_THREADS - 1) * 9);
+  fe_t ex = t ? lds_get(cur + (t - 1) * 9) : Fr::one();
+  __syncthreads();
+  return ex;
+}
+
+// a^(r-2) with the assembly multiplier (left-to-right square-and-multiply over the fixed exponent)
+__device__ __noinline__ fe_t fr_inv_ps(const fe_t &a) {
+  constexpr uint32_t e[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};   // r - 2
+  fe_t acc = a;   // top bit of r - 2 is bit 253
+  for (int i = 252; i >= 0; i--) {
+    acc = fr_sqr_ps(acc);
+    if ((e[i >> 5] >> (i & 31)) & 1u) acc = fr_mul_ps(acc, a);
+  }
+  return acc;
+}
+
+// MODE 0: self-contained (the tile product is inverted by one wavefront of the workgroup) -- for short vectors and the last level;
+// MODE 1: tile_prod[b] = product of the tile's non-zero elements;  MODE 2: invert with tile_prod[b] already holding the INVERSE of the
+// tile product (the host recursion inverts the tile products with the same three steps, so a 2^26 vector costs 17 Fermat inversions).
+template <int MODE> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_batch_invert(fe_t *__restrict__ data, uint64_t n, fe_t *__restrict__ tile_prod) {
+  __shared__ uint32_t buf[2 * FRSCAN_THREADS * 9];
+  __shared__ uint32_t inv_total[8];
+  const uint64_t base = (uint64_t)blockIdx.x * FRSCAN_TILE;
+  fe_t a[FRSCAN_EPT], pre[FRSCAN_EPT];   // pre[j] = a[0] * ... * a[j] with zeros replaced by one
+  uint32_t zero_mask = 0;
+  fe_t run = Fr::one();
+#pragma unroll
+  for (uint32_t j = 0; j < FRSCAN_EPT; j++) {
+    const uint64_t i = base + j * FRSCAN_THREADS + threadIdx.x;
+    a[j] = i < n ? g_load(&data[i]) : Fr::one();
+    if (Fr::is_zero(a[j])) { zero_mask |= 1u << j; a[j] = Fr::one(); }
+    run = j ? fr_mul_ps(run, a[j]) : a[j];
+    pre[j] = run;
+  }
+  fe_t total, total_r;
+  const fe_t left = block_exclusive_mul_scan<false>(run, buf, total);
+  if (MODE == 1) { if (threadIdx.x == 0) g_store(&tile_prod[blockIdx.x], total); return; }
+  const fe_t right = block_exclusive_mul_scan<true>(run, buf, total_r);
+  fe_t inv_t;
+  if (MODE == 0) {
+    if (threadIdx.x < 64) {   // one wavefront inverts the tile product (every lane the same value: no divergence, one result kept)
+      const fe_t inv = fr_inv_ps(total);
+      if (threadIdx.x == 0) lds_put(inv_total, inv);
+    }
+    __syncthreads();
+    inv_t = lds_get(inv_total);
+  } else inv_t = g_load(&tile_prod[blockIdx.x]);
+  fe_t inv = fr_mul_ps(fr_mul_ps(inv_t, left), right);   // (product of this thread's elements)^-1
+#pragma unroll
+  for (int j = FRSCAN_EPT - 1; j >= 0; j--) {
+    const fe_t out = j ? fr_mul_ps(inv, pre[j - 1]) : inv;
+    inv = fr_mul_ps(inv, a[j]);
+    const uint64_t i = base + (uint64_t)j * FRSCAN_THREADS + threadIdx.x;
+    if (i < n) g_store(&data[i], (zero_mask >> j) & 1u ? Fr::zero() : out);
+  }
+}
+
+// tile <-> registers: thread t gets elements [t * 8, t * 8 + 8) of the tile; global accesses are coalesced (lane = consecutive element)
+__device__ __forceinline__ void tile_load(const fe_t *__restrict__ src, uint64_t base, uint64_t n, uint32_t *tile, fe_t (&a)[FRSCAN_EPT]) {
+#pragma unroll
+  for (uint32_t j = 0; j < FRSCAN_EPT; j++) {
+    const uint32_t e = j * FRSCAN_THREADS + threadIdx.x;
+    const fe_t v = base + e < n ? g_load(&src[base + e]) : Fr::one();
+    lds_put(tile + (e >> 3) * 65 + (e & 7) * 8, v);
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < FRSCAN_EPT; j++) a[j] = lds_get(tile + threadIdx.x * 65 + j * 8);
+  __syncthreads();
+}
+
+// PHASE 0: tile_prod[b] = product of tile b.  PHASE 1: dst[i] = tile_prefix[b] * (product of the tile's elements before i).
+template <int PHASE> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_prefix_product(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint64_t n,
+                                                                                           fe_t *__restrict__ tile_prod, const fe_t *__restrict__ tile_prefix) {
+  extern __shared__ uint32_t sm[];
+  uint32_t *tile = sm, *buf = sm + FRSCAN_THREADS * 65;
+  const uint64_t base = (uint64_t)blockIdx.x * FRSCAN_TILE;
+  fe_t a[FRSCAN_EPT];
+  tile_load(src, base, n, tile, a);
+  fe_t run = a[0];
+#pragma unroll
+  for (uint32_t j = 1; j < FRSCAN_EPT; j++) run = fr_mul_ps(run, a[j]);
+  fe_t total;
+  fe_t ex = block_exclusive_mul_scan<false>(run, buf, total);
+  if (PHASE == 0) { if (threadIdx.x == 0) g_store(&tile_prod[blockIdx.x], total); return; }
+  ex = fr_mul_ps(ex, g_load(&tile_prefix[blockIdx.x]));
+#pragma unroll
+  for (uint32_t j = 0; j < FRSCAN_EPT; j++) {
+    lds_put(tile + threadIdx.x * 65 + j * 8, ex);
+    ex = fr_mul_ps(ex, a[j]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < FRSCAN_EPT; j++) {
+    const uint32_t e = j * FRSCAN_THREADS + threadIdx.x;
+    if (base + e < n) g_store(&dst[base + e], lds_get(tile + (e >> 3) * 65 + (e & 7) * 8));
+  }
+}
+
+// exclusive scan of the m tile products by one workgroup (thread t owns a contiguous run); total_out = product of everything
+__global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_scan_tile_products(const fe_t *__restrict__ tile_prod, fe_t *__restrict__ tile_prefix, uint32_t m, fe_t *__restrict__ total_out) {
+  __shared__ uint32_t buf[2 * FRSCAN_THREADS * 9];
+  const uint32_t per = (m + FRSCAN_THREADS - 1) / FRSCAN_THREADS, lo = min(m, threadIdx.x * per), hi = min(m, lo + per);
+  fe_t run = Fr::one();
+  for (uint32_t i = lo; i < hi; i++) run = fr_mul_ps(run, g_load(&tile_prod[i]));
+  fe_t total;
+  fe_t ex = block_exclusive_mul_scan<false>(run, buf, total);
+  for (uint32_t i = lo; i < hi; i++) { g_store(&tile_prefix[i], ex); ex = fr_mul_ps(ex, g_load(&tile_prod[i])); }
+  if (threadIdx.x == 0) g_store(total_out, total);
+}
+
+#endif  // __HIPCC__
+}  // namespace zk

@@ -1,0 +1,101 @@
+// g1fft.cuh -- DFT over G1 points: best_fft::<Fr, G1> of halo2_proofs [EXT-recalled src/arithmetic.rs], the transform behind
+// g_to_lagrange / ParamsKZG::downsize [REF integration/tests/integration.rs:12-22; SURVEY 8a row a3, 8f-2]:
+//     a'[i] = sum_j omega^(ij) a[j]      (natural order in, natural order out, no scaling)
+//
+// Every butterfly costs one 254-bit scalar multiple of a point (~4000 field multiplications) against 192 B of traffic, so the kernels are
+// plain radix-2 stages over a work array of XYZZ points in HBM -- there is nothing for LDS tiling to win.  The points are permuted into
+// bit-reversed order on load, the stages then run decimation-in-time exactly like the serial reference:
+//     stage s (m = 2^s):  t = w^j * a[g + j + m];  a[g + j + m] = a[g + j] - t;  a[g + j] += t,   w = omega^(n / 2m)
+// Butterflies with j == 0 (all of stage 0) skip the scalar multiple.
+#pragma once
+#include "fp_asm.cuh"
+#include "g1.cuh"
+
+namespace zk {
+#ifdef __HIPCC__
+
+// k * p for a canonical (non-Montgomery) 256-bit k: fixed 2-bit windows from the top, table {p, 2p, 3p} in registers.  Uniform schedule
+// across the wavefront (the digit only selects the table entry), the exceptional cases are handled inside g1_xyzz_add_ps.
+__device__ __noinline__ g1_xyzz_t g1_xyzz_mul_fr(const g1_xyzz_t &p, const fe_t &k) {
+  if (g1_xyzz_is_identity(p)) return p;
+  const g1_xyzz_t p2 = g1_xyzz_dbl_ps(p);
+  g1_xyzz_t p3 = p2; g1_xyzz_add_ps(p3, p);
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (int i = 126; i >= 0; i--) {   // r < 2^254: digit 127 is always zero
+    acc = g1_xyzz_dbl_ps(g1_xyzz_dbl_ps(acc));
+    const uint32_t d = (k.l[i >> 4] >> ((i & 15) * 2)) & 3u;
+    if (d) {
+      g1_xyzz_t sel;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        sel.x.l[j] = d == 1 ? p.x.l[j] : d == 2 ? p2.x.l[j] : p3.x.l[j];
+        sel.y.l[j] = d == 1 ? p.y.l[j] : d == 2 ? p2.y.l[j] : p3.y.l[j];
+        sel.zz.l[j] = d == 1 ? p.zz.l[j] : d == 2 ? p2.zz.l[j] : p3.zz.l[j];
+        sel.zzz.l[j] = d == 1 ? p.zzz.l[j] : d == 2 ? p2.zzz.l[j] : p3.zzz.l[j];
+      }
+      g1_xyzz_add_ps(acc, sel);
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ g1_xyzz_t g1fft_load_xyzz(const g1_xyzz_t *p) {
+  g1_xyzz_t r; r.x = g_load(&p->x); r.y = g_load(&p->y); r.zz = g_load(&p->zz); r.zzz = g_load(&p->zzz); return r;
+}
+__device__ __forceinline__ void g1fft_store_xyzz(g1_xyzz_t *p, const g1_xyzz_t &v) {
+  g_store(&p->x, v.x); g_store(&p->y, v.y); g_store(&p->zz, v.zz); g_store(&p->zzz, v.zzz);
+}
+
+// work[bitrev(i)] = in[i] as XYZZ.  JAC = 1: 96-byte Jacobian input (any representative); JAC = 0: 64-byte affine input.
+template <int JAC> __global__ void __launch_bounds__(256) k_g1fft_load(const void *__restrict__ in, g1_xyzz_t *__restrict__ work, uint32_t log_n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << log_n)) return;
+  const uint32_t r = log_n ? __brev(i) >> (32 - log_n) : 0;
+  g1_xyzz_t v;
+  if (JAC) {
+    const g1_jac_t *src = static_cast<const g1_jac_t *>(in) + i;
+    g1_jac_t q; q.x = g_load(&src->x); q.y = g_load(&src->y); q.z = g_load(&src->z);
+    if (Fq::is_zero(q.z)) v = g1_xyzz_identity();
+    else { v.x = q.x; v.y = q.y; v.zz = fq_sqr_ps(q.z); v.zzz = fq_mul_ps(v.zz, q.z); }
+  } else {
+    const g1_affine_t *src = static_cast<const g1_affine_t *>(in) + i;
+    g1_affine_t q; q.x = g_load(&src->x); q.y = g_load(&src->y);
+    v = g1_xyzz_from_affine(q);
+  }
+  g1fft_store_xyzz(&work[r], v);
+}
+
+// one decimation-in-time stage; tw[i] = omega^i (Montgomery), i < n / 2
+__global__ void __launch_bounds__(256) k_g1fft_stage(g1_xyzz_t *__restrict__ work, const fe_t *__restrict__ tw, uint32_t log_n, uint32_t s) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (1u << log_n) / 2) return;
+  const uint32_t m = 1u << s, j = t & (m - 1), ia = ((t >> s) << (s + 1)) + j, ib = ia + m;
+  g1_xyzz_t a = g1fft_load_xyzz(&work[ia]), b = g1fft_load_xyzz(&work[ib]);
+  if (j) {
+    fe_t one_c = Fr::zero(); one_c.l[0] = 1;
+    const fe_t k = fr_mul_ps(g_load(&tw[(uint64_t)j << (log_n - 1 - s)]), one_c);   // Montgomery -> canonical
+    b = g1_xyzz_mul_fr(b, k);
+  }
+  g1_xyzz_t lo = a; g1_xyzz_add_ps(lo, b);
+  b.y = Fq::neg(b.y);
+  g1_xyzz_add_ps(a, b);
+  g1fft_store_xyzz(&work[ia], lo); g1fft_store_xyzz(&work[ib], a);
+}
+
+// out[i] = scale * work[i], normalised.  JAC = 1: Jacobian (x, y, R) / all-zero identity; JAC = 0: affine, identity (0, 0).
+// scale == nullptr: no scalar multiple.
+template <int JAC> __global__ void __launch_bounds__(256) k_g1fft_store(const g1_xyzz_t *__restrict__ work, void *__restrict__ out, uint32_t log_n, const fe_t *__restrict__ scale) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << log_n)) return;
+  g1_xyzz_t v = g1fft_load_xyzz(&work[i]);
+  if (scale) {
+    fe_t one_c = Fr::zero(); one_c.l[0] = 1;
+    v = g1_xyzz_mul_fr(v, fr_mul_ps(g_load(scale), one_c));
+  }
+  const g1_jac_t r = g1_xyzz_to_jac_normalised(v);
+  if (JAC) { g1_jac_t *dst = static_cast<g1_jac_t *>(out) + i; g_store(&dst->x, r.x); g_store(&dst->y, r.y); g_store(&dst->z, r.z); }
+  else { g1_affine_t *dst = static_cast<g1_affine_t *>(out) + i; g_store(&dst->x, r.x); g_store(&dst->y, r.y); }
+}
+
+#endif  // __HIPCC__
+}  // namespace zk

@@ -61,13 +61,33 @@ def best_multiexp(coeffs, bases) -> np.ndarray:
 
 
 def best_fft(a, omega: np.ndarray, log_n: int) -> None:
-    """in place; a is a host [2^log_n, 4] uint64 array or a device tensor of 2^log_n * 32 bytes."""
+    """in place; a is a host [2^log_n, 4] uint64 array or a device tensor of 2^log_n * 32 bytes (G = Fr), or -- the G = G1
+    instantiation used by g_to_lagrange -- a host [2^log_n, 12] array / device tensor of 2^log_n * 96 bytes of Jacobian points."""
     if _is_device(a):
-        assert a.numel() * a.element_size() == 32 << log_n
+        nbytes = a.numel() * a.element_size()
+        if nbytes == 96 << log_n:
+            check(lib().mi355_g1_fft_dev(ptr(a), log_n, ptr(omega)))
+            return
+        assert nbytes == 32 << log_n
         check(lib().mi355_ntt_fr_dev(ptr(a), log_n, ptr(omega)))
+    elif a.ndim == 2 and a.shape[1] == 12:
+        assert a.shape == (1 << log_n, 12) and a.dtype == np.uint64
+        check(lib().mi355_g1_fft_host(ptr(a), log_n, ptr(omega)))
     else:
         assert a.shape == (1 << log_n, 4) and a.dtype == np.uint64
         check(lib().mi355_ntt_fr_host(ptr(a), log_n, ptr(omega)))
+
+
+def g_to_lagrange(g_dev, k: int):
+    """g_to_lagrange(g_projective, k) [EXT-recalled halo2_proofs src/arithmetic.rs]: g_lagrange = n^-1 * best_fft(g, omega^-1, k), as a new
+    device tensor of 2^k affine points; g_dev: device tensor (or raw device address) holding at least 2^k affine points."""
+    import torch
+    n = 1 << k
+    w_inv = pow(pow(FR_ROOT_OF_UNITY, 1 << (FR_S - k), R_MOD), R_MOD - 2, R_MOD)
+    out = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
+    src = C.c_void_p(g_dev) if isinstance(g_dev, int) else ptr(g_dev)
+    check(lib().mi355_g_to_lagrange_dev(src, ptr(out), k, ptr(fr(w_inv)), ptr(fr(pow(n, R_MOD - 2, R_MOD)))))
+    return out
 
 
 def eval_polynomial(poly, point: np.ndarray) -> np.ndarray:
@@ -87,6 +107,23 @@ def fr_vec_op(op: str, dst, a, b):
     n = a.numel() * a.element_size() // 32
     check(lib().mi355_fr_vec_op_dev({"add": 0, "sub": 1, "mul": 2}[op], ptr(dst), ptr(a), ptr(b), n))
     return dst
+
+
+def batch_invert(a):
+    """ff::BatchInvert on a device-resident Fr vector, in place: a[i] = a[i]^-1, zeros stay zero."""
+    check(lib().mi355_fr_batch_invert_dev(ptr(a), a.numel() * a.element_size() // 32))
+    return a
+
+
+def prefix_product(src, dst=None, want_total: bool = False):
+    """the grand-product column of the permutation / lookup arguments: dst[0] = 1, dst[i] = prod_{j<i} src[j] (device tensors; dst
+    defaults to a new tensor).  want_total: also return prod_{j<n} src[j] (the value that must be one for a valid argument)."""
+    import torch
+    if dst is None:
+        dst = torch.empty_like(src)
+    total = np.zeros(4, dtype=np.uint64) if want_total else None
+    check(lib().mi355_fr_prefix_product_dev(ptr(dst), ptr(src), src.numel() * src.element_size() // 32, ptr(total) if want_total else None))
+    return (dst, total) if want_total else dst
 
 
 def g1_sum(points: np.ndarray) -> np.ndarray:
@@ -254,6 +291,25 @@ class ParamsKZG:
             fn = lib().mi355_msm_g1_batch_host
         assert n <= self.n and (not lagrange or n == self.n)
         check(fn(self._gl if lagrange else self._g, 0, arr, len(polys), n, ptr(out)))
+        return out
+
+    def downsize(self, k: int) -> None:
+        """ParamsKZG::downsize(k) [REF integration/tests/integration.rs:17-22]: keep g[..2^k], rebuild g_lagrange = g_to_lagrange(g, k)
+        (a size-2^k inverse DFT over G1 points, on the device).  The coefficient basis keeps its registration (and window tables)."""
+        assert k <= self.k, "downsize: k must not exceed the current degree"
+        if k == self.k:
+            return
+        w_inv = pow(pow(FR_ROOT_OF_UNITY, 1 << (FR_S - k), R_MOD), R_MOD - 2, R_MOD)
+        h = C.c_uint64()
+        check(lib().mi355_srs_downsize(self._g, k, ptr(fr(w_inv)), ptr(fr(pow(1 << k, R_MOD - 2, R_MOD))), C.byref(h)))
+        check(lib().mi355_srs_release(self._gl))
+        self._gl = h.value
+        self.k, self.n = k, 1 << k
+
+    def read_g(self, lagrange: bool = False) -> np.ndarray:
+        """the first n points of g (or g_lagrange) back on the host: [n, 8] (what ParamsKZG::write serialises)."""
+        out = np.zeros((self.n, 8), dtype=np.uint64)
+        check(lib().mi355_srs_read_host(self._gl if lagrange else self._g, 0, self.n, ptr(out)))
         return out
 
     def g_slice(self, offset: int, n: int) -> SrsSlice:

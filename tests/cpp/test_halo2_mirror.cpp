@@ -17,6 +17,8 @@ void orc_g1_mul(void *o, const void *p, const void *scalar_mont);
 void orc_g1_generator(void *o);
 void orc_best_fft(void *a, const void *omega, uint32_t log_n, int threads);
 void orc_ifft(void *a, const void *omega_inv, uint32_t log_n, const void *divisor, int threads);
+void orc_g_to_lagrange(void *out, const void *g, uint32_t k, const void *omega_inv, const void *n_inv);
+void orc_best_fft_g1(void *a, const void *omega, uint32_t log_n);
 void orc_eval_polynomial(void *out, const void *poly, uint64_t n, const void *point);
 void orc_coeff_to_extended(void *dst, const void *coeffs, uint32_t k, uint32_t ext_k, const void *g, const void *gi, const void *ew, int threads);
 }
@@ -93,6 +95,28 @@ int main(int argc, char **argv) {
   Fr x = rand_fr(rng), ev = eval_polynomial(a, x), wev; orc_eval_polynomial(wev.data(), a.data(), n, x.data());
   EXPECT(ev == wev);
   EXPECT(f[5] == eval_polynomial(a, mi355zk::halo2::detail::fr_pow(dom.omega, 5)));   // a'[i] = a(omega^i)
+  // --- best_fft over G1 and ParamsKZG::downsize against the oracle
+  {
+    const uint32_t k5 = 5; const uint64_t n5 = 32;
+    EvaluationDomain d5(3, k5);
+    std::vector<G1> jac(n5), wj(n5);
+    const Fr one_q = {0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full};   // R mod p
+    for (uint64_t i = 0; i < n5; i++) { std::memcpy(jac[i].data(), bases[i].data(), 64); std::memcpy(jac[i].data() + 8, one_q.data(), 32); }
+    wj = jac; orc_best_fft_g1(wj.data(), d5.omega.data(), k5);
+    best_fft(jac, d5.omega, k5);
+    for (uint64_t i = 0; i < n5; i++) { G1Affine w; orc_g1_to_affine(w.data(), wj[i].data()); EXPECT(std::memcmp(jac[i].data(), w.data(), 64) == 0 && std::memcmp(jac[i].data() + 8, one_q.data(), 32) == 0); }
+    std::vector<G1Affine> rev(bases.rbegin(), bases.rend());
+    ParamsKZG params(k, bases, rev);
+    params.downsize(k5);
+    EXPECT(params.k == k5 && params.n == n5);
+    std::vector<G1Affine> want(n5), got = params.get_g_lagrange(), g5 = params.get_g();
+    orc_g_to_lagrange(want.data(), bases.data(), k5, d5.omega_inv.data(), d5.ifft_divisor.data());
+    EXPECT(got == want); EXPECT(std::equal(g5.begin(), g5.end(), bases.begin()));
+    std::vector<Fr> s5(sc.begin(), sc.begin() + n5);
+    G1 c = params.commit_lagrange(s5), wc; orc_best_multiexp(wc.data(), s5.data(), want.data(), n5, 1); G1Affine wca; orc_g1_to_affine(wca.data(), wc.data());
+    EXPECT(std::memcmp(c.data(), wca.data(), 64) == 0);
+    threw = false; try { params.downsize(k5 + 1); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
+  }
   std::printf(failures ? "FAILED (%d)\n" : "all checks passed\n", failures);
   return failures ? 1 : 0;
 }

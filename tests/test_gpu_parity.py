@@ -454,3 +454,117 @@ def test_batched_commitments_split_oversized_batches(zk, points):
     assert lib.mi355_msm_g1_batch_dev(params._g, 0, arr, 0, n, zk._capi.ptr(out)) == 0
     assert lib.mi355_msm_g1_batch_dev(params._g, 500, arr, 1, n, zk._capi.ptr(out)) == zk._capi.EBADARG   # slice past the basis
     params.release()
+
+
+def _affine_to_jac(a):
+    a = np.asarray(a, dtype=np.uint64)
+    j = np.zeros((a.shape[0], 12), dtype=np.uint64)
+    j[:, :8] = a
+    one_q = np.array(pyref.to_limbs(pyref.MONT_R % pyref.P_MOD), dtype=np.uint64)
+    j[(a != 0).any(axis=1), 8:] = one_q
+    return j
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 5, 7])
+def test_g1_fft_matches_oracle(zk, points, k):
+    """best_fft::<Fr, G1> (mi355_g1_fft_host / _dev) against the oracle's serial restatement; inputs include the identity, repeated
+    points (the doubling branch of the butterfly) and a non-normalised Jacobian representative."""
+    import torch
+    h2 = zk.halo2
+    n = 1 << k
+    pts = points[100:100 + n].copy()
+    if n >= 8:
+        pts[3] = 0; pts[5] = pts[4]; pts[6] = pts[4]; pts[6][4:] = cref.g1_to_affine(cref.g1_mul(pts[4], h2.fr(R - 1)))[4:]   # identity, P == Q, P == -Q
+    jac = _affine_to_jac(pts)
+    if n >= 2:   # scale point 1 to another representative: (X l^2, Y l^3, Z l)
+        lam = 0x1234567
+        X, Y = (cref.limbs_to_int(cref.f_to_canonical_vec(cref.FQ, jac[1, 4 * i:4 * i + 4].reshape(1, 4))[0]) for i in (0, 1))
+        P = pyref.P_MOD
+        rep = [X * lam * lam % P, Y * lam ** 3 % P, lam]
+        jac[1] = np.concatenate([cref.f_from_canonical_vec(cref.FQ, np.array(pyref.to_limbs(v), dtype=np.uint64).reshape(1, 4))[0] for v in rep])
+    w = h2.fr(pow(h2.FR_ROOT_OF_UNITY, 1 << (28 - k), R))
+    want = cref.g1_to_affine(cref.best_fft_g1(jac, w, k))
+    a = jac.copy(); h2.best_fft(a, w, k)
+    assert all((affine_of(a[i]) == want[i]).all() for i in range(n))
+    d = torch.from_numpy(jac.view(np.int64)).cuda(); h2.best_fft(d, w, k)
+    assert (d.cpu().numpy().view(np.uint64) == a).all()
+
+
+def test_downsize_rebuilds_g_lagrange(zk):
+    """ParamsKZG::downsize [REF integration/tests/integration.rs:17-22]: g_lagrange of the downsized parameters == oracle g_to_lagrange
+    (small k), == the closed-form Lagrange basis of a fresh setup with the same tau (larger k), and commit == commit_lagrange after."""
+    import torch
+    h2 = zk.halo2
+    tau = 0x5343524f4c4c0001
+    big = h2.ParamsKZG.setup(7, tau)
+    g_host = big.read_g()
+    assert (g_host == big._owner[0].cpu().numpy().view(np.uint64).reshape(128, 8)).all()
+    big.downsize(5)
+    assert (big.k, big.n) == (5, 32)
+    w_inv = pow(pow(h2.FR_ROOT_OF_UNITY, 1 << 23, R), R - 2, R)
+    want = cref.g_to_lagrange(g_host[:32], 5, h2.fr(w_inv), h2.fr(pow(32, R - 2, R)))
+    assert (big.read_g(lagrange=True) == want).all() and (big.read_g() == g_host[:32]).all()
+    # the stand-alone transform on caller-owned device memory gives the same points
+    assert (h2.g_to_lagrange(big._owner[0], 5).cpu().numpy().view(np.uint64).reshape(32, 8) == want).all()
+    big.release()
+    p14 = h2.ParamsKZG.setup(14, tau)
+    p14.precompute()
+    p14.downsize(12)
+    p12 = h2.ParamsKZG.setup(12, tau)
+    assert (p14.read_g(lagrange=True) == p12.read_g(lagrange=True)).all()
+    rng = np.random.default_rng(99)
+    evals = rand_fr(rng, 1 << 12)
+    dom = h2.EvaluationDomain(3, 12)
+    coeffs = evals.copy(); dom.lagrange_to_coeff(coeffs)
+    assert (p14.commit_lagrange(evals) == p14.commit(coeffs)).all()
+    assert (p14.commit(coeffs) == p12.commit(coeffs)).all()
+    with pytest.raises(AssertionError):
+        p14.downsize(13)
+    p14.release(); p12.release()
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 255, 256, 2047, 2048, 2049, 5000, 100003, 1 << 18])
+def test_batch_invert_and_prefix_product_match_oracle(zk, n):
+    """mi355_fr_batch_invert_dev / mi355_fr_prefix_product_dev against the oracle (ff::BatchInvert, grand-product column): zeros stay
+    zero, tile boundaries (2048), ragged tails, in-place operation."""
+    import torch
+    h2 = zk.halo2
+    rng = np.random.default_rng(7000 + n)
+    a = rand_fr(rng, n)                         # contains 0, 1, r - 1 when n >= 4
+    if n > 2100:
+        a[2047] = 0; a[2048] = 0; a[n - 1] = 0
+    d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    h2.batch_invert(d)
+    got = d.cpu().numpy().view(np.uint64).reshape(n, 4)
+    assert (got == cref.batch_invert(a)).all()
+    b = rand_fr(rng, n, full=False)
+    if n > 4:
+        b[3] = cref.fr_mont(1); b[4] = cref.fr_mont(R - 1)
+    src = torch.from_numpy(b.view(np.int64).copy()).cuda()
+    z, total = h2.prefix_product(src, want_total=True)
+    wz, wt = cref.prefix_product(b)
+    assert (z.cpu().numpy().view(np.uint64).reshape(n, 4) == wz).all() and (total == wt).all()
+    h2.prefix_product(src, dst=src)             # in place
+    assert (src.cpu().numpy().view(np.uint64).reshape(n, 4) == wz).all()
+    if n > 3000:                                # a zero factor makes everything after it zero
+        b[2500] = 0
+        z2, t2 = h2.prefix_product(torch.from_numpy(b.view(np.int64).copy()).cuda(), want_total=True)
+        z2 = z2.cpu().numpy().view(np.uint64).reshape(n, 4)
+        assert (z2[:2501] == wz[:2501]).all() and (z2[2501:] == 0).all() and (t2 == 0).all()
+
+
+def test_permutation_grand_product_closes(zk):
+    """the permutation-argument identity the grand product exists for: with numerators a permutation of the denominators,
+    z = prefix_product(num * batch_invert(den)) ends at one."""
+    import torch
+    h2 = zk.halo2
+    n = 1 << 16
+    rng = np.random.default_rng(31)
+    den = rand_fr(rng, n, full=False); den[den.sum(axis=1) == 0] = cref.fr_mont(1)
+    num = den[rng.permutation(n)]
+    d = torch.from_numpy(den.view(np.int64).copy()).cuda(); m = torch.from_numpy(num.view(np.int64).copy()).cuda()
+    h2.batch_invert(d)
+    h2.fr_vec_op("mul", d, d, m)
+    z, total = h2.prefix_product(d, want_total=True)
+    assert (total == cref.fr_mont(1)).all()
+    assert (z[0].cpu().numpy().view(np.uint64) == cref.fr_mont(1)).all()

@@ -182,3 +182,32 @@ def test_quotient_pipeline_replay_device_resident(zk, k):
     got = affine_of(params.commit(h[:n].contiguous()))
     assert (got == field_commit(h[:n].contiguous(), TAU + 5)).all()
     params.release()
+
+
+@pytest.mark.parametrize("n", [(1 << 24) + 3, (1 << 27) + 5])
+def test_batch_invert_and_grand_product_at_size(zk, n):
+    """batch inversion at sizes where the tile products are themselves batch-inverted (one and two levels of recursion):
+    a * a^-1 == 1 wherever a != 0, zeros stay zero, inverting twice restores the input; and the grand product of
+    (a, a^-1 interleaved) closes at one with z[2i] == 1."""
+    h2 = zk.halo2
+    a = dev_scalars(n, 77)
+    a[5] = 0; a[n - 1] = 0; a[2048 * 33] = 0
+    inv = a.clone()
+    h2.batch_invert(inv)
+    prod = torch.empty_like(a)
+    h2.fr_vec_op("mul", prod, a, inv)
+    one = torch.from_numpy(cref.fr_mont(1).view(np.int64)).cuda()
+    is_zero = (a == 0).all(dim=1)
+    assert int(is_zero.sum()) >= 3
+    assert bool(((prod == one).all(dim=1) | is_zero).all())
+    assert bool((inv[is_zero] == 0).all()) and bool((prod[is_zero] == 0).all())
+    back = inv.clone(); h2.batch_invert(back)
+    assert torch.equal(back, a)
+    m = min(n, 1 << 24) & ~1
+    inter = torch.stack([a[:m // 2], inv[:m // 2]], dim=1).reshape(m, 4).contiguous()
+    nz = ~is_zero[:m // 2]
+    inter[0::2][~nz] = one; inter[1::2][~nz] = one
+    z, total = h2.prefix_product(inter, want_total=True)
+    assert (total == cref.fr_mont(1)).all()
+    assert bool((z[0::2] == one).all())
+    assert torch.equal(z[1::2], inter[0::2])

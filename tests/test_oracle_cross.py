@@ -178,3 +178,52 @@ def test_commit_equals_commit_lagrange_on_synthetic_srs():
     c2 = jac_to_py(cref.best_multiexp(fr_vec(evals), gl, 2))
     want = pyref.g1_mul(pyref.G1_GEN, pyref.eval_poly(coeffs, tau))   # commit(p) = p(tau).G
     assert c1 == c2 == want
+
+
+def affine_to_jac(a):
+    """[n,8] affine -> [n,12] Jacobian with z = R (identity stays all-zero)."""
+    a = np.asarray(a, dtype=np.uint64)
+    j = np.zeros((a.shape[0], 12), dtype=np.uint64)
+    j[:, :8] = a
+    one_q = np.array(pyref.to_limbs(pyref.MONT_R % P), dtype=np.uint64)
+    nz = (a != 0).any(axis=1)
+    j[nz, 8:] = one_q
+    return j
+
+
+def test_g1_fft_and_g_to_lagrange_oracle():
+    """best_fft over G1 points against its definition (row i = MSM of the inputs with scalars omega^(ij)), and g_to_lagrange against the
+    closed form L_i(tau) G of the synthetic SRS -- the property ParamsKZG::downsize relies on."""
+    k, n = 3, 8
+    rng = random.Random(11)
+    w = pyref.omega(k)
+    tau = rng.randrange(2, R)
+    g, gl, _, _ = cref.srs_setup(k, fr_vec([tau])[0], fr_vec([w])[0])
+    pts = g.copy(); pts[5] = 0                                     # an identity among the inputs
+    got = cref.g1_to_affine(cref.best_fft_g1(affine_to_jac(pts), fr_vec([w])[0], k))
+    for i in range(n):
+        want = cref.g1_to_affine(cref.msm_naive(fr_vec([pow(w, i * j, R) for j in range(n)]), pts))
+        assert (got[i] == want).all(), i
+    w_inv, n_inv = pow(w, -1, R), pow(n, -1, R)
+    assert (cref.g_to_lagrange(g, k, fr_vec([w_inv])[0], fr_vec([n_inv])[0]) == gl).all()
+    # downsize: the first 2^(k-1) powers of tau give the Lagrange basis of the half-size domain
+    g2, gl2, _, _ = cref.srs_setup(k - 1, fr_vec([tau])[0], fr_vec([pyref.omega(k - 1)])[0])
+    assert (g2 == g[: n // 2]).all()
+    w2_inv = pow(pyref.omega(k - 1), -1, R)
+    assert (cref.g_to_lagrange(g[: n // 2], k - 1, fr_vec([w2_inv])[0], fr_vec([pow(n // 2, -1, R)])[0]) == gl2).all()
+
+
+def test_batch_invert_and_grand_product_oracle():
+    """ff::BatchInvert and the grand-product column against big-int arithmetic."""
+    rng = random.Random(21)
+    vals = [rng.randrange(R) for _ in range(300)]
+    vals[0] = 0; vals[17] = 0; vals[299] = 0; vals[5] = 1; vals[6] = R - 1
+    inv = fr_ints(cref.batch_invert(fr_vec(vals)))
+    assert inv == [pow(v, -1, R) if v else 0 for v in vals]
+    z, total = cref.prefix_product(fr_vec(vals[1:17]))
+    acc, want = 1, []
+    for v in vals[1:17]:
+        want.append(acc); acc = acc * v % R
+    assert fr_ints(z) == want and fr_ints(total.reshape(1, 4)) == [acc]
+    z0, t0 = cref.prefix_product(fr_vec([]).reshape(0, 4))
+    assert z0.shape[0] == 0 and fr_ints(t0.reshape(1, 4)) == [1]
