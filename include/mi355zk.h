@@ -95,6 +95,11 @@ int mi355_g1_sum_host(const void *g1_points_host, uint64_t n, void *out_g1_host)
 int mi355_msm_set_normalise(int on);
 /* tuning: window bits c for subsequent MSMs (0 = automatic from n)                                             */
 int mi355_msm_set_window_bits(int c);
+/* pipelined schedule of a large single MSM: the point range is cut into `chunks` slices and the (memory-bound) sort of slice k + 1
+ * runs under the (ALU-bound) accumulation of slice k on separate HIP streams; results are identical.  Off by default (measured
+ * slower on MI355X: the accumulation holds every wave slot; env MI355_MSM_CHUNKS).  chunks = 1 disables, 0 restores the default;
+ * min_log_n = smallest log2(n) that is cut.                                                                                       */
+int mi355_msm_set_pipeline(uint32_t chunks, uint32_t min_log_n);
 
 /* ---- NTT: halo2_proofs::arithmetic::best_fft(a, omega, log_n): in place, natural order in -> natural order out,
  *      a'[i] = sum_j a[j] omega^(ij), no scaling.  omega: 32 B Montgomery, must have order 2^log_n.            */

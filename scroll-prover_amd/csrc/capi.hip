@@ -51,12 +51,20 @@ struct NttPlan {
 };
 struct Prof { double ms = 0; uint64_t launches = 0; };
 
+struct MsmSlot { int id = 0; hipEvent_t sorted = nullptr, acc_done = nullptr, red_done = nullptr; bool used = false; };   // per-chunk buffers + events of the pipelined MSM
+
 struct Ctx {
   std::mutex mu;
   bool inited = false;
   int device = -1;
   hipDeviceProp_t prop;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  hipStream_t aux_stream[2] = {nullptr, nullptr};   // side streams of the pipelined MSM (sort | reduction); the accumulation stays on `stream`
+  hipEvent_t ev_fork = nullptr;
+  MsmSlot msm_slot[2];
+  uint32_t msm_chunks = 1;       // MI355_MSM_CHUNKS / mi355_msm_set_pipeline (off by default: measured slower)
+  uint32_t msm_chunk_min_log = 23;
+  int last_chunks = 1;
   std::unordered_map<uint64_t, Srs> srs;
   uint64_t next_handle = 1;
   std::map<std::string, Buf> ws;           // grow-only workspace arena, keyed by role
@@ -82,7 +90,7 @@ int need_init() { return g.inited ? MI355_OK : fail(MI355_ENODEVICE, "mi355_init
 int ws_get(const char *role, size_t bytes, void **out) {
   Buf &b = g.ws[role];
   if (b.cap < bytes) {
-    if (b.p) { HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    if (b.p) { HIPCHK(hipStreamSynchronize(g.stream)); for (int i = 0; i < 2; i++) if (g.aux_stream[i]) HIPCHK(hipStreamSynchronize(g.aux_stream[i])); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     size_t cap = bytes + bytes / 8 + 256;
     HIPCHK(hipMalloc(&b.p, cap)); b.cap = cap;
   }
@@ -93,13 +101,15 @@ int ws_get(const char *role, size_t bytes, void **out) {
 struct Span { std::string name; hipEvent_t a, b; };
 std::vector<Span> g_spans;
 struct Scope {
-  bool on; hipEvent_t a = nullptr, b = nullptr; std::string name;
-  Scope(const char *n) : on(g.profiling), name(n) { if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, g.stream); } }
-  ~Scope() { if (on) { (void)hipEventRecord(b, g.stream); g_spans.push_back({name, a, b}); } }
+  bool on; hipEvent_t a = nullptr, b = nullptr; std::string name; hipStream_t st;
+  Scope(const char *n, hipStream_t s = nullptr) : on(g.profiling), name(n), st(s ? s : g.stream) { if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); } }
+  void close() { if (on) { (void)hipEventRecord(b, st); g_spans.push_back({name, a, b}); on = false; } }
+  ~Scope() { close(); }
 };
 void resolve_spans() {
   if (g_spans.empty()) return;
   hipStreamSynchronize(g.stream);
+  for (int i = 0; i < 2; i++) if (g.aux_stream[i]) hipStreamSynchronize(g.aux_stream[i]);
   for (auto &s : g_spans) { float ms = 0; hipEventElapsedTime(&ms, s.a, s.b); Prof &p = g.prof[s.name]; p.ms += ms; p.launches++; hipEventDestroy(s.a); hipEventDestroy(s.b); }
   g_spans.clear();
 }
@@ -131,31 +141,24 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
   return msm_batch_impl(bases, &scalars, 1, n, out_host, pre);
 }
 
+// One MSM (or one chunk of a pipelined MSM) enqueued on three streams: st.a digits + sort (HBM-bound), st.b bucket accumulation
+// (ALU-bound), st.c fix-up + bucket reduction (latency-bound).  With st.a == st.b == st.c this is the plain serial schedule.
 // M commitments over the same basis slice in one pass: (polynomial m, window w) is window m * W + w of one big bucket problem, so the
-// per-call fixed costs (launches, the latency-bound reduction tail) are paid once per batch.  out_host: M x 96 B.
-int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre) {
-  if (M == 0) return MI355_OK;
-  if (n == 0) { memset(out_host, 0, (size_t)M * sizeof(g1_jac_t)); return MI355_OK; }
-  if (n >= (1ull << 31)) return fail(MI355_EBADARG, "msm: n must be < 2^31");
-  const g1_affine_t *bases0 = bases;
+// per-call fixed costs (launches, the latency-bound reduction tail) are paid once per batch.  out_dev: M x 96 B, device.
+struct MsmStreams { hipStream_t a, b, c; };
+
+int msm_enqueue(const g1_affine_t *bases, const fe_t *const *polys_dev, uint32_t M, uint64_t n, g1_jac_t *out_dev, const PreTable *pre, MsmSlot &slot,
+                const MsmStreams &st, bool normalise) {
+  const bool piped = st.a != st.b;
+  const std::string sfx = slot.id ? "#" + std::to_string(slot.id) : std::string();
+  auto role = [&](const char *r) { return std::string(r) + sfx; };
+#define WS(name, bytes, ptr) CHK(ws_get(role(name).c_str(), bytes, (void **)&ptr))
   MsmPlan P; P.n = (uint32_t)n; P.batch = M; P.c = (uint32_t)choose_c(n);
   // precomputed rows 2^(c w) P available and cheaper than the per-window schedule at this n -> all windows share one bucket set
   const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)P.c, false) && n * (uint64_t)pre->w < (1ull << 31);
   if (shared) { P.c = (uint32_t)pre->c; bases = pre->table; }
   P.windows = (255 + P.c - 1) / P.c; P.nb = 1u << (P.c - 1);
   const uint64_t emax = (uint64_t)M * n * P.windows;
-  {
-    // a batch that would overflow the 32-bit entry index, the coarse histogram's LDS or a sensible workspace (16 B per entry) is
-    // processed as two half batches
-    const uint32_t kb = P.c - 1, cbits = kb <= 11 ? 0 : (kb - 11 > 10 ? 10 : kb - 11);
-    const uint64_t regions = (uint64_t)M * (shared ? 1 : P.windows) << cbits, bk = (uint64_t)M * (shared ? 1 : P.windows) << kb;
-    if (M > 1 && (emax > (1ull << 29) || regions * 4 > 48 * 1024 || bk >= (1ull << 28))) {
-      const uint32_t h = M / 2;
-      int rc = msm_batch_impl(bases0, polys_host, h, n, out_host, pre);
-      if (rc != MI355_OK) return rc;
-      return msm_batch_impl(bases0, polys_host + h, M - h, n, (char *)out_host + (size_t)h * sizeof(g1_jac_t), pre);
-    }
-  }
   if (emax >= (1ull << 32)) return fail(MI355_EBADARG, "msm: n * windows must be < 2^32");
   const uint64_t want_threads = (uint64_t)g.prop.multiProcessorCount * 256 * g.seg_factor;   // segments per lane slot (MI355_SEG_FACTOR)
   uint64_t seg = (emax + want_threads - 1) / want_threads; if (seg < 16) seg = 16; if (seg > 4096) seg = 4096;
@@ -186,46 +189,47 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
   const uint32_t vwindows = M * P.windows;   // (polynomial, window) pairs
 
   uint32_t *enc, *hist, *offsets, *cursor, *sorted, *scan_sums, *coarse_hist, *coarse_off, *coarse_cursor, *tile_start; uint64_t *pairs;
-  g1_xyzz29_t *buckets, *part; g1_xyzz_t *chunk_out, *window_sums; int32_t *part_id; g1_jac_t *out_dev;
+  g1_xyzz29_t *buckets, *part; g1_xyzz_t *chunk_out, *window_sums; int32_t *part_id;
+  // stage-A-only buffers are shared by all slots (the sort stages of successive chunks run one after the other on st.a)
   CHK(ws_get("msm.digits", emax * 4, (void **)&enc));
   CHK(ws_get("msm.pairs", emax * 8, (void **)&pairs));
   CHK(ws_get("msm.hist", ((size_t)nbuckets + 1) * 4, (void **)&hist));
-  CHK(ws_get("msm.offsets", ((size_t)nbuckets + 1) * 4, (void **)&offsets));
   CHK(ws_get("msm.cursor", ((size_t)nbuckets + 1) * 4, (void **)&cursor));
   CHK(ws_get("msm.coarse_hist", ((size_t)S.regions + 1) * 4, (void **)&coarse_hist));
   CHK(ws_get("msm.coarse_off", ((size_t)S.regions + 1) * 4, (void **)&coarse_off));
   CHK(ws_get("msm.coarse_cursor", ((size_t)S.regions + 1) * 4, (void **)&coarse_cursor));
   CHK(ws_get("msm.tile_start", ((size_t)S.regions + 1) * 4, (void **)&tile_start));
-  CHK(ws_get("msm.sorted", emax * 4, (void **)&sorted));
   const uint32_t scan_n = nbuckets + 1, scan_blocks = ceil_div(scan_n, SCAN_BLOCK * SCAN_ITEMS);
   const uint32_t cscan_n = S.regions + 1, cscan_blocks = ceil_div(cscan_n, SCAN_BLOCK * SCAN_ITEMS);
   CHK(ws_get("msm.scan_sums", (size_t)(scan_blocks + cscan_blocks) * 4, (void **)&scan_sums));
-  CHK(ws_get("msm.buckets", (size_t)nbuckets * sizeof(g1_xyzz29_t), (void **)&buckets));
-  CHK(ws_get("msm.part", (size_t)tn * 2 * sizeof(g1_xyzz29_t), (void **)&part));
-  CHK(ws_get("msm.part_id", (size_t)tn * 2 * 4, (void **)&part_id));
+  // per-slot: what the accumulation and the reduction of this chunk read while the next chunk is being sorted
+  WS("msm.offsets", ((size_t)nbuckets + 1) * 4, offsets);
+  WS("msm.sorted", emax * 4, sorted);
+  WS("msm.buckets", (size_t)nbuckets * sizeof(g1_xyzz29_t), buckets);
+  WS("msm.part", (size_t)tn * 2 * sizeof(g1_xyzz29_t), part);
+  WS("msm.part_id", (size_t)tn * 2 * 4, part_id);
   const uint32_t big_cap = tn / FIXUP_SERIAL_MAX + 2;
-  uint32_t *big_list; CHK(ws_get("msm.big_list", ((size_t)big_cap * 3 + 1) * 4, (void **)&big_list));
+  uint32_t *big_list; WS("msm.big_list", ((size_t)big_cap * 3 + 1) * 4, big_list);
   uint32_t *big_count = big_list + (size_t)big_cap * 3;
-  CHK(ws_get("msm.chunk_out", (size_t)nchunks * sizeof(g1_xyzz_t), (void **)&chunk_out));
+  WS("msm.chunk_out", (size_t)nchunks * sizeof(g1_xyzz_t), chunk_out);
   g1_xyzz_t *tree_a, *tree_b;
   { const size_t lvl = (size_t)ceil_div(chunks_per_window, 256 * TREE_PER_THREAD) * red_windows + 1;
-    CHK(ws_get("msm.tree_a", lvl * sizeof(g1_xyzz_t), (void **)&tree_a)); CHK(ws_get("msm.tree_b", lvl * sizeof(g1_xyzz_t), (void **)&tree_b)); }
-  CHK(ws_get("msm.window_sums", (size_t)red_windows * sizeof(g1_xyzz_t), (void **)&window_sums));
-  CHK(ws_get("msm.out", (size_t)M * sizeof(g1_jac_t), (void **)&out_dev));
-  const fe_t **polys_dev; CHK(ws_get("msm.polys", (size_t)M * sizeof(void *), (void **)&polys_dev));
-  HIPCHK(hipMemcpyAsync(polys_dev, polys_host, (size_t)M * sizeof(void *), hipMemcpyHostToDevice, g.stream));
+    WS("msm.tree_a", lvl * sizeof(g1_xyzz_t), tree_a); WS("msm.tree_b", lvl * sizeof(g1_xyzz_t), tree_b); }
+  WS("msm.window_sums", (size_t)red_windows * sizeof(g1_xyzz_t), window_sums);
+#undef WS
 
-  hipStream_t s = g.stream;
   const int grid_stream = g.prop.multiProcessorCount * 8;
   {
-    Scope total("msm_total");
+    hipStream_t s = st.a;
+    // the accumulation and the fix-up of the chunk that used this slot before must be done with `sorted` / `offsets`
+    if (piped && slot.used) { HIPCHK(hipStreamWaitEvent(s, slot.acc_done, 0)); HIPCHK(hipStreamWaitEvent(s, slot.red_done, 0)); }
     {
-      Scope sc("msm_digits");
+      Scope sc("msm_digits", s);
       HIPCHK(hipMemsetAsync(coarse_hist, 0, ((size_t)S.regions + 1) * 4, s));
       hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream / M > 0 ? grid_stream / M : 1, M), dim3(256), (size_t)S.regions * 4, s, polys_dev, enc, P, coarse_hist, S.fb, S.cb_bits, S.shared);
     }
     {
-      Scope sc("msm_sort");
+      Scope sc("msm_sort", s);
       HIPCHK(hipMemsetAsync(hist, 0, ((size_t)nbuckets + 1) * 4, s));
       hipLaunchKernelGGL(k_scan_partial, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, cscan_n);
       hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums + scan_blocks, cscan_blocks);
@@ -247,38 +251,115 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
         else hipLaunchKernelGGL(k_sort_l2_scatter<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
       }
     }
+    if (piped) { HIPCHK(hipEventRecord(slot.sorted, s)); HIPCHK(hipStreamWaitEvent(st.b, slot.sorted, 0)); }
+  }
+  {
+    hipStream_t s = st.b;
+    // the reduction of the chunk that used this slot before must be done with `buckets` / `part`
+    if (piped && slot.used) HIPCHK(hipStreamWaitEvent(s, slot.red_done, 0));
     {
-      Scope sc("msm_accumulate");
+      Scope sc("msm_accumulate", s);
       HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
 #define ACC_LAUNCH(V) hipLaunchKernelGGL(k_msm_accumulate<V>, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, P.n, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask)
       switch (g.acc_variant) { case 0: ACC_LAUNCH(0); break; case 1: ACC_LAUNCH(1); break; case 2: ACC_LAUNCH(2); break; default: ACC_LAUNCH(3); break; }
 #undef ACC_LAUNCH
     }
+    if (piped) { HIPCHK(hipEventRecord(slot.acc_done, s)); HIPCHK(hipStreamWaitEvent(st.c, slot.acc_done, 0)); }
+  }
+  {
+    hipStream_t s = st.c;
+    Scope sc("msm_reduce", s);
+    HIPCHK(hipMemsetAsync(big_count, 0, 4, s));
+    hipLaunchKernelGGL(k_msm_fixup, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap);
+    hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
+    { MsmPlan PR = P; PR.windows = red_windows; hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk); }
     {
-      Scope sc("msm_reduce");
-      HIPCHK(hipMemsetAsync(big_count, 0, 4, s));
-      hipLaunchKernelGGL(k_msm_fixup, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap);
-      hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
-      { MsmPlan PR = P; PR.windows = red_windows; hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk); }
-      {
-        // tree-sum the chunk results per window, ping-ponging inside chunk_out's spare half
-        const g1_xyzz_t *cur = chunk_out; uint32_t cnt = chunks_per_window; g1_xyzz_t *bufs[2] = {tree_a, tree_b}; int which = 0;
-        while (true) {
-          const uint32_t outn = ceil_div(cnt, 256 * TREE_PER_THREAD);
-          g1_xyzz_t *dst = outn == 1 ? window_sums : bufs[which];
-          hipLaunchKernelGGL(k_msm_tree_sum, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
-          if (outn == 1) break;
-          cur = dst; cnt = outn; which ^= 1;
-        }
+      // tree-sum the chunk results per window, ping-ponging inside chunk_out's spare half
+      const g1_xyzz_t *cur = chunk_out; uint32_t cnt = chunks_per_window; g1_xyzz_t *bufs[2] = {tree_a, tree_b}; int which = 0;
+      while (true) {
+        const uint32_t outn = ceil_div(cnt, 256 * TREE_PER_THREAD);
+        g1_xyzz_t *dst = outn == 1 ? window_sums : bufs[which];
+        hipLaunchKernelGGL(k_msm_tree_sum, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
+        if (outn == 1) break;
+        cur = dst; cnt = outn; which ^= 1;
       }
-      hipLaunchKernelGGL(k_msm_final, dim3(M), dim3(64), 0, s, window_sums, red_wpp, shared ? 0u : P.c, out_dev, g.normalise ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_msm_final, dim3(M), dim3(64), 0, s, window_sums, red_wpp, shared ? 0u : P.c, out_dev, normalise ? 1 : 0);
+  }
+  if (piped) HIPCHK(hipEventRecord(slot.red_done, st.c));
+  slot.used = true;
+  HIPCHK(hipGetLastError());
+  g.last_c = (int)P.c; g.last_w = (int)P.windows; g.last_entries += emax;
+  return MI355_OK;
+}
+
+// Chunks of a pipelined MSM: the point range is cut into K slices, every slice is a complete MSM over its part of the basis (and of the
+// window tables), and the memory-bound sort of slice k + 1 runs under the ALU-bound accumulation of slice k; the K partial results are
+// added at the end.  OFF by default (MI355_MSM_CHUNKS / mi355_msm_set_pipeline): on MI355X the accumulation holds every wave slot for its
+// whole run, so the sort of the next slice barely progresses next to it -- measured 74.9 ms (1 chunk), 75.6 (2), 80.2 (4), 91.1 (8) at 2^26.
+uint32_t msm_chunks_for(uint32_t M, uint64_t n) {
+  if (g.msm_chunks <= 1 || M != 1 || n < (1ull << g.msm_chunk_min_log)) return 1;
+  uint32_t k = g.msm_chunks;
+  while (k > 1 && n / k < ((1ull << g.msm_chunk_min_log) >> 2)) k--;
+  return k;
+}
+
+int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre) {
+  if (M == 0) return MI355_OK;
+  if (n == 0) { memset(out_host, 0, (size_t)M * sizeof(g1_jac_t)); return MI355_OK; }
+  if (n >= (1ull << 31)) return fail(MI355_EBADARG, "msm: n must be < 2^31");
+  if (M > 1) {
+    // a batch that would overflow the 32-bit entry index, the coarse histogram's LDS or a sensible workspace (16 B per entry) is
+    // processed as two half batches
+    uint32_t c = (uint32_t)choose_c(n);
+    const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)c, false) && n * (uint64_t)pre->w < (1ull << 31);
+    if (shared) c = (uint32_t)pre->c;
+    const uint32_t W = (255 + c - 1) / c, kb = c - 1, cbits = kb <= 11 ? 0 : (kb - 11 > 10 ? 10 : kb - 11);
+    const uint64_t emax = (uint64_t)M * n * W, regions = (uint64_t)M * (shared ? 1 : W) << cbits, bk = (uint64_t)M * (shared ? 1 : W) << kb;
+    if (emax > (1ull << 29) || regions * 4 > 48 * 1024 || bk >= (1ull << 28)) {
+      const uint32_t h = M / 2;
+      int rc = msm_batch_impl(bases, polys_host, h, n, out_host, pre);
+      if (rc != MI355_OK) return rc;
+      return msm_batch_impl(bases, polys_host + h, M - h, n, (char *)out_host + (size_t)h * sizeof(g1_jac_t), pre);
     }
   }
+  const uint32_t K = msm_chunks_for(M, n);
+  g.last_entries = 0;
+  g1_jac_t *out_dev; const fe_t **polys_dev;
+  CHK(ws_get("msm.out", (size_t)(K + 1) * M * sizeof(g1_jac_t), (void **)&out_dev));
+  CHK(ws_get("msm.polys", (size_t)K * M * sizeof(void *), (void **)&polys_dev));
+  hipStream_t s = g.stream;
+  Scope total("msm_total", s);
+  if (K == 1) {
+    HIPCHK(hipMemcpyAsync(polys_dev, polys_host, (size_t)M * sizeof(void *), hipMemcpyHostToDevice, s));
+    MsmStreams st{s, s, s};
+    CHK(msm_enqueue(bases, polys_dev, M, n, out_dev, pre, g.msm_slot[0], st, g.normalise));
+  } else {
+    std::vector<const fe_t *> ptrs((size_t)K * M);
+    std::vector<uint64_t> lo(K + 1);
+    for (uint32_t k = 0; k <= K; k++) lo[k] = n * k / K;
+    for (uint32_t k = 0; k < K; k++) for (uint32_t m = 0; m < M; m++) ptrs[(size_t)k * M + m] = polys_host[m] + lo[k];
+    HIPCHK(hipMemcpyAsync(polys_dev, ptrs.data(), ptrs.size() * sizeof(void *), hipMemcpyHostToDevice, s));
+    // the side streams start after everything already queued on the caller's stream (the scalars may still be in flight there)
+    HIPCHK(hipEventRecord(g.ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(g.aux_stream[0], g.ev_fork, 0)); HIPCHK(hipStreamWaitEvent(g.aux_stream[1], g.ev_fork, 0));
+    MsmStreams st{g.aux_stream[0], s, g.aux_stream[1]};
+    for (uint32_t k = 0; k < K; k++) {
+      PreTable pk; const PreTable *pp = nullptr;
+      if (pre) { pk = *pre; if (pk.table) pk.table += lo[k]; pp = &pk; }
+      CHK(msm_enqueue(bases + lo[k], polys_dev + (size_t)k * M, M, lo[k + 1] - lo[k], out_dev + (size_t)(k + 1) * M, pp, g.msm_slot[k & 1], st, false));
+    }
+    HIPCHK(hipStreamWaitEvent(s, g.msm_slot[0].red_done, 0)); HIPCHK(hipStreamWaitEvent(s, g.msm_slot[1].red_done, 0));
+    HIPCHK(hipEventRecord(g.ev_fork, st.a)); HIPCHK(hipStreamWaitEvent(s, g.ev_fork, 0));   // join the sort stream too
+    hipLaunchKernelGGL(k_g1_sum_strided, dim3(M), dim3(64), 0, s, out_dev + M, K, M, out_dev, g.normalise ? 1 : 0);
+  }
   HIPCHK(hipGetLastError());
+  total.close();
   HIPCHK(hipMemcpyAsync(out_host, out_dev, (size_t)M * sizeof(g1_jac_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  g.msm_slot[0].used = g.msm_slot[1].used = false;
   resolve_spans();
-  g.last_c = (int)P.c; g.last_w = (int)P.windows; g.last_entries = emax;
+  g.last_chunks = (int)K;
   return MI355_OK;
 }
 
@@ -462,6 +543,14 @@ int mi355_init(int device_id) {
   if (strncmp(g.prop.gcnArchName, "gfx950", 6) != 0) return fail(MI355_ENODEVICE, std::string("device is ") + g.prop.gcnArchName + ", this library is built for gfx950 only");
   HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
   g.stream = g.own_stream; g.device = device_id;
+  for (int i = 0; i < 2; i++) {
+    { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); const char *e = getenv("MI355_AUX_PRIO"); const bool high = !(e && e[0] == '0');
+      HIPCHK(hipStreamCreateWithPriority(&g.aux_stream[i], hipStreamNonBlocking, high ? hi : lo)); }   // the side streams outrank the accumulation
+    g.msm_slot[i].id = i; g.msm_slot[i].used = false;
+    HIPCHK(hipEventCreateWithFlags(&g.msm_slot[i].sorted, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&g.msm_slot[i].acc_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&g.msm_slot[i].red_done, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming));
+  { const char *e = getenv("MI355_MSM_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 16) g.msm_chunks = (uint32_t)v; } }
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -501,6 +590,11 @@ int mi355_shutdown(void) {
   g.ntt_plans.clear();
   if (g.fixed_base_table) { hipFree(g.fixed_base_table); g.fixed_base_table = nullptr; }
   if (g.own_stream) hipStreamDestroy(g.own_stream);
+  for (int i = 0; i < 2; i++) {
+    if (g.aux_stream[i]) { hipStreamDestroy(g.aux_stream[i]); g.aux_stream[i] = nullptr; }
+    if (g.msm_slot[i].sorted) { hipEventDestroy(g.msm_slot[i].sorted); hipEventDestroy(g.msm_slot[i].acc_done); hipEventDestroy(g.msm_slot[i].red_done); g.msm_slot[i] = MsmSlot(); }
+  }
+  if (g.ev_fork) { hipEventDestroy(g.ev_fork); g.ev_fork = nullptr; }
   g.own_stream = g.stream = nullptr; g.inited = false; g.device = -1;
   return MI355_OK;
 }
@@ -642,6 +736,12 @@ int mi355_msm_g1_batch_host(uint64_t srs_handle, uint64_t base_offset, const voi
     }
     CHK(msm_batch_impl(bases, ptrs.data(), mg, n, (char *)out_g1_host + (size_t)m0 * sizeof(g1_jac_t), &pre));
   }
+  return MI355_OK;
+}
+int mi355_msm_set_pipeline(uint32_t chunks, uint32_t min_log_n) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (chunks > 16 || min_log_n > 31) return fail(MI355_EBADARG, "msm_set_pipeline: chunks <= 16, min_log_n <= 31");
+  g.msm_chunks = chunks ? chunks : 1; g.msm_chunk_min_log = chunks ? min_log_n : 23;
   return MI355_OK;
 }
 int mi355_msm_g1_adhoc_host(const void *bases_host, const void *scalars_host, uint64_t n, void *out_g1_host) {

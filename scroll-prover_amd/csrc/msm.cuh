@@ -436,6 +436,18 @@ __global__ void k_g1_sum(const g1_jac_t *__restrict__ pts, uint32_t n, g1_jac_t 
   *out = g1_xyzz_to_jac_normalised(acc);
 }
 
+// out[m] = sum_k pts[k * stride + m], k < count: the fold of the per-chunk partial results of a pipelined MSM (one workgroup per polynomial)
+__global__ void k_g1_sum_strided(const g1_jac_t *__restrict__ pts, uint32_t count, uint32_t stride, g1_jac_t *__restrict__ out, int normalise) {
+  if (threadIdx.x != 0) return;
+  g1_xyzz_t acc = g1_xyzz_identity();
+  for (uint32_t k = 0; k < count; k++) { g1_jac_t p = pts[(size_t)k * stride + blockIdx.x]; g1_xyzz_add_ps(acc, g1_jac_to_xyzz(p)); }
+  if (normalise) { out[blockIdx.x] = g1_xyzz_to_jac_normalised(acc); return; }
+  g1_jac_t r;
+  if (g1_xyzz_is_identity(acc)) { r.x = Fq::zero(); r.y = Fq::zero(); r.z = Fq::zero(); }
+  else { r.x = fq_mul_ps(acc.x, fq_sqr_ps(acc.zz)); r.y = fq_mul_ps(acc.y, fq_sqr_ps(acc.zzz)); r.z = acc.zzz; }
+  out[blockIdx.x] = r;
+}
+
 // ---- window precomputation for a registered basis: T[w][i] = 2^(c w) * P_i, affine, w < W (row 0 = the basis itself).
 // One thread per point: c doublings, one inversion per row.  One-off cost at registration (about 6.4 k field multiplications per point).
 __device__ __forceinline__ fe_t fq_inv_ps(const fe_t &a) {

@@ -568,3 +568,32 @@ def test_permutation_grand_product_closes(zk):
     z, total = h2.prefix_product(d, want_total=True)
     assert (total == cref.fr_mont(1)).all()
     assert (z[0].cpu().numpy().view(np.uint64) == cref.fr_mont(1)).all()
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 4, 7])
+def test_pipelined_msm_chunks_do_not_change_the_result(zk, points, chunks):
+    """mi355_msm_set_pipeline: the point range cut into slices whose sort / accumulate / reduce stages overlap on three streams;
+    every slice count must give the oracle's point (plain bases and window tables, slices of a registered basis, ragged n)."""
+    import torch
+    h2 = zk.halo2
+    lib, check = zk._capi.lib(), zk._capi.check
+    params = h2.ParamsKZG.from_host(11, points, points[::-1].copy())
+    rng = np.random.default_rng(600 + chunks)
+    check(lib.mi355_msm_set_pipeline(chunks, 6))
+    try:
+        for pre in (False, True):
+            if pre:
+                params.precompute(c=7)
+            for off, n in ((0, 2048), (0, 1999), (37, 1500), (0, 64), (5, 63)):
+                sc = rand_fr(rng, n)
+                want = cref.g1_to_affine(cref.best_multiexp(sc, points[off:off + n]))
+                for _ in range(2):      # twice: slot reuse across calls
+                    got = affine_of(h2.best_multiexp(sc, params.g_slice(off, n)))
+                    assert (got == want).all(), (pre, off, n)
+                d = torch.from_numpy(sc.view(np.int64)).cuda()
+                assert (affine_of(h2.best_multiexp(d, params.g_slice(off, n))) == want).all()
+        zero = np.tile(cref.fr_mont(0), (2048, 1))
+        assert (h2.best_multiexp(zero, params.g_slice(0, 2048)) == 0).all()
+    finally:
+        check(lib.mi355_msm_set_pipeline(0, 0))
+    params.release()
