@@ -185,7 +185,7 @@ int msm_enqueue(const g1_affine_t *bases, const fe_t *const *polys_dev, uint32_t
   const bool big_t2 = S.fb <= 11 && g.sort_t2 == 32768;   // level-2 tile: 32768 entries (128 KiB of indices) unless the fine table is large
   S.t2 = big_t2 ? 32768 : g.sort_t2 == 8192 ? 8192 : 16384;
   if (S.fb > 12 || (1u << S.cb_bits) > SORT_MAX_BINS) return fail(MI355_EBADARG, "msm: window bits out of range for the sorter");
-  const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions;
+  const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions + 8;   // + 8: the XCD-aware tile order rounds the tile count up to a multiple of 8
   const uint32_t vwindows = M * P.windows;   // (polynomial, window) pairs
 
   uint32_t *enc, *hist, *offsets, *cursor, *sorted, *scan_sums, *coarse_hist, *coarse_off, *coarse_cursor, *tile_start; uint64_t *pairs;

@@ -228,8 +228,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_sort_tile_prefix(const uint32_t 
   if (threadIdx.x == 0) tile_start[S.regions] = running;
 }
 __device__ __forceinline__ bool sort_l2_tile(const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start, const SortPlan &S, uint32_t &region, uint32_t &s, uint32_t &e) {
-  const uint32_t tile = blockIdx.x;
-  if (tile >= tile_start[S.regions]) return false;
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so workgroup b = 8 q + x takes the q-th tile of XCD x's contiguous
+  // eighth of the tile list -- consecutive tiles (same coarse region, same few MB of `sorted`) then meet in ONE L2, which merges their
+  // short interleaved runs before they reach HBM
+  const uint32_t total = tile_start[S.regions], per_xcd = (total + 7) >> 3, q = blockIdx.x >> 3;
+  const uint32_t tile = (blockIdx.x & 7) * per_xcd + q;
+  if (q >= per_xcd || tile >= total) return false;
   uint32_t lo = 0, hi = S.regions;  // tile_start[lo] <= tile < tile_start[hi]
   while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tile_start[mid] <= tile) lo = mid; else hi = mid; }
   region = lo;
