@@ -150,7 +150,9 @@ def main() -> None:
         if world == 1:
             return local_msm()
         # RCCL over xGMI: one all_gather of 96 B per rank, then the fold on the device (scroll-prover_amd/distributed.py)
-        return zk.distributed.sharded_multiexp(local_msm, h2.g1_sum, "cpu" if share else dev)
+        if share:
+            return zk.distributed.sharded_multiexp(local_msm, h2.g1_sum, "cpu")
+        return zk.distributed.sharded_multiexp_device(zk._capi, handle.value, scalars, n)
 
     def barrier():
         if world > 1:

@@ -79,6 +79,10 @@ int mi355_srs_dev_ptr(uint64_t handle, void **dev_ptr_out);
  *      out_g1 receives 96 B (normalised Jacobian, see above) in host memory.                                  */
 int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *scalars_host, uint64_t n, void *out_g1_host);
 int mi355_msm_g1_dev(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_host);
+/* multi-GPU leg: the per-GPU partial sum stays in device memory (96 B at out_g1_dev, written in stream order, no host
+ * synchronisation) so that it can be handed to the RCCL all-gather directly; mi355_g1_sum_dev folds the gathered partials.        */
+int mi355_msm_g1_dev_async(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_dev);
+int mi355_g1_sum_dev(const void *points_jac_dev, uint64_t n, void *out_g1_host);
 /* `batch` commitments over the SAME basis slice in one pass (e.g. all advice columns of a phase: create_proof commits them one
  * after the other): scalars_dev is a host array of `batch` device pointers (n x 32 B each), out receives
  * batch x 96 B.  Results are identical to `batch` separate calls; the fixed per-call costs are paid once.                          */

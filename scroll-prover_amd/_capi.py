@@ -28,6 +28,8 @@ SIGNATURES = {
     "mi355_srs_dev_ptr": (_int, [_u64, C.POINTER(_vp)]),
     "mi355_msm_g1_host": (_int, [_u64, _u64, _vp, _u64, _vp]),
     "mi355_msm_g1_dev": (_int, [_u64, _u64, _vp, _u64, _vp]),
+    "mi355_msm_g1_dev_async": (_int, [_u64, _u64, _vp, _u64, _vp]),
+    "mi355_g1_sum_dev": (_int, [_vp, _u64, _vp]),
     "mi355_msm_g1_batch_dev": (_int, [_u64, _u64, C.POINTER(_vp), _u32, _u64, _vp]),
     "mi355_msm_g1_batch_host": (_int, [_u64, _u64, C.POINTER(_vp), _u32, _u64, _vp]),
     "mi355_msm_set_pipeline": (_int, [_u32, _u32]),

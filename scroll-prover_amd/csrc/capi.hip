@@ -135,7 +135,7 @@ int choose_c(uint64_t n) {
 
 struct PreTable { const g1_affine_t *table = nullptr; uint64_t row_stride = 0; int c = 0, w = 0; };   // table already offset to the slice start
 
-int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre);
+int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre, void *out_dev_user = nullptr);
 
 int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void *out_host, const PreTable *pre = nullptr) {
   return msm_batch_impl(bases, &scalars, 1, n, out_host, pre);
@@ -304,9 +304,13 @@ uint32_t msm_chunks_for(uint32_t M, uint64_t n) {
   return k;
 }
 
-int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre) {
+// out_dev_user (M = 1 only): the result stays in device memory and the call returns without waiting for the stream.
+int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre, void *out_dev_user) {
   if (M == 0) return MI355_OK;
-  if (n == 0) { memset(out_host, 0, (size_t)M * sizeof(g1_jac_t)); return MI355_OK; }
+  if (n == 0) {
+    if (out_dev_user) { HIPCHK(hipMemsetAsync(out_dev_user, 0, (size_t)M * sizeof(g1_jac_t), g.stream)); return MI355_OK; }
+    memset(out_host, 0, (size_t)M * sizeof(g1_jac_t)); return MI355_OK;
+  }
   if (n >= (1ull << 31)) return fail(MI355_EBADARG, "msm: n must be < 2^31");
   if (M > 1) {
     // a batch that would overflow the 32-bit entry index, the coarse histogram's LDS or a sensible workspace (16 B per entry) is
@@ -355,11 +359,16 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
   }
   HIPCHK(hipGetLastError());
   total.close();
+  g.msm_slot[0].used = g.msm_slot[1].used = false;
+  g.last_chunks = (int)K;
+  if (out_dev_user) {   // asynchronous: the caller's stream order protects the result
+    HIPCHK(hipMemcpyAsync(out_dev_user, out_dev, (size_t)M * sizeof(g1_jac_t), hipMemcpyDeviceToDevice, s));
+    if (g.profiling) resolve_spans();
+    return MI355_OK;
+  }
   HIPCHK(hipMemcpyAsync(out_host, out_dev, (size_t)M * sizeof(g1_jac_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  g.msm_slot[0].used = g.msm_slot[1].used = false;
   resolve_spans();
-  g.last_chunks = (int)K;
   return MI355_OK;
 }
 
@@ -699,6 +708,25 @@ int mi355_msm_g1_dev(uint64_t srs_handle, uint64_t base_offset, const void *scal
   if (!out_g1_host || (n && !scalars_dev)) return fail(MI355_EBADARG, "msm: null pointer");
   const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
   return msm_dev_impl(bases, (const fe_t *)scalars_dev, n, out_g1_host, &pre);
+}
+int mi355_msm_g1_dev_async(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_dev) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!out_g1_dev || (n && !scalars_dev)) return fail(MI355_EBADARG, "msm: null pointer");
+  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
+  const fe_t *sc = (const fe_t *)scalars_dev;
+  return msm_batch_impl(bases, &sc, 1, n, nullptr, &pre, out_g1_dev);
+}
+int mi355_g1_sum_dev(const void *pts_dev, uint64_t n, void *out_g1_host) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!out_g1_host || (n && !pts_dev) || n > (1u << 20)) return fail(MI355_EBADARG, "g1_sum: bad argument");
+  g1_jac_t *dev; CHK(ws_get("io.g1sum", sizeof(g1_jac_t), (void **)&dev));
+  hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(64), 0, g.stream, (const g1_jac_t *)pts_dev, (uint32_t)n, dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_g1_host, dev, sizeof(g1_jac_t), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return MI355_OK;
 }
 int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *scalars_host, uint64_t n, void *out_g1_host) {
   std::lock_guard<std::mutex> lk(g.mu);

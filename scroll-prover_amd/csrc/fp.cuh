@@ -132,6 +132,38 @@ template <class P> struct Fp {
     e[0] -= 2;  // low words of both moduli are >= 2
     return pow(a, e);
   }
+
+  // a^-1 by the binary extended Euclidean algorithm (Montgomery form in and out; 0 -> 0).  Data-dependent control flow: meant for the
+  // places where ONE lane normalises a result -- about 20 k simple instructions instead of the ladder's ~380 dependent multiplications
+  // (k_msm_final spent 0.4 ms of a 3 ms MSM in the ladder).  Invariants: u = x1 * a, v = x2 * a (mod m); gcd(a, m) = 1.
+  ZK_HD static void w_halve(uint32_t *w) { for (int i = 0; i < 7; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31); w[7] >>= 1; }
+  ZK_HD static void w_halve_mod(uint32_t *x) {   // x / 2 mod m; x + m < 2^255 never leaves the eight words
+    if (x[0] & 1u) { uint32_t c = 0; for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)x[i] + P::mod(i) + c; x[i] = (uint32_t)t; c = (uint32_t)(t >> 32); } }
+    w_halve(x);
+  }
+  ZK_HD static bool w_geq(const uint32_t *a, const uint32_t *b) { for (int i = 7; i >= 0; i--) if (a[i] != b[i]) return a[i] > b[i]; return true; }
+  ZK_HD static bool w_is_one(const uint32_t *w) { uint32_t o = w[0] ^ 1u; for (int i = 1; i < 8; i++) o |= w[i]; return o == 0; }
+  ZK_HD static void w_sub(uint32_t *a, const uint32_t *b) {   // a -= b, a >= b
+    uint32_t borrow = 0; for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)a[i] - b[i] - borrow; a[i] = (uint32_t)t; borrow = (uint32_t)(t >> 63); }
+  }
+  ZK_HD static void w_sub_mod(uint32_t *a, const uint32_t *b) {   // a = a - b mod m, both < m
+    uint32_t borrow = 0; for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)a[i] - b[i] - borrow; a[i] = (uint32_t)t; borrow = (uint32_t)(t >> 63); }
+    if (borrow) { uint32_t c = 0; for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)a[i] + P::mod(i) + c; a[i] = (uint32_t)t; c = (uint32_t)(t >> 32); } }
+  }
+  ZK_HD static fe_t inv_bgcd(const fe_t &a) {
+    if (is_zero(a)) return a;
+    uint32_t u[8], v[8], x1[8], x2[8];
+    for (int i = 0; i < 8; i++) { u[i] = a.l[i]; v[i] = P::mod(i); x1[i] = i == 0; x2[i] = 0; }
+    while (!w_is_one(u) && !w_is_one(v)) {
+      while (!(u[0] & 1u)) { w_halve(u); w_halve_mod(x1); }
+      while (!(v[0] & 1u)) { w_halve(v); w_halve_mod(x2); }
+      if (w_geq(u, v)) { w_sub(u, v); w_sub_mod(x1, x2); } else { w_sub(v, u); w_sub_mod(x2, x1); }
+    }
+    fe_t r, r2; const bool from_u = w_is_one(u);
+    for (int i = 0; i < 8; i++) { r.l[i] = from_u ? x1[i] : x2[i]; r2.l[i] = P::r2(i); }
+    // r = (a_plain R)^-1 as a plain residue; two Montgomery products with R^2 give a_plain^-1 * R
+    return mul(mul(r, r2), r2);
+  }
 };
 
 #if defined(__HIPCC__)

@@ -47,3 +47,26 @@ def allgather_partials(partial: np.ndarray, device=None) -> np.ndarray:
 def sharded_multiexp(local_msm: Callable[[], np.ndarray], fold: Callable[[np.ndarray], np.ndarray], device=None) -> np.ndarray:
     """local_msm() -> this rank's partial sum over its own shard; fold([world,12]) -> their sum.  Same result on every rank."""
     return fold(allgather_partials(local_msm(), device))
+
+
+def sharded_multiexp_device(capi, srs_handle: int, scalars_dev, n: int, base_offset: int = 0) -> np.ndarray:
+    """the production form of the exchange (backend "nccl" = RCCL): this rank's partial sum never leaves the GPU --
+    mi355_msm_g1_dev_async leaves 96 bytes in device memory in stream order, ONE all_gather_into_tensor moves world x 96 bytes over
+    xGMI, mi355_g1_sum_dev folds and normalises them on the device; the only host synchronisation is the final 96-byte read-back.
+    Call mi355_msm_set_normalise(0) first so that the per-rank Horner tail skips its inversion.  Same result on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    key = ("dev", world, str(scalars_dev.device))
+    if key not in _BUFFERS:
+        _BUFFERS[key] = (torch.empty(96, dtype=torch.uint8, device=scalars_dev.device), torch.empty(world * 96, dtype=torch.uint8, device=scalars_dev.device))
+    mine, out = _BUFFERS[key]
+    lib = capi.lib()
+    capi.check(lib.mi355_msm_g1_dev_async(srs_handle, base_offset, capi.ptr(scalars_dev), n, capi.ptr(mine)))
+    if world > 1:
+        dist.all_gather_into_tensor(out, mine)
+    else:
+        out = mine
+    result = np.zeros(12, dtype=np.uint64)
+    capi.check(lib.mi355_g1_sum_dev(capi.ptr(out), world, capi.ptr(result)))
+    return result

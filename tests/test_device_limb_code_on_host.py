@@ -54,6 +54,8 @@ def test_field_ops_bit_exact(hs):
             assert (op(hs, w, 6, a) == np.array(pyref.to_limbs(vals[i]), dtype=np.uint64)).all()
         for i in range(0, 40):
             assert (op(hs, w, 3, mont[i]) == cref.f_inv(w, mont[i])).all()
+        for i in range(len(vals)):                                        # binary-Euclid inverse used by the one-lane normalisations
+            assert (op(hs, w, 9, mont[i]) == cref.f_inv(w, mont[i])).all(), vals[i]
 
 
 def _pt(Pt):

@@ -597,3 +597,35 @@ def test_pipelined_msm_chunks_do_not_change_the_result(zk, points, chunks):
     finally:
         check(lib.mi355_msm_set_pipeline(0, 0))
     params.release()
+
+
+def test_device_resident_partial_and_fold(zk, points):
+    """mi355_msm_g1_dev_async + mi355_g1_sum_dev (the multi-GPU leg without host round trips): the partial stays in device memory in
+    stream order, un-normalised when asked; folding the partials of two point-range shards gives the oracle's MSM."""
+    import torch
+    h2 = zk.halo2
+    lib, check, ptr = zk._capi.lib(), zk._capi.check, zk._capi.ptr
+    n = 2048
+    params = h2.ParamsKZG.from_host(11, points, points)
+    rng = np.random.default_rng(515)
+    sc = rand_fr(rng, n)
+    d = torch.from_numpy(sc.view(np.int64)).cuda()
+    want = cref.g1_to_affine(cref.best_multiexp(sc, points))
+    parts = torch.zeros(3 * 96, dtype=torch.uint8, device="cuda")
+    check(lib.mi355_msm_set_normalise(0))
+    try:
+        cuts = (0, 700, 2048, 2048)         # third shard empty -> identity partial
+        for r in range(3):
+            lo, hi = cuts[r], cuts[r + 1]
+            check(lib.mi355_msm_g1_dev_async(params._g, lo, ptr(d[lo:hi]) if hi > lo else None, hi - lo, C.c_void_p(parts.data_ptr() + 96 * r)))
+    finally:
+        check(lib.mi355_msm_set_normalise(1))
+    out = np.zeros(12, dtype=np.uint64)
+    check(lib.mi355_g1_sum_dev(ptr(parts), 3, ptr(out)))
+    assert (affine_of(out) == want).all()
+    assert (parts[192:].cpu().numpy() == 0).all()
+    # the single-rank form of distributed.sharded_multiexp_device
+    got = zk.distributed.sharded_multiexp_device(zk._capi, params._g, d, n)
+    assert (affine_of(got) == want).all()
+    assert lib.mi355_msm_g1_dev_async(params._g, 0, ptr(d), n, None) == zk._capi.EBADARG
+    params.release()
