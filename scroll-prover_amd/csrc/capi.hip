@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -81,11 +82,24 @@ struct Ctx {
   uint32_t ntt_tile_log = 11;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
   bool ntt29 = true;   // unsaturated 29-bit NTT kernels (MI355_NTT_SAT=1 selects the saturated 8x32 ones for A/B runs)
   bool profiling = false;
+  bool trace = false;           // MI355_TRACE=1: one stderr line per MSM / NTT call (host wall time; device transforms are synchronised for it)
   std::map<std::string, Prof> prof;
   int last_c = 0, last_w = 0; uint64_t last_entries = 0;
 } g;
 
 int need_init() { return g.inited ? MI355_OK : fail(MI355_ENODEVICE, "mi355_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)"); }
+
+// MI355_TRACE: per-call counters for the integrator (metrics / logging)
+struct CallTrace {
+  const char *what; uint64_t n; double bytes_per_unit; std::chrono::steady_clock::time_point t0;
+  CallTrace(const char *w, uint64_t n_, double bpu) : what(w), n(n_), bytes_per_unit(bpu), t0(std::chrono::steady_clock::now()) {}
+  void done(const char *extra = "") {
+    if (!g.trace) return;
+    (void)hipStreamSynchronize(g.stream);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[mi355zk] %s n=%llu %.3f ms %.2f M units/s %.1f GB/s algorithmic%s\n", what, (unsigned long long)n, ms, n / ms / 1e3, n * bytes_per_unit / ms / 1e6, extra);
+  }
+};
 
 int ws_get(const char *role, size_t bytes, void **out) {
   Buf &b = g.ws[role];
@@ -329,6 +343,7 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
   }
   const uint32_t K = msm_chunks_for(M, n);
   g.last_entries = 0;
+  CallTrace tr("msm_g1", (uint64_t)M * n, 96.0);
   g1_jac_t *out_dev; const fe_t **polys_dev;
   CHK(ws_get("msm.out", (size_t)(K + 1) * M * sizeof(g1_jac_t), (void **)&out_dev));
   CHK(ws_get("msm.polys", (size_t)K * M * sizeof(void *), (void **)&polys_dev));
@@ -364,11 +379,13 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
   if (out_dev_user) {   // asynchronous: the caller's stream order protects the result
     HIPCHK(hipMemcpyAsync(out_dev_user, out_dev, (size_t)M * sizeof(g1_jac_t), hipMemcpyDeviceToDevice, s));
     if (g.profiling) resolve_spans();
+    tr.done(" (device result)");
     return MI355_OK;
   }
   HIPCHK(hipMemcpyAsync(out_host, out_dev, (size_t)M * sizeof(g1_jac_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   resolve_spans();
+  { char buf[64]; snprintf(buf, sizeof buf, " batch=%u c=%d W=%d", M, g.last_c, g.last_w); tr.done(buf); }
   return MI355_OK;
 }
 
@@ -449,6 +466,7 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     }
   }
   NttPlan *p; CHK(get_plan(log_n, omega, &p));
+  CallTrace tr("ntt_fr", N, 64.0);
   Scope total("ntt_total");
   if (p->levels == 1) {
     const uint32_t lm = p->log_m[0], tile = 1u << lm;
@@ -485,6 +503,8 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     else hipLaunchKernelGGL(k_ntt_final, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, dst, lm, log_a, log_b, lc, p->tw_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
   }
   HIPCHK(hipGetLastError());
+  total.close();
+  tr.done();
   return MI355_OK;
 }
 
@@ -575,6 +595,7 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_fr_prefix_product<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_fr_prefix_product<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  { const char *e = getenv("MI355_TRACE"); g.trace = e && e[0] == '1'; }
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 3; }

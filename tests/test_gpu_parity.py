@@ -629,3 +629,45 @@ def test_device_resident_partial_and_fold(zk, points):
     assert (affine_of(got) == want).all()
     assert lib.mi355_msm_g1_dev_async(params._g, 0, ptr(d), n, None) == zk._capi.EBADARG
     params.release()
+
+
+def test_results_are_deterministic_across_runs_and_schedules(zk, points):
+    """the reference's (disabled) test_deterministic / test_vk_same intent [REF integration/tests/integration.rs:51-174]: commitments are
+    canonical group elements, so repeated runs, other window widths and the batched / pipelined schedules give byte-identical output."""
+    import torch
+    h2 = zk.halo2
+    lib, check = zk._capi.lib(), zk._capi.check
+    params = h2.ParamsKZG.from_host(11, points, points[::-1].copy())
+    rng = np.random.default_rng(808)
+    sc = rand_fr(rng, 2048)
+    d = torch.from_numpy(sc.view(np.int64)).cuda()
+    ref = params.commit(d).copy()
+    outs = [params.commit(d).copy() for _ in range(3)] + [params.commit(sc).copy()]
+    for c in (7, 12):
+        check(lib.mi355_msm_set_window_bits(c)); outs.append(params.commit(d).copy()); check(lib.mi355_msm_set_window_bits(0))
+    params.precompute(c=9); outs.append(params.commit(d).copy())
+    outs.append(params.commit_many([d, d])[1].copy())
+    check(lib.mi355_msm_set_pipeline(3, 6)); outs.append(params.commit(d).copy()); check(lib.mi355_msm_set_pipeline(0, 0))
+    assert all((o == ref).all() for o in outs)
+    a = rand_fr(rng, 1 << 11)
+    dom = h2.EvaluationDomain(4, 11)
+    f1 = a.copy(); dom.coeff_to_lagrange(f1)
+    f2 = torch.from_numpy(a.view(np.int64).copy()).cuda(); dom.coeff_to_lagrange(f2); dom.coeff_to_lagrange(f2); dom.lagrange_to_coeff(f2); 
+    assert (f2.cpu().numpy().view(np.uint64).reshape(-1, 4) == f1).all()
+    params.release()
+
+
+def test_trace_env_prints_per_call_counters():
+    """MI355_TRACE=1: one stderr line per MSM / NTT call with n, ms and the algorithmic GB/s (metrics hook)."""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import __graft_entry__ as ge; zk = ge.load_package(); zk.init(0); h2 = zk.halo2\n"
+        "from oracle import cref\n"
+        "G = cref.g1_generator(); pts = np.tile(G, (64, 1)); sc = np.tile(cref.fr_mont(3), (64, 1))\n"
+        "h2.best_multiexp(sc, pts)\n"
+        "a = np.tile(cref.fr_mont(5), (256, 1)); h2.best_fft(a, h2.fr(pow(h2.FR_ROOT_OF_UNITY, 1 << 20, h2.R_MOD)), 8)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI355_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "[mi355zk] msm_g1 n=64" in r.stderr and "[mi355zk] ntt_fr n=256" in r.stderr, r.stderr[-2000:]
