@@ -56,15 +56,16 @@ def sharded_multiexp_device(capi, srs_handle: int, scalars_dev, n: int, base_off
     Call mi355_msm_set_normalise(0) first so that the per-rank Horner tail skips its inversion.  Same result on every rank."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    grouped = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if grouped else 1
     key = ("dev", world, str(scalars_dev.device))
     if key not in _BUFFERS:
         _BUFFERS[key] = (torch.empty(96, dtype=torch.uint8, device=scalars_dev.device), torch.empty(world * 96, dtype=torch.uint8, device=scalars_dev.device))
     mine, out = _BUFFERS[key]
     lib = capi.lib()
     capi.check(lib.mi355_msm_g1_dev_async(srs_handle, base_offset, capi.ptr(scalars_dev), n, capi.ptr(mine)))
-    if world > 1:
-        dist.all_gather_into_tensor(out, mine)
+    if grouped:
+        dist.all_gather_into_tensor(out, mine)     # also with one rank: the same RCCL call, so a 1-GPU box exercises the real path
     else:
         out = mine
     result = np.zeros(12, dtype=np.uint64)

@@ -671,3 +671,29 @@ def test_trace_env_prints_per_call_counters():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "[mi355zk] msm_g1 n=64" in r.stderr and "[mi355zk] ntt_fr n=256" in r.stderr, r.stderr[-2000:]
+
+
+def test_rccl_allgather_path_on_one_rank(points):
+    """distributed.sharded_multiexp_device through a real RCCL communicator (backend "nccl", world size 1 on this one-GPU box): the
+    partial is produced on the library stream, gathered by RCCL and folded on the device without host round trips."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    np.save("/tmp/_mi355_pts.npy", points[:512])
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge; from oracle import cref\n"
+        "torch.cuda.set_device(0); dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "zk = ge.load_package(); zk.init(0); h2 = zk.halo2; lib, check = zk._capi.lib(), zk._capi.check\n"
+        "check(lib.mi355_set_stream(torch.cuda.current_stream().cuda_stream))\n"
+        "pts = np.load('/tmp/_mi355_pts.npy'); params = h2.ParamsKZG.from_host(9, pts, pts)\n"
+        "rng = np.random.default_rng(3); sc = rng.integers(0, 2**64, size=(512, 4), dtype=np.uint64); sc[:, 3] &= np.uint64((1 << 60) - 1)\n"
+        "d = torch.from_numpy(sc.view(np.int64)).cuda()\n"
+        "check(lib.mi355_msm_set_normalise(0))\n"
+        "for _ in range(3): got = zk.distributed.sharded_multiexp_device(zk._capi, params._g, d, 512)\n"
+        "want = cref.g1_to_affine(cref.best_multiexp(sc, pts))\n"
+        "assert (got[:8] == want).all(), (got, want)\n"
+        "dist.barrier(); dist.destroy_process_group(); print('RCCL-OK')\n"
+    ) % root
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
