@@ -259,7 +259,7 @@ int msm_enqueue(const g1_affine_t *bases, const fe_t *const *polys_dev, uint32_t
       hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums, scan_blocks);
       hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, offsets, cursor, scan_n);
       {
-        const size_t lds2 = (size_t)(3 * (1u << S.fb) + 32) * 4 + (size_t)S.t2 * 4;
+        const size_t lds2 = (size_t)(3 * (1u << S.fb) + 32) * 4 + (size_t)S.t2 * 6;   // histogram / offsets / bases + staged indices (4 B) and their bins (2 B)
         if (S.t2 == 8192) hipLaunchKernelGGL(k_sort_l2_scatter<8>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
         else if (big_t2) hipLaunchKernelGGL(k_sort_l2_scatter<32>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
         else hipLaunchKernelGGL(k_sort_l2_scatter<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);

@@ -272,13 +272,14 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
   __syncthreads();
   const uint32_t total = tile_bin_offsets(h, lstart, gbase, FB, cursor + (region << S.fb), scratch32);
   __syncthreads();
+  // the bin of every staged entry travels in a 16-bit side array (fine < 4096): the write-out needs no search over lstart
+  uint16_t *stage_bin = reinterpret_cast<uint16_t *>(stage + 1024 * EPT);
 #pragma unroll
-  for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) stage[lstart[fine[k]] + rank[k]] = idx[k];
+  for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) { const uint32_t pos = lstart[fine[k]] + rank[k]; stage[pos] = idx[k]; stage_bin[pos] = (uint16_t)fine[k]; }
   __syncthreads();
   for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
-    uint32_t lo = 0, hi = FB;   // largest bin with lstart[bin] <= sidx
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lstart[mid] <= sidx) lo = mid; else hi = mid; }
-    sorted[gbase[lo] + (sidx - lstart[lo])] = stage[sidx];
+    const uint32_t b = stage_bin[sidx];
+    sorted[gbase[b] + (sidx - lstart[b])] = stage[sidx];
   }
 }
 
