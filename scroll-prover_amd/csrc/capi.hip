@@ -63,6 +63,7 @@ struct Ctx {
   hipStream_t aux_stream[2] = {nullptr, nullptr};   // side streams of the pipelined MSM (sort | reduction); the accumulation stays on `stream`
   hipEvent_t ev_fork = nullptr;
   MsmSlot msm_slot[2];
+  std::vector<const fe_t *> polys_stage;
   uint32_t msm_chunks = 1;       // MI355_MSM_CHUNKS / mi355_msm_set_pipeline (off by default: measured slower)
   uint32_t msm_chunk_min_log = 23;
   int last_chunks = 1;
@@ -161,7 +162,7 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
 // per-call fixed costs (launches, the latency-bound reduction tail) are paid once per batch.  out_dev: M x 96 B, device.
 struct MsmStreams { hipStream_t a, b, c; };
 
-int msm_enqueue(const g1_affine_t *bases, const fe_t *const *polys_dev, uint32_t M, uint64_t n, g1_jac_t *out_dev, const PreTable *pre, MsmSlot &slot,
+int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const *polys_dev, uint32_t M, uint64_t n, g1_jac_t *out_dev, const PreTable *pre, MsmSlot &slot,
                 const MsmStreams &st, bool normalise) {
   const bool piped = st.a != st.b;
   const std::string sfx = slot.id ? "#" + std::to_string(slot.id) : std::string();
@@ -240,7 +241,7 @@ int msm_enqueue(const g1_affine_t *bases, const fe_t *const *polys_dev, uint32_t
     {
       Scope sc("msm_digits", s);
       HIPCHK(hipMemsetAsync(coarse_hist, 0, ((size_t)S.regions + 1) * 4, s));
-      hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream / M > 0 ? grid_stream / M : 1, M), dim3(256), (size_t)S.regions * 4, s, polys_dev, enc, P, coarse_hist, S.fb, S.cb_bits, S.shared);
+      hipLaunchKernelGGL(k_msm_digits, dim3(grid_stream / M > 0 ? grid_stream / M : 1, M), dim3(256), (size_t)S.regions * 4, s, inl, polys_dev, enc, P, coarse_hist, S.fb, S.cb_bits, S.shared);
     }
     {
       Scope sc("msm_sort", s);
@@ -344,21 +345,25 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
   const uint32_t K = msm_chunks_for(M, n);
   g.last_entries = 0;
   CallTrace tr("msm_g1", (uint64_t)M * n, 96.0);
-  g1_jac_t *out_dev; const fe_t **polys_dev;
+  g1_jac_t *out_dev; const fe_t **polys_dev = nullptr;
   CHK(ws_get("msm.out", (size_t)(K + 1) * M * sizeof(g1_jac_t), (void **)&out_dev));
-  CHK(ws_get("msm.polys", (size_t)K * M * sizeof(void *), (void **)&polys_dev));
   hipStream_t s = g.stream;
   Scope total("msm_total", s);
+  PolyPtrs inl; for (int i = 0; i < 8; i++) inl.p[i] = nullptr;
   if (K == 1) {
-    HIPCHK(hipMemcpyAsync(polys_dev, polys_host, (size_t)M * sizeof(void *), hipMemcpyHostToDevice, s));
+    if (M <= 8) for (uint32_t m = 0; m < M; m++) inl.p[m] = polys_host[m];
+    else {
+      // the pointer array is staged through a buffer the library owns (the caller's array may be a temporary)
+      CHK(ws_get("msm.polys", (size_t)M * sizeof(void *), (void **)&polys_dev));
+      g.polys_stage.assign(polys_host, polys_host + M);
+      HIPCHK(hipMemcpyAsync(polys_dev, g.polys_stage.data(), (size_t)M * sizeof(void *), hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
     MsmStreams st{s, s, s};
-    CHK(msm_enqueue(bases, polys_dev, M, n, out_dev, pre, g.msm_slot[0], st, g.normalise));
+    CHK(msm_enqueue(bases, inl, polys_dev, M, n, out_dev, pre, g.msm_slot[0], st, g.normalise));
   } else {
-    std::vector<const fe_t *> ptrs((size_t)K * M);
     std::vector<uint64_t> lo(K + 1);
     for (uint32_t k = 0; k <= K; k++) lo[k] = n * k / K;
-    for (uint32_t k = 0; k < K; k++) for (uint32_t m = 0; m < M; m++) ptrs[(size_t)k * M + m] = polys_host[m] + lo[k];
-    HIPCHK(hipMemcpyAsync(polys_dev, ptrs.data(), ptrs.size() * sizeof(void *), hipMemcpyHostToDevice, s));
     // the side streams start after everything already queued on the caller's stream (the scalars may still be in flight there)
     HIPCHK(hipEventRecord(g.ev_fork, s));
     HIPCHK(hipStreamWaitEvent(g.aux_stream[0], g.ev_fork, 0)); HIPCHK(hipStreamWaitEvent(g.aux_stream[1], g.ev_fork, 0));
@@ -366,7 +371,8 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
     for (uint32_t k = 0; k < K; k++) {
       PreTable pk; const PreTable *pp = nullptr;
       if (pre) { pk = *pre; if (pk.table) pk.table += lo[k]; pp = &pk; }
-      CHK(msm_enqueue(bases + lo[k], polys_dev + (size_t)k * M, M, lo[k + 1] - lo[k], out_dev + (size_t)(k + 1) * M, pp, g.msm_slot[k & 1], st, false));
+      inl.p[0] = polys_host[0] + lo[k];   // pipelined MSMs are single-polynomial (msm_chunks_for)
+      CHK(msm_enqueue(bases + lo[k], inl, nullptr, M, lo[k + 1] - lo[k], out_dev + (size_t)(k + 1) * M, pp, g.msm_slot[k & 1], st, false));
     }
     HIPCHK(hipStreamWaitEvent(s, g.msm_slot[0].red_done, 0)); HIPCHK(hipStreamWaitEvent(s, g.msm_slot[1].red_done, 0));
     HIPCHK(hipEventRecord(g.ev_fork, st.a)); HIPCHK(hipStreamWaitEvent(s, g.ev_fork, 0));   // join the sort stream too

@@ -71,7 +71,10 @@ __device__ __forceinline__ void store_sat_as_xyzz29(g1_xyzz29_t *p, const g1_xyz
 }
 
 // ---- 1. digits.  Plane layout enc[w * n + i]: 0 for a zero digit, else |d| (1 .. 2^(c-1)) with bit 31 = sign.
-__global__ void __launch_bounds__(256) k_msm_digits(const fe_t *const *__restrict__ polys, uint32_t *__restrict__ enc, MsmPlan P,
+// up to 8 polynomial pointers travel as a kernel argument (copied at launch: no staging copy, nothing for an asynchronous caller to keep
+// alive); larger batches pass a device array
+struct PolyPtrs { const fe_t *p[8]; };
+__global__ void __launch_bounds__(256) k_msm_digits(PolyPtrs inl, const fe_t *const *__restrict__ polys, uint32_t *__restrict__ enc, MsmPlan P,
                                                      uint32_t *__restrict__ coarse_hist, uint32_t fb, uint32_t cb_bits, uint32_t shared) {
   // the level-1 (coarse) histogram of the sorter is taken here, while the digits are in registers: LDS counters per block,
   // one global atomic per non-empty bin at the end (dynamic LDS = regions * 4 bytes)
@@ -80,10 +83,11 @@ __global__ void __launch_bounds__(256) k_msm_digits(const fe_t *const *__restric
   for (uint32_t b = threadIdx.x; b < regions; b += blockDim.x) hist_lds[b] = 0;
   __syncthreads();
   const uint32_t stride = gridDim.x * blockDim.x, m = blockIdx.y;   // grid.y = batch
+  const fe_t *__restrict__ poly = polys ? polys[m] : inl.p[m];
   const uint32_t half = 1u << (P.c - 1), mask = (1u << P.c) - 1;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
     fe_t one_c = Fr::zero(); one_c.l[0] = 1;
-    const fe_t k = fr_mul_ps(g_load(&polys[m][i]), one_c);   // Montgomery -> canonical (= to_repr())
+    const fe_t k = fr_mul_ps(g_load(&poly[i]), one_c);   // Montgomery -> canonical (= to_repr())
     uint32_t carry = 0;
     for (uint32_t w = 0; w < P.windows; w++) {
       const uint32_t bit = w * P.c, word = bit >> 5, sh = bit & 31;
