@@ -88,12 +88,14 @@ __global__ void __launch_bounds__(256) k_msm_digits(PolyPtrs inl, const fe_t *co
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
     fe_t one_c = Fr::zero(); one_c.l[0] = 1;
     const fe_t k = fr_mul_ps(g_load(&poly[i]), one_c);   // Montgomery -> canonical (= to_repr())
+    // the scalar is consumed c bits at a time by shifting the whole 256-bit value right (8 funnel shifts per window, static
+    // register indices); indexing k.l[bit >> 5] with a runtime window position would put the limbs in scratch memory
+    uint32_t l0 = k.l[0], l1 = k.l[1], l2 = k.l[2], l3 = k.l[3], l4 = k.l[4], l5 = k.l[5], l6 = k.l[6], l7 = k.l[7];
     uint32_t carry = 0;
     for (uint32_t w = 0; w < P.windows; w++) {
-      const uint32_t bit = w * P.c, word = bit >> 5, sh = bit & 31;
-      uint32_t raw = 0;
-      if (word < 8) { raw = k.l[word] >> sh; if (sh + P.c > 32 && word + 1 < 8) raw |= k.l[word + 1] << (32 - sh); }
-      raw = (raw & mask) + carry;
+      const uint32_t raw = (l0 & mask) + carry;
+      l0 = __funnelshift_r(l0, l1, P.c); l1 = __funnelshift_r(l1, l2, P.c); l2 = __funnelshift_r(l2, l3, P.c); l3 = __funnelshift_r(l3, l4, P.c);
+      l4 = __funnelshift_r(l4, l5, P.c); l5 = __funnelshift_r(l5, l6, P.c); l6 = __funnelshift_r(l6, l7, P.c); l7 >>= P.c;
       uint32_t e;
       if (raw > half) { e = (1u << P.c) - raw; if (e) e |= 0x80000000u; carry = 1; } else { e = raw; carry = 0; }   // raw == 2^c: digit 0, carry 1
       enc[((uint64_t)m * P.windows + w) * P.n + i] = e;
@@ -165,14 +167,20 @@ constexpr uint32_t SORT_MAX_BINS = 4096;
 struct SortPlan { uint32_t n, windows /* batch * W */, wpp /* W */, nb, fb, cb_bits, t1, t2, regions, shared; };   // shared = 1: all windows feed ONE bucket set (precomputed 2^(cw) P tables)
 
 // Per-tile bin bookkeeping shared by both scatter kernels (1024 threads): lstart[] = exclusive scan of the tile histogram,
-// gbase[] = start of this tile's run inside each global bin (ONE returning global atomic per non-empty bin).
-__device__ __forceinline__ uint32_t tile_bin_offsets(const uint32_t *h, uint32_t *lstart, uint32_t *gbase, uint32_t nbins, uint32_t *global_cursor, uint32_t *scratch32) {
+// gb[] = start of this tile's run inside each global bin (ONE returning global atomic per non-empty bin).  The atomics' results stay in
+// registers: the caller stores them to LDS (tile_bin_publish) only after the staging pass, so their ~2 us round trip to the memory-side
+// atomic unit overlaps with the LDS work instead of stalling the whole workgroup at a barrier.
+__device__ __forceinline__ uint32_t tile_bin_offsets(const uint32_t *h, uint32_t *lstart, uint32_t (&gb)[4], uint32_t nbins, uint32_t *global_cursor, uint32_t *scratch32) {
   const uint32_t bpt = (nbins + 1023) >> 10, b0 = threadIdx.x * bpt;   // bpt <= 4
   uint32_t local[4], sum = 0;
   for (uint32_t k = 0; k < 4; k++) { local[k] = (k < bpt && b0 + k < nbins) ? h[b0 + k] : 0; sum += local[k]; }
   uint32_t total; uint32_t ex = block_exclusive_scan(sum, scratch32, total);
-  for (uint32_t k = 0; k < 4; k++) if (k < bpt && b0 + k < nbins) { lstart[b0 + k] = ex; gbase[b0 + k] = local[k] ? atomicAdd(&global_cursor[b0 + k], local[k]) : 0; ex += local[k]; }
+  for (uint32_t k = 0; k < 4; k++) { gb[k] = 0; if (k < bpt && b0 + k < nbins) { lstart[b0 + k] = ex; if (local[k]) gb[k] = atomicAdd(&global_cursor[b0 + k], local[k]); ex += local[k]; } }
   return total;
+}
+__device__ __forceinline__ void tile_bin_publish(uint32_t *gbase, const uint32_t (&gb)[4], uint32_t nbins) {
+  const uint32_t bpt = (nbins + 1023) >> 10, b0 = threadIdx.x * bpt;
+  for (uint32_t k = 0; k < 4; k++) if (k < bpt && b0 + k < nbins) gbase[b0 + k] = gb[k];
 }
 // Level-1 scatter, LDS-staged: the tile is counting-sorted inside LDS first so that the global stores are coalesced runs
 // (the direct version wrote 8-byte records at random: 3.4x write amplification measured with WRITE_SIZE).
@@ -198,7 +206,8 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(con
   __syncthreads();
   // w = m * W + w_in: polynomial m of the batch, window w_in.  shared buckets: one bucket set per polynomial, payload names row w_in of the table
   const uint32_t m_poly = w / S.wpp, w_in = w - m_poly * S.wpp;
-  const uint32_t total = tile_bin_offsets(h, lstart, gbase, CB, coarse_cursor + (S.shared ? m_poly * CB : w * CB), scratch32);
+  uint32_t gb[4];
+  const uint32_t total = tile_bin_offsets(h, lstart, gb, CB, coarse_cursor + (S.shared ? m_poly * CB : w * CB), scratch32);
   const uint32_t idx_base = S.shared ? w_in * S.n : 0;
   __syncthreads();
 #pragma unroll
@@ -206,6 +215,7 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(con
     const uint32_t bucket = (e[k] & 0x7fffffffu) - 1, i = i0 + k * 1024 + threadIdx.x;
     stage[lstart[bucket >> S.fb] + rank[k]] = ((uint64_t)bucket << 32) | (uint64_t)((idx_base + i) | (e[k] & 0x80000000u));
   }
+  tile_bin_publish(gbase, gb, CB);
   __syncthreads();
   for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
     const uint64_t pr = stage[sidx];
@@ -274,12 +284,14 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
     if (p < e) { const uint64_t pr = pairs[p]; idx[k] = (uint32_t)pr; fine[k] = (uint32_t)(pr >> 32); rank[k] = atomicAdd(&h[fine[k]], 1u); }
   }
   __syncthreads();
-  const uint32_t total = tile_bin_offsets(h, lstart, gbase, FB, cursor + (region << S.fb), scratch32);
+  uint32_t gb[4];
+  const uint32_t total = tile_bin_offsets(h, lstart, gb, FB, cursor + (region << S.fb), scratch32);
   __syncthreads();
   // the bin of every staged entry travels in a 16-bit side array (fine < 4096): the write-out needs no search over lstart
   uint16_t *stage_bin = reinterpret_cast<uint16_t *>(stage + 1024 * EPT);
 #pragma unroll
   for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) { const uint32_t pos = lstart[fine[k]] + rank[k]; stage[pos] = idx[k]; stage_bin[pos] = (uint16_t)fine[k]; }
+  tile_bin_publish(gbase, gb, FB);
   __syncthreads();
   for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
     const uint32_t b = stage_bin[sidx];
