@@ -201,8 +201,12 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(con
   for (int k = 0; k < EPT; k++) {
     const uint32_t i = i0 + k * 1024 + threadIdx.x;
     e[k] = i < i1 ? plane[i] : 0;
-    if (e[k]) rank[k] = atomicAdd(&h[((e[k] & 0x7fffffffu) - 1) >> S.fb], 1u);
   }
+  // all EPT loads are in flight before the first returning LDS atomic: in one fused loop the compiler keeps program order
+  // (load k, wait, atomic k, load k + 1, ...) and the tile pays EPT memory round trips -- measured 15 us against 5.9 us per tile
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < EPT; k++) if (e[k]) rank[k] = atomicAdd(&h[((e[k] & 0x7fffffffu) - 1) >> S.fb], 1u);
   __syncthreads();
   // w = m * W + w_in: polynomial m of the batch, window w_in.  shared buckets: one bucket set per polynomial, payload names row w_in of the table
   const uint32_t m_poly = w / S.wpp, w_in = w - m_poly * S.wpp;
@@ -281,8 +285,11 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
   for (int k = 0; k < EPT; k++) {
     const uint32_t p = s + k * 1024 + threadIdx.x;
     fine[k] = 0xffffffffu;
-    if (p < e) { const uint64_t pr = pairs[p]; idx[k] = (uint32_t)pr; fine[k] = (uint32_t)(pr >> 32); rank[k] = atomicAdd(&h[fine[k]], 1u); }
+    if (p < e) { const uint64_t pr = pairs[p]; idx[k] = (uint32_t)pr; fine[k] = (uint32_t)(pr >> 32); }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // as in the level-1 kernel: every load in flight before the first returning LDS atomic
+#pragma unroll
+  for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) rank[k] = atomicAdd(&h[fine[k]], 1u);
   __syncthreads();
   uint32_t gb[4];
   const uint32_t total = tile_bin_offsets(h, lstart, gb, FB, cursor + (region << S.fb), scratch32);
