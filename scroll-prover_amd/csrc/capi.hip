@@ -73,7 +73,7 @@ struct Ctx {
   std::map<std::string, NttPlan> ntt_plans;  // key = log_n | omega bytes
   g1_affine_t *fixed_base_table = nullptr;
   int force_c = 0;
-  uint32_t sort_t2 = 8192;      // MI355_SORT_T2 = 8192 | 16384 | 32768
+  uint32_t sort_t2 = 0;         // MI355_SORT_T2 = 8192 | 16384 (0: by size)
   uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
   bool normalise = true;        // mi355_msm_set_normalise(0): MSM results come back as an un-normalised Jacobian representative
   uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): bit 0 nontemporal gathers, bit 1 prefetched bucket ends -- neither measurably helps
@@ -197,8 +197,9 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   S.regions = red_windows << S.cb_bits;
   if ((size_t)S.regions * 4 > 48 * 1024) return fail(MI355_EBADARG, "msm: batch too large for the coarse histogram (split the batch)");
   S.t1 = g.sort_t1;                           // level-1 tile: 1024 threads x 8 or 16 entries (64 / 128 KiB of LDS staging)
-  const bool big_t2 = S.fb <= 11 && g.sort_t2 == 32768;   // level-2 tile: 32768 entries (128 KiB of indices) unless the fine table is large
-  S.t2 = big_t2 ? 32768 : g.sort_t2 == 8192 ? 8192 : 16384;
+  // level-2 tile (6 B of LDS per entry next to the 3 x 2^fb words of bin bookkeeping): 16384 entries give twice the run length in
+  // `sorted` (fewer partial-line store transactions, the limiter of this kernel) at one workgroup per CU; worth it for big sorts
+  S.t2 = g.sort_t2 ? g.sort_t2 : (emax >= (1ull << 27) && S.fb <= 11 ? 16384 : 8192);
   if (S.fb > 12 || (1u << S.cb_bits) > SORT_MAX_BINS) return fail(MI355_EBADARG, "msm: window bits out of range for the sorter");
   const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions + 8;   // + 8: the XCD-aware tile order rounds the tile count up to a multiple of 8
   const uint32_t vwindows = M * P.windows;   // (polynomial, window) pairs
@@ -262,7 +263,6 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
       {
         const size_t lds2 = (size_t)(3 * (1u << S.fb) + 32) * 4 + (size_t)S.t2 * 6;   // histogram / offsets / bases + staged indices (4 B) and their bins (2 B)
         if (S.t2 == 8192) hipLaunchKernelGGL(k_sort_l2_scatter<8>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
-        else if (big_t2) hipLaunchKernelGGL(k_sort_l2_scatter<32>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
         else hipLaunchKernelGGL(k_sort_l2_scatter<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
       }
     }
@@ -590,7 +590,6 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -606,7 +605,7 @@ int mi355_init(int device_id) {
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 3; }
   { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
-  { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384 || v == 32768) g.sort_t2 = (uint32_t)v; } }
+  { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
   { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
