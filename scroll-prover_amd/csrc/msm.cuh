@@ -333,13 +333,22 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
     const uint32_t w = gi / n;
     return &bases[(uint64_t)w * row_stride + (gi - w * n)];
   };
-  auto gather = [&](uint32_t e) -> g1_affine_t { return (VARIANT & 1) ? load_affine_nt(base_of(e)) : load_affine(base_of(e)); };
-  // software pipeline: the gather of entry pos+1 (index, then 64-byte base) is issued before the ~10 field multiplications of entry pos
+  auto gather = [&](uint32_t e) -> g1_affine_t { return load_affine(base_of(e)); };
+  // software pipeline: the gather of entry pos+1 (index, then 64-byte base) is issued before the ~10 field multiplications of entry pos.
+  // VARIANT & 1 (A/B knob): the index stream runs one entry further ahead than the bases, so that the gather address is already in a
+  // register when the iteration starts.
   uint32_t ent = sorted[start];
+  uint32_t ent_next = start + 1 < end ? sorted[start + 1] : 0;
   g1_affine_t p = gather(ent);
   for (uint32_t pos = start; pos < end; pos++) {
-    uint32_t ent_next = 0; g1_affine_t p_next = p;
-    if (pos + 1 < end) { ent_next = sorted[pos + 1]; p_next = gather(ent_next); }
+    g1_affine_t p_next = p;
+    uint32_t ent_next2 = 0;
+    if (VARIANT & 1) {
+      if (pos + 1 < end) p_next = gather(ent_next);
+      if (pos + 2 < end) ent_next2 = sorted[pos + 2];
+    } else {
+      if (pos + 1 < end) { ent_next = sorted[pos + 1]; p_next = gather(ent_next); }
+    }
     if (pos >= b_end) {
       // leave bucket b: it ends inside this thread's range
       if (b_start >= start) store_xyzz29(&bucket_sums[b], acc);                           // began here too: sole owner
@@ -354,7 +363,7 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
       }
     }
     g1_xyzz29_madd(acc, p, (ent >> 31) != 0);
-    ent = ent_next; p = p_next;
+    ent = ent_next; if (VARIANT & 1) ent_next = ent_next2; p = p_next;
   }
   // bucket b is still open at `end`
   if (b_start >= start && b_end <= end) store_xyzz29(&bucket_sums[b], acc);
