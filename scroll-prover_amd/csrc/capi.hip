@@ -78,6 +78,7 @@ struct Ctx {
   bool normalise = true;        // mi355_msm_set_normalise(0): MSM results come back as an un-normalised Jacobian representative
   uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): bit 0 nontemporal gathers, bit 1 prefetched bucket ends -- neither measurably helps
   uint32_t seg_factor = 16;
+  uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
   uint32_t ntt_radix_log = 2;   // MI355_NTT_RADIX_LOG
   uint32_t ntt_tile_log = 11;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
@@ -185,9 +186,9 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   const uint32_t acc_threads = ceil_div(emax, seg), acc_blocks = ceil_div(acc_threads, 256);
   const uint32_t tn = acc_blocks * 256;
   // running-sum chunk per reduce thread: every thread is one serial chain of 2*chunk additions plus a ~(c-1)-bit scalar multiple, so the
-  // chain is kept short (the kernel is latency-bound) as long as there are enough buckets to give the GPU ~256k chains
+  // chain is kept short (the kernel is latency-bound) as long as there are enough buckets to give the GPU ~128k chains (measured at 2^21 buckets: 2.58 ms with 256k chains of 8 buckets, 2.11 ms with 128k of 16, 2.63 ms with 64k of 32)
   uint32_t chunk = 64; while (chunk > P.nb) chunk >>= 1;
-  while (chunk > 8 && (uint64_t)(P.nb / chunk) * red_windows < 262144) chunk >>= 1;
+  while (chunk > 8 && (uint64_t)(P.nb / chunk) * red_windows < g.reduce_chains) chunk >>= 1;
   const uint32_t chunks_per_window = P.nb / chunk, nchunks = chunks_per_window * red_windows;
 
   // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest (<= 9)
@@ -604,6 +605,7 @@ int mi355_init(int device_id) {
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 3; }
+  { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
   { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
