@@ -78,6 +78,7 @@ struct Ctx {
   bool normalise = true;        // mi355_msm_set_normalise(0): MSM results come back as an un-normalised Jacobian representative
   uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): bit 0 nontemporal gathers, bit 1 prefetched bucket ends -- neither measurably helps
   uint32_t seg_factor = 16;
+  uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
   uint32_t ntt_radix_log = 2;   // MI355_NTT_RADIX_LOG
@@ -193,7 +194,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
 
   // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest (<= 9)
   SortPlan S; S.n = P.n; S.windows = M * P.windows; S.wpp = P.windows; S.nb = P.nb;
-  { uint32_t kb = P.c - 1; uint32_t fb = kb < 11 ? kb : 11; if (kb - fb > 10) fb = kb - 10; S.fb = fb; S.cb_bits = kb - fb; }
+  { uint32_t kb = P.c - 1; uint32_t fb = kb < g.sort_fb ? kb : g.sort_fb; if (kb - fb > 11) fb = kb - 11; S.fb = fb; S.cb_bits = kb - fb; }
   S.shared = shared ? 1 : 0;
   S.regions = red_windows << S.cb_bits;
   if ((size_t)S.regions * 4 > 48 * 1024) return fail(MI355_EBADARG, "msm: batch too large for the coarse histogram (split the batch)");
@@ -606,6 +607,7 @@ int mi355_init(int device_id) {
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 3; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
+  { const char *e = getenv("MI355_SORT_FB"); if (e) { int v = atoi(e); if (v >= 9 && v <= 12) g.sort_fb = (uint32_t)v; } }
   { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
