@@ -85,6 +85,39 @@ inline Fr eval_polynomial(const std::vector<Fr> &poly, const Fr &point) {
   return out;
 }
 
+// ------------------------------------------------------------------------------------------------ halo2curves G1Affine::to_bytes / from_bytes
+// The 32-byte compressed form written to transcripts, proofs and .vkey files [EXT-recalled halo2curves derive/curve.rs; pinned by the
+// fixture KAT A4, SURVEY 8a-0]: little-endian canonical x, bit 254 (0x40 of byte 31) = parity of canonical y, identity = all zero.
+// Host arithmetic (a few field operations per point): proofs carry a dozen points, nothing here is a hot path.
+using G1Bytes = std::array<uint8_t, 32>;
+inline G1Bytes g1_to_bytes(const G1Affine &p) {
+  G1Bytes out{};
+  bool ident = true; for (auto w : p) ident = ident && w == 0;
+  if (ident) return out;
+  zk::fe_t x, y; std::memcpy(&x, p.data(), 32); std::memcpy(&y, p.data() + 4, 32);
+  const zk::fe_t xc = zk::Fq::to_canonical(x), yc = zk::Fq::to_canonical(y);
+  std::memcpy(out.data(), &xc, 32);
+  out[31] |= (uint8_t)((yc.l[0] & 1u) << 6);
+  return out;
+}
+// returns false for encodings that are not a curve point (x >= p, or x^3 + 3 a non-residue), as from_bytes' CtOption does
+inline bool g1_from_bytes(const G1Bytes &b, G1Affine &out) {
+  G1Bytes t = b; const unsigned sign = (t[31] >> 6) & 1u; t[31] &= 0x3f;
+  zk::fe_t xc; std::memcpy(&xc, t.data(), 32);
+  if (zk::Fq::is_zero(xc)) { out.fill(0); return sign == 0; }
+  for (int i = 7; i >= 0; i--) { const uint32_t m = zk::FqP::mod(i); if (xc.l[i] != m) { if (xc.l[i] > m) return false; break; } if (i == 0) return false; }
+  const zk::fe_t x = zk::Fq::from_canonical(xc);
+  zk::fe_t three = zk::Fq::zero(); three.l[0] = 3; three = zk::Fq::from_canonical(three);
+  const zk::fe_t y2 = zk::Fq::add(zk::Fq::mul(zk::Fq::sqr(x), x), three);
+  uint32_t e[8]; { uint64_t c = 1; for (int i = 0; i < 8; i++) { c += zk::FqP::mod(i); e[i] = (uint32_t)c; c >>= 32; } }   // p + 1
+  for (int i = 0; i < 8; i++) e[i] = (e[i] >> 2) | (i < 7 ? e[i + 1] << 30 : 0);                                          // (p + 1) / 4: p = 3 mod 4
+  zk::fe_t y = zk::Fq::pow(y2, e);
+  if (!zk::Fq::eq(zk::Fq::sqr(y), y2)) return false;
+  if ((zk::Fq::to_canonical(y).l[0] & 1u) != sign) y = zk::Fq::neg(y);
+  std::memcpy(out.data(), &x, 32); std::memcpy(out.data() + 4, &y, 32);
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ poly/domain.rs
 class EvaluationDomain {
  public:

@@ -19,6 +19,8 @@ void orc_best_fft(void *a, const void *omega, uint32_t log_n, int threads);
 void orc_ifft(void *a, const void *omega_inv, uint32_t log_n, const void *divisor, int threads);
 void orc_g_to_lagrange(void *out, const void *g, uint32_t k, const void *omega_inv, const void *n_inv);
 void orc_best_fft_g1(void *a, const void *omega, uint32_t log_n);
+void orc_g1_compress(uint8_t out[32], const void *p);
+int orc_g1_decompress(void *o, const uint8_t in[32]);
 void orc_eval_polynomial(void *out, const void *poly, uint64_t n, const void *point);
 void orc_coeff_to_extended(void *dst, const void *coeffs, uint32_t k, uint32_t ext_k, const void *g, const void *gi, const void *ew, int threads);
 }
@@ -39,6 +41,28 @@ int main(int argc, char **argv) {
   EXPECT(EvaluationDomain(5, 26).extended_k == 28); EXPECT(EvaluationDomain(4, 10).extended_k == 12); EXPECT(EvaluationDomain(3, 10).extended_k == 11);
   bool threw = false; try { EvaluationDomain bad(9, 26); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
   threw = false; try { best_multiexp(std::vector<Fr>(3), std::vector<G1Affine>(4)); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
+  // --- compressed G1 codec against the oracle (itself pinned by the .vkey fixtures): encode, decode, rejects
+  {
+    std::mt19937_64 rc(7); G1Affine Gc; orc_g1_generator(Gc.data());
+    std::vector<G1Affine> bases(64);
+    for (auto &pt : bases) { Fr sk = rand_fr(rc); G1 j; orc_g1_mul(j.data(), Gc.data(), sk.data()); orc_g1_to_affine(pt.data(), j.data()); }
+    for (uint64_t i = 0; i < 64; i++) {
+      G1Bytes want; orc_g1_compress(want.data(), bases[i].data());
+      const G1Bytes got = g1_to_bytes(bases[i]);
+      EXPECT(got == want);
+      G1Affine back; EXPECT(g1_from_bytes(got, back) && back == bases[i]);
+      G1Bytes flipped = got; flipped[31] ^= 0x40;                              // the other root: -P
+      G1Affine neg, wneg; EXPECT(g1_from_bytes(flipped, neg)); EXPECT(orc_g1_decompress(wneg.data(), flipped.data()) == 1 && neg == wneg);
+      EXPECT(neg[0] == bases[i][0] && neg != bases[i]);
+    }
+    G1Affine id{}; EXPECT(g1_to_bytes(id) == G1Bytes{});
+    G1Affine out; EXPECT(g1_from_bytes(G1Bytes{}, out) && out == id);
+    G1Bytes bad{}; for (auto &b : bad) b = 0xff; bad[31] = 0x3f;               // x >= p
+    EXPECT(!g1_from_bytes(bad, out));
+    int rejected = 0;                                                          // about half of all x are not on the curve
+    for (uint8_t v = 1; v < 40; v++) { G1Bytes t{}; t[0] = v; G1Affine o1, o2; const bool a = g1_from_bytes(t, o1); const int b = orc_g1_decompress(o2.data(), t.data()); EXPECT(a == (b == 1)); if (a) EXPECT(o1 == o2); else rejected++; }
+    EXPECT(rejected > 5);
+  }
   if (host_only) {
     // without a GPU every compute entry point must fail loudly (no CPU fallback)
     threw = false; try { init(0); } catch (const Error &e) { threw = e.code == MI355_ENODEVICE; } 
