@@ -344,6 +344,23 @@ def test_error_paths_do_not_crash(zk, points):
     assert lib.mi355_srs_precompute(424242, 0, 0) == capi.EBADARG
     # n == 0: identity / no-op, as best_multiexp on empty slices
     assert lib.mi355_msm_g1_adhoc_host(capi.ptr(points[:1]), capi.ptr(sc), 0, capi.ptr(out)) == capi.OK and (out == 0).all()
+    # entry points added later in the round: same contract (bad argument -> EBADARG, never a crash)
+    h = C.c_uint64()
+    assert lib.mi355_srs_downsize(424242, 3, capi.ptr(sc[0]), capi.ptr(sc[1]), C.byref(h)) == capi.EBADARG
+    assert lib.mi355_srs_read_host(424242, 0, 1, capi.ptr(out)) == capi.EBADARG
+    assert lib.mi355_g1_fft_host(capi.ptr(out), 29, capi.ptr(sc[0])) == capi.EBADARG
+    assert lib.mi355_g1_fft_host(None, 2, capi.ptr(sc[0])) == capi.EBADARG
+    assert lib.mi355_g_to_lagrange_dev(None, None, 2, capi.ptr(sc[0]), capi.ptr(sc[1])) == capi.EBADARG
+    assert lib.mi355_fr_batch_invert_dev(None, 5) == capi.EBADARG and lib.mi355_fr_batch_invert_dev(None, 0) == capi.OK
+    assert lib.mi355_fr_prefix_product_dev(None, None, 5, None) == capi.EBADARG
+    assert lib.mi355_msm_set_pipeline(99, 0) == capi.EBADARG
+    assert lib.mi355_msm_g1_batch_host(424242, 0, None, 0, 8, capi.ptr(out)) == capi.EBADARG
+    assert lib.mi355_g1_sum_dev(None, 3, capi.ptr(out)) == capi.EBADARG
+    h2 = zk.halo2
+    small = h2.ParamsKZG.from_host(3, points[:8], points[:8])
+    assert lib.mi355_srs_downsize(small._g, 4, capi.ptr(sc[0]), capi.ptr(sc[1]), C.byref(h)) == capi.EBADARG   # 2^k exceeds the basis
+    assert lib.mi355_srs_read_host(small._g, 4, 5, capi.ptr(np.zeros((5, 8), dtype=np.uint64))) == capi.EBADARG
+    small.release()
     # a working call still works afterwards
     got = affine_of(zk.halo2.best_multiexp(sc, points[:8]))
     assert (got == cref.g1_to_affine(cref.best_multiexp(sc, points[:8]))).all()
