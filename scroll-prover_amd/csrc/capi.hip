@@ -133,6 +133,7 @@ void resolve_spans() {
 
 // ------------------------------------------------------------------------------------------------ MSM
 uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+uint32_t log2_ceil(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }
 
 // measured on MI355X, in units of one bucket addition (~0.077 ns at 13 G adds/s): sort ~0.18 per entry, bucket reduction ~8.2 per bucket
 // (the reduction kernels are latency-bound serial chains, far from the ALU rate)
@@ -172,7 +173,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
 #define WS(name, bytes, ptr) CHK(ws_get(role(name).c_str(), bytes, (void **)&ptr))
   MsmPlan P; P.n = (uint32_t)n; P.batch = M; P.c = (uint32_t)choose_c(n);
   // precomputed rows 2^(c w) P available and cheaper than the per-window schedule at this n -> all windows share one bucket set
-  const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)P.c, false) && n * (uint64_t)pre->w < (1ull << 31);
+  const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)P.c, false) && ((uint64_t)pre->w << log2_ceil(n)) < (1ull << 31);
   if (shared) { P.c = (uint32_t)pre->c; bases = pre->table; }
   P.windows = (255 + P.c - 1) / P.c; P.nb = 1u << (P.c - 1);
   const uint64_t emax = (uint64_t)M * n * P.windows;
@@ -195,7 +196,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest (<= 9)
   SortPlan S; S.n = P.n; S.windows = M * P.windows; S.wpp = P.windows; S.nb = P.nb;
   { uint32_t kb = P.c - 1; uint32_t fb = kb < g.sort_fb ? kb : g.sort_fb; if (kb - fb > 11) fb = kb - 11; S.fb = fb; S.cb_bits = kb - fb; }
-  S.shared = shared ? 1 : 0;
+  S.shared = shared ? 1 : 0; S.nshift = log2_ceil(n);
   S.regions = red_windows << S.cb_bits;
   if ((size_t)S.regions * 4 > 48 * 1024) return fail(MI355_EBADARG, "msm: batch too large for the coarse histogram (split the batch)");
   S.t1 = g.sort_t1;                           // level-1 tile: 1024 threads x 8 or 16 entries (64 / 128 KiB of LDS staging)
@@ -277,7 +278,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
     {
       Scope sc("msm_accumulate", s);
       HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
-#define ACC_LAUNCH(V) hipLaunchKernelGGL(k_msm_accumulate<V>, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, P.n, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask)
+#define ACC_LAUNCH(V) hipLaunchKernelGGL(k_msm_accumulate<V>, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, S.nshift, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask)
       switch (g.acc_variant) { case 0: ACC_LAUNCH(0); break; case 1: ACC_LAUNCH(1); break; case 2: ACC_LAUNCH(2); break; default: ACC_LAUNCH(3); break; }
 #undef ACC_LAUNCH
     }
@@ -333,7 +334,7 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
     // a batch that would overflow the 32-bit entry index, the coarse histogram's LDS or a sensible workspace (16 B per entry) is
     // processed as two half batches
     uint32_t c = (uint32_t)choose_c(n);
-    const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)c, false) && n * (uint64_t)pre->w < (1ull << 31);
+    const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)c, false) && ((uint64_t)pre->w << log2_ceil(n)) < (1ull << 31);
     if (shared) c = (uint32_t)pre->c;
     const uint32_t W = (255 + c - 1) / c, kb = c - 1, cbits = kb <= 11 ? 0 : (kb - 11 > 10 ? 10 : kb - 11);
     const uint64_t emax = (uint64_t)M * n * W, regions = (uint64_t)M * (shared ? 1 : W) << cbits, bk = (uint64_t)M * (shared ? 1 : W) << kb;

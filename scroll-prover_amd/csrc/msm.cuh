@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const uint32_t *__res
 //   level 2: tiles inside each coarse region, bin = fine key (2^fb bins)             -> exact bucket offsets + sorted[]
 // Order inside a bucket is arbitrary (group addition commutes), so nothing needs to be stable.
 constexpr uint32_t SORT_MAX_BINS = 4096;
-struct SortPlan { uint32_t n, windows /* batch * W */, wpp /* W */, nb, fb, cb_bits, t1, t2, regions, shared; };   // shared = 1: all windows feed ONE bucket set (precomputed 2^(cw) P tables)
+struct SortPlan { uint32_t n, windows /* batch * W */, wpp /* W */, nb, fb, cb_bits, t1, t2, regions, shared, nshift /* ceil(log2 n): table row of an entry = payload >> nshift */; };   // shared = 1: all windows feed ONE bucket set (precomputed 2^(cw) P tables)
 
 // Per-tile bin bookkeeping shared by both scatter kernels (1024 threads): lstart[] = exclusive scan of the tile histogram,
 // gb[] = start of this tile's run inside each global bin (ONE returning global atomic per non-empty bin).  The atomics' results stay in
@@ -212,7 +212,7 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(con
   const uint32_t m_poly = w / S.wpp, w_in = w - m_poly * S.wpp;
   uint32_t gb[4];
   const uint32_t total = tile_bin_offsets(h, lstart, gb, CB, coarse_cursor + (S.shared ? m_poly * CB : w * CB), scratch32);
-  const uint32_t idx_base = S.shared ? w_in * S.n : 0;
+  const uint32_t idx_base = S.shared ? w_in << S.nshift : 0;   // (row, point) packed by shift: the accumulation unpacks with a shift and a mask
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < EPT; k++) if (e[k]) {
@@ -311,7 +311,7 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
 // bucket_sums must be zero-filled (all-zero XYZZ = identity) before launch.
 template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
                                                         uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg,
-                                                        uint32_t n, uint64_t row_stride, uint32_t gather_mask) {
+                                                        uint32_t nshift, uint64_t row_stride, uint32_t gather_mask) {
   const uint32_t total = offsets[nbuckets];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t start64 = (uint64_t)t * seg;
@@ -326,12 +326,12 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
   // the accumulator lives in the 9 x 29-bit unsaturated field (g1_29.cuh): one v_mad_u64_u32 per limb product, no carry chain;
   // it is flushed as a raw 144-byte record
   g1_xyzz29_t acc = g1_xyzz29_identity();
-  // row_stride != 0: entry index = w * n + i names row w of the precomputed table T[w][.] = 2^(c w) P (rows row_stride points apart)
+  // row_stride != 0: entry payload (w << nshift) | i names row w of the precomputed table T[w][.] = 2^(c w) P (rows row_stride points apart)
   auto base_of = [&](uint32_t e) -> const g1_affine_t * {
     const uint32_t gi = e & gather_mask;   // gather_mask = 0x7fffffff (index bits); smaller only in timing experiments
     if (row_stride == 0) return &bases[gi];
-    const uint32_t w = gi / n;
-    return &bases[(uint64_t)w * row_stride + (gi - w * n)];
+    const uint32_t w = gi >> nshift;       // entry payload = (table row << nshift) | point
+    return &bases[(uint64_t)w * row_stride + (gi & ((1u << nshift) - 1))];
   };
   auto gather = [&](uint32_t e) -> g1_affine_t { return load_affine(base_of(e)); };
   // software pipeline: the gather of entry pos+1 (index, then 64-byte base) is issued before the ~10 field multiplications of entry pos.
