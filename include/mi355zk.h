@@ -62,6 +62,12 @@ int mi355_synchronize(void);
  *      A handle is one basis (n affine points) resident in HBM.                                               */
 int mi355_srs_register_host(const void *bases_affine_host, uint64_t n, uint64_t *handle_out);
 int mi355_srs_register_dev(const void *bases_affine_dev, uint64_t n, int copy, uint64_t *handle_out);
+/* Prover::load_params for one degree [REF bin/src/trace_prover.rs:35-36; prover/src/utils.rs EXT-recalled]: a RawBytes params{k} file
+ * (u32 LE k | g[2^k] x 64 B | g_lagrange[2^k] x 64 B | g2 128 B | s_g2 128 B; any other length is rejected, as load_params does)
+ * streamed straight into device memory through two pinned staging buffers and registered as two library-owned bases.
+ * flags bit 0: validate every point on the device (identity, or reduced coordinates on y^2 = x^3 + 3 -- the check SerdeFormat::RawBytes
+ * makes on the CPU and RawBytesUnchecked skips).  g2_out / s_g2_out (optional, 128 B each) receive the two G2 points untouched.     */
+int mi355_srs_load_params_file(const char *path, uint32_t flags, uint32_t *k_out, uint64_t *g_handle_out, uint64_t *g_lagrange_handle_out, void *g2_out, void *s_g2_out);
 int mi355_srs_release(uint64_t handle);
 /* Optional, once per basis: build T[w][i] = 2^(c w) * P_i (w < W = ceil(255 / c), affine, W * n * 64 B of HBM) so that all
  * windows of an MSM on this basis share ONE bucket set: no per-window Horner (255 serial doublings), W x fewer bucket

@@ -18,6 +18,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -176,6 +177,16 @@ class ParamsKZG {
     check(mi355_srs_register_host(g_lagrange.data(), n, &gl_));
     if (window_tables) { check(mi355_srs_precompute(g_, 0, 0)); check(mi355_srs_precompute(gl_, 0, 0)); }
   }
+  // Prover::load_params for one degree: the RawBytes file is streamed into HBM by the library (exact-length rule; validate = check every
+  // point on the device); g2 / s_g2 are kept as the raw 128-byte encodings
+  static std::unique_ptr<ParamsKZG> read(const std::string &path, bool validate = false) {
+    uint32_t kk = 0; uint64_t hg = 0, hl = 0; std::array<uint8_t, 128> g2{}, sg2{};
+    check(mi355_srs_load_params_file(path.c_str(), validate ? 1u : 0u, &kk, &hg, &hl, g2.data(), sg2.data()));
+    std::unique_ptr<ParamsKZG> p(new ParamsKZG(kk, hg, hl));
+    p->g2 = g2; p->s_g2 = sg2;
+    return p;
+  }
+  std::array<uint8_t, 128> g2{}, s_g2{};
   ParamsKZG(const ParamsKZG &) = delete;
   ParamsKZG &operator=(const ParamsKZG &) = delete;
   ~ParamsKZG() { if (g_) mi355_srs_release(g_); if (gl_) mi355_srs_release(gl_); }
@@ -221,6 +232,7 @@ class ParamsKZG {
   }
 
  private:
+  ParamsKZG(uint32_t k_, uint64_t hg, uint64_t hl) : k(k_), n(uint64_t(1) << k_), g_(hg), gl_(hl) {}
   uint64_t g_ = 0, gl_ = 0;
 };
 

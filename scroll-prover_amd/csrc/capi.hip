@@ -666,6 +666,67 @@ int mi355_srs_register_host(const void *bases, uint64_t n, uint64_t *handle_out)
   if (e != hipSuccess) { hipFree(s.dev); return fail(MI355_EHIP, std::string("srs upload: ") + hipGetErrorString(e)); }
   *handle_out = g.next_handle++; g.srs[*handle_out] = s; return MI355_OK;
 }
+// Prover::load_params for one degree: stream a RawBytes params file into device memory (two pinned staging buffers: the read of chunk
+// i + 1 overlaps the DMA of chunk i), optionally validate every point on the device, register both bases as library-owned handles.
+static int stream_file_to_device(FILE *f, void *dev, size_t bytes, void *pinned[2], hipEvent_t ev[2], size_t chunk) {
+  size_t done = 0; int which = 0;
+  while (done < bytes) {
+    const size_t len = std::min(chunk, bytes - done);
+    HIPCHK(hipEventSynchronize(ev[which]));                       // the previous copy out of this staging buffer has finished
+    if (fread(pinned[which], 1, len, f) != len) return fail(MI355_EBADARG, "srs_load_params_file: short read");
+    HIPCHK(hipMemcpyAsync((char *)dev + done, pinned[which], len, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipEventRecord(ev[which], g.stream));
+    done += len; which ^= 1;
+  }
+  return MI355_OK;
+}
+int mi355_srs_load_params_file(const char *path, uint32_t flags, uint32_t *k_out, uint64_t *g_handle_out, uint64_t *g_lagrange_handle_out, void *g2_out, void *s_g2_out) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!path || !k_out || !g_handle_out || !g_lagrange_handle_out) return fail(MI355_EBADARG, "srs_load_params_file: null pointer");
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(MI355_EBADARG, std::string("srs_load_params_file: cannot open ") + path);
+  uint8_t hdr[4];
+  int rc = MI355_OK; Srs sg, sl; void *pinned[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; uint32_t *bad = nullptr;
+  do {
+    if (fread(hdr, 1, 4, f) != 4) { rc = fail(MI355_EBADARG, "srs_load_params_file: empty file"); break; }
+    const uint32_t k = (uint32_t)hdr[0] | ((uint32_t)hdr[1] << 8) | ((uint32_t)hdr[2] << 16) | ((uint32_t)hdr[3] << 24);
+    if (k == 0 || k > 28) { rc = fail(MI355_EBADARG, "srs_load_params_file: k out of range (not a RawBytes params file)"); break; }
+    const uint64_t n = 1ull << k, want = 4 + 2 * n * sizeof(g1_affine_t) + 256;
+    if (fseek(f, 0, SEEK_END) != 0 || (uint64_t)ftell(f) != want) { rc = fail(MI355_EBADARG, "srs_load_params_file: file length does not match 4 + 2 * 2^k * 64 + 256 (load_params rejects it too)"); break; }
+    fseek(f, 4, SEEK_SET);
+    const size_t chunk = std::min<uint64_t>(64ull << 20, n * sizeof(g1_affine_t));
+    sg.n = sl.n = n; sg.owned = sl.owned = true;
+    if (hipMalloc((void **)&sg.dev, n * sizeof(g1_affine_t)) != hipSuccess || hipMalloc((void **)&sl.dev, n * sizeof(g1_affine_t)) != hipSuccess) { (void)hipGetLastError(); rc = fail(MI355_EOOM, "srs_load_params_file: device allocation failed"); break; }
+    bool okp = true;
+    for (int i = 0; i < 2; i++) okp = okp && hipHostMalloc(&pinned[i], chunk, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess && hipEventRecord(ev[i], g.stream) == hipSuccess;
+    if (!okp) { rc = fail(MI355_EOOM, "srs_load_params_file: pinned staging allocation failed"); break; }
+    if ((rc = stream_file_to_device(f, sg.dev, n * sizeof(g1_affine_t), pinned, ev, chunk)) != MI355_OK) break;
+    if ((rc = stream_file_to_device(f, sl.dev, n * sizeof(g1_affine_t), pinned, ev, chunk)) != MI355_OK) break;
+    uint8_t tail[256];
+    if (fread(tail, 1, 256, f) != 256) { rc = fail(MI355_EBADARG, "srs_load_params_file: short read (g2 / s_g2)"); break; }
+    if (g2_out) memcpy(g2_out, tail, 128);
+    if (s_g2_out) memcpy(s_g2_out, tail + 128, 128);
+    if (flags & 1u) {
+      if (ws_get("io.validate", 4, (void **)&bad) != MI355_OK) { rc = MI355_EHIP; break; }
+      (void)hipMemsetAsync(bad, 0, 4, g.stream);
+      hipLaunchKernelGGL(k_g1_validate, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, sg.dev, n, bad);
+      hipLaunchKernelGGL(k_g1_validate, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, sl.dev, n, bad);
+      uint32_t nbad = 0;
+      if (hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) { rc = fail(MI355_EHIP, "srs_load_params_file: validation failed to run"); break; }
+      if (nbad) { rc = fail(MI355_EBADARG, "srs_load_params_file: " + std::to_string(nbad) + " point(s) are not on the curve"); break; }
+    }
+    if (hipStreamSynchronize(g.stream) != hipSuccess) { rc = fail(MI355_EHIP, "srs_load_params_file: copy failed"); break; }
+    *k_out = k;
+    *g_handle_out = g.next_handle++; g.srs[*g_handle_out] = sg;
+    *g_lagrange_handle_out = g.next_handle++; g.srs[*g_lagrange_handle_out] = sl;
+  } while (false);
+  fclose(f);
+  if (rc != MI355_OK) (void)hipStreamSynchronize(g.stream);
+  for (int i = 0; i < 2; i++) { if (ev[i]) hipEventDestroy(ev[i]); if (pinned[i]) (void)hipHostFree(pinned[i]); }
+  if (rc != MI355_OK) { if (sg.dev) (void)hipFree(sg.dev); if (sl.dev) (void)hipFree(sl.dev); }
+  return rc;
+}
 int mi355_srs_register_dev(const void *bases_dev, uint64_t n, int copy, uint64_t *handle_out) {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());

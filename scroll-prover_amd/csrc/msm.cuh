@@ -485,6 +485,28 @@ __global__ void k_g1_sum_strided(const g1_jac_t *__restrict__ pts, uint32_t coun
   out[blockIdx.x] = r;
 }
 
+// every point is the identity (0, 0) or satisfies y^2 = x^3 + 3 with both coordinates reduced: what SerdeFormat::RawBytes checks point by
+// point on the CPU while reading a params file [EXT-recalled halo2curves]; here one streaming pass over the basis in HBM
+__global__ void __launch_bounds__(256) k_g1_validate(const g1_affine_t *__restrict__ pts, uint64_t n, uint32_t *__restrict__ bad) {
+  uint32_t local = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const g1_affine_t p = load_affine(&pts[i]);
+    if (g1_affine_is_identity(p)) continue;
+    bool ok = true;
+    for (int c = 0; c < 2 && ok; c++) {   // coordinate < p (canonical Montgomery residue)
+      const fe_t &v = c ? p.y : p.x; bool lt = false;
+      for (int k = 7; k >= 0; k--) { if (v.l[k] != FqP::mod(k)) { lt = v.l[k] < FqP::mod(k); break; } }
+      ok = lt;
+    }
+    if (ok) {
+      fe_t three = Fq::zero(); three.l[0] = 3; three = Fq::from_canonical(three);
+      ok = Fq::eq(fq_sqr_ps(p.y), Fq::add(fq_mul_ps(fq_sqr_ps(p.x), p.x), three));
+    }
+    if (!ok) local++;
+  }
+  if (local) atomicAdd(bad, local);
+}
+
 // ---- window precomputation for a registered basis: T[w][i] = 2^(c w) * P_i, affine, w < W (row 0 = the basis itself).
 // One thread per point: c doublings, one inversion per row.  One-off cost at registration (about 6.4 k field multiplications per point).
 __device__ __forceinline__ fe_t fq_inv_ps(const fe_t &a) {

@@ -390,11 +390,17 @@ def read_params(path: str):
     return k, g, gl, tail[:128], tail[128:]
 
 
-def params_from_file(path: str) -> "ParamsKZG":
-    """Prover::load_params [REF bin/src/trace_prover.rs:35-36] for one degree: parse the file and register both bases in HBM."""
-    k, g, gl, g2, s_g2 = read_params(path)
-    p = ParamsKZG.from_host(k, np.ascontiguousarray(g), np.ascontiguousarray(gl))
-    p.g2, p.s_g2 = g2, s_g2
+def params_from_file(path: str, validate: bool = False, downsize_to: int = 0) -> "ParamsKZG":
+    """Prover::load_params(dir, degree) [REF bin/src/trace_prover.rs:35-36] for one degree: the file is streamed into HBM by the library
+    (mi355_srs_load_params_file: pinned double-buffered reads, exact-length rule, optional on-device point validation) and both bases
+    are registered; downsize_to < k reproduces load_params on a larger file (g truncated, g_lagrange rebuilt on the device)."""
+    k, hg, hl = C.c_uint32(), C.c_uint64(), C.c_uint64()
+    g2 = (C.c_uint8 * 128)(); s_g2 = (C.c_uint8 * 128)()
+    check(lib().mi355_srs_load_params_file(path.encode(), 1 if validate else 0, C.byref(k), C.byref(hg), C.byref(hl), g2, s_g2))
+    p = ParamsKZG(k.value, hg.value, hl.value)
+    p.g2, p.s_g2 = bytes(g2), bytes(s_g2)
+    if downsize_to and downsize_to < p.k:
+        p.downsize(downsize_to)
     return p
 
 

@@ -141,6 +141,24 @@ int main(int argc, char **argv) {
     EXPECT(std::memcmp(c.data(), wca.data(), 64) == 0);
     threw = false; try { params.downsize(k5 + 1); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
   }
+  // --- ParamsKZG::read: a RawBytes params file written here, streamed into HBM by the library
+  {
+    const uint32_t k6 = 6; const uint64_t n6 = 64;
+    const char *path = "/tmp/mi355_cpp_params6";
+    FILE *f = std::fopen(path, "wb");
+    const uint8_t hdr[4] = {6, 0, 0, 0}; std::vector<uint8_t> tail(256); for (size_t i = 0; i < 256; i++) tail[i] = (uint8_t)i;
+    std::fwrite(hdr, 1, 4, f); std::fwrite(bases.data(), 64, n6, f); std::fwrite(bases.data() + n6, 64, n6, f); std::fwrite(tail.data(), 1, 256, f); std::fclose(f);
+    auto p6 = ParamsKZG::read(path, /*validate=*/true);
+    EXPECT(p6->k == k6 && p6->n == n6 && p6->g2[5] == 5 && p6->s_g2[0] == 128);
+    std::vector<G1Affine> g6 = p6->get_g(), gl6 = p6->get_g_lagrange();
+    EXPECT(std::equal(g6.begin(), g6.end(), bases.begin()) && std::equal(gl6.begin(), gl6.end(), bases.begin() + n6));
+    std::vector<Fr> s6(sc.begin(), sc.begin() + n6);
+    G1 c6 = p6->commit(s6), w6; orc_best_multiexp(w6.data(), s6.data(), bases.data(), n6, 1); G1Affine w6a; orc_g1_to_affine(w6a.data(), w6.data());
+    EXPECT(std::memcmp(c6.data(), w6a.data(), 64) == 0);
+    f = std::fopen(path, "ab"); std::fputc(0, f); std::fclose(f);                       // one byte too long: rejected like load_params
+    threw = false; try { ParamsKZG::read(path); } catch (const Error &e) { threw = e.code == MI355_EBADARG; } EXPECT(threw);
+    std::remove(path);
+  }
   std::printf(failures ? "FAILED (%d)\n" : "all checks passed\n", failures);
   return failures ? 1 : 0;
 }

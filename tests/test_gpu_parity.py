@@ -714,3 +714,54 @@ def test_rccl_allgather_path_on_one_rank(points):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_params_file_loader_streams_into_device_memory(zk, points, tmp_path):
+    """mi355_srs_load_params_file (Prover::load_params for one degree): exact-length rule, points land in HBM unchanged, G2 tail
+    returned, optional on-device validation (what SerdeFormat::RawBytes checks and RawBytesUnchecked skips), downsize on load."""
+    h2 = zk.halo2
+    lib, capi = zk._capi.lib(), zk._capi
+    k, n = 9, 512
+    g, gl = points[:n].copy(), points[n:2 * n].copy()
+    g[17] = 0                                                        # an identity point is legal
+    g2, s_g2 = bytes(range(128)), bytes(range(128, 256))
+    path = str(tmp_path / "params9")
+    h2.write_params(path, k, g, gl, g2, s_g2)
+    for validate in (False, True):
+        p = h2.params_from_file(path, validate=validate)
+        assert (p.k, p.n) == (k, n) and p.g2 == g2 and p.s_g2 == s_g2
+        assert (p.read_g() == g).all() and (p.read_g(lagrange=True) == gl).all()
+        sc = rand_fr(np.random.default_rng(12), n)
+        assert (affine_of(p.commit(sc)) == cref.g1_to_affine(cref.best_multiexp(sc, g))).all()
+        p.release()
+    # a point off the curve / a coordinate that is not reduced: accepted unchecked (as RawBytesUnchecked), rejected with validation
+    for what in ("off_curve", "unreduced"):
+        bad = gl.copy()
+        if what == "off_curve":
+            bad[100, 4] ^= np.uint64(1)
+        else:
+            bad[100, :4] = np.array(pyref.to_limbs(pyref.P_MOD), dtype=np.uint64)   # x = p
+        h2.write_params(path, k, g, bad, g2, s_g2)
+        p = h2.params_from_file(path); p.release()
+        with pytest.raises(capi.Mi355Error):
+            h2.params_from_file(path, validate=True)
+        assert b"not on the curve" in lib.mi355_last_error()
+    # the exact-length rule of load_params, and files that are not there
+    h2.write_params(path, k, g, gl, g2, s_g2)
+    with open(path, "ab") as f:
+        f.write(b"\x00")
+    with pytest.raises(capi.Mi355Error):
+        h2.params_from_file(path)
+    with open(path, "wb") as f:
+        f.write((9).to_bytes(4, "little") + bytes(1000))
+    with pytest.raises(capi.Mi355Error):
+        h2.params_from_file(path)
+    with pytest.raises(capi.Mi355Error):
+        h2.params_from_file(str(tmp_path / "missing"))
+    # load + downsize in one go equals a fresh setup of the smaller degree (synthetic SRS with known tau)
+    big = h2.ParamsKZG.setup(11, 77)
+    h2.write_params(path, 11, big.read_g(), big.read_g(lagrange=True))
+    small = h2.params_from_file(path, validate=True, downsize_to=9)
+    ref = h2.ParamsKZG.setup(9, 77)
+    assert small.k == 9 and (small.read_g() == ref.read_g()).all() and (small.read_g(lagrange=True) == ref.read_g(lagrange=True)).all()
+    big.release(); small.release(); ref.release()
