@@ -140,6 +140,9 @@ int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n
  * data[i] *= table[i mod period] (period a power of two <= 4096; EvaluationDomain::divide_by_vanishing_poly multiplies the extended
  * evaluations by the inverted t_evaluations, whose period is 2^(extended_k - k)).  The pointwise glue of SURVEY 8f-1.            */
 int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_dev, uint64_t n);
+/* dst = a + scalar * b (a_dev == NULL: dst = scalar * b; dst may alias a or b): the running linear combination sum_i v^i p_i(X) of the
+ * multi-open argument and every other "poly * scalar" of create_proof [EXT-recalled halo2_proofs poly: Polynomial * F, + ].       */
+int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, const void *scalar, uint64_t n);
 int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_host, uint32_t period);
 /* the multiplicative scans of the permutation / lookup arguments [EXT-recalled halo2_proofs src/plonk/permutation/prover.rs,
  * src/plonk/lookup/prover.rs]: data[i] = data[i]^-1 with zeros left zero (ff::BatchInvert), and the grand product

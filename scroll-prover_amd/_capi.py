@@ -47,6 +47,7 @@ SIGNATURES = {
     "mi355_extended_to_coeff_dev": (_int, [_vp, _u32, _vp, _vp, _vp, _vp]),
     "mi355_distribute_powers_fr_dev": (_int, [_vp, _u64, _vp]),
     "mi355_coset_ntt_fr_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
+    "mi355_fr_vec_axpy_dev": (_int, [_vp, _vp, _vp, _vp, _u64]),
     "mi355_fr_vec_op_dev": (_int, [_int, _vp, _vp, _vp, _u64]),
     "mi355_fr_vec_mul_periodic_dev": (_int, [_vp, _u64, _vp, _u32]),
     "mi355_g1_fft_dev": (_int, [_vp, _u32, _vp]),

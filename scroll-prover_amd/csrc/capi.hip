@@ -1063,6 +1063,16 @@ int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_
   HIPCHK(hipGetLastError());
   return MI355_OK;
 }
+int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, const void *scalar, uint64_t n) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!scalar || (n && (!dst_dev || !b_dev))) return fail(MI355_EBADARG, "fr_vec_axpy: null pointer");
+  if (n == 0) return MI355_OK;
+  fe_t s; memcpy(&s, scalar, 32);
+  hipLaunchKernelGGL(k_fr_vec_axpy, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, (fe_t *)dst_dev, (const fe_t *)a_dev, (const fe_t *)b_dev, s, n);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
 int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n) {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());

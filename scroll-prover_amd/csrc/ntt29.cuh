@@ -249,6 +249,14 @@ __global__ void __launch_bounds__(256) k_fr_vec_op(int op, fe_t *__restrict__ ds
     g_store(&dst[i], r);
   }
 }
+// dst = a + s * b (s a scalar): the linear combinations sum_i v^i p_i(X) of the multi-open argument, one polynomial at a time
+__global__ void __launch_bounds__(256) k_fr_vec_axpy(fe_t *__restrict__ dst, const fe_t *__restrict__ a, const fe_t *__restrict__ b, fe_t s_sat, uint64_t n) {
+  const fe29_t s = Fr29::from_sat(s_sat);   // s * 2^261: the product with b * 2^256 lands back in the ABI domain
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const fe_t sb = fr29_finish(Fr29::mul(Fr29::from_sat_plain(g_load(&b[i])), s));
+    g_store(&dst[i], a ? Fr::add(g_load(&a[i]), sb) : sb);
+  }
+}
 __global__ void __launch_bounds__(256) k_fr_vec_mul_periodic(fe_t *__restrict__ data, uint64_t n, const fe_t *__restrict__ table, uint32_t period_mask) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     g_store(&data[i], fr29_finish(Fr29::mul(Fr29::from_sat_plain(g_load(&data[i])), Fr29::from_sat(g_load(&table[i & period_mask])))));

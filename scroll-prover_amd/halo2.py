@@ -109,6 +109,13 @@ def fr_vec_op(op: str, dst, a, b):
     return dst
 
 
+def fr_vec_axpy(dst, a, b, scalar: np.ndarray):
+    """dst = a + scalar * b on device-resident Fr vectors (a = None: dst = scalar * b)."""
+    n = b.numel() * b.element_size() // 32
+    check(lib().mi355_fr_vec_axpy_dev(ptr(dst), ptr(a) if a is not None else None, ptr(b), ptr(scalar), n))
+    return dst
+
+
 def batch_invert(a):
     """ff::BatchInvert on a device-resident Fr vector, in place: a[i] = a[i]^-1, zeros stay zero."""
     check(lib().mi355_fr_batch_invert_dev(ptr(a), a.numel() * a.element_size() // 32))

@@ -765,3 +765,25 @@ def test_params_file_loader_streams_into_device_memory(zk, points, tmp_path):
     ref = h2.ParamsKZG.setup(9, 77)
     assert small.k == 9 and (small.read_g() == ref.read_g()).all() and (small.read_g(lagrange=True) == ref.read_g(lagrange=True)).all()
     big.release(); small.release(); ref.release()
+
+
+@pytest.mark.parametrize("n", [1, 255, 4097, 100003])
+def test_fr_vec_axpy_matches_big_int_arithmetic(zk, n):
+    """dst = a + s * b (and dst = s * b), in place too: the linear-combination step of the multi-open argument."""
+    import torch
+    h2 = zk.halo2
+    rng = np.random.default_rng(4400 + n)
+    a, b = rand_fr(rng, n), rand_fr(rng, n)
+    s_int = int(rng.integers(1, 2**62)) * 0x1000000000000001 % R
+    da, db = torch.from_numpy(a.view(np.int64).copy()).cuda(), torch.from_numpy(b.view(np.int64).copy()).cuda()
+    out = torch.empty_like(da)
+    h2.fr_vec_axpy(out, da, db, h2.fr(s_int))
+    ai = [cref.limbs_to_int(x) for x in cref.f_to_canonical_vec(cref.FR, a)]
+    bi = [cref.limbs_to_int(x) for x in cref.f_to_canonical_vec(cref.FR, b)]
+    want = cref.f_from_canonical_vec(cref.FR, np.array([pyref.to_limbs((x + s_int * y) % R) for x, y in zip(ai, bi)], dtype=np.uint64))
+    assert (out.cpu().numpy().view(np.uint64).reshape(n, 4) == want).all()
+    h2.fr_vec_axpy(da, da, db, h2.fr(s_int))                      # dst aliases a
+    assert torch.equal(da, out)
+    h2.fr_vec_axpy(db, None, db, h2.fr(R - 1))                    # dst = -b, in place
+    neg = cref.f_from_canonical_vec(cref.FR, np.array([pyref.to_limbs((R - y) % R) for y in bi], dtype=np.uint64))
+    assert (db.cpu().numpy().view(np.uint64).reshape(n, 4) == neg).all()
