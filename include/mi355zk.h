@@ -149,6 +149,10 @@ int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_
  * dst[0] = 1, dst[i] = prod_{j<i} src[j] (dst may alias src; total_out_host, optional, receives prod_{j<n} src[j] and makes the
  * call synchronous).  Asynchronous on the library stream otherwise.                                                               */
 int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n);
+/* kate_division(poly, z) = (poly(X) - poly(z)) / (X - z) [EXT-recalled halo2_proofs src/arithmetic.rs], the quotient polynomials of the
+ * multi-open argument: n coefficients in, n - 1 out (q_i = a_(i+1) + z q_(i+1), a parallel scan).  dst must not overlap poly, except
+ * dst == poly + 1 element (the quotient then replaces coefficients 1 .. n-1 in place).                                             */
+int mi355_fr_kate_division_dev(void *dst_dev, const void *poly_dev, uint64_t n, const void *z);
 int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host);
 
 /* ---- halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i  (the evaluations written to the

@@ -384,6 +384,12 @@ void orc_batch_invert(fe *a, uint64_t n) {
   for (uint64_t i = n; i-- > 0;) { if (fe_is_zero(&a[i])) continue; fe t; fe_mul(&t, &acc, &a[i], &FR); fe_mul(&a[i], &acc, &scratch[i], &FR); acc = t; }
   free(scratch);
 }
+/* halo2_proofs::arithmetic::kate_division(a, b) [EXT-recalled src/arithmetic.rs]: quotient of a(X) by (X - b), remainder dropped:
+ * from the top coefficient down, q_(i-1) = a_i + b * q_i.  q has n - 1 coefficients. */
+void orc_kate_division(fe *q, const fe *a, uint64_t n, const fe *b) {
+  fe tmp = {{0, 0, 0, 0}};
+  for (uint64_t i = n - 1; i >= 1; i--) { fe lead; fe_add(&lead, &a[i], &tmp, &FR); q[i - 1] = lead; fe_mul(&tmp, &lead, b, &FR); }
+}
 /* the grand-product column: z[0] = 1, z[i + 1] = z[i] * v[i] [EXT-recalled halo2_proofs src/plonk/permutation/prover.rs]; returns z[n] in *total */
 void orc_prefix_product(fe *z, const fe *v, uint64_t n, fe *total) {
   fe acc = FR.r;

@@ -178,6 +178,13 @@ def g_to_lagrange(g_affine, k: int, omega_inv, n_inv):
     lib().orc_g_to_lagrange(_p(out), _p(g), C.c_uint32(k), _p(np.ascontiguousarray(omega_inv)), _p(np.ascontiguousarray(n_inv))); return out
 
 
+def kate_division(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64); q = np.zeros((max(a.shape[0] - 1, 0), 4), dtype=np.uint64)
+    if a.shape[0] > 1:
+        lib().orc_kate_division(_p(q), _p(a), C.c_uint64(a.shape[0]), _p(np.ascontiguousarray(b)))
+    return q
+
+
 def batch_invert(a):
     a = np.array(a, dtype=np.uint64, copy=True, order="C"); lib().orc_batch_invert(_p(a), C.c_uint64(a.shape[0])); return a
 

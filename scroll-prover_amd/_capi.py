@@ -56,6 +56,7 @@ SIGNATURES = {
     "mi355_srs_load_params_file": (_int, [C.c_char_p, _u32, C.POINTER(_u32), C.POINTER(_u64), C.POINTER(_u64), _vp, _vp]),
     "mi355_srs_downsize": (_int, [_u64, _u32, _vp, _vp, C.POINTER(_u64)]),
     "mi355_srs_read_host": (_int, [_u64, _u64, _u64, _vp]),
+    "mi355_fr_kate_division_dev": (_int, [_vp, _vp, _u64, _vp]),
     "mi355_fr_batch_invert_dev": (_int, [_vp, _u64]),
     "mi355_fr_prefix_product_dev": (_int, [_vp, _vp, _u64, _vp]),
     "mi355_eval_polynomial_dev": (_int, [_vp, _u64, _vp, _vp]),

@@ -552,6 +552,20 @@ int batch_invert_impl(fe_t *data, uint64_t n, int level) {
   return MI355_OK;
 }
 
+// P_j = src_j + m * P_(j-1) over n elements (dst may alias src); reverse: index j lives at memory position n - 1 - j
+int linrec_impl(const fe_t *src, fe_t *dst, uint64_t n, const fe_t &m, bool reverse, int level) {
+  const uint32_t tiles = (uint32_t)ceil_div(n, FRSCAN_TILE);
+  const size_t lds = (size_t)(FRSCAN_THREADS * 65 + 2 * FRSCAN_THREADS * 9) * 4;
+  hipStream_t s = g.stream;
+  if (tiles <= 1) { hipLaunchKernelGGL(k_fr_linrec<1>, dim3(1), dim3(FRSCAN_THREADS), lds, s, src, dst, n, m, reverse ? 1 : 0, (fe_t *)nullptr); return MI355_OK; }
+  fe_t *tile_tot; const std::string role = "frscan.linrec" + std::to_string(level);
+  CHK(ws_get(role.c_str(), (size_t)tiles * sizeof(fe_t), (void **)&tile_tot));
+  hipLaunchKernelGGL(k_fr_linrec<0>, dim3(tiles), dim3(FRSCAN_THREADS), lds, s, src, dst, n, m, reverse ? 1 : 0, tile_tot);
+  CHK(linrec_impl(tile_tot, tile_tot, tiles, Fr::pow_u64(m, FRSCAN_TILE), false, level + 1));   // the value of the recurrence at every tile end
+  hipLaunchKernelGGL(k_fr_linrec<1>, dim3(tiles), dim3(FRSCAN_THREADS), lds, s, src, dst, n, m, reverse ? 1 : 0, tile_tot);
+  return MI355_OK;
+}
+
 int with_host_io(void *data_host, size_t in_bytes, size_t out_bytes, size_t dev_bytes, const char *role, int (*body)(void *dev, void *ud), void *ud) {
   void *dev; CHK(ws_get(role, dev_bytes, &dev));
   HIPCHK(hipMemcpyAsync(dev, data_host, in_bytes, hipMemcpyHostToDevice, g.stream));
@@ -603,6 +617,8 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_fr_prefix_product<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_fr_prefix_product<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_fr_linrec<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_fr_linrec<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   { const char *e = getenv("MI355_TRACE"); g.trace = e && e[0] == '1'; }
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
@@ -1070,6 +1086,17 @@ int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, c
   if (n == 0) return MI355_OK;
   fe_t s; memcpy(&s, scalar, 32);
   hipLaunchKernelGGL(k_fr_vec_axpy, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, (fe_t *)dst_dev, (const fe_t *)a_dev, (const fe_t *)b_dev, s, n);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+int mi355_fr_kate_division_dev(void *dst_dev, const void *poly_dev, uint64_t n, const void *z) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  CHK(need_init());
+  if (!z || n == 0 || !poly_dev || (n > 1 && !dst_dev)) return fail(MI355_EBADARG, "fr_kate_division: null pointer or empty polynomial");
+  if (n >= (1ull << 40)) return fail(MI355_EBADARG, "fr_kate_division: n too large");
+  if (n == 1) return MI355_OK;   // a constant: the quotient is empty
+  fe_t m; memcpy(&m, z, 32);
+  CHK(linrec_impl((const fe_t *)poly_dev + 1, (fe_t *)dst_dev, n - 1, m, true, 0));
   HIPCHK(hipGetLastError());
   return MI355_OK;
 }

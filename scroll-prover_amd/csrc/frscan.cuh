@@ -156,5 +156,60 @@ __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_scan_tile_products(const 
   if (threadIdx.x == 0) g_store(total_out, total);
 }
 
+// ---- first-order linear recurrence with a constant multiplier: P_j = b_j + m * P_(j-1), P_(-1) = 0, j < n.
+// halo2's kate_division(a, z) = (a(X) - a(z)) / (X - z) [EXT-recalled halo2_proofs src/arithmetic.rs; the quotient polynomials of the
+// multi-open (SHPLONK) argument, SURVEY 3.2 step 10] is this recurrence read from the top coefficient down: q_i = a_(i+1) + z * q_(i+1).
+// REVERSE maps recurrence index j to memory index n - 1 - j for loads and stores alike.  Tile scheme as the prefix product: tile totals
+// (FINAL = 0) -> the same recurrence over the totals with multiplier m^2048 (host-side recursion) -> per-tile completion with the carried-in
+// value folded into the tile's first element (FINAL = 1).  Because every thread's 8-element run has the SAME multiplier m^8, the
+// workgroup scan of the affine maps only has to scan the offsets: v_t += v_(t - o) * m^(8 o).
+template <int FINAL> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_linrec(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint64_t n, fe_t m, int reverse,
+                                                                                   fe_t *__restrict__ tile_tot) {
+  extern __shared__ uint32_t sm[];
+  uint32_t *tile = sm, *buf = sm + FRSCAN_THREADS * 65;
+  const uint64_t base = (uint64_t)blockIdx.x * FRSCAN_TILE;
+  fe_t a[FRSCAN_EPT];
+#pragma unroll
+  for (uint32_t j = 0; j < FRSCAN_EPT; j++) {
+    const uint32_t e = j * FRSCAN_THREADS + threadIdx.x;
+    const uint64_t jj = base + e;
+    const fe_t v = jj < n ? g_load(&src[reverse ? n - 1 - jj : jj]) : Fr::zero();
+    lds_put(tile + (e >> 3) * 65 + (e & 7) * 8, v);
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < FRSCAN_EPT; j++) a[j] = lds_get(tile + threadIdx.x * 65 + j * 8);
+  __syncthreads();
+  if (FINAL && tile_tot && blockIdx.x > 0 && threadIdx.x == 0) a[0] = Fr::add(a[0], fr_mul_ps(m, g_load(&tile_tot[blockIdx.x - 1])));
+  fe_t run = a[0];
+#pragma unroll
+  for (uint32_t j = 1; j < FRSCAN_EPT; j++) run = Fr::add(a[j], fr_mul_ps(m, run));
+  // inclusive scan of the thread offsets with multiplier m^8 per thread step
+  fe_t pw = fr_sqr_ps(fr_sqr_ps(fr_sqr_ps(m)));   // m^8
+  uint32_t *cur = buf, *nxt = buf + FRSCAN_THREADS * 9;
+  const uint32_t t = threadIdx.x;
+  fe_t v = run;
+  lds_put(cur + t * 9, v);
+  __syncthreads();
+  for (uint32_t o = 1; o < FRSCAN_THREADS; o <<= 1) {
+    if (t >= o) v = Fr::add(v, fr_mul_ps(lds_get(cur + (t - o) * 9), pw));
+    lds_put(nxt + t * 9, v);
+    __syncthreads();
+    uint32_t *tmp = cur; cur = nxt; nxt = tmp;
+    pw = fr_sqr_ps(pw);
+  }
+  if (!FINAL) { if (t == FRSCAN_THREADS - 1) g_store(&tile_tot[blockIdx.x], v); return; }
+  fe_t P = t ? lds_get(cur + (t - 1) * 9) : Fr::zero();   // value of the recurrence just before this thread's run
+#pragma unroll
+  for (uint32_t j = 0; j < FRSCAN_EPT; j++) { P = Fr::add(a[j], fr_mul_ps(m, P)); lds_put(tile + threadIdx.x * 65 + j * 8, P); }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < FRSCAN_EPT; j++) {
+    const uint32_t e = j * FRSCAN_THREADS + threadIdx.x;
+    const uint64_t jj = base + e;
+    if (jj < n) g_store(&dst[reverse ? n - 1 - jj : jj], lds_get(tile + (e >> 3) * 65 + (e & 7) * 8));
+  }
+}
+
 #endif  // __HIPCC__
 }  // namespace zk

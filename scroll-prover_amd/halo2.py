@@ -116,6 +116,16 @@ def fr_vec_axpy(dst, a, b, scalar: np.ndarray):
     return dst
 
 
+def kate_division(poly, z: np.ndarray, dst=None):
+    """halo2_proofs::arithmetic::kate_division: (poly(X) - poly(z)) / (X - z) on a device-resident coefficient vector -> n - 1 coefficients."""
+    import torch
+    n = poly.numel() * poly.element_size() // 32
+    if dst is None:
+        dst = torch.empty((max(n - 1, 0), 4), dtype=torch.int64, device=poly.device)
+    check(lib().mi355_fr_kate_division_dev(ptr(dst) if n > 1 else None, ptr(poly), n, ptr(z)))
+    return dst
+
+
 def batch_invert(a):
     """ff::BatchInvert on a device-resident Fr vector, in place: a[i] = a[i]^-1, zeros stay zero."""
     check(lib().mi355_fr_batch_invert_dev(ptr(a), a.numel() * a.element_size() // 32))

@@ -787,3 +787,26 @@ def test_fr_vec_axpy_matches_big_int_arithmetic(zk, n):
     h2.fr_vec_axpy(db, None, db, h2.fr(R - 1))                    # dst = -b, in place
     neg = cref.f_from_canonical_vec(cref.FR, np.array([pyref.to_limbs((R - y) % R) for y in bi], dtype=np.uint64))
     assert (db.cpu().numpy().view(np.uint64).reshape(n, 4) == neg).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 9, 2047, 2048, 2049, 2050, 4097, 100003])
+def test_kate_division_matches_oracle(zk, n):
+    """mi355_fr_kate_division_dev against the oracle's restatement of halo2's loop, and the defining identity p(X) - p(z) = (X - z) q(X)."""
+    import torch
+    h2 = zk.halo2
+    rng = np.random.default_rng(5100 + n)
+    a = rand_fr(rng, n)
+    z_int = int(rng.integers(2, 2**62)) * 0xfffffffb % R
+    z = h2.fr(z_int)
+    d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    q = h2.kate_division(d, z)
+    want = cref.kate_division(a, z)
+    assert q.shape[0] == n - 1 and (q.cpu().numpy().view(np.uint64).reshape(n - 1, 4) == want).all()
+    if n >= 3:
+        r = h2.fr(0x123456789abcdef % R)
+        pr, pz, qr = (cref.limbs_to_int(cref.f_to_canonical_vec(cref.FR, v.reshape(1, 4))[0]) for v in (h2.eval_polynomial(d, r), h2.eval_polynomial(d, z), h2.eval_polynomial(q, r)))
+        assert (pr - pz) % R == (0x123456789abcdef - z_int) * qr % R
+        # shifted in place: dst == poly + 1 element
+        lib, check = zk._capi.lib(), zk._capi.check
+        check(lib.mi355_fr_kate_division_dev(C.c_void_p(d.data_ptr() + 32), zk._capi.ptr(d), n, zk._capi.ptr(z)))
+        assert (d[1:].cpu().numpy().view(np.uint64).reshape(n - 1, 4) == want).all()

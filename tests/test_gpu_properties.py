@@ -211,3 +211,17 @@ def test_batch_invert_and_grand_product_at_size(zk, n):
     assert (total == cref.fr_mont(1)).all()
     assert bool((z[0::2] == one).all())
     assert torch.equal(z[1::2], inter[0::2])
+
+
+def test_kate_division_at_size(zk):
+    """kate_division over 2^22 + 5 coefficients (two levels of the tile-total recursion): p(r) - p(z) == (r - z) q(r) at random r."""
+    h2 = zk.halo2
+    n = (1 << 22) + 5
+    p = dev_scalars(n, 91)
+    z_int, r_int = 0x1234567890abcdef1234 % R, 0xfedcba0987654321 % R
+    q = h2.kate_division(p, h2.fr(z_int))
+    val = lambda v: cref.limbs_to_int(cref.f_to_canonical_vec(cref.FR, np.asarray(v).reshape(1, 4))[0])
+    pr, pz, qr = val(h2.eval_polynomial(p, h2.fr(r_int))), val(h2.eval_polynomial(p, h2.fr(z_int))), val(h2.eval_polynomial(q, h2.fr(r_int)))
+    assert (pr - pz) % R == (r_int - z_int) * qr % R
+    # the top quotient coefficient is the top coefficient of p
+    assert torch.equal(q[-1], p[-1])

@@ -227,3 +227,18 @@ def test_batch_invert_and_grand_product_oracle():
     assert fr_ints(z) == want and fr_ints(total.reshape(1, 4)) == [acc]
     z0, t0 = cref.prefix_product(fr_vec([]).reshape(0, 4))
     assert z0.shape[0] == 0 and fr_ints(t0.reshape(1, 4)) == [1]
+
+
+def test_kate_division_oracle():
+    """kate_division against big-int polynomial arithmetic: p(X) = (X - z) q(X) + p(z)."""
+    rng = random.Random(33)
+    for n in (1, 2, 5, 40):
+        coeffs = [rng.randrange(R) for _ in range(n)]
+        z = rng.randrange(R)
+        q = fr_ints(cref.kate_division(fr_vec(coeffs).reshape(n, 4), fr_vec([z])[0]))
+        assert len(q) == n - 1
+        back = [0] * n                                    # (X - z) q(X) + p(z)
+        for i, c in enumerate(q):
+            back[i + 1] = (back[i + 1] + c) % R; back[i] = (back[i] - z * c) % R
+        back[0] = (back[0] + pyref.eval_poly(coeffs, z)) % R
+        assert back == coeffs
