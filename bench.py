@@ -275,6 +275,8 @@ def main() -> None:
         polys = [rand_scalars(1 << kk, 900 + i, dev) for i in range(5)]
         ext = torch.empty((1 << domp.extended_k, 4), dtype=torch.int64, device=dev)
         hh = C.c_uint64(); check(lib.mi355_srs_register_dev(ptr(g), 1 << kk, 0, C.byref(hh)))
+        if not args.no_precompute and not args.window_bits:
+            check(lib.mi355_srs_precompute(hh.value, 0, 0))      # registration-time work, as for the headline basis
         torch.cuda.synchronize(); t4 = time.perf_counter()
         for i in range(11):
             check(lib.mi355_msm_g1_dev(hh.value, 0, ptr(polys[i % 5]), 1 << kk, ptr(out)))
