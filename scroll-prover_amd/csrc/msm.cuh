@@ -14,10 +14,13 @@
 //   4 k_msm_fixup(_big) buckets that straddle thread boundaries: sum their partials (one lane, or a workgroup for giant ones)
 //   5 k_msm_bucket_reduce / k_msm_tree_sum   sum_b (b+1) * B[b] by short chunked running sums, then multi-block
 //                       wavefront-shuffle + LDS trees
-//   6 k_msm_final       Horner over windows (none with window tables), normalise to (x, y, 1)
+//   6 k_msm_final       Horner over windows (none with window tables), normalise to (x, y, 1) with a one-lane Euclidean inverse
 //
-// Algorithmic HBM bytes: 96 B per (scalar, point) pair.  The kernel is VALU-integer bound
-// (~11 field multiplications x ~300 instructions per mixed addition), see DESIGN.md.
+// A batch of M polynomials over one basis (mi355_msm_g1_batch_*) runs the same kernels once with (polynomial m, window w) as
+// window m * W + w: grid.y = m in the digits kernel, a bucket set per polynomial, M workgroups in k_msm_final.
+//
+// Algorithmic HBM bytes: 96 B per (scalar, point) pair.  The accumulation is VALU-integer bound
+// (10 field multiplications = ~1650 v_mad_u64_u32 + ~700 other instructions per mixed addition), see DESIGN.md section 4.
 #pragma once
 #include "fp_asm.cuh"
 #include "g1_29.cuh"
