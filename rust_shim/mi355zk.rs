@@ -23,6 +23,9 @@ extern "C" {
     pub fn mi355_srs_register_host(bases_affine_host: *const c_void, n: u64, handle_out: *mut u64) -> c_int;
     pub fn mi355_srs_release(handle: u64) -> c_int;
     pub fn mi355_srs_precompute(handle: u64, n_hint: u64, c: c_int) -> c_int;
+    pub fn mi355_srs_downsize(g_handle: u64, k: u32, omega_inv: *const c_void, n_inv: *const c_void, g_lagrange_handle_out: *mut u64) -> c_int;
+    pub fn mi355_srs_read_host(handle: u64, offset: u64, n: u64, out_affine_host: *mut c_void) -> c_int;
+    pub fn mi355_g1_fft_host(points_jac_host: *mut c_void, log_n: u32, omega: *const c_void) -> c_int;
     pub fn mi355_msm_g1_host(srs: u64, base_offset: u64, scalars_host: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_msm_g1_batch_host(srs: u64, base_offset: u64, scalars_host: *const *const c_void, batch: u32, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_msm_g1_adhoc_host(bases: *const c_void, scalars: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
@@ -108,6 +111,24 @@ pub fn multiexp_g1_many(polys: &[&[Fr]], bases: &[G1Affine]) -> Option<Vec<G1>> 
     let rc = unsafe { mi355_msm_g1_batch_host(h, off, ptrs.as_ptr(), polys.len() as u32, n as u64, out.as_mut_ptr() as *mut c_void) };
     if rc != MI355_OK { return None; }
     unsafe { out.set_len(polys.len()); }
+    Some(out)
+}
+
+/// `g_to_lagrange(g, k)` for `ParamsKZG::downsize` / `setup`: a size-2^k inverse FFT over curve points, minutes on the CPU.
+/// `g` must be (a prefix of) a registered basis; returns the new `g_lagrange` (and registers it).  None -> run the CPU code.
+pub fn g_to_lagrange(g: &[G1Affine], k: u32, omega_inv: &Fr, n_inv: &Fr) -> Option<Vec<G1Affine>> {
+    if !available() { return None; }
+    let n = 1usize << k;
+    let (h, off) = srs_handle(&g[..n])?;
+    if off != 0 { return None; }
+    let mut hl = 0u64;
+    let rc = unsafe { mi355_srs_downsize(h, k, omega_inv as *const Fr as *const c_void, n_inv as *const Fr as *const c_void, &mut hl) };
+    if rc != MI355_OK { return None; }
+    let mut out: Vec<G1Affine> = Vec::with_capacity(n);
+    let rc = unsafe { mi355_srs_read_host(hl, 0, n as u64, out.as_mut_ptr() as *mut c_void) };
+    unsafe { let _ = mi355_srs_release(hl); }          // the caller's Vec is registered by address on first use, like every basis
+    if rc != MI355_OK { return None; }
+    unsafe { out.set_len(n); }
     Some(out)
 }
 
