@@ -711,7 +711,10 @@ def test_rccl_allgather_path_on_one_rank(points):
         "assert (got[:8] == want).all(), (got, want)\n"
         "dist.barrier(); dist.destroy_process_group(); print('RCCL-OK')\n"
     ) % root
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
