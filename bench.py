@@ -354,7 +354,7 @@ def main() -> None:
                          "pairs_per_launch": pairs_per_launch,
                          "alu": {"achieved": (pairs_per_launch * W / (acc_avg_ms * 1e-3)) if acc_avg_ms > 0 else None, "peak": MADD_CHAIN_PEAK, "unit": "G1 mixed additions/s",
                                  "frac": (pairs_per_launch * W / (acc_avg_ms * 1e-3) / MADD_CHAIN_PEAK) if acc_avg_ms > 0 else None,
-                                 "source": "profiles/r01_microbench_final.log (xyzz29 madd chain, 3 waves/SIMD)"},
+                                 "source": "profiles/r01_microbench_final.log (xyzz29 madd chain, 3 waves/SIMD, boost clock); SQ counters: VALU 98.9 % busy at the sustained 2.03 GHz, profiles/r01_end_sq_counters.md"},
                          "note": "algorithmic bytes = 96 B per (scalar, point) pair x pairs per launch (SURVEY 8d); the kernel is VALU-integer bound, see DESIGN.md"},
             "cpu_baseline": cpu, "ntt": ntt,
         }
