@@ -90,7 +90,13 @@ struct Ctx {
   int last_c = 0, last_w = 0; uint64_t last_entries = 0;
 } g;
 
-int need_init() { return g.inited ? MI355_OK : fail(MI355_ENODEVICE, "mi355_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)"); }
+// Every compute entry point starts here.  The HIP current device is per host thread and calls arrive from whichever thread runs
+// create_proof (rayon workers included, SURVEY 8b "Threading"), so the bound device is re-selected on the calling thread each time.
+int need_init() {
+  if (!g.inited) return fail(MI355_ENODEVICE, "mi355_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)");
+  if (hipSetDevice(g.device) != hipSuccess) { (void)hipGetLastError(); return fail(MI355_EHIP, "hipSetDevice failed on the calling thread"); }
+  return MI355_OK;
+}
 
 // MI355_TRACE: per-call counters for the integrator (metrics / logging)
 struct CallTrace {
