@@ -584,6 +584,15 @@ int with_host_io(void *data_host, size_t in_bytes, size_t out_bytes, size_t dev_
 
 }  // namespace
 
+// No exception may cross the C boundary (the Rust callers are `extern "C"` and would abort): every multi-line entry point runs inside
+// this guard, which turns allocation failures and anything else the host-side C++ might throw into error codes.
+template <class F> int guarded(F body) {
+  try { return body(); }
+  catch (const std::bad_alloc &) { return fail(MI355_EOOM, "host allocation failed"); }
+  catch (const std::exception &e) { return fail(MI355_EHIP, std::string("unexpected host exception: ") + e.what()); }
+  catch (...) { return fail(MI355_EHIP, "unexpected host exception"); }
+}
+
 // ================================================================================================ C ABI
 extern "C" {
 
@@ -591,6 +600,7 @@ const char *mi355_last_error(void) { return g_err.c_str(); }
 const char *mi355_version(void) { return "mi355zk 0.1.0 (gfx950; BN254 G1 MSM + Fr NTT)"; }
 
 int mi355_init(int device_id) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   if (g.inited) return g.device == device_id ? MI355_OK : fail(MI355_EBADARG, "already bound to another device (one device per process)");
   int count = 0;
@@ -638,9 +648,11 @@ int mi355_init(int device_id) {
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
   g.inited = true;
   return MI355_OK;
+  });
 }
 
 int mi355_shutdown(void) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   if (!g.inited) return MI355_OK;
   hipStreamSynchronize(g.stream);
@@ -659,26 +671,32 @@ int mi355_shutdown(void) {
   if (g.ev_fork) { hipEventDestroy(g.ev_fork); g.ev_fork = nullptr; }
   g.own_stream = g.stream = nullptr; g.inited = false; g.device = -1;
   return MI355_OK;
+  });
 }
 
 int mi355_set_stream(void *hip_stream) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   HIPCHK(hipStreamSynchronize(g.stream));
   g.stream = (hipStream_t)hip_stream;   // NULL = the HIP null (legacy default) stream, which is torch's default stream
   return MI355_OK;
+  });
 }
 int mi355_reset_stream(void) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   HIPCHK(hipStreamSynchronize(g.stream));
   g.stream = g.own_stream;
   return MI355_OK;
+  });
 }
 int mi355_synchronize(void) { std::lock_guard<std::mutex> lk(g.mu); CHK(need_init()); HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans(); return MI355_OK; }
 
 // ---- SRS
 int mi355_srs_register_host(const void *bases, uint64_t n, uint64_t *handle_out) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!bases || !handle_out || n == 0) return fail(MI355_EBADARG, "srs_register: null pointer or n == 0");
@@ -687,6 +705,7 @@ int mi355_srs_register_host(const void *bases, uint64_t n, uint64_t *handle_out)
   hipError_t e = hipMemcpy(s.dev, bases, n * sizeof(g1_affine_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) { hipFree(s.dev); return fail(MI355_EHIP, std::string("srs upload: ") + hipGetErrorString(e)); }
   *handle_out = g.next_handle++; g.srs[*handle_out] = s; return MI355_OK;
+  });
 }
 // Prover::load_params for one degree: stream a RawBytes params file into device memory (two pinned staging buffers: the read of chunk
 // i + 1 overlaps the DMA of chunk i), optionally validate every point on the device, register both bases as library-owned handles.
@@ -703,6 +722,7 @@ static int stream_file_to_device(FILE *f, void *dev, size_t bytes, void *pinned[
   return MI355_OK;
 }
 int mi355_srs_load_params_file(const char *path, uint32_t flags, uint32_t *k_out, uint64_t *g_handle_out, uint64_t *g_lagrange_handle_out, void *g2_out, void *s_g2_out) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!path || !k_out || !g_handle_out || !g_lagrange_handle_out) return fail(MI355_EBADARG, "srs_load_params_file: null pointer");
@@ -748,8 +768,10 @@ int mi355_srs_load_params_file(const char *path, uint32_t flags, uint32_t *k_out
   for (int i = 0; i < 2; i++) { if (ev[i]) hipEventDestroy(ev[i]); if (pinned[i]) (void)hipHostFree(pinned[i]); }
   if (rc != MI355_OK) { if (sg.dev) (void)hipFree(sg.dev); if (sl.dev) (void)hipFree(sl.dev); }
   return rc;
+  });
 }
 int mi355_srs_register_dev(const void *bases_dev, uint64_t n, int copy, uint64_t *handle_out) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!bases_dev || !handle_out || n == 0) return fail(MI355_EBADARG, "srs_register_dev: null pointer or n == 0");
@@ -757,8 +779,10 @@ int mi355_srs_register_dev(const void *bases_dev, uint64_t n, int copy, uint64_t
   if (copy) { s.owned = true; HIPCHK(hipMalloc((void **)&s.dev, n * sizeof(g1_affine_t))); HIPCHK(hipMemcpyAsync(s.dev, bases_dev, n * sizeof(g1_affine_t), hipMemcpyDeviceToDevice, g.stream)); HIPCHK(hipStreamSynchronize(g.stream)); }
   else { s.owned = false; s.dev = (g1_affine_t *)bases_dev; }
   *handle_out = g.next_handle++; g.srs[*handle_out] = s; return MI355_OK;
+  });
 }
 int mi355_srs_release(uint64_t handle) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   auto it = g.srs.find(handle);
   if (it == g.srs.end()) return fail(MI355_EBADARG, "srs_release: unknown handle");
@@ -766,8 +790,10 @@ int mi355_srs_release(uint64_t handle) {
   if (it->second.owned) hipFree(it->second.dev);
   if (it->second.pre) hipFree(it->second.pre);
   g.srs.erase(it); return MI355_OK;
+  });
 }
 int mi355_srs_precompute(uint64_t handle, uint64_t n_hint, int c) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   auto it = g.srs.find(handle);
@@ -787,24 +813,31 @@ int mi355_srs_precompute(uint64_t handle, uint64_t n_hint, int c) {
   HIPCHK(hipStreamSynchronize(g.stream));
   sr.pre_c = c; sr.pre_w = W;
   return MI355_OK;
+  });
 }
 int mi355_srs_pre_dev_ptr(uint64_t handle, void **dev_ptr_out, int *c_out, int *windows_out) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   auto it = g.srs.find(handle);
   if (it == g.srs.end() || !dev_ptr_out) return fail(MI355_EBADARG, "srs_pre_dev_ptr: unknown handle");
   *dev_ptr_out = it->second.pre; if (c_out) *c_out = it->second.pre_c; if (windows_out) *windows_out = it->second.pre_w; return MI355_OK;
+  });
 }
 int mi355_srs_len(uint64_t handle, uint64_t *n_out) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   auto it = g.srs.find(handle);
   if (it == g.srs.end() || !n_out) return fail(MI355_EBADARG, "srs_len: unknown handle");
   *n_out = it->second.n; return MI355_OK;
+  });
 }
 int mi355_srs_dev_ptr(uint64_t handle, void **dev_ptr_out) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   auto it = g.srs.find(handle);
   if (it == g.srs.end() || !dev_ptr_out) return fail(MI355_EBADARG, "srs_dev_ptr: unknown handle");
   *dev_ptr_out = it->second.dev; return MI355_OK;
+  });
 }
 
 // ---- MSM
@@ -817,21 +850,26 @@ static int srs_slice(uint64_t handle, uint64_t off, uint64_t n, const g1_affine_
   return MI355_OK;
 }
 int mi355_msm_g1_dev(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_host || (n && !scalars_dev)) return fail(MI355_EBADARG, "msm: null pointer");
   const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
   return msm_dev_impl(bases, (const fe_t *)scalars_dev, n, out_g1_host, &pre);
+  });
 }
 int mi355_msm_g1_dev_async(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_dev) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_dev || (n && !scalars_dev)) return fail(MI355_EBADARG, "msm: null pointer");
   const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
   const fe_t *sc = (const fe_t *)scalars_dev;
   return msm_batch_impl(bases, &sc, 1, n, nullptr, &pre, out_g1_dev);
+  });
 }
 int mi355_g1_sum_dev(const void *pts_dev, uint64_t n, void *out_g1_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_host || (n && !pts_dev) || n > (1u << 20)) return fail(MI355_EBADARG, "g1_sum: bad argument");
@@ -841,8 +879,10 @@ int mi355_g1_sum_dev(const void *pts_dev, uint64_t n, void *out_g1_host) {
   HIPCHK(hipMemcpyAsync(out_g1_host, dev, sizeof(g1_jac_t), hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
   return MI355_OK;
+  });
 }
 int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *scalars_host, uint64_t n, void *out_g1_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_host || (n && !scalars_host)) return fail(MI355_EBADARG, "msm: null pointer");
@@ -850,16 +890,20 @@ int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *sca
   fe_t *sc = nullptr;
   if (n) { CHK(ws_get("io.scalars", n * sizeof(fe_t), (void **)&sc)); HIPCHK(hipMemcpyAsync(sc, scalars_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
   return msm_dev_impl(bases, sc, n, out_g1_host, &pre);
+  });
 }
 int mi355_msm_g1_batch_dev(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_dev, uint32_t batch, uint64_t n, void *out_g1_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_host || (batch && !scalars_dev)) return fail(MI355_EBADARG, "msm_batch: null pointer");
   for (uint32_t m = 0; m < batch; m++) if (n && !scalars_dev[m]) return fail(MI355_EBADARG, "msm_batch: null polynomial pointer");
   const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
   return msm_batch_impl(bases, (const fe_t *const *)scalars_dev, batch, n, out_g1_host, &pre);
+  });
 }
 int mi355_msm_g1_batch_host(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_host, uint32_t batch, uint64_t n, void *out_g1_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_host || (batch && !scalars_host)) return fail(MI355_EBADARG, "msm_batch: null pointer");
@@ -879,14 +923,18 @@ int mi355_msm_g1_batch_host(uint64_t srs_handle, uint64_t base_offset, const voi
     CHK(msm_batch_impl(bases, ptrs.data(), mg, n, (char *)out_g1_host + (size_t)m0 * sizeof(g1_jac_t), &pre));
   }
   return MI355_OK;
+  });
 }
 int mi355_msm_set_pipeline(uint32_t chunks, uint32_t min_log_n) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   if (chunks > 16 || min_log_n > 31) return fail(MI355_EBADARG, "msm_set_pipeline: chunks <= 16, min_log_n <= 31");
   g.msm_chunks = chunks ? chunks : 1; g.msm_chunk_min_log = chunks ? min_log_n : 23;
   return MI355_OK;
+  });
 }
 int mi355_msm_g1_adhoc_host(const void *bases_host, const void *scalars_host, uint64_t n, void *out_g1_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_host || (n && (!scalars_host || !bases_host))) return fail(MI355_EBADARG, "msm: null pointer");
@@ -897,8 +945,10 @@ int mi355_msm_g1_adhoc_host(const void *bases_host, const void *scalars_host, ui
     HIPCHK(hipMemcpyAsync(bs, bases_host, n * sizeof(g1_affine_t), hipMemcpyHostToDevice, g.stream));
   }
   return msm_dev_impl(bs, sc, n, out_g1_host);
+  });
 }
 int mi355_g1_sum_host(const void *pts_host, uint64_t n, void *out_g1_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_g1_host || (n && !pts_host) || n > (1u << 20)) return fail(MI355_EBADARG, "g1_sum: bad argument");
@@ -909,16 +959,21 @@ int mi355_g1_sum_host(const void *pts_host, uint64_t n, void *out_g1_host) {
   HIPCHK(hipMemcpyAsync(out_g1_host, dev, sizeof(g1_jac_t), hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
   return MI355_OK;
+  });
 }
 int mi355_msm_set_window_bits(int c) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   if (c != 0 && (c < 2 || c > 24)) return fail(MI355_EBADARG, "window bits must be 0 (auto) or in [2, 24]");
   g.force_c = c; return MI355_OK;
+  });
 }
 int mi355_msm_set_normalise(int on) { std::lock_guard<std::mutex> lk(g.mu); g.normalise = on != 0; return MI355_OK; }
 int mi355_msm_last_plan(int *c_out, int *windows_out, uint64_t *entries_out) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   if (c_out) *c_out = g.last_c; if (windows_out) *windows_out = g.last_w; if (entries_out) *entries_out = g.last_entries; return MI355_OK;
+  });
 }
 
 // ---- NTT
@@ -928,28 +983,35 @@ static int check_ntt_args(const void *data, uint32_t log_n, const void *omega) {
   return MI355_OK;
 }
 int mi355_ntt_fr_dev(void *data_dev, uint32_t log_n, const void *omega) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init()); CHK(check_ntt_args(data_dev, log_n, omega));
   CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_n, (fe_t *)data_dev, log_n, omega, nullptr, nullptr));
   return finish_async();
+  });
 }
 int mi355_intt_fr_dev(void *data_dev, uint32_t log_n, const void *omega_inv, const void *divisor) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init()); CHK(check_ntt_args(data_dev, log_n, omega_inv));
   if (!divisor) return fail(MI355_EBADARG, "intt: null divisor");
   fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], divisor, 32);
   CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_n, (fe_t *)data_dev, log_n, omega_inv, nullptr, post));
   return finish_async();
+  });
 }
 int mi355_coeff_to_extended_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init()); CHK(check_ntt_args(dst_dev, log_ext, extended_omega));
   if (!coeffs_dev || !g_coset || !g_coset_inv || log_n > log_ext) return fail(MI355_EBADARG, "coeff_to_extended: bad argument");
   fe_t pre[3]; pre[0] = Fr::one(); memcpy(&pre[1], g_coset, 32); memcpy(&pre[2], g_coset_inv, 32);
   CHK(ntt_dev_impl((const fe_t *)coeffs_dev, 1ull << log_n, (fe_t *)dst_dev, log_ext, extended_omega, pre, nullptr));
   return finish_async();
+  });
 }
 int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init()); CHK(check_ntt_args(data_dev, log_ext, extended_omega_inv));
   if (!g_coset || !g_coset_inv || !extended_ifft_divisor) return fail(MI355_EBADARG, "extended_to_coeff: null pointer");
@@ -958,17 +1020,21 @@ int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_
   post[0] = d; post[1] = Fr::mul(d, gci); post[2] = Fr::mul(d, gc);
   CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_ext, (fe_t *)data_dev, log_ext, extended_omega_inv, nullptr, post));
   return finish_async();
+  });
 }
 
 struct NttHostArgs { uint32_t log_n; const void *omega; const void *divisor; };
 int mi355_ntt_fr_host(void *data_host, uint32_t log_n, const void *omega) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init()); CHK(check_ntt_args(data_host, log_n, omega));
   NttHostArgs a{log_n, omega, nullptr};
   const size_t bytes = sizeof(fe_t) << log_n;
   return with_host_io(data_host, bytes, bytes, bytes, "io.ntt", [](void *dev, void *ud) { auto *a = (NttHostArgs *)ud; return ntt_dev_impl((const fe_t *)dev, 1ull << a->log_n, (fe_t *)dev, a->log_n, a->omega, nullptr, nullptr); }, &a);
+  });
 }
 int mi355_intt_fr_host(void *data_host, uint32_t log_n, const void *omega_inv, const void *divisor) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init()); CHK(check_ntt_args(data_host, log_n, omega_inv));
   if (!divisor) return fail(MI355_EBADARG, "intt: null divisor");
@@ -977,29 +1043,37 @@ int mi355_intt_fr_host(void *data_host, uint32_t log_n, const void *omega_inv, c
   return with_host_io(data_host, bytes, bytes, bytes, "io.ntt", [](void *dev, void *ud) {
     auto *a = (NttHostArgs *)ud; fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], a->divisor, 32);
     return ntt_dev_impl((const fe_t *)dev, 1ull << a->log_n, (fe_t *)dev, a->log_n, a->omega, nullptr, post); }, &a);
+  });
 }
 // ---- DFT over G1 points (best_fft::<Fr, G1>, g_to_lagrange)
 int mi355_g1_fft_dev(void *points_jac_dev, uint32_t log_n, const void *omega) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init()); CHK(check_ntt_args(points_jac_dev, log_n, omega));
   CHK(g1fft_impl(points_jac_dev, 1, points_jac_dev, 1, log_n, omega, nullptr));
   return finish_async();
+  });
 }
 int mi355_g1_fft_host(void *points_jac_host, uint32_t log_n, const void *omega) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init()); CHK(check_ntt_args(points_jac_host, log_n, omega));
   NttHostArgs a{log_n, omega, nullptr};
   const size_t bytes = sizeof(g1_jac_t) << log_n;
   return with_host_io(points_jac_host, bytes, bytes, bytes, "io.g1fft", [](void *dev, void *ud) { auto *a = (NttHostArgs *)ud; return g1fft_impl(dev, 1, dev, 1, a->log_n, a->omega, nullptr); }, &a);
+  });
 }
 int mi355_g_to_lagrange_dev(const void *g_affine_dev, void *g_lagrange_affine_dev, uint32_t log_n, const void *omega_inv, const void *n_inv) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init()); CHK(check_ntt_args(g_affine_dev, log_n, omega_inv));
   if (!g_lagrange_affine_dev || !n_inv) return fail(MI355_EBADARG, "g_to_lagrange: null pointer");
   CHK(g1fft_impl(g_affine_dev, 0, g_lagrange_affine_dev, 0, log_n, omega_inv, n_inv));
   return finish_async();
+  });
 }
 int mi355_srs_downsize(uint64_t g_handle, uint32_t k, const void *omega_inv, const void *n_inv, uint64_t *g_lagrange_handle_out) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   auto it = g.srs.find(g_handle);
@@ -1012,8 +1086,10 @@ int mi355_srs_downsize(uint64_t g_handle, uint32_t k, const void *omega_inv, con
   if (rc == MI355_OK && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MI355_EHIP, "srs_downsize: stream synchronize failed");
   if (rc != MI355_OK) { (void)hipFree(s.dev); return rc; }
   *g_lagrange_handle_out = g.next_handle++; g.srs[*g_lagrange_handle_out] = s; return MI355_OK;
+  });
 }
 int mi355_srs_read_host(uint64_t handle, uint64_t offset, uint64_t n, void *out_affine_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   auto it = g.srs.find(handle);
@@ -1021,8 +1097,10 @@ int mi355_srs_read_host(uint64_t handle, uint64_t offset, uint64_t n, void *out_
   if (offset > it->second.n || n > it->second.n - offset) return fail(MI355_EBADARG, "srs_read_host: range exceeds the registered basis");
   if (n) { HIPCHK(hipMemcpyAsync(out_affine_host, it->second.dev + offset, n * sizeof(g1_affine_t), hipMemcpyDeviceToHost, g.stream)); HIPCHK(hipStreamSynchronize(g.stream)); }
   return MI355_OK;
+  });
 }
 int mi355_coeff_to_extended_host(void *dst_host, const void *coeffs_host, uint32_t log_n, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega) {
+  return guarded([&]() -> int {
   {
     std::lock_guard<std::mutex> lk(g.mu);
     CHK(need_init()); CHK(check_ntt_args(dst_host, log_ext, extended_omega));
@@ -1035,8 +1113,10 @@ int mi355_coeff_to_extended_host(void *dst_host, const void *coeffs_host, uint32
     HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans();
   }
   return MI355_OK;
+  });
 }
 int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
+  return guarded([&]() -> int {
   void *dev;
   {
     std::lock_guard<std::mutex> lk(g.mu);
@@ -1051,10 +1131,12 @@ int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *
     HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans();
   }
   return MI355_OK;
+  });
 }
 
 // ---- distribute_powers / coset NTT
 int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *factor) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!factor || (n && !data_dev)) return fail(MI355_EBADARG, "distribute_powers: null pointer");
@@ -1063,8 +1145,10 @@ int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *facto
   hipLaunchKernelGGL(k_distribute_powers, dim3(ceil_div(n, (uint64_t)EVAL_RUN * 256)), dim3(256), 0, g.stream, (fe_t *)data_dev, n, f);
   HIPCHK(hipGetLastError());
   return MI355_OK;
+  });
 }
 int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, const void *coset_factor, const void *omega) {
+  return guarded([&]() -> int {
   {
     std::lock_guard<std::mutex> lk(g.mu);
     CHK(need_init()); CHK(check_ntt_args(dst_dev, log_n, omega));
@@ -1073,10 +1157,12 @@ int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n
   }
   CHK(mi355_distribute_powers_fr_dev(dst_dev, 1ull << log_n, coset_factor));
   return mi355_ntt_fr_dev(dst_dev, log_n, omega);
+  });
 }
 
 // ---- element-wise vector operations on resident polynomials
 int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_dev, uint64_t n) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (op < 0 || op > 2 || (n && (!dst_dev || !a_dev || !b_dev))) return fail(MI355_EBADARG, "fr_vec_op: bad argument");
@@ -1084,8 +1170,10 @@ int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_
   hipLaunchKernelGGL(k_fr_vec_op, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, op, (fe_t *)dst_dev, (const fe_t *)a_dev, (const fe_t *)b_dev, n);
   HIPCHK(hipGetLastError());
   return MI355_OK;
+  });
 }
 int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, const void *scalar, uint64_t n) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!scalar || (n && (!dst_dev || !b_dev))) return fail(MI355_EBADARG, "fr_vec_axpy: null pointer");
@@ -1094,8 +1182,10 @@ int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, c
   hipLaunchKernelGGL(k_fr_vec_axpy, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, (fe_t *)dst_dev, (const fe_t *)a_dev, (const fe_t *)b_dev, s, n);
   HIPCHK(hipGetLastError());
   return MI355_OK;
+  });
 }
 int mi355_fr_kate_division_dev(void *dst_dev, const void *poly_dev, uint64_t n, const void *z) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!z || n == 0 || !poly_dev || (n > 1 && !dst_dev)) return fail(MI355_EBADARG, "fr_kate_division: null pointer or empty polynomial");
@@ -1105,8 +1195,10 @@ int mi355_fr_kate_division_dev(void *dst_dev, const void *poly_dev, uint64_t n, 
   CHK(linrec_impl((const fe_t *)poly_dev + 1, (fe_t *)dst_dev, n - 1, m, true, 0));
   HIPCHK(hipGetLastError());
   return MI355_OK;
+  });
 }
 int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (n && !data_dev) return fail(MI355_EBADARG, "fr_batch_invert: null pointer");
@@ -1115,8 +1207,10 @@ int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n) {
   CHK(batch_invert_impl((fe_t *)data_dev, n, 0));
   HIPCHK(hipGetLastError());
   return MI355_OK;
+  });
 }
 int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (n && (!dst_dev || !src_dev)) return fail(MI355_EBADARG, "fr_prefix_product: null pointer");
@@ -1134,8 +1228,10 @@ int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, 
   HIPCHK(hipGetLastError());
   if (total_out_host) { HIPCHK(hipMemcpyAsync(total_out_host, total, sizeof(fe_t), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
   return MI355_OK;
+  });
 }
 int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_host, uint32_t period) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!table_host || period == 0 || (period & (period - 1)) || period > 4096 || (n && !data_dev)) return fail(MI355_EBADARG, "fr_vec_mul_periodic: period must be a power of two <= 4096");
@@ -1146,10 +1242,12 @@ int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_
   hipLaunchKernelGGL(k_fr_vec_mul_periodic, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, (fe_t *)data_dev, n, tab, period - 1);
   HIPCHK(hipGetLastError());
   return MI355_OK;
+  });
 }
 
 // ---- eval_polynomial
 int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!out_fr_host || !point || (n && !poly_dev)) return fail(MI355_EBADARG, "eval_polynomial: null pointer");
@@ -1169,8 +1267,10 @@ int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *poin
   resolve_spans();
   memcpy(out_fr_host, &res, 32);
   return MI355_OK;
+  });
 }
 int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *point, void *out_fr_host) {
+  return guarded([&]() -> int {
   void *dev = nullptr;
   {
     std::lock_guard<std::mutex> lk(g.mu);
@@ -1179,6 +1279,7 @@ int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *po
     if (n) { CHK(ws_get("io.ntt", n * sizeof(fe_t), &dev)); HIPCHK(hipMemcpyAsync(dev, poly_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
   }
   return mi355_eval_polynomial_dev(dev, n, point, out_fr_host);
+  });
 }
 
 // ---- synthetic SRS
@@ -1190,6 +1291,7 @@ static int ensure_fixed_base_table() {
   return MI355_OK;
 }
 int mi355_g1_fixed_base_mul_dev(void *points_dev, const void *scalars_dev, uint64_t n) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!points_dev || !scalars_dev) return fail(MI355_EBADARG, "fixed_base_mul: null pointer");
@@ -1197,8 +1299,10 @@ int mi355_g1_fixed_base_mul_dev(void *points_dev, const void *scalars_dev, uint6
   hipLaunchKernelGGL(k_fixed_base_mul, dim3(ceil_div(n, 256)), dim3(256), 0, g.stream, g.fixed_base_table, (const fe_t *)scalars_dev, (g1_affine_t *)points_dev, n);
   HIPCHK(hipGetLastError());
   return MI355_OK;
+  });
 }
 int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const void *tau, const void *omega) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   if (!g_dev || !g_lagrange_dev || !tau || !omega || k > 28) return fail(MI355_EBADARG, "srs_setup: bad argument");
@@ -1215,10 +1319,12 @@ int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const voi
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(g.stream));
   return MI355_OK;
+  });
 }
 
 // ---- test hook: read back a workspace buffer ("msm.sorted", "msm.offsets", ...) after a call
 int mi355_debug_ws_read(const char *role, uint64_t offset, void *dst_host, uint64_t bytes) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   CHK(need_init());
   auto it = g.ws.find(role ? role : "");
@@ -1226,12 +1332,14 @@ int mi355_debug_ws_read(const char *role, uint64_t offset, void *dst_host, uint6
   HIPCHK(hipStreamSynchronize(g.stream));
   HIPCHK(hipMemcpy(dst_host, (const char *)it->second.p + offset, bytes, hipMemcpyDeviceToHost));
   return MI355_OK;
+  });
 }
 
 // ---- profiling
 int mi355_profile_enable(int on) { std::lock_guard<std::mutex> lk(g.mu); g.profiling = on != 0; return MI355_OK; }
 int mi355_profile_reset(void) { std::lock_guard<std::mutex> lk(g.mu); if (g.inited) resolve_spans(); g.prof.clear(); return MI355_OK; }
 int mi355_profile_get(const char *name, double *ms_out, uint64_t *launches_out) {
+  return guarded([&]() -> int {
   std::lock_guard<std::mutex> lk(g.mu);
   if (!name) return fail(MI355_EBADARG, "profile_get: null name");
   if (g.inited) resolve_spans();
@@ -1239,6 +1347,7 @@ int mi355_profile_get(const char *name, double *ms_out, uint64_t *launches_out) 
   if (ms_out) *ms_out = it == g.prof.end() ? 0.0 : it->second.ms;
   if (launches_out) *launches_out = it == g.prof.end() ? 0 : it->second.launches;
   return MI355_OK;
+  });
 }
 
 }  // extern "C"
