@@ -813,3 +813,27 @@ def test_kate_division_matches_oracle(zk, n):
         lib, check = zk._capi.lib(), zk._capi.check
         check(lib.mi355_fr_kate_division_dev(C.c_void_p(d.data_ptr() + 32), zk._capi.ptr(d), n, zk._capi.ptr(z)))
         assert (d[1:].cpu().numpy().view(np.uint64).reshape(n - 1, 4) == want).all()
+
+
+def test_shutdown_releases_everything_and_reinit_works():
+    """mi355_shutdown / mi355_init life cycle (own process): after shutdown every compute entry point fails loudly with
+    MI355_ENODEVICE, stale handles are gone, and a second init gives a working library again."""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import __graft_entry__ as ge; zk = ge.load_package(); capi = zk._capi\n"
+        "from oracle import cref\n"
+        "lib = capi.lib(); zk.init(0); h2 = zk.halo2\n"
+        "G = cref.g1_generator(); pts = np.tile(G, (32, 1)); sc = np.tile(cref.fr_mont(3), (32, 1)); out = np.zeros(12, dtype=np.uint64)\n"
+        "p = h2.ParamsKZG.from_host(5, pts, pts); p.precompute(); first = p.commit(sc).copy()\n"
+        "a = np.tile(cref.fr_mont(5), (256, 1)); h2.best_fft(a, h2.fr(pow(h2.FR_ROOT_OF_UNITY, 1 << 20, h2.R_MOD)), 8)\n"
+        "assert lib.mi355_shutdown() == 0 and lib.mi355_shutdown() == 0\n"
+        "assert lib.mi355_msm_g1_host(p._g, 0, capi.ptr(sc), 32, capi.ptr(out)) == capi.ENODEVICE\n"
+        "assert lib.mi355_ntt_fr_host(capi.ptr(a), 8, capi.ptr(sc[0])) == capi.ENODEVICE\n"
+        "zk.init(0)\n"
+        "assert lib.mi355_msm_g1_host(p._g, 0, capi.ptr(sc), 32, capi.ptr(out)) == capi.EBADARG      # the old handle died with the context\n"
+        "q = h2.ParamsKZG.from_host(5, pts, pts); assert (q.commit(sc) == first).all()\n"
+        "want = cref.g1_to_affine(cref.g1_mul(G, cref.fr_mont(96))); assert (first[:8] == want).all()\n"
+        "print('LIFECYCLE-OK')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "LIFECYCLE-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
