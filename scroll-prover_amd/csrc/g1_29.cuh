@@ -72,6 +72,50 @@ template <bool FUSED_Y3 = true> ZK_HD void g1_xyzz29_madd(g1_xyzz29_t &acc, cons
   acc.x = X3; acc.y = Y3; acc.zz = ZZ3; acc.zzz = Fq29::mul(acc.zzz, PPP);
 }
 
+// 2 * acc for an accumulator under the invariants above (dbl-2008-s-1).  Output: x < 9.1 p (limbs <= 2^29 + 8), y < 5.4 p
+// (limbs <= 2^29 + 8), zz / zzz tight -- again a valid accumulator.
+ZK_HD g1_xyzz29_t g1_xyzz29_dbl(const g1_xyzz29_t &a) {
+  if (g1_xyzz29_is_identity(a)) return a;
+  const fe29_t xt = Fq29::reduce_small(Fq29::normalise(a.x));   // tight, < 2 p (x^2 of a 14 p value would leave the < 2 p output range)
+  const fe29_t yc = Fq29::carry(a.y);                           // limbs <= 2^29 + 2, value < 6.1 p
+  const fe29_t U = Fq29::dbl(yc);                               // limbs <= 2^30 + 4, < 12.2 p   (U^2 = 149 p^2 < 2^261 p = 168 p^2)
+  const fe29_t V = Fq29::sqr(U), W = Fq29::mul(U, V), S = Fq29::mul(xt, V);   // tight, < 1.9 p / 1.2 p / 1.1 p
+  const fe29_t xx = Fq29::sqr(xt);
+  const fe29_t M = Fq29::carry(Fq29::add(Fq29::dbl(xx), xx));                  // 3 x^2, limbs <= 2^29 + 8, < 3.3 p
+  g1_xyzz29_t r;
+  r.x = Fq29::sub8(Fq29::sqr(M), Fq29::dbl(S));                 // < 1.1 p + 8 p
+  const fe29_t t = Fq29::sub16(S, r.x);                          // < 17.1 p
+  r.y = Fq29::sub4(Fq29::mul(M, t), Fq29::mul(W, yc));           // < 1.4 p + 4 p
+  r.zz = Fq29::mul(V, a.zz); r.zzz = Fq29::mul(W, a.zzz);
+  return r;
+}
+
+// acc += q, both accumulators under the invariants above (add-2008-s).  The loose coordinates only ever enter multiplications
+// (U1 = X1 ZZ2, S1 = Y1 ZZZ2, ...), after which the body is the mixed addition's with (U1, S1) in the place of (X1, Y1): same
+// expression shapes, same or tighter bounds.  12 M + 2 S.
+ZK_HD void g1_xyzz29_add(g1_xyzz29_t &acc, const g1_xyzz29_t &q) {
+  if (g1_xyzz29_is_identity(q)) return;
+  if (g1_xyzz29_is_identity(acc)) { acc = q; return; }
+  const fe29_t U1 = Fq29::mul(acc.x, q.zz), S1 = Fq29::mul(acc.y, q.zzz);      // tight, < 1.1 p
+  const fe29_t U2 = Fq29::mul(q.x, acc.zz), S2 = Fq29::mul(q.y, acc.zzz);      // tight, < 1.1 p
+  const fe29_t Pd = Fq29::sub4(U2, U1);                                        // < 5.1 p
+  const fe29_t Rd = Fq29::sub4(S2, S1);                                        // < 5.1 p
+  const fe29_t PP = Fq29::sqr(Pd);                                             // < 1.2 p
+  const fe29_t ZZt = Fq29::mul(acc.zz, PP);                                    // zero iff Pd == 0 (both zz != 0)
+  if (Fq29::is_zero_tight(ZZt)) {
+    // q == +-acc: doubling or annihilation
+    if (Fq29::is_zero_tight(Fq29::mul(Rd, Fq29::one()))) acc = g1_xyzz29_dbl(acc);
+    else acc = g1_xyzz29_identity();
+    return;
+  }
+  const fe29_t PPP = Fq29::mul(Pd, PP);                                        // < 1.1 p
+  const fe29_t Q = Fq29::mul(U1, PP);                                          // < 1.1 p
+  const fe29_t X3 = Fq29::sub8(Fq29::sub4(Fq29::sqr(Rd), PPP), Fq29::dbl(Q)); // (1.2 + 4) p + 8 p = 13.2 p
+  const fe29_t Y3 = Fq29::mul_sub(Rd, Fq29::sub16(Q, X3), S1, PPP);           // as in the mixed addition, with the tight S1 for Y1
+  acc.x = X3; acc.y = Y3;
+  acc.zz = Fq29::mul(ZZt, q.zz); acc.zzz = Fq29::mul(Fq29::mul(acc.zzz, PPP), q.zzz);
+}
+
 // accumulator -> the saturated XYZZ record the reduction kernels consume (R = 2^256 Montgomery, fully reduced)
 ZK_HD g1_xyzz_t g1_xyzz29_to_sat(const g1_xyzz29_t &a) {
   g1_xyzz_t r;

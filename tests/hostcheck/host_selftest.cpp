@@ -84,3 +84,24 @@ extern "C" void hs_f29_reduce_small(int which, uint32_t *out9, const uint32_t *i
   fe29_t r = which ? Fr29::reduce_small(v) : Fq29::reduce_small(v);
   for (int i = 0; i < 9; i++) out9[i] = r.l[i];
 }
+
+// ---- 29-bit full addition / doubling (g1_29.cuh): groups of mixed additions are combined with g1_xyzz29_add (loose inputs), and
+// a double-and-add ladder runs on g1_xyzz29_dbl / g1_xyzz29_add; results leave as saturated XYZZ for the oracle comparison
+extern "C" void hs_xyzz29_grouped_sum(void *out_xyzz, const void *affine, const uint8_t *signs, uint64_t n, uint64_t group) {
+  const g1_affine_t *p = (const g1_affine_t *)affine;
+  g1_xyzz29_t total = g1_xyzz29_identity();
+  for (uint64_t g0 = 0; g0 < n; g0 += group) {
+    g1_xyzz29_t acc = g1_xyzz29_identity();
+    for (uint64_t i = g0; i < n && i < g0 + group; i++) g1_xyzz29_madd(acc, p[i], signs[i] & 1);
+    g1_xyzz29_add(total, acc);
+  }
+  *(g1_xyzz_t *)out_xyzz = g1_xyzz29_to_sat(total);
+}
+extern "C" void hs_xyzz29_ladder(void *out_xyzz, const void *affine, const uint8_t *signs, uint64_t n, uint32_t k) {
+  const g1_affine_t *p = (const g1_affine_t *)affine;
+  g1_xyzz29_t base = g1_xyzz29_identity();
+  for (uint64_t i = 0; i < n; i++) g1_xyzz29_madd(base, p[i], signs[i] & 1);   // a loose accumulator as the ladder's base point
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  for (int bit = 31; bit >= 0; bit--) { acc = g1_xyzz29_dbl(acc); if ((k >> bit) & 1) g1_xyzz29_add(acc, base); }
+  *(g1_xyzz_t *)out_xyzz = g1_xyzz29_to_sat(acc);
+}

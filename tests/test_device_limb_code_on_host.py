@@ -180,3 +180,50 @@ def test_reduce_small_boundaries(hs):
             hs.hs_f29_reduce_small(w, out, inp)
             got = sum(int(out[i]) << (29 * i) for i in range(9))
             assert got % m == v % m and got < 2 * m and all(out[i] <= M for i in range(8)), (w, v // m)
+
+
+def test_xyzz29_full_addition_and_doubling(hs):
+    """g1_xyzz29_add / g1_xyzz29_dbl: accumulators with lazy coordinates (the output of chains of mixed additions) combined by full
+    additions, including equal and opposite partial sums and empty groups, and a double-and-add ladder over a lazy base point."""
+    rng = random.Random(77)
+    G = pyref.G1_GEN
+    pool = [pyref.g1_mul(G, rng.randrange(1, R)) for _ in range(10)]
+
+    def arrays(seq):
+        pts = np.stack([_pt(p) if p is not None else np.zeros(8, dtype=np.uint64) for p, _ in seq])
+        return pts, (C.c_uint8 * len(seq))(*[s for _, s in seq])
+
+    def total(seq):
+        want = None
+        for p, s in seq:
+            want = pyref.g1_add(want, pyref.g1_neg(p) if s else p)
+        return want
+
+    def as_point(out):
+        jac = np.zeros(12, dtype=np.uint64); hs.hs_xyzz_to_jac(p_(jac), p_(out))
+        return pyref.g1_jacobian_from_limbs(jac[:4], jac[4:8], jac[8:])
+
+    def grouped(seq, group):
+        pts, signs = arrays(seq)
+        out = np.zeros(16, dtype=np.uint64)
+        hs.hs_xyzz29_grouped_sum(p_(out), p_(pts), signs, C.c_uint64(len(seq)), C.c_uint64(group))
+        assert as_point(out) == total(seq), (seq, group)
+
+    for trial in range(40):
+        n = rng.randrange(1, 60)
+        grouped([(rng.choice(pool), rng.randrange(2)) for _ in range(n)], rng.randrange(1, 9))
+    A, B, Cp = pool[0], pool[1], pool[2]
+    grouped([(A, 0), (B, 0), (A, 0), (B, 0)], 2)                 # equal partial sums: the doubling branch of the full addition
+    grouped([(A, 0), (B, 0), (A, 1), (B, 1)], 2)                 # opposite partial sums: annihilation
+    grouped([(A, 0), (A, 1), (B, 0), (Cp, 0)], 2)                # an empty (identity) group first
+    grouped([(B, 0), (Cp, 0), (A, 0), (A, 1)], 2)                # an identity group second
+    grouped([(A, 0)] * 33, 3)                                    # 3A + 3A + ... : doubling then general additions of multiples
+    grouped([(None, 0), (None, 0), (A, 0)], 2)
+    for trial in range(12):
+        seq = [(rng.choice(pool), rng.randrange(2)) for _ in range(rng.randrange(1, 20))]
+        k = rng.choice([0, 1, 2, 3, 5, 255, 65536, 2**31 + 12345, 2**32 - 1, rng.randrange(2**32)])
+        pts, signs = arrays(seq)
+        out = np.zeros(16, dtype=np.uint64)
+        hs.hs_xyzz29_ladder(p_(out), p_(pts), signs, C.c_uint64(len(seq)), C.c_uint32(k))
+        base = total(seq)
+        assert as_point(out) == (pyref.g1_mul(base, k) if (base is not None and k) else None), (seq, k)
