@@ -62,12 +62,13 @@ __device__ __forceinline__ void store_xyzz29(g1_xyzz29_t *p, const g1_xyzz29_t &
 #pragma unroll
   for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-__device__ __forceinline__ g1_xyzz_t load_xyzz29_as_sat(const g1_xyzz29_t *p) {
+__device__ __forceinline__ g1_xyzz29_t load_xyzz29(const g1_xyzz29_t *p) {
   g1_xyzz29_t v; uint32_t *w = reinterpret_cast<uint32_t *>(&v); const uint4 *q = reinterpret_cast<const uint4 *>(p);
 #pragma unroll
   for (int i = 0; i < 9; i++) { const uint4 a = q[i]; w[4 * i] = a.x; w[4 * i + 1] = a.y; w[4 * i + 2] = a.z; w[4 * i + 3] = a.w; }
-  return g1_xyzz29_to_sat(v);
+  return v;
 }
+__device__ __forceinline__ g1_xyzz_t load_xyzz29_as_sat(const g1_xyzz29_t *p) { return g1_xyzz29_to_sat(load_xyzz29(p)); }
 __device__ __forceinline__ void store_sat_as_xyzz29(g1_xyzz29_t *p, const g1_xyzz_t &v) {
   g1_xyzz29_t r; r.x = Fq29::from_sat(v.x); r.y = Fq29::from_sat(v.y); r.zz = Fq29::from_sat(v.zz); r.zzz = Fq29::from_sat(v.zzz);
   store_xyzz29(p, r);
@@ -387,7 +388,19 @@ __device__ __forceinline__ void fixup_take(g1_xyzz_t &acc, const g1_xyzz29_t *__
   if (part_id[2 * t] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz29_as_sat(&part[2 * (uint64_t)t]));
   else if (part_id[2 * t + 1] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz29_as_sat(&part[2 * (uint64_t)t + 1]));
 }
-__global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
+// A29 = 1 (MI355_REDUCE29): the fix-up and the bucket reduction stay in the 29-bit field (g1_xyzz29_add / _dbl): no conversion of every
+// 144-byte record to the saturated form (4 multiplications each) and the faster multiplier; records then always hold valid accumulators.
+__device__ __forceinline__ void fixup_take29(g1_xyzz29_t &acc, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t t, uint32_t b) {
+  if (part_id[2 * t] == (int32_t)b) g1_xyzz29_add(acc, load_xyzz29(&part[2 * (uint64_t)t]));
+  else if (part_id[2 * t + 1] == (int32_t)b) g1_xyzz29_add(acc, load_xyzz29(&part[2 * (uint64_t)t + 1]));
+}
+__device__ __forceinline__ g1_xyzz29_t shfl_down_xyzz29(const g1_xyzz29_t &v, uint32_t o) {
+  g1_xyzz29_t r; const uint32_t *s = reinterpret_cast<const uint32_t *>(&v); uint32_t *d = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+  for (int i = 0; i < 36; i++) d[i] = __shfl_down(s[i], o);
+  return r;
+}
+template <int A29> __global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
                                                    const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg,
                                                    uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,31 +414,59 @@ __global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ 
     if (idx < big_cap) { big_list[3 * idx] = b; big_list[3 * idx + 1] = t0; big_list[3 * idx + 2] = t1; }
     return;
   }
-  g1_xyzz_t acc = g1_xyzz_identity();
-  for (uint32_t t = t0; t <= t1; t++) fixup_take(acc, part, part_id, t, b);
-  store_sat_as_xyzz29(&bucket_sums[b], acc);
+  if (A29) {
+    g1_xyzz29_t acc = g1_xyzz29_identity();
+    for (uint32_t t = t0; t <= t1; t++) fixup_take29(acc, part, part_id, t, b);
+    store_xyzz29(&bucket_sums[b], acc);
+  } else {
+    g1_xyzz_t acc = g1_xyzz_identity();
+    for (uint32_t t = t0; t <= t1; t++) fixup_take(acc, part, part_id, t, b);
+    store_sat_as_xyzz29(&bucket_sums[b], acc);
+  }
 }
-__global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyzz29_t *__restrict__ bucket_sums, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id,
+template <int A29> __global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyzz29_t *__restrict__ bucket_sums, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id,
                                                        const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count) {
-  __shared__ g1_xyzz_t lds[4];
   if (blockIdx.x >= *big_count) return;
   const uint32_t b = big_list[3 * blockIdx.x], t0 = big_list[3 * blockIdx.x + 1], t1 = big_list[3 * blockIdx.x + 2];
-  g1_xyzz_t acc = g1_xyzz_identity();
-  for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) fixup_take(acc, part, part_id, t, b);
-  for (uint32_t o = 32; o >= 1; o >>= 1) { g1_xyzz_t other = shfl_down_xyzz(acc, o); g1_xyzz_add_ps(acc, other); }
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz_add_ps(acc, lds[k]); store_sat_as_xyzz29(&bucket_sums[b], acc); }
+  if (A29) {
+    __shared__ g1_xyzz29_t lds29[4];
+    g1_xyzz29_t acc = g1_xyzz29_identity();
+    for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) fixup_take29(acc, part, part_id, t, b);
+    for (uint32_t o = 32; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
+    if ((threadIdx.x & 63) == 0) lds29[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz29_add(acc, lds29[k]); store_xyzz29(&bucket_sums[b], acc); }
+  } else {
+    __shared__ g1_xyzz_t lds[4];
+    g1_xyzz_t acc = g1_xyzz_identity();
+    for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) fixup_take(acc, part, part_id, t, b);
+    for (uint32_t o = 32; o >= 1; o >>= 1) { g1_xyzz_t other = shfl_down_xyzz(acc, o); g1_xyzz_add_ps(acc, other); }
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz_add_ps(acc, lds[k]); store_sat_as_xyzz29(&bucket_sums[b], acc); }
+  }
 }
 
 // ---- 6a. chunked running sums: thread j of window w covers buckets [j*K, (j+1)*K) and emits
 //          T + (j*K) * S  where S = sum B_i, T = sum (i_local + 1) B_i
-__global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {
+template <int A29> __global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {
   const uint32_t chunks_per_window = P.nb / chunk;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= chunks_per_window * P.windows) return;
   const uint32_t w = g / chunks_per_window, j = g - w * chunks_per_window;
   const g1_xyzz29_t *B = bucket_sums + (uint64_t)w * P.nb + (uint64_t)j * chunk;
+  if (A29) {
+    g1_xyzz29_t run = g1_xyzz29_identity(), T = g1_xyzz29_identity();
+    for (uint32_t i = chunk; i-- > 0;) { g1_xyzz29_add(run, load_xyzz29(&B[i])); g1_xyzz29_add(T, run); }
+    if (j != 0) {
+      const uint32_t k = j * chunk;
+      g1_xyzz29_t kS = g1_xyzz29_identity();
+      for (int bit = 31 - __clz(k); bit >= 0; bit--) { kS = g1_xyzz29_dbl(kS); if ((k >> bit) & 1) g1_xyzz29_add(kS, run); }
+      g1_xyzz29_add(T, kS);
+    }
+    store_xyzz29(reinterpret_cast<g1_xyzz29_t *>(chunk_out) + g, T);   // the 29-bit tree and Horner kernels take it from here
+    return;
+  }
   g1_xyzz_t run = g1_xyzz_identity(), T = g1_xyzz_identity();
   for (uint32_t i = chunk; i-- > 0;) { g1_xyzz_add_ps(run, load_xyzz29_as_sat(&B[i])); g1_xyzz_add_ps(T, run); }
   if (j != 0) {
@@ -450,6 +491,37 @@ __global__ void __launch_bounds__(256) k_msm_tree_sum(const g1_xyzz_t *__restric
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) { for (uint32_t k = 1; k < 4; k++) g1_xyzz_add_ps(acc, lds[k]); store_xyzz(&out[(uint64_t)w * out_per_window + blockIdx.x], acc); }
+}
+// the same tree and the Horner tail on 29-bit records (MI355_REDUCE29 path)
+__global__ void __launch_bounds__(256) k_msm_tree_sum29(const g1_xyzz29_t *__restrict__ in, uint32_t in_per_window, g1_xyzz29_t *__restrict__ out, uint32_t out_per_window) {
+  __shared__ g1_xyzz29_t lds[4];
+  const uint32_t w = blockIdx.y, first = blockIdx.x * 256 * TREE_PER_THREAD;
+  const g1_xyzz29_t *src = in + (uint64_t)w * in_per_window;
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  for (uint32_t k = 0; k < TREE_PER_THREAD; k++) { const uint32_t i = first + k * 256 + threadIdx.x; if (i < in_per_window) g1_xyzz29_add(acc, load_xyzz29(&src[i])); }
+  for (uint32_t o = 32; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (uint32_t k = 1; k < 4; k++) g1_xyzz29_add(acc, lds[k]); store_xyzz29(&out[(uint64_t)w * out_per_window + blockIdx.x], acc); }
+}
+__device__ __forceinline__ void msm_emit_result(const g1_xyzz_t &acc, g1_jac_t *out, int normalise) {
+  if (normalise) { *out = g1_xyzz_to_jac_normalised(acc); return; }
+  // un-normalised Jacobian representative (X ZZ^2, Y ZZZ^2, ZZZ): skips the inversion; used for the per-GPU partial sums, which are
+  // folded (and normalised once) by k_g1_sum
+  g1_jac_t r;
+  if (g1_xyzz_is_identity(acc)) { r.x = Fq::zero(); r.y = Fq::zero(); r.z = Fq::zero(); }
+  else { r.x = fq_mul_ps(acc.x, fq_sqr_ps(acc.zz)); r.y = fq_mul_ps(acc.y, fq_sqr_ps(acc.zzz)); r.z = acc.zzz; }
+  *out = r;
+}
+__global__ void k_msm_final29(const g1_xyzz29_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
+  if (threadIdx.x != 0) return;
+  window_sums += (uint64_t)blockIdx.x * windows; out += blockIdx.x;
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  for (uint32_t w = windows; w-- > 0;) {
+    for (uint32_t k = 0; k < c; k++) acc = g1_xyzz29_dbl(acc);
+    g1_xyzz29_add(acc, load_xyzz29(&window_sums[w]));
+  }
+  msm_emit_result(g1_xyzz29_to_sat(acc), out, normalise);
 }
 // ---- 7. Horner over windows + normalisation.  One lane; 255 doublings are inherently serial.
 __global__ void k_msm_final(const g1_xyzz_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
