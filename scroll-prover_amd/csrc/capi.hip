@@ -142,9 +142,11 @@ void resolve_spans() {
 uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 uint32_t log2_ceil(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }
 
-// measured on MI355X, in units of one bucket addition (~0.077 ns at 13 G adds/s): sort ~0.18 per entry, bucket reduction ~8.2 per bucket
-// (the reduction kernels are latency-bound serial chains, far from the ALU rate)
-double msm_cost(uint64_t n, int c, bool shared) { const double W = (255 + c - 1) / c, nb = (double)(1ull << (c - 1)); return 1.18 * W * (double)n + 8.2 * nb * (shared ? 1.0 : W); }
+// measured on MI355X, in units of one bucket addition (~0.07 ns at 14 G adds/s): sort ~0.18 per entry, bucket reduction ~8.2 per bucket
+// (fix-up, running sums, tree); without window tables the result also waits for the serial Horner tail over the windows (255 doublings
+// in one lane, ~2 ms = 3e7 units).  The ordering this model gives for c was re-checked against tools/bench_window_choice.py at the end
+// of the round (k = 18 ... 24).
+double msm_cost(uint64_t n, int c, bool shared) { const double W = (255 + c - 1) / c, nb = (double)(1ull << (c - 1)); return 1.18 * W * (double)n + 8.2 * nb * (shared ? 1.0 : W) + (shared ? 0.0 : 3.0e7); }
 
 int choose_c(uint64_t n) {
   if (g.force_c) return g.force_c;
