@@ -239,6 +239,13 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   const uint32_t big_cap = tn / FIXUP_SERIAL_MAX + 2;
   uint32_t *big_list; WS("msm.big_list", ((size_t)big_cap * 3 + 1) * 4, big_list);
   uint32_t *big_count = big_list + (size_t)big_cap * 3;
+  // buckets that span >= FIXUP_HUGE_MIN accumulate threads (at most tn / FIXUP_HUGE_MIN of them) get FIXUP_SLICES workgroups each
+  const uint32_t huge_cap = g.reduce29 ? tn / FIXUP_HUGE_MIN + 2 : 0;
+  uint32_t *huge_list = nullptr, *huge_count = nullptr; g1_xyzz29_t *huge_part = nullptr;
+  if (huge_cap) {
+    WS("msm.huge_list", ((size_t)huge_cap * 3 + 1) * 4, huge_list); huge_count = huge_list + (size_t)huge_cap * 3;
+    WS("msm.huge_part", (size_t)huge_cap * FIXUP_SLICES * sizeof(g1_xyzz29_t), huge_part);
+  }
   WS("msm.chunk_out", (size_t)nchunks * sizeof(g1_xyzz29_t), chunk_out);   // 144 B: large enough for either record form
   g1_xyzz_t *tree_a, *tree_b;
   { const size_t lvl = (size_t)ceil_div(chunks_per_window, 256 * TREE_PER_THREAD) * red_windows + 1;
@@ -299,11 +306,14 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
     HIPCHK(hipMemsetAsync(big_count, 0, 4, s));
     MsmPlan PR = P; PR.windows = red_windows;
     if (g.reduce29) {
-      hipLaunchKernelGGL(k_msm_fixup<1>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap);
+      HIPCHK(hipMemsetAsync(huge_count, 0, 4, s));
+      hipLaunchKernelGGL(k_msm_fixup<1>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap, huge_list, huge_count, huge_cap);
       hipLaunchKernelGGL(k_msm_fixup_big<1>, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
+      hipLaunchKernelGGL(k_msm_fixup_huge, dim3(huge_cap * FIXUP_SLICES), dim3(256), 0, s, part, part_id, huge_list, huge_count, huge_part);
+      hipLaunchKernelGGL(k_msm_fixup_huge_fold, dim3(huge_cap), dim3(64), 0, s, buckets, huge_list, huge_count, (const g1_xyzz29_t *)huge_part);
       hipLaunchKernelGGL(k_msm_bucket_reduce<1>, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
     } else {
-      hipLaunchKernelGGL(k_msm_fixup<0>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap);
+      hipLaunchKernelGGL(k_msm_fixup<0>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
       hipLaunchKernelGGL(k_msm_fixup_big<0>, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
       hipLaunchKernelGGL(k_msm_bucket_reduce<0>, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
     }

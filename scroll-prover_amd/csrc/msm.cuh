@@ -358,13 +358,16 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
       if (b_start >= start) store_xyzz29(&bucket_sums[b], acc);                           // began here too: sole owner
       else { store_xyzz29(&part[2 * (uint64_t)t], acc); id_first = (int32_t)b; }          // began in an earlier thread
       acc = g1_xyzz29_identity();
-      if (VARIANT & 2) {
-        b++; b_start = b_end; b_end = next_end;
-        while (pos >= b_end) { b++; b_start = b_end; b_end = offsets[b + 1]; }            // empty buckets (rare with uniform digits)
-        next_end = (b + 2 <= nbuckets) ? offsets[b + 2] : b_end;
-      } else {
-        do { b++; b_start = b_end; b_end = offsets[b + 1]; } while (pos >= b_end);
+      b++; b_start = b_end; b_end = (VARIANT & 2) ? next_end : offsets[b + 1];
+      if (pos >= b_end) {
+        // a run of empty buckets follows (low-entropy scalars: an all-equal column leaves ~2^21 / W empty buckets between two giant
+        // ones, and walking them one dependent load at a time kept a handful of lanes busy for 35 ms): binary search for the bucket
+        // that contains `pos` -- offsets[lo] <= pos < offsets[hi]
+        uint32_t l2 = b, h2 = nbuckets;
+        while (h2 - l2 > 1) { const uint32_t mid = (l2 + h2) >> 1; if (offsets[mid] <= pos) l2 = mid; else h2 = mid; }
+        b = l2; b_start = offsets[b]; b_end = offsets[b + 1];
       }
+      if (VARIANT & 2) next_end = (b + 2 <= nbuckets) ? offsets[b + 2] : b_end;
     }
     g1_xyzz29_madd(acc, p, (ent >> 31) != 0);
     ent = ent_next; if (VARIANT & 1) ent_next = ent_next2; p = p_next;
@@ -383,7 +386,7 @@ __device__ __forceinline__ fe_t shfl_down_fe(const fe_t &v, uint32_t o) { fe_t r
 __device__ __forceinline__ g1_xyzz_t shfl_down_xyzz(const g1_xyzz_t &v, uint32_t o) {
   g1_xyzz_t r; r.x = shfl_down_fe(v.x, o); r.y = shfl_down_fe(v.y, o); r.zz = shfl_down_fe(v.zz, o); r.zzz = shfl_down_fe(v.zzz, o); return r;
 }
-constexpr uint32_t FIXUP_SERIAL_MAX = 32;
+constexpr uint32_t FIXUP_SERIAL_MAX = 32, FIXUP_HUGE_MIN = 2048, FIXUP_SLICES = 16;
 __device__ __forceinline__ void fixup_take(g1_xyzz_t &acc, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t t, uint32_t b) {
   if (part_id[2 * t] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz29_as_sat(&part[2 * (uint64_t)t]));
   else if (part_id[2 * t + 1] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz29_as_sat(&part[2 * (uint64_t)t + 1]));
@@ -402,7 +405,8 @@ __device__ __forceinline__ g1_xyzz29_t shfl_down_xyzz29(const g1_xyzz29_t &v, ui
 }
 template <int A29> __global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
                                                    const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg,
-                                                   uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap) {
+                                                   uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
+                                                   uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, uint32_t huge_cap) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   const uint32_t s = offsets[b], e = offsets[b + 1];
@@ -410,6 +414,11 @@ template <int A29> __global__ void __launch_bounds__(256) k_msm_fixup(const uint
   const uint32_t t0 = s / seg, t1 = (e - 1) / seg;
   if (t0 == t1) return;  // sole owner wrote it
   if (t1 - t0 > FIXUP_SERIAL_MAX) {
+    if (huge_cap && t1 - t0 >= FIXUP_HUGE_MIN) {   // thousands of partials: several workgroups (k_msm_fixup_huge)
+      const uint32_t idx = atomicAdd(huge_count, 1u);
+      if (idx < huge_cap) { huge_list[3 * idx] = b; huge_list[3 * idx + 1] = t0; huge_list[3 * idx + 2] = t1; }
+      return;
+    }
     const uint32_t idx = atomicAdd(big_count, 1u);
     if (idx < big_cap) { big_list[3 * idx] = b; big_list[3 * idx + 1] = t0; big_list[3 * idx + 2] = t1; }
     return;
@@ -445,6 +454,31 @@ template <int A29> __global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyz
     __syncthreads();
     if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz_add_ps(acc, lds[k]); store_sat_as_xyzz29(&bucket_sums[b], acc); }
   }
+}
+// A giant bucket (an all-ones selector column puts every point into ONE bucket) spans up to a million accumulate threads: its partials
+// are summed by FIXUP_SLICES workgroups (one slice of the span each) into huge_part and folded by one wavefront.
+// grid = huge_cap * FIXUP_SLICES resp. huge_cap; at most (accumulate threads) / FIXUP_HUGE_MIN buckets can qualify.
+__global__ void __launch_bounds__(256) k_msm_fixup_huge(const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, const uint32_t *__restrict__ huge_list,
+                                                        const uint32_t *__restrict__ huge_count, g1_xyzz29_t *__restrict__ huge_part) {
+  __shared__ g1_xyzz29_t lds29[4];
+  const uint32_t idx = blockIdx.x / FIXUP_SLICES, sl = blockIdx.x - idx * FIXUP_SLICES;
+  if (idx >= *huge_count) return;
+  const uint32_t b = huge_list[3 * idx], t0 = huge_list[3 * idx + 1], t1 = huge_list[3 * idx + 2], span = t1 - t0 + 1;
+  const uint32_t lo = t0 + (uint32_t)((uint64_t)span * sl / FIXUP_SLICES), hi = t0 + (uint32_t)((uint64_t)span * (sl + 1) / FIXUP_SLICES);   // [lo, hi)
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) fixup_take29(acc, part, part_id, t, b);
+  for (uint32_t o = 32; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
+  if ((threadIdx.x & 63) == 0) lds29[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz29_add(acc, lds29[k]); store_xyzz29(&huge_part[(uint64_t)idx * FIXUP_SLICES + sl], acc); }
+}
+__global__ void __launch_bounds__(64) k_msm_fixup_huge_fold(g1_xyzz29_t *__restrict__ bucket_sums, const uint32_t *__restrict__ huge_list, const uint32_t *__restrict__ huge_count,
+                                                            const g1_xyzz29_t *__restrict__ huge_part) {
+  const uint32_t idx = blockIdx.x;
+  if (idx >= *huge_count) return;
+  g1_xyzz29_t acc = threadIdx.x < FIXUP_SLICES ? load_xyzz29(&huge_part[(uint64_t)idx * FIXUP_SLICES + threadIdx.x]) : g1_xyzz29_identity();
+  for (uint32_t o = FIXUP_SLICES / 2; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
+  if (threadIdx.x == 0) store_xyzz29(&bucket_sums[huge_list[3 * idx]], acc);
 }
 
 // ---- 6a. chunked running sums: thread j of window w covers buckets [j*K, (j+1)*K) and emits
