@@ -94,7 +94,18 @@ __global__ void __launch_bounds__(256) k_msm_digits(PolyPtrs inl, const fe_t *co
     const fe_t k = fr_mul_ps(g_load(&poly[i]), one_c);   // Montgomery -> canonical (= to_repr())
     // the scalar is consumed c bits at a time by shifting the whole 256-bit value right (8 funnel shifts per window, static
     // register indices); indexing k.l[bit >> 5] with a runtime window position would put the limbs in scratch memory
-    uint32_t l0 = k.l[0], l1 = k.l[1], l2 = k.l[2], l3 = k.l[3], l4 = k.l[4], l5 = k.l[5], l6 = k.l[6], l7 = k.l[7];
+    // k and r - k name the same term up to the sign of the point: take the smaller one.  Uniform scalars gain nothing, but the small
+    // NEGATIVE values of real witness columns (-1, -2, ...) become one-window scalars instead of 254-bit ones (an all "-1" column:
+    // 18.2 -> 3.3 ms at 2^24).
+    fe_t t; { uint32_t borrow = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { const uint64_t d = (uint64_t)FrP::mod(q) - k.l[q] - borrow; t.l[q] = (uint32_t)d; borrow = (uint32_t)(d >> 63); } }
+    bool flip = false;
+#pragma unroll
+    for (int q = 7; q >= 0; q--) { if (t.l[q] != k.l[q]) { flip = t.l[q] < k.l[q]; break; } }
+    const uint32_t sign_flip = flip ? 0x80000000u : 0u;
+    uint32_t l0 = flip ? t.l[0] : k.l[0], l1 = flip ? t.l[1] : k.l[1], l2 = flip ? t.l[2] : k.l[2], l3 = flip ? t.l[3] : k.l[3];
+    uint32_t l4 = flip ? t.l[4] : k.l[4], l5 = flip ? t.l[5] : k.l[5], l6 = flip ? t.l[6] : k.l[6], l7 = flip ? t.l[7] : k.l[7];
     uint32_t carry = 0;
     for (uint32_t w = 0; w < P.windows; w++) {
       const uint32_t raw = (l0 & mask) + carry;
@@ -102,6 +113,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(PolyPtrs inl, const fe_t *co
       l4 = __funnelshift_r(l4, l5, P.c); l5 = __funnelshift_r(l5, l6, P.c); l6 = __funnelshift_r(l6, l7, P.c); l7 >>= P.c;
       uint32_t e;
       if (raw > half) { e = (1u << P.c) - raw; if (e) e |= 0x80000000u; carry = 1; } else { e = raw; carry = 0; }   // raw == 2^c: digit 0, carry 1
+      if (e) e ^= sign_flip;
       enc[((uint64_t)m * P.windows + w) * P.n + i] = e;
       if (e) atomicAdd(&hist_lds[m * per_poly + (shared ? 0 : w * CB) + (((e & 0x7fffffffu) - 1) >> fb)], 1u);
     }
