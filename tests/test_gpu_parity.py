@@ -238,14 +238,17 @@ def test_giant_buckets_take_the_parallel_fixup(zk):
     k = 17
     params = h2.ParamsKZG.setup(k, 0xABCDEF0123)
     n = 1 << k
-    for val in (1, 2**40 + 3, pyref.R_MOD - 1):
-        sc = np.tile(h2.fr(val), (n, 1))
-        got = affine_of(params.commit(sc))
-        # sum_i val * tau^i G = val * (tau^n - 1)/(tau - 1) G
-        tau = 0xABCDEF0123
-        s = val * (pow(tau, n, R) - 1) * pow(tau - 1, -1, R) % R
-        want = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), h2.fr(s)))
-        assert (got == want).all()
+    for tables in (False, True):          # per-window bucket sets, then ONE shared set (window tables): buckets of 2^17 entries span
+        if tables:                        # thousands of accumulate threads -> the multi-workgroup fix-up (k_msm_fixup_huge) as well
+            params.precompute()
+        for val in (1, 2**40 + 3, pyref.R_MOD - 1, pyref.R_MOD - 2**70 - 9, 0x1234567890abcdef1234567890abcdef1234567890abcdef):
+            sc = np.tile(h2.fr(val), (n, 1))
+            got = affine_of(params.commit(sc))
+            # sum_i val * tau^i G = val * (tau^n - 1)/(tau - 1) G
+            tau = 0xABCDEF0123
+            s = val * (pow(tau, n, R) - 1) * pow(tau - 1, -1, R) % R
+            want = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), h2.fr(s)))
+            assert (got == want).all(), (tables, hex(val))
     params.release()
     _ = torch
 
