@@ -85,3 +85,40 @@ def test_g1_wire_codec_against_released_vkeys(zk, kat, vk, proto, npts):
     assert h2.g1_to_bytes(np.zeros(12, dtype=np.uint64)) == bytes(32) and (h2.g1_from_bytes(bytes(32)) == 0).all()
     with pytest.raises(ValueError):
         h2.g1_from_bytes((4).to_bytes(32, "little"))      # x = 4: 4^3 + 3 = 67 is not a square mod p
+
+
+def test_signed_digit_recoding_algorithm():
+    """The recoding k_msm_digits applies (restated here in integers): take the smaller of k and r - k, cut it into c-bit windows from
+    the bottom, turn raw values above 2^(c-1) into negative digits with a carry.  Properties the kernels rely on: W = ceil(255 / c)
+    windows always absorb the last carry, |digit| <= 2^(c-1) (bucket index = |digit| - 1 < 2^(c-1)), and the digits reconstruct
+    +-k (mod r) with the sign that moved to the point."""
+    import random
+    R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    rng = random.Random(2024)
+
+    def recode(k, c):
+        flip = (R - k) < k
+        v = R - k if flip else k
+        W = (255 + c - 1) // c
+        half, digits, carry = 1 << (c - 1), [], 0
+        for w in range(W):
+            raw = ((v >> (w * c)) & ((1 << c) - 1)) + carry
+            if raw > half:
+                d, carry = raw - (1 << c), 1
+            else:
+                d, carry = raw, 0
+            digits.append(-d if flip else d)
+        return digits, carry
+
+    samples = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, (R + 1) // 2, (1 << 253) - 1, (1 << 252), R >> 1, 0x1234567890abcdef1234567890abcdef1234567890abcdef]
+    samples += [rng.randrange(R) for _ in range(300)] + [rng.randrange(1 << 64) for _ in range(50)] + [R - rng.randrange(1 << 64) for _ in range(50)]
+    for c in range(2, 25):
+        for k in samples:
+            digits, carry = recode(k, c)
+            assert carry == 0, (c, hex(k))
+            assert all(abs(d) <= 1 << (c - 1) for d in digits)
+            assert sum(d << (w * c) for w, d in enumerate(digits)) % R == k % R, (c, hex(k))
+        # small negative values use ONE window once c covers them
+        if c >= 8:
+            digits, _ = recode(R - 100, c)
+            assert digits[0] == -100 and all(d == 0 for d in digits[1:])
