@@ -23,6 +23,10 @@
 
 using namespace zk;
 
+// the ABI is plain bytes: these sizes are what the Rust / C++ / Python bindings assume (halo2curves Fr 32 B, G1Affine 64 B, G1 96 B)
+static_assert(sizeof(fe_t) == 32 && sizeof(g1_affine_t) == 64 && sizeof(g1_jac_t) == 96, "ABI element sizes");
+static_assert(sizeof(g1_xyzz_t) == 128 && sizeof(g1_xyzz29_t) == 144, "device record sizes (workspace layout, 16-byte vector accesses)");
+
 namespace {
 
 thread_local std::string g_err;
