@@ -9,14 +9,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355zk.so")
 SOURCES = ["capi.hip"]
-HEADERS = ["fp.cuh", "fp_asm.cuh", "fp_asm_gen.inc", "fp29.cuh", "g1.cuh", "g1_29.cuh", "msm.cuh", "ntt.cuh", "ntt29.cuh", os.path.join("..", "..", "include", "mi355zk.h")]
+
+
+def _deps():
+    """every source the library is built from: csrc/*.hip|*.cuh|*.inc and the public header (a fixed list once missed two new headers)"""
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cuh", ".inc"))]
+    return files + [os.path.join(HERE, "..", "include", "mi355zk.h")]
 
 
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in _deps())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
