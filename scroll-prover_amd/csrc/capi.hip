@@ -82,7 +82,6 @@ struct Ctx {
   bool normalise = true;        // mi355_msm_set_normalise(0): MSM results come back as an un-normalised Jacobian representative
   uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): bit 0 nontemporal gathers, bit 1 prefetched bucket ends -- neither measurably helps
   uint32_t seg_factor = 16;
-  bool reduce29 = true;         // MI355_REDUCE29=0: fix-up, bucket reduction, tree and Horner tail on the saturated field (A/B)
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
@@ -221,7 +220,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   const uint32_t vwindows = M * P.windows;   // (polynomial, window) pairs
 
   uint32_t *enc, *hist, *offsets, *cursor, *sorted, *scan_sums, *coarse_hist, *coarse_off, *coarse_cursor, *tile_start; uint64_t *pairs;
-  g1_xyzz29_t *buckets, *part; g1_xyzz_t *chunk_out, *window_sums; int32_t *part_id;
+  g1_xyzz29_t *buckets, *part, *chunk_out, *window_sums; int32_t *part_id;
   // stage-A-only buffers are shared by all slots (the sort stages of successive chunks run one after the other on st.a)
   CHK(ws_get("msm.digits", emax * 4, (void **)&enc));
   CHK(ws_get("msm.pairs", emax * 8, (void **)&pairs));
@@ -244,14 +243,12 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   uint32_t *big_list; WS("msm.big_list", ((size_t)big_cap * 3 + 1) * 4, big_list);
   uint32_t *big_count = big_list + (size_t)big_cap * 3;
   // buckets that span >= FIXUP_HUGE_MIN accumulate threads (at most tn / FIXUP_HUGE_MIN of them) get FIXUP_SLICES workgroups each
-  const uint32_t huge_cap = g.reduce29 ? tn / FIXUP_HUGE_MIN + 2 : 0;
-  uint32_t *huge_list = nullptr, *huge_count = nullptr; g1_xyzz29_t *huge_part = nullptr;
-  if (huge_cap) {
-    WS("msm.huge_list", ((size_t)huge_cap * 3 + 1) * 4, huge_list); huge_count = huge_list + (size_t)huge_cap * 3;
-    WS("msm.huge_part", (size_t)huge_cap * FIXUP_SLICES * sizeof(g1_xyzz29_t), huge_part);
-  }
+  const uint32_t huge_cap = tn / FIXUP_HUGE_MIN + 2;
+  uint32_t *huge_list, *huge_count; g1_xyzz29_t *huge_part;
+  WS("msm.huge_list", ((size_t)huge_cap * 3 + 1) * 4, huge_list); huge_count = huge_list + (size_t)huge_cap * 3;
+  WS("msm.huge_part", (size_t)huge_cap * FIXUP_SLICES * sizeof(g1_xyzz29_t), huge_part);
   WS("msm.chunk_out", (size_t)nchunks * sizeof(g1_xyzz29_t), chunk_out);   // 144 B: large enough for either record form
-  g1_xyzz_t *tree_a, *tree_b;
+  g1_xyzz29_t *tree_a, *tree_b;
   { const size_t lvl = (size_t)ceil_div(chunks_per_window, 256 * TREE_PER_THREAD) * red_windows + 1;
     WS("msm.tree_a", lvl * sizeof(g1_xyzz29_t), tree_a); WS("msm.tree_b", lvl * sizeof(g1_xyzz29_t), tree_b); }
   WS("msm.window_sums", (size_t)red_windows * sizeof(g1_xyzz29_t), window_sums);
@@ -309,40 +306,25 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
     Scope sc("msm_reduce", s);
     HIPCHK(hipMemsetAsync(big_count, 0, 4, s));
     MsmPlan PR = P; PR.windows = red_windows;
-    if (g.reduce29) {
-      HIPCHK(hipMemsetAsync(huge_count, 0, 4, s));
-      hipLaunchKernelGGL(k_msm_fixup<1>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap, huge_list, huge_count, huge_cap);
-      hipLaunchKernelGGL(k_msm_fixup_big<1>, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
-      hipLaunchKernelGGL(k_msm_fixup_huge, dim3(huge_cap * FIXUP_SLICES), dim3(256), 0, s, part, part_id, huge_list, huge_count, huge_part);
-      hipLaunchKernelGGL(k_msm_fixup_huge_fold, dim3(huge_cap), dim3(64), 0, s, buckets, huge_list, huge_count, (const g1_xyzz29_t *)huge_part);
-      hipLaunchKernelGGL(k_msm_bucket_reduce<1>, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
-    } else {
-      hipLaunchKernelGGL(k_msm_fixup<0>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
-      hipLaunchKernelGGL(k_msm_fixup_big<0>, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
-      hipLaunchKernelGGL(k_msm_bucket_reduce<0>, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
-    }
-    if (g.reduce29) {
-      const g1_xyzz29_t *cur = (const g1_xyzz29_t *)chunk_out; uint32_t cnt = chunks_per_window; g1_xyzz29_t *bufs[2] = {(g1_xyzz29_t *)tree_a, (g1_xyzz29_t *)tree_b}; int which = 0;
+    // the whole tail runs on the 29-bit field (g1_xyzz29_add / _dbl): records are never converted to the saturated form on the way
+    HIPCHK(hipMemsetAsync(huge_count, 0, 4, s));
+    hipLaunchKernelGGL(k_msm_fixup, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap, huge_list, huge_count, huge_cap);
+    hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
+    hipLaunchKernelGGL(k_msm_fixup_huge, dim3(huge_cap * FIXUP_SLICES), dim3(256), 0, s, part, part_id, huge_list, huge_count, huge_part);
+    hipLaunchKernelGGL(k_msm_fixup_huge_fold, dim3(huge_cap), dim3(64), 0, s, buckets, huge_list, huge_count, (const g1_xyzz29_t *)huge_part);
+    hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
+    {
+      // tree-sum the chunk results per window, ping-ponging between two small buffers
+      const g1_xyzz29_t *cur = chunk_out; uint32_t cnt = chunks_per_window; g1_xyzz29_t *bufs[2] = {tree_a, tree_b}; int which = 0;
       while (true) {
         const uint32_t outn = ceil_div(cnt, 256 * TREE_PER_THREAD);
-        g1_xyzz29_t *dst = outn == 1 ? (g1_xyzz29_t *)window_sums : bufs[which];
+        g1_xyzz29_t *dst = outn == 1 ? window_sums : bufs[which];
         hipLaunchKernelGGL(k_msm_tree_sum29, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
         if (outn == 1) break;
         cur = dst; cnt = outn; which ^= 1;
       }
-      hipLaunchKernelGGL(k_msm_final29, dim3(M), dim3(64), 0, s, (const g1_xyzz29_t *)window_sums, red_wpp, shared ? 0u : P.c, out_dev, normalise ? 1 : 0);
-    } else {
-      // tree-sum the chunk results per window, ping-ponging between two small buffers
-      const g1_xyzz_t *cur = chunk_out; uint32_t cnt = chunks_per_window; g1_xyzz_t *bufs[2] = {tree_a, tree_b}; int which = 0;
-      while (true) {
-        const uint32_t outn = ceil_div(cnt, 256 * TREE_PER_THREAD);
-        g1_xyzz_t *dst = outn == 1 ? window_sums : bufs[which];
-        hipLaunchKernelGGL(k_msm_tree_sum, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
-        if (outn == 1) break;
-        cur = dst; cnt = outn; which ^= 1;
-      }
-      hipLaunchKernelGGL(k_msm_final, dim3(M), dim3(64), 0, s, window_sums, red_wpp, shared ? 0u : P.c, out_dev, normalise ? 1 : 0);
     }
+    hipLaunchKernelGGL(k_msm_final29, dim3(M), dim3(64), 0, s, (const g1_xyzz29_t *)window_sums, red_wpp, shared ? 0u : P.c, out_dev, normalise ? 1 : 0);
   }
   if (piped) HIPCHK(hipEventRecord(slot.red_done, st.c));
   slot.used = true;
@@ -675,7 +657,6 @@ int mi355_init(int device_id) {
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 3; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_FB"); if (e) { int v = atoi(e); if (v >= 9 && v <= 12) g.sort_fb = (uint32_t)v; } }
-  { const char *e = getenv("MI355_REDUCE29"); if (e) g.reduce29 = e[0] == '1'; }
   { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }

@@ -12,12 +12,12 @@
 //                       bases (64 B each) and does mixed additions.  Perfectly load-balanced for any scalar
 //                       distribution (witness columns are mostly 0/1/small values).
 //   4 k_msm_fixup(_big) buckets that straddle thread boundaries: sum their partials (one lane, or a workgroup for giant ones)
-//   5 k_msm_bucket_reduce / k_msm_tree_sum   sum_b (b+1) * B[b] by short chunked running sums, then multi-block
+//   5 k_msm_bucket_reduce / k_msm_tree_sum29   sum_b (b+1) * B[b] by short chunked running sums, then multi-block
 //                       wavefront-shuffle + LDS trees
-//   6 k_msm_final       Horner over windows (none with window tables), normalise to (x, y, 1) with a one-lane Euclidean inverse
+//   6 k_msm_final29     Horner over windows (none with window tables), normalise to (x, y, 1) with a one-lane Euclidean inverse
 //
 // A batch of M polynomials over one basis (mi355_msm_g1_batch_*) runs the same kernels once with (polynomial m, window w) as
-// window m * W + w: grid.y = m in the digits kernel, a bucket set per polynomial, M workgroups in k_msm_final.
+// window m * W + w: grid.y = m in the digits kernel, a bucket set per polynomial, M workgroups in k_msm_final29.  Steps 4-6 run on the 29-bit field as well (g1_xyzz29_add / _dbl).
 //
 // Algorithmic HBM bytes: 96 B per (scalar, point) pair.  The accumulation is VALU-integer bound
 // (10 field multiplications = ~1650 v_mad_u64_u32 + ~700 other instructions per mixed addition), see DESIGN.md section 4.
@@ -67,11 +67,6 @@ __device__ __forceinline__ g1_xyzz29_t load_xyzz29(const g1_xyzz29_t *p) {
 #pragma unroll
   for (int i = 0; i < 9; i++) { const uint4 a = q[i]; w[4 * i] = a.x; w[4 * i + 1] = a.y; w[4 * i + 2] = a.z; w[4 * i + 3] = a.w; }
   return v;
-}
-__device__ __forceinline__ g1_xyzz_t load_xyzz29_as_sat(const g1_xyzz29_t *p) { return g1_xyzz29_to_sat(load_xyzz29(p)); }
-__device__ __forceinline__ void store_sat_as_xyzz29(g1_xyzz29_t *p, const g1_xyzz_t &v) {
-  g1_xyzz29_t r; r.x = Fq29::from_sat(v.x); r.y = Fq29::from_sat(v.y); r.zz = Fq29::from_sat(v.zz); r.zzz = Fq29::from_sat(v.zzz);
-  store_xyzz29(p, r);
 }
 
 // ---- 1. digits.  Plane layout enc[w * n + i]: 0 for a zero digit, else |d| (1 .. 2^(c-1)) with bit 31 = sign.
@@ -394,17 +389,9 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
 // ---- 5. fix-up of buckets that straddle thread boundaries.  Small spans are summed by one lane; a bucket that spans more than
 //         FIXUP_SERIAL_MAX accumulate-threads (skewed scalars: zeros/ones/small values, or the short top window) is queued and
 //         reduced by a whole workgroup (wavefront-shuffle tree + LDS) in k_msm_fixup_big.
-__device__ __forceinline__ fe_t shfl_down_fe(const fe_t &v, uint32_t o) { fe_t r; for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], o); return r; }
-__device__ __forceinline__ g1_xyzz_t shfl_down_xyzz(const g1_xyzz_t &v, uint32_t o) {
-  g1_xyzz_t r; r.x = shfl_down_fe(v.x, o); r.y = shfl_down_fe(v.y, o); r.zz = shfl_down_fe(v.zz, o); r.zzz = shfl_down_fe(v.zzz, o); return r;
-}
 constexpr uint32_t FIXUP_SERIAL_MAX = 32, FIXUP_HUGE_MIN = 2048, FIXUP_SLICES = 16;
-__device__ __forceinline__ void fixup_take(g1_xyzz_t &acc, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t t, uint32_t b) {
-  if (part_id[2 * t] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz29_as_sat(&part[2 * (uint64_t)t]));
-  else if (part_id[2 * t + 1] == (int32_t)b) g1_xyzz_add_ps(acc, load_xyzz29_as_sat(&part[2 * (uint64_t)t + 1]));
-}
-// A29 = 1 (MI355_REDUCE29): the fix-up and the bucket reduction stay in the 29-bit field (g1_xyzz29_add / _dbl): no conversion of every
-// 144-byte record to the saturated form (4 multiplications each) and the faster multiplier; records then always hold valid accumulators.
+// The fix-up and the whole reduction tail stay in the 29-bit field (g1_xyzz29_add / _dbl): no conversion of the 144-byte records to the
+// saturated form (4 multiplications each) and the faster multiplier; records always hold valid accumulators (g1_29.cuh invariants).
 __device__ __forceinline__ void fixup_take29(g1_xyzz29_t &acc, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t t, uint32_t b) {
   if (part_id[2 * t] == (int32_t)b) g1_xyzz29_add(acc, load_xyzz29(&part[2 * (uint64_t)t]));
   else if (part_id[2 * t + 1] == (int32_t)b) g1_xyzz29_add(acc, load_xyzz29(&part[2 * (uint64_t)t + 1]));
@@ -415,7 +402,7 @@ __device__ __forceinline__ g1_xyzz29_t shfl_down_xyzz29(const g1_xyzz29_t &v, ui
   for (int i = 0; i < 36; i++) d[i] = __shfl_down(s[i], o);
   return r;
 }
-template <int A29> __global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
+__global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
                                                    const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg,
                                                    uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
                                                    uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, uint32_t huge_cap) {
@@ -435,37 +422,21 @@ template <int A29> __global__ void __launch_bounds__(256) k_msm_fixup(const uint
     if (idx < big_cap) { big_list[3 * idx] = b; big_list[3 * idx + 1] = t0; big_list[3 * idx + 2] = t1; }
     return;
   }
-  if (A29) {
-    g1_xyzz29_t acc = g1_xyzz29_identity();
-    for (uint32_t t = t0; t <= t1; t++) fixup_take29(acc, part, part_id, t, b);
-    store_xyzz29(&bucket_sums[b], acc);
-  } else {
-    g1_xyzz_t acc = g1_xyzz_identity();
-    for (uint32_t t = t0; t <= t1; t++) fixup_take(acc, part, part_id, t, b);
-    store_sat_as_xyzz29(&bucket_sums[b], acc);
-  }
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  for (uint32_t t = t0; t <= t1; t++) fixup_take29(acc, part, part_id, t, b);
+  store_xyzz29(&bucket_sums[b], acc);
 }
-template <int A29> __global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyzz29_t *__restrict__ bucket_sums, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id,
+__global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyzz29_t *__restrict__ bucket_sums, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id,
                                                        const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count) {
+  __shared__ g1_xyzz29_t lds29[4];
   if (blockIdx.x >= *big_count) return;
   const uint32_t b = big_list[3 * blockIdx.x], t0 = big_list[3 * blockIdx.x + 1], t1 = big_list[3 * blockIdx.x + 2];
-  if (A29) {
-    __shared__ g1_xyzz29_t lds29[4];
-    g1_xyzz29_t acc = g1_xyzz29_identity();
-    for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) fixup_take29(acc, part, part_id, t, b);
-    for (uint32_t o = 32; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
-    if ((threadIdx.x & 63) == 0) lds29[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz29_add(acc, lds29[k]); store_xyzz29(&bucket_sums[b], acc); }
-  } else {
-    __shared__ g1_xyzz_t lds[4];
-    g1_xyzz_t acc = g1_xyzz_identity();
-    for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) fixup_take(acc, part, part_id, t, b);
-    for (uint32_t o = 32; o >= 1; o >>= 1) { g1_xyzz_t other = shfl_down_xyzz(acc, o); g1_xyzz_add_ps(acc, other); }
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz_add_ps(acc, lds[k]); store_sat_as_xyzz29(&bucket_sums[b], acc); }
-  }
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) fixup_take29(acc, part, part_id, t, b);
+  for (uint32_t o = 32; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
+  if ((threadIdx.x & 63) == 0) lds29[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (uint32_t k = 1; k < (blockDim.x >> 6); k++) g1_xyzz29_add(acc, lds29[k]); store_xyzz29(&bucket_sums[b], acc); }
 }
 // A giant bucket (an all-ones selector column puts every point into ONE bucket) spans up to a million accumulate threads: its partials
 // are summed by FIXUP_SLICES workgroups (one slice of the span each) into huge_part and folded by one wavefront.
@@ -495,50 +466,25 @@ __global__ void __launch_bounds__(64) k_msm_fixup_huge_fold(g1_xyzz29_t *__restr
 
 // ---- 6a. chunked running sums: thread j of window w covers buckets [j*K, (j+1)*K) and emits
 //          T + (j*K) * S  where S = sum B_i, T = sum (i_local + 1) B_i
-template <int A29> __global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {
+__global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {
   const uint32_t chunks_per_window = P.nb / chunk;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= chunks_per_window * P.windows) return;
   const uint32_t w = g / chunks_per_window, j = g - w * chunks_per_window;
   const g1_xyzz29_t *B = bucket_sums + (uint64_t)w * P.nb + (uint64_t)j * chunk;
-  if (A29) {
-    g1_xyzz29_t run = g1_xyzz29_identity(), T = g1_xyzz29_identity();
-    for (uint32_t i = chunk; i-- > 0;) { g1_xyzz29_add(run, load_xyzz29(&B[i])); g1_xyzz29_add(T, run); }
-    if (j != 0) {
-      const uint32_t k = j * chunk;
-      g1_xyzz29_t kS = g1_xyzz29_identity();
-      for (int bit = 31 - __clz(k); bit >= 0; bit--) { kS = g1_xyzz29_dbl(kS); if ((k >> bit) & 1) g1_xyzz29_add(kS, run); }
-      g1_xyzz29_add(T, kS);
-    }
-    store_xyzz29(reinterpret_cast<g1_xyzz29_t *>(chunk_out) + g, T);   // the 29-bit tree and Horner kernels take it from here
-    return;
-  }
-  g1_xyzz_t run = g1_xyzz_identity(), T = g1_xyzz_identity();
-  for (uint32_t i = chunk; i-- > 0;) { g1_xyzz_add_ps(run, load_xyzz29_as_sat(&B[i])); g1_xyzz_add_ps(T, run); }
+  g1_xyzz29_t run = g1_xyzz29_identity(), T = g1_xyzz29_identity();
+  for (uint32_t i = chunk; i-- > 0;) { g1_xyzz29_add(run, load_xyzz29(&B[i])); g1_xyzz29_add(T, run); }
   if (j != 0) {
     const uint32_t k = j * chunk;
-    g1_xyzz_t kS = g1_xyzz_identity();
-    for (int bit = 31 - __clz(k); bit >= 0; bit--) { kS = g1_xyzz_dbl_ps(kS); if ((k >> bit) & 1) g1_xyzz_add_ps(kS, run); }
-    g1_xyzz_add_ps(T, kS);
+    g1_xyzz29_t kS = g1_xyzz29_identity();
+    for (int bit = 31 - __clz(k); bit >= 0; bit--) { kS = g1_xyzz29_dbl(kS); if ((k >> bit) & 1) g1_xyzz29_add(kS, run); }
+    g1_xyzz29_add(T, kS);
   }
-  store_xyzz(&chunk_out[g], T);
+  store_xyzz29(&chunk_out[g], T);
 }
-// ---- 6b. per window: tree-sum of the chunk results (wavefront shuffles, then LDS across waves)
 // ---- 6b. per window: tree-sum of the chunk results.  grid = (blocks, windows); a block folds up to 256 * TREE_PER_THREAD inputs
 //          (wavefront shuffles, then LDS across the 4 waves) into one output; launched repeatedly until one value per window is left.
 constexpr uint32_t TREE_PER_THREAD = 4;
-__global__ void __launch_bounds__(256) k_msm_tree_sum(const g1_xyzz_t *__restrict__ in, uint32_t in_per_window, g1_xyzz_t *__restrict__ out, uint32_t out_per_window) {
-  __shared__ g1_xyzz_t lds[4];
-  const uint32_t w = blockIdx.y, first = blockIdx.x * 256 * TREE_PER_THREAD;
-  const g1_xyzz_t *src = in + (uint64_t)w * in_per_window;
-  g1_xyzz_t acc = g1_xyzz_identity();
-  for (uint32_t k = 0; k < TREE_PER_THREAD; k++) { const uint32_t i = first + k * 256 + threadIdx.x; if (i < in_per_window) g1_xyzz_add_ps(acc, load_xyzz(&src[i])); }
-  for (uint32_t o = 32; o >= 1; o >>= 1) { g1_xyzz_t other = shfl_down_xyzz(acc, o); g1_xyzz_add_ps(acc, other); }
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) { for (uint32_t k = 1; k < 4; k++) g1_xyzz_add_ps(acc, lds[k]); store_xyzz(&out[(uint64_t)w * out_per_window + blockIdx.x], acc); }
-}
-// the same tree and the Horner tail on 29-bit records (MI355_REDUCE29 path)
 __global__ void __launch_bounds__(256) k_msm_tree_sum29(const g1_xyzz29_t *__restrict__ in, uint32_t in_per_window, g1_xyzz29_t *__restrict__ out, uint32_t out_per_window) {
   __shared__ g1_xyzz29_t lds[4];
   const uint32_t w = blockIdx.y, first = blockIdx.x * 256 * TREE_PER_THREAD;
@@ -559,6 +505,7 @@ __device__ __forceinline__ void msm_emit_result(const g1_xyzz_t &acc, g1_jac_t *
   else { r.x = fq_mul_ps(acc.x, fq_sqr_ps(acc.zz)); r.y = fq_mul_ps(acc.y, fq_sqr_ps(acc.zzz)); r.z = acc.zzz; }
   *out = r;
 }
+// ---- 7. Horner over windows + normalisation.  One lane; 255 doublings are inherently serial (none with window tables).
 __global__ void k_msm_final29(const g1_xyzz29_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
   if (threadIdx.x != 0) return;
   window_sums += (uint64_t)blockIdx.x * windows; out += blockIdx.x;
@@ -568,23 +515,6 @@ __global__ void k_msm_final29(const g1_xyzz29_t *__restrict__ window_sums, uint3
     g1_xyzz29_add(acc, load_xyzz29(&window_sums[w]));
   }
   msm_emit_result(g1_xyzz29_to_sat(acc), out, normalise);
-}
-// ---- 7. Horner over windows + normalisation.  One lane; 255 doublings are inherently serial.
-__global__ void k_msm_final(const g1_xyzz_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
-  if (threadIdx.x != 0) return;
-  window_sums += (uint64_t)blockIdx.x * windows; out += blockIdx.x;      // one block per polynomial of the batch
-  g1_xyzz_t acc = g1_xyzz_identity();
-  for (uint32_t w = windows; w-- > 0;) {
-    for (uint32_t k = 0; k < c; k++) acc = g1_xyzz_dbl_ps(acc);
-    g1_xyzz_add_ps(acc, load_xyzz(&window_sums[w]));
-  }
-  if (normalise) { *out = g1_xyzz_to_jac_normalised(acc); return; }
-  // un-normalised Jacobian representative (X ZZ^2, Y ZZZ^2, ZZZ): skips the ~380 serial multiplications of the inversion; used for the
-  // per-GPU partial sums, which are folded (and normalised once) by k_g1_sum
-  g1_jac_t r;
-  if (g1_xyzz_is_identity(acc)) { r.x = Fq::zero(); r.y = Fq::zero(); r.z = Fq::zero(); }
-  else { r.x = fq_mul_ps(acc.x, fq_sqr_ps(acc.zz)); r.y = fq_mul_ps(acc.y, fq_sqr_ps(acc.zzz)); r.z = acc.zzz; }
-  *out = r;
 }
 // sum of n Jacobian points (fold of per-GPU partial results), normalised
 __global__ void k_g1_sum(const g1_jac_t *__restrict__ pts, uint32_t n, g1_jac_t *__restrict__ out) {
