@@ -53,6 +53,30 @@ def test_no_gpu_means_loud_failure_not_fallback(zk):
         zk.halo2.best_multiexp(sc, bs)
     with pytest.raises(zk.Mi355Error):
         zk.init(0)
+    # every compute entry point added later in the round fails the same way (no silent CPU path anywhere)
+    import ctypes as C
+    capi, ptr = zk._capi, zk._capi.ptr
+    h, k = C.c_uint64(), C.c_uint32()
+    arr = (C.c_void_p * 1)(sc.ctypes.data)
+    jac = np.zeros((4, 12), dtype=np.uint64)
+    calls = [
+        lib.mi355_msm_g1_batch_host(1, 0, arr, 1, 4, ptr(out)),
+        lib.mi355_msm_g1_batch_dev(1, 0, arr, 1, 4, ptr(out)),
+        lib.mi355_msm_g1_dev_async(1, 0, ptr(sc), 4, ptr(out)),
+        lib.mi355_g1_sum_dev(ptr(jac), 4, ptr(out)),
+        lib.mi355_g1_fft_host(ptr(jac), 2, ptr(sc[0])),
+        lib.mi355_g_to_lagrange_dev(ptr(bs), ptr(bs), 2, ptr(sc[0]), ptr(sc[1])),
+        lib.mi355_srs_downsize(1, 1, ptr(sc[0]), ptr(sc[1]), C.byref(h)),
+        lib.mi355_srs_read_host(1, 0, 1, ptr(bs)),
+        lib.mi355_srs_load_params_file(b"/nonexistent", 0, C.byref(k), C.byref(h), C.byref(h), None, None),
+        lib.mi355_fr_batch_invert_dev(ptr(sc), 4),
+        lib.mi355_fr_prefix_product_dev(ptr(sc), ptr(sc), 4, None),
+        lib.mi355_fr_kate_division_dev(ptr(sc), ptr(sc), 4, ptr(sc[0])),
+        lib.mi355_fr_vec_axpy_dev(ptr(sc), ptr(sc), ptr(sc), ptr(sc[0]), 4),
+        lib.mi355_eval_polynomial_host(ptr(sc), 4, ptr(sc[0]), ptr(sc[1])),
+        lib.mi355_srs_register_host(ptr(bs), 4, C.byref(h)),
+    ]
+    assert all(rc == capi.ENODEVICE for rc in calls), calls
 
 
 def test_missing_library_raises(zk, monkeypatch):
