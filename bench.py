@@ -139,9 +139,6 @@ def main() -> None:
 
     out = np.zeros(12, dtype=np.uint64)
 
-    if world > 1:
-        check(lib.mi355_msm_set_normalise(0))   # per-GPU partial sums are folded (and normalised once) after the all-gather
-
     def local_msm():
         check(lib.mi355_msm_g1_dev(handle.value, 0, ptr(scalars), n, ptr(out)))
         return out

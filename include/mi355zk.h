@@ -26,8 +26,14 @@
  * library: without a usable gfx950 device every compute entry point fails with MI355_ENODEVICE and the
  * caller (the Rust shim) decides what to do.
  *
- * Threading: one device per process (one process per GPU); entry points are serialised by an
- * internal mutex and may be called from any thread.
+ * Threading: entry points are serialised by an internal mutex and may be called from any thread (rayon workers): the bound device
+ * is re-selected on the calling thread.  The MSM options (mi355_msm_set_normalise / _set_window_bits) are per calling THREAD.
+ *
+ * Devices: mi355_init(id) binds one device (one process per GPU).  mi355_init_multi(ids, n) binds n devices to ONE process -- the shape
+ * of the reference, where one prover process holds one params_map [REF integration/src/prove.rs:11-21]: registered bases are then
+ * sharded by point range over the devices, every MSM entry point fans out behind the same signature, the per-device partial sums are
+ * exchanged with one ncclAllGather (RCCL over xGMI) and folded on the first device.  NTTs and all other entry points run on
+ * the first device (replicas only at k <= 26).
  */
 #ifndef MI355ZK_H
 #define MI355ZK_H
@@ -46,6 +52,13 @@ extern "C" {
 /* ---- lifecycle ------------------------------------------------------------------------------------------- */
 /* Bind this process to HIP device `device_id` (ordinal within HIP_VISIBLE_DEVICES) and create the stream.    */
 int mi355_init(int device_id);
+/* SURVEY 8b's `mi355_init(const int *device_ids, int n_devices)`: bind n_devices (1..16) devices to this process, create one RCCL
+ * communicator over them (ncclCommInitAll; librccl.so.1 is loaded on demand, MI355_ERCCL if that fails) and enable peer access.
+ * device_ids[0] is the primary device.  Listing one physical device twice is a TEST mode (needs MI355_ALLOW_DUP_DEVICES=1: a one-GPU box
+ * can then run the N = 2 control flow with real kernels; the exchange becomes a device copy because no communicator can span one device
+ * twice).  MI355_MULTI_FORCE=1 sends even a one-device MSM through the partial + exchange + fold path (a real one-rank ncclAllGather).   */
+int mi355_init_multi(const int *device_ids, int n_devices);
+int mi355_device_count(int *n_out);
 int mi355_shutdown(void);
 const char *mi355_last_error(void);
 const char *mi355_version(void);
@@ -68,6 +81,10 @@ int mi355_srs_register_dev(const void *bases_affine_dev, uint64_t n, int copy, u
  * flags bit 0: validate every point on the device (identity, or reduced coordinates on y^2 = x^3 + 3 -- the check SerdeFormat::RawBytes
  * makes on the CPU and RawBytesUnchecked skips).  g2_out / s_g2_out (optional, 128 B each) receive the two G2 points untouched.     */
 int mi355_srs_load_params_file(const char *path, uint32_t flags, uint32_t *k_out, uint64_t *g_handle_out, uint64_t *g_lagrange_handle_out, void *g2_out, void *s_g2_out);
+/* `&params.g[..n]` as a handle of its own (ParamsKZG::downsize keeps g[..2^k]; load_params_map clones + downsizes
+ * [REF integration/tests/integration.rs:17-22]): the first n points of `parent_handle`, SHARING its device memory and window tables --
+ * no copy, no second 48 GiB table.  Handles that share memory may be released in any order; the last one frees it.                 */
+int mi355_srs_register_prefix(uint64_t parent_handle, uint64_t n, uint64_t *handle_out);
 int mi355_srs_release(uint64_t handle);
 /* Optional, once per basis: build T[w][i] = 2^(c w) * P_i (w < W = ceil(255 / c), affine, W * n * 64 B of HBM) so that all
  * windows of an MSM on this basis share ONE bucket set: no per-window Horner (255 serial doublings), W x fewer bucket
@@ -100,10 +117,10 @@ int mi355_msm_g1_adhoc_host(const void *bases_affine_host, const void *scalars_h
 /* sum of `n` G1 (Jacobian, any representative) points: the fold `results.iter().fold(identity, |a, b| a + b)` of
  * best_multiexp, used to combine per-GPU partial sums after the RCCL all-gather.                  */
 int mi355_g1_sum_host(const void *g1_points_host, uint64_t n, void *out_g1_host);
-/* normalise = 0: subsequent MSM results are SOME Jacobian representative of the sum (as best_multiexp's C::Curve is) instead of the
+/* (per calling thread) normalise = 0: subsequent MSM results are SOME Jacobian representative of the sum (as best_multiexp's C::Curve is) instead of the
  * normalised one; saves the serial field inversion (~0.4 ms) where the result is folded again anyway (per-GPU partial sums).      */
 int mi355_msm_set_normalise(int on);
-/* tuning: window bits c for subsequent MSMs (0 = automatic from n)                                             */
+/* tuning (per calling thread): window bits c for subsequent MSMs (0 = automatic from n)                        */
 int mi355_msm_set_window_bits(int c);
 /* pipelined schedule of a large single MSM: the point range is cut into `chunks` slices and the (memory-bound) sort of slice k + 1
  * runs under the (ALU-bound) accumulation of slice k on separate HIP streams; results are identical.  Off by default (measured
@@ -186,8 +203,11 @@ int mi355_profile_enable(int on);
  * accumulated milliseconds and launch count since the last mi355_profile_reset().                             */
 int mi355_profile_get(const char *name, double *ms_out, uint64_t *launches_out);
 int mi355_profile_reset(void);
-/* (c, windows, entries) chosen by the last MSM, for G1-adds accounting                                        */
+/* (c, windows, entries) chosen by the last MSM (on the primary device), for G1-adds accounting                 */
 int mi355_msm_last_plan(int *c_out, int *windows_out, uint64_t *entries_out);
+/* how the last MSM ran: device slots that took part; the exchange: "none" | "rccl_allgather" | "device_copy" (static string); whether the
+ * window tables (one shared bucket set) were used on the primary device; point-range slices of the host-pointer path (1 = one copy)  */
+int mi355_msm_last_run(int *devices_out, const char **exchange_out, int *shared_tables_out, int *host_slices_out);
 
 /* test hook: copy `bytes` of the internal workspace buffer `role` (e.g. "msm.offsets", "msm.sorted") to the host   */
 int mi355_debug_ws_read(const char *role, uint64_t offset, void *dst_host, uint64_t bytes);

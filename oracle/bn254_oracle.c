@@ -290,6 +290,19 @@ void orc_best_multiexp(g1j *out, const fe *coeffs, const g1a *bases, uint64_t n,
   } else { g1j acc; g1j_set_identity(&acc); multiexp_serial(coeffs, bases, n, &acc); *out = acc; }
 }
 
+/* test-input generator (no reference counterpart): out[i] = scalars[i] * G as affine points, split over threads.  Gives the parity
+ * tests 2^20 independent curve points in seconds (BASELINE config #2: "2^20 random scalars/points"). */
+typedef struct { g1a *o; const fe *s; uint64_t n; } gen_job;
+static void *gen_worker(void *arg) { gen_job *j = (gen_job *)arg; g1a gen; orc_g1_generator(&gen); for (uint64_t i = 0; i < j->n; i++) { g1j t; orc_g1_mul(&t, &gen, &j->s[i]); g1j_to_affine(&j->o[i], &t); } return NULL; }
+void orc_g1_mul_generator_vec(g1a *out, const fe *scalars_mont, uint64_t n, int num_threads) {
+  if (num_threads < 1) num_threads = 1;
+  if ((uint64_t)num_threads > n) num_threads = n ? (int)n : 1;
+  gen_job *jobs = (gen_job *)malloc(num_threads * sizeof(gen_job)); pthread_t *th = (pthread_t *)malloc(num_threads * sizeof(pthread_t));
+  for (int k = 0; k < num_threads; k++) { uint64_t s = n * k / num_threads, e = n * (k + 1) / num_threads; jobs[k].o = out + s; jobs[k].s = scalars_mont + s; jobs[k].n = e - s; pthread_create(&th[k], NULL, gen_worker, &jobs[k]); }
+  for (int k = 0; k < num_threads; k++) pthread_join(th[k], NULL);
+  free(jobs); free(th);
+}
+
 /* ------------------------------------------------------------------ NTT ------ */
 /* definitional oracle: a'[i] = sum_j a[j] * omega^(i j), O(n^2) */
 void orc_dft_naive(fe *out, const fe *a, uint64_t n, const fe *omega) {

@@ -109,6 +109,13 @@ def g1_mul(p, s_mont):
     o = np.zeros(12, dtype=np.uint64); lib().orc_g1_mul(_p(o), _p(np.ascontiguousarray(p)), _p(np.ascontiguousarray(s_mont))); return o
 
 
+def g1_mul_generator_vec(scalars, threads: int | None = None):
+    """[n,8] affine points scalars[i] * G (threaded test-input generator)."""
+    threads = threads or os.cpu_count() or 1
+    s = np.ascontiguousarray(scalars); o = np.zeros((s.shape[0], 8), dtype=np.uint64)
+    lib().orc_g1_mul_generator_vec(_p(o), _p(s), C.c_uint64(s.shape[0]), C.c_int(threads)); return o
+
+
 def g1_add(p, q):
     o = np.zeros(12, dtype=np.uint64); lib().orc_g1_add(_p(o), _p(np.ascontiguousarray(p)), _p(np.ascontiguousarray(q))); return o
 

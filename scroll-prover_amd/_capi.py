@@ -13,6 +13,8 @@ _vp, _u64, _u32, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
 # name -> (restype, argtypes): one row per symbol of include/mi355zk.h (tests/test_capi_symbols.py cross-checks the header)
 SIGNATURES = {
     "mi355_init": (_int, [_int]),
+    "mi355_init_multi": (_int, [C.POINTER(_int), _int]),
+    "mi355_device_count": (_int, [C.POINTER(_int)]),
     "mi355_shutdown": (_int, []),
     "mi355_last_error": (C.c_char_p, []),
     "mi355_version": (C.c_char_p, []),
@@ -21,6 +23,7 @@ SIGNATURES = {
     "mi355_synchronize": (_int, []),
     "mi355_srs_register_host": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "mi355_srs_register_dev": (_int, [_vp, _u64, _int, C.POINTER(_u64)]),
+    "mi355_srs_register_prefix": (_int, [_u64, _u64, C.POINTER(_u64)]),
     "mi355_srs_release": (_int, [_u64]),
     "mi355_srs_precompute": (_int, [_u64, _u64, _int]),
     "mi355_srs_pre_dev_ptr": (_int, [_u64, C.POINTER(_vp), C.POINTER(_int), C.POINTER(_int)]),
@@ -68,6 +71,7 @@ SIGNATURES = {
     "mi355_profile_reset": (_int, []),
     "mi355_debug_ws_read": (_int, [C.c_char_p, _u64, _vp, _u64]),
     "mi355_msm_last_plan": (_int, [C.POINTER(_int), C.POINTER(_int), C.POINTER(_u64)]),
+    "mi355_msm_last_run": (_int, [C.POINTER(_int), C.POINTER(C.c_char_p), C.POINTER(_int), C.POINTER(_int)]),
 }
 
 
@@ -108,9 +112,15 @@ def check(rc: int) -> None:
 _initialised = False
 
 
-def init(device_id: int = 0) -> None:
+def init(device_id=0) -> None:
+    """device_id: an int (one process per GPU) or a list of ints (mi355_init_multi: several devices behind one process)."""
     global _initialised
-    check(lib().mi355_init(device_id))
+    if isinstance(device_id, (list, tuple)):
+        ids = (C.c_int * len(device_id))(*device_id)
+        check(lib().mi355_init_multi(ids, len(device_id)))
+        device_id = device_id[0]
+    else:
+        check(lib().mi355_init(device_id))
     _initialised = True
     # device-resident operands come from torch: run the library on torch's current stream so that kernels are ordered
     # with the tensor producers/consumers (the host-pointer ABI used by the Rust shim is synchronous and unaffected)

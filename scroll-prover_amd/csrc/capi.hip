@@ -9,8 +9,11 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <memory>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -43,7 +46,16 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
   } while (0)
 #define CHK(expr) do { int _r = (expr); if (_r != MI355_OK) return _r; } while (0)
 
-struct Srs { g1_affine_t *dev = nullptr; uint64_t n = 0; bool owned = false; g1_affine_t *pre = nullptr; int pre_c = 0, pre_w = 0; };
+// A registered basis.  One device: ONE shard holding all n points.  mi355_init_multi with D devices: shard d = points [lo, lo + n) on device slot d
+// (fixed point-range shards); window tables are per shard (row stride = shard length).  The device memory (SrsMem) is shared
+// between a handle and its prefix views (mi355_srs_register_prefix) and freed with the last of them.
+struct Shard { int slot = 0; uint64_t lo = 0, n = 0; g1_affine_t *dev = nullptr; bool owned = false; };
+void free_shards(std::vector<Shard> &sh);
+struct SrsMem { std::vector<Shard> sh; ~SrsMem() { free_shards(sh); } };
+// window tables T[w][i] = 2^(c w) P_i, one allocation per shard (pre[i] belongs to shard i of the basis, rows `stride[i]` points apart).
+// A prefix view starts out sharing its parent's tables and gets private ones only when a much smaller n calls for another window width.
+struct SrsTables { std::vector<g1_affine_t *> pre; std::vector<uint64_t> stride; std::vector<int> slot; int c = 0, w = 0; ~SrsTables(); };
+struct Srs { uint64_t n = 0; std::shared_ptr<SrsMem> mem; std::shared_ptr<SrsTables> tab; };
 struct Buf { void *p = nullptr; size_t cap = 0; };
 struct NttPlan {
   uint32_t log_n = 0, levels = 0, log_m[3] = {0, 0, 0};
@@ -58,9 +70,18 @@ struct Prof { double ms = 0; uint64_t launches = 0; };
 
 struct MsmSlot { int id = 0; hipEvent_t sorted = nullptr, acc_done = nullptr, red_done = nullptr; bool used = false; };   // per-chunk buffers + events of the pipelined MSM
 
+struct Span { std::string name; hipEvent_t a, b; };
 struct Ctx {
-  std::mutex mu;
   bool inited = false;
+  int slot = 0;                 // index in g_ctx (0 = primary)
+  std::vector<Span> spans;      // profiling: (name, start, stop) event pairs resolved after the stream is idle
+  g1_jac_t *xchg_send = nullptr, *xchg_recv = nullptr;   // multi-device exchange: this device's 96-byte partial / the gathered D x 96 bytes
+  void *comm = nullptr;         // ncclComm_t of this device (mi355_init_multi with distinct devices)
+  hipEvent_t ev_xchg = nullptr;
+  // host-pointer MSM: chunked copy on its own stream, overlapped with the digit extraction (msm_host_single)
+  hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr};
+  void *pin_ring = nullptr; size_t pin_ring_bytes = 0;
+  uint32_t host_chunks = 8;     // MI355_HOST_CHUNKS
   int device = -1;
   hipDeviceProp_t prop;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -71,15 +92,11 @@ struct Ctx {
   uint32_t msm_chunks = 1;       // MI355_MSM_CHUNKS / mi355_msm_set_pipeline (off by default: measured slower)
   uint32_t msm_chunk_min_log = 23;
   int last_chunks = 1;
-  std::unordered_map<uint64_t, Srs> srs;
-  uint64_t next_handle = 1;
   std::map<std::string, Buf> ws;           // grow-only workspace arena, keyed by role
   std::map<std::string, NttPlan> ntt_plans;  // key = log_n | omega bytes
   g1_affine_t *fixed_base_table = nullptr;
-  int force_c = 0;
   uint32_t sort_t2 = 0;         // MI355_SORT_T2 = 8192 | 16384 (0: by size)
   uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
-  bool normalise = true;        // mi355_msm_set_normalise(0): MSM results come back as an un-normalised Jacobian representative
   uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): bit 0 nontemporal gathers, bit 1 prefetched bucket ends -- neither measurably helps
   uint32_t seg_factor = 16;
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
@@ -91,15 +108,59 @@ struct Ctx {
   bool profiling = false;
   bool trace = false;           // MI355_TRACE=1: one stderr line per MSM / NTT call (host wall time; device transforms are synchronised for it)
   std::map<std::string, Prof> prof;
-  int last_c = 0, last_w = 0; uint64_t last_entries = 0;
-} g;
+  int last_c = 0, last_w = 0; uint64_t last_entries = 0; bool last_shared = false; int last_host_slices = 1;
+};
+
+// One context per bound device; slot 0 is the primary (every single-device entry point runs there).  All entry points are serialised by
+// g_mu.  `g` names the context the CURRENT THREAD works on: the API thread after need_init() (primary), or one of the per-device worker
+// threads of a sharded MSM (msm_multi), which is why the pointer is thread-local.
+constexpr int MAX_DEV = 16;
+std::mutex g_mu;
+Ctx g_ctx[MAX_DEV];
+int g_ndev = 0;
+bool g_dup_devices = false;     // test mode: the same physical device bound to several slots (exchange by device copies instead of RCCL)
+bool g_force_exchange = false;  // MI355_MULTI_FORCE=1: take the sharded path (partials + exchange + fold) even with one device
+thread_local Ctx *g_cur = &g_ctx[0];
+#define g (*g_cur)
+std::unordered_map<uint64_t, Srs> g_srs;
+uint64_t g_next_handle = 1;
+int g_last_devices = 1; const char *g_last_exchange = "none";
+
+// per-THREAD MSM options (mi355_msm_set_normalise / _set_window_bits): a rayon worker that asks for un-normalised partial sums must not
+// change what another worker's commit returns (SURVEY 8b "Threading")
+struct MsmOpts { bool normalise = true; int force_c = 0; };
+thread_local MsmOpts t_opts;
+
+void use_ctx(int slot) { g_cur = &g_ctx[slot]; }
+void free_shards(std::vector<Shard> &sh) {
+  for (auto &x : sh) {
+    if (x.slot < g_ndev && g_ctx[x.slot].inited) (void)hipSetDevice(g_ctx[x.slot].device);
+    if (x.owned && x.dev) (void)hipFree(x.dev);
+    x.dev = nullptr;
+  }
+  sh.clear();
+}
+SrsTables::~SrsTables() {
+  for (size_t i = 0; i < pre.size(); i++) if (pre[i]) {
+    if (slot[i] < g_ndev && g_ctx[slot[i]].inited) { (void)hipSetDevice(g_ctx[slot[i]].device); (void)hipStreamSynchronize(g_ctx[slot[i]].stream); }
+    (void)hipFree(pre[i]);
+  }
+}
+// signed-digit recoding of min(k, r - k) < 2^253: W = ceil(254 / c) windows always absorb the carry of the top digit (253 bits of
+// magnitude + 1); c <= 24 is the sorter's key range (23 bucket bits = 12 fine + 11 coarse)
+constexpr int MSM_SCALAR_BITS = 255, MSM_MAX_C = 22;
 
 // Every compute entry point starts here.  The HIP current device is per host thread and calls arrive from whichever thread runs
 // create_proof (rayon workers included, SURVEY 8b "Threading"), so the bound device is re-selected on the calling thread each time.
-int need_init() {
-  if (!g.inited) return fail(MI355_ENODEVICE, "mi355_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)");
+int bind_ctx(int slot) {
+  use_ctx(slot);
   if (hipSetDevice(g.device) != hipSuccess) { (void)hipGetLastError(); return fail(MI355_EHIP, "hipSetDevice failed on the calling thread"); }
   return MI355_OK;
+}
+int need_init() {
+  use_ctx(0);
+  if (g_ndev == 0 || !g.inited) return fail(MI355_ENODEVICE, "mi355_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)");
+  return bind_ctx(0);
 }
 
 // MI355_TRACE: per-call counters for the integrator (metrics / logging)
@@ -124,21 +185,19 @@ int ws_get(const char *role, size_t bytes, void **out) {
   *out = b.p; return MI355_OK;
 }
 
-// ---- profiling: a list of (name, start, stop) event pairs resolved after the stream is idle
-struct Span { std::string name; hipEvent_t a, b; };
-std::vector<Span> g_spans;
+// ---- profiling: a list of (name, start, stop) event pairs per context, resolved after the stream is idle
 struct Scope {
   bool on; hipEvent_t a = nullptr, b = nullptr; std::string name; hipStream_t st;
   Scope(const char *n, hipStream_t s = nullptr) : on(g.profiling), name(n), st(s ? s : g.stream) { if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); } }
-  void close() { if (on) { (void)hipEventRecord(b, st); g_spans.push_back({name, a, b}); on = false; } }
+  void close() { if (on) { (void)hipEventRecord(b, st); g.spans.push_back({name, a, b}); on = false; } }
   ~Scope() { close(); }
 };
 void resolve_spans() {
-  if (g_spans.empty()) return;
-  hipStreamSynchronize(g.stream);
-  for (int i = 0; i < 2; i++) if (g.aux_stream[i]) hipStreamSynchronize(g.aux_stream[i]);
-  for (auto &s : g_spans) { float ms = 0; hipEventElapsedTime(&ms, s.a, s.b); Prof &p = g.prof[s.name]; p.ms += ms; p.launches++; hipEventDestroy(s.a); hipEventDestroy(s.b); }
-  g_spans.clear();
+  if (g.spans.empty()) return;
+  (void)hipStreamSynchronize(g.stream);
+  for (int i = 0; i < 2; i++) if (g.aux_stream[i]) (void)hipStreamSynchronize(g.aux_stream[i]);
+  for (auto &s : g.spans) { float ms = 0; (void)hipEventElapsedTime(&ms, s.a, s.b); Prof &p = g.prof[s.name]; p.ms += ms; p.launches++; (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  g.spans.clear();
 }
 
 // ------------------------------------------------------------------------------------------------ MSM
@@ -149,13 +208,13 @@ uint32_t log2_ceil(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; re
 // (fix-up, running sums, tree); without window tables the result also waits for the serial Horner tail over the windows (255 doublings
 // in one lane, ~2 ms = 3e7 units).  The ordering this model gives for c was re-checked against tools/bench_window_choice.py at the end
 // of the round (k = 18 ... 24).
-double msm_cost(uint64_t n, int c, bool shared) { const double W = (255 + c - 1) / c, nb = (double)(1ull << (c - 1)); return 1.18 * W * (double)n + 8.2 * nb * (shared ? 1.0 : W) + (shared ? 0.0 : 3.0e7); }
+double msm_cost(uint64_t n, int c, bool shared) { const double W = (MSM_SCALAR_BITS + c - 1) / c, nb = (double)(1ull << (c - 1)); return 1.18 * W * (double)n + 8.2 * nb * (shared ? 1.0 : W) + (shared ? 0.0 : 3.0e7); }
 
 int choose_c(uint64_t n) {
-  if (g.force_c) return g.force_c;
+  if (t_opts.force_c) return t_opts.force_c;
   double best = 1e300; int best_c = 8;
-  for (int c = 4; c <= 22; c++) {
-    const double W = (255 + c - 1) / c, nb = (double)(1ull << (c - 1));
+  for (int c = 4; c <= MSM_MAX_C; c++) {
+    const double W = (MSM_SCALAR_BITS + c - 1) / c, nb = (double)(1ull << (c - 1));
     if (W * nb * sizeof(g1_xyzz29_t) > 6.0e9) continue;
     const double cost = msm_cost(n, c, false);
     if (cost < best) { best = cost; best_c = c; }
@@ -165,10 +224,68 @@ int choose_c(uint64_t n) {
 
 struct PreTable { const g1_affine_t *table = nullptr; uint64_t row_stride = 0; int c = 0, w = 0; };   // table already offset to the slice start
 
-int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre, void *out_dev_user = nullptr);
+int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre, void *out_dev_user = nullptr, bool accumulate_plan = false);
 
 int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void *out_host, const PreTable *pre = nullptr) {
   return msm_batch_impl(bases, &scalars, 1, n, out_host, pre);
+}
+
+// The shape of one MSM pass -- window bits, table use, sorter key split, entry / bucket counts -- derived in ONE place for the launch code
+// (msm_enqueue) and for the batch splitter (msm_batch_impl), which must agree on what fits.
+struct MsmShape { bool shared; uint32_t c, W, fb, cb_bits, regions; uint64_t emax, nbuckets; };
+int msm_shape(uint64_t n, uint32_t M, const PreTable *pre, MsmShape &o, const MsmShape *forced = nullptr) {
+  if (forced) { o.c = forced->c; o.shared = forced->shared; }
+  else {
+    o.c = (uint32_t)choose_c(n);
+    // precomputed rows 2^(c w) P available and cheaper than the per-window schedule at this n -> all windows share one bucket set
+    o.shared = pre && pre->table && !t_opts.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)o.c, false) && ((uint64_t)pre->w << log2_ceil(n)) < (1ull << 31);
+    if (o.shared) o.c = (uint32_t)pre->c;
+  }
+  o.W = (MSM_SCALAR_BITS + o.c - 1) / o.c;
+  o.emax = (uint64_t)M * n * o.W;
+  const uint32_t kb = o.c - 1; uint32_t fb = kb < g.sort_fb ? kb : g.sort_fb; if (kb - fb > 11) fb = kb - 11;
+  o.fb = fb; o.cb_bits = kb - fb;
+  const uint64_t sets = (uint64_t)M * (o.shared ? 1 : o.W);
+  o.nbuckets = sets << kb;
+  const uint64_t regions = sets << o.cb_bits; o.regions = (uint32_t)std::min<uint64_t>(regions, 0xffffffffu);
+  if (o.emax >= (1ull << 32)) return fail(MI355_EBADARG, "msm: n * windows must be < 2^32");
+  if (o.nbuckets >= (1ull << 31)) return fail(MI355_EBADARG, "msm: too many buckets (split the batch)");
+  if (regions * 4 > 48 * 1024) return fail(MI355_EBADARG, "msm: batch too large for the coarse histogram (split the batch)");
+  if (o.fb > 12 || (1u << o.cb_bits) > SORT_MAX_BINS) return fail(MI355_EBADARG, "msm: window bits out of range for the sorter");
+  return MI355_OK;
+}
+
+// The reduction tail of one MSM pass: sum_b (b + 1) B[b] per bucket set by short chunked running sums, a multi-block tree per set, the
+// Horner over windows (none with window tables) and the normalisation.  Runs entirely on the 29-bit field.
+int msm_reduce_tail(const MsmShape &sh, uint32_t M, const g1_xyzz29_t *buckets, g1_jac_t *out_dev, bool normalise, hipStream_t s, const std::string &sfx) {
+  auto role = [&](const char *r) { return std::string(r) + sfx; };
+  const uint32_t nb = 1u << (sh.c - 1), red_wpp = sh.shared ? 1 : sh.W, red_windows = M * red_wpp;
+  // running-sum chunk per reduce thread: every thread is one serial chain of 2*chunk additions plus a ~(c-1)-bit scalar multiple, so the
+  // chain is kept short (the kernel is latency-bound) as long as there are enough buckets to give the GPU ~128k chains (measured at 2^21 buckets: 2.58 ms with 256k chains of 8 buckets, 2.11 ms with 128k of 16, 2.63 ms with 64k of 32)
+  uint32_t chunk = 64; while (chunk > nb) chunk >>= 1;
+  while (chunk > 8 && (uint64_t)(nb / chunk) * red_windows < g.reduce_chains) chunk >>= 1;
+  const uint32_t chunks_per_window = nb / chunk, nchunks = chunks_per_window * red_windows;
+  g1_xyzz29_t *chunk_out, *tree_a, *tree_b, *window_sums;
+  CHK(ws_get(role("msm.chunk_out").c_str(), (size_t)nchunks * sizeof(g1_xyzz29_t), (void **)&chunk_out));
+  { const size_t lvl = (size_t)ceil_div(chunks_per_window, 256 * TREE_PER_THREAD) * red_windows + 1;
+    CHK(ws_get(role("msm.tree_a").c_str(), lvl * sizeof(g1_xyzz29_t), (void **)&tree_a)); CHK(ws_get(role("msm.tree_b").c_str(), lvl * sizeof(g1_xyzz29_t), (void **)&tree_b)); }
+  CHK(ws_get(role("msm.window_sums").c_str(), (size_t)red_windows * sizeof(g1_xyzz29_t), (void **)&window_sums));
+  MsmPlan PR; PR.n = 0; PR.c = sh.c; PR.windows = red_windows; PR.nb = nb; PR.seg = 0; PR.batch = M;
+  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
+  {
+    // tree-sum the chunk results per window, ping-ponging between two small buffers
+    const g1_xyzz29_t *cur = chunk_out; uint32_t cnt = chunks_per_window; g1_xyzz29_t *bufs[2] = {tree_a, tree_b}; int which = 0;
+    while (true) {
+      const uint32_t outn = ceil_div(cnt, 256 * TREE_PER_THREAD);
+      g1_xyzz29_t *dst = outn == 1 ? window_sums : bufs[which];
+      hipLaunchKernelGGL(k_msm_tree_sum29, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
+      if (outn == 1) break;
+      cur = dst; cnt = outn; which ^= 1;
+    }
+  }
+  hipLaunchKernelGGL(k_msm_final29, dim3(M), dim3(64), 0, s, (const g1_xyzz29_t *)window_sums, red_wpp, sh.shared ? 0u : sh.c, out_dev, normalise ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
 }
 
 // One MSM (or one chunk of a pipelined MSM) enqueued on three streams: st.a digits + sort (HBM-bound), st.b bucket accumulation
@@ -177,50 +294,42 @@ int msm_dev_impl(const g1_affine_t *bases, const fe_t *scalars, uint64_t n, void
 // per-call fixed costs (launches, the latency-bound reduction tail) are paid once per batch.  out_dev: M x 96 B, device.
 struct MsmStreams { hipStream_t a, b, c; };
 
+// forced: take (c, shared) from a shape computed for another length (the slices of a host-chunked MSM must agree on the bucket layout);
+// set_index / set_count: this pass fills bucket set `set_index` of `set_count` (each nbuckets records); skip_tail: stop after the fix-up
+// (the caller folds the sets and runs msm_reduce_tail once).
 int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const *polys_dev, uint32_t M, uint64_t n, g1_jac_t *out_dev, const PreTable *pre, MsmSlot &slot,
-                const MsmStreams &st, bool normalise) {
+                const MsmStreams &st, bool normalise, const MsmShape *forced = nullptr, uint32_t set_index = 0, uint32_t set_count = 1, bool skip_tail = false) {
   const bool piped = st.a != st.b;
   const std::string sfx = slot.id ? "#" + std::to_string(slot.id) : std::string();
   auto role = [&](const char *r) { return std::string(r) + sfx; };
 #define WS(name, bytes, ptr) CHK(ws_get(role(name).c_str(), bytes, (void **)&ptr))
-  MsmPlan P; P.n = (uint32_t)n; P.batch = M; P.c = (uint32_t)choose_c(n);
-  // precomputed rows 2^(c w) P available and cheaper than the per-window schedule at this n -> all windows share one bucket set
-  const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)P.c, false) && ((uint64_t)pre->w << log2_ceil(n)) < (1ull << 31);
-  if (shared) { P.c = (uint32_t)pre->c; bases = pre->table; }
-  P.windows = (255 + P.c - 1) / P.c; P.nb = 1u << (P.c - 1);
-  const uint64_t emax = (uint64_t)M * n * P.windows;
-  if (emax >= (1ull << 32)) return fail(MI355_EBADARG, "msm: n * windows must be < 2^32");
+  MsmShape sh; CHK(msm_shape(n, M, pre, sh, forced));
+  const bool shared = sh.shared;
+  if (shared) bases = pre->table;
+  MsmPlan P; P.n = (uint32_t)n; P.batch = M; P.c = sh.c; P.windows = sh.W; P.nb = 1u << (P.c - 1);
+  const uint64_t emax = sh.emax;
   const uint64_t want_threads = (uint64_t)g.prop.multiProcessorCount * 256 * g.seg_factor;   // segments per lane slot (MI355_SEG_FACTOR)
   uint64_t seg = (emax + want_threads - 1) / want_threads; if (seg < 16) seg = 16; if (seg > 4096) seg = 4096;
   P.seg = (uint32_t)seg;
   const uint32_t red_wpp = shared ? 1 : P.windows;        // bucket sets per polynomial
   const uint32_t red_windows = M * red_wpp;               // bucket sets to reduce
-  if ((uint64_t)red_windows * P.nb >= (1ull << 31)) return fail(MI355_EBADARG, "msm: too many buckets (split the batch)");
-  const uint32_t nbuckets = red_windows * P.nb;
+  const uint32_t nbuckets = (uint32_t)sh.nbuckets;
   const uint32_t acc_threads = ceil_div(emax, seg), acc_blocks = ceil_div(acc_threads, 256);
   const uint32_t tn = acc_blocks * 256;
-  // running-sum chunk per reduce thread: every thread is one serial chain of 2*chunk additions plus a ~(c-1)-bit scalar multiple, so the
-  // chain is kept short (the kernel is latency-bound) as long as there are enough buckets to give the GPU ~128k chains (measured at 2^21 buckets: 2.58 ms with 256k chains of 8 buckets, 2.11 ms with 128k of 16, 2.63 ms with 64k of 32)
-  uint32_t chunk = 64; while (chunk > P.nb) chunk >>= 1;
-  while (chunk > 8 && (uint64_t)(P.nb / chunk) * red_windows < g.reduce_chains) chunk >>= 1;
-  const uint32_t chunks_per_window = P.nb / chunk, nchunks = chunks_per_window * red_windows;
-
-  // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest (<= 9)
+  // sort plan: fine bits fb (<= 12, LDS histogram of 2^fb bins), coarse bits = the rest
   SortPlan S; S.n = P.n; S.windows = M * P.windows; S.wpp = P.windows; S.nb = P.nb;
-  { uint32_t kb = P.c - 1; uint32_t fb = kb < g.sort_fb ? kb : g.sort_fb; if (kb - fb > 11) fb = kb - 11; S.fb = fb; S.cb_bits = kb - fb; }
+  S.fb = sh.fb; S.cb_bits = sh.cb_bits;
   S.shared = shared ? 1 : 0; S.nshift = log2_ceil(n);
-  S.regions = red_windows << S.cb_bits;
-  if ((size_t)S.regions * 4 > 48 * 1024) return fail(MI355_EBADARG, "msm: batch too large for the coarse histogram (split the batch)");
+  S.regions = sh.regions;
   S.t1 = g.sort_t1;                           // level-1 tile: 1024 threads x 8 or 16 entries (64 / 128 KiB of LDS staging)
   // level-2 tile (6 B of LDS per entry next to the 3 x 2^fb words of bin bookkeeping): 16384 entries give twice the run length in
   // `sorted` (fewer partial-line store transactions, the limiter of this kernel) at one workgroup per CU; worth it for big sorts
   S.t2 = g.sort_t2 ? g.sort_t2 : (emax >= (1ull << 27) && S.fb <= 11 ? 16384 : 8192);
-  if (S.fb > 12 || (1u << S.cb_bits) > SORT_MAX_BINS) return fail(MI355_EBADARG, "msm: window bits out of range for the sorter");
   const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions + 8;   // + 8: the XCD-aware tile order rounds the tile count up to a multiple of 8
   const uint32_t vwindows = M * P.windows;   // (polynomial, window) pairs
 
   uint32_t *enc, *hist, *offsets, *cursor, *sorted, *scan_sums, *coarse_hist, *coarse_off, *coarse_cursor, *tile_start; uint64_t *pairs;
-  g1_xyzz29_t *buckets, *part, *chunk_out, *window_sums; int32_t *part_id;
+  g1_xyzz29_t *buckets, *part; int32_t *part_id;
   // stage-A-only buffers are shared by all slots (the sort stages of successive chunks run one after the other on st.a)
   CHK(ws_get("msm.digits", emax * 4, (void **)&enc));
   CHK(ws_get("msm.pairs", emax * 8, (void **)&pairs));
@@ -236,7 +345,8 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   // per-slot: what the accumulation and the reduction of this chunk read while the next chunk is being sorted
   WS("msm.offsets", ((size_t)nbuckets + 1) * 4, offsets);
   WS("msm.sorted", emax * 4, sorted);
-  WS("msm.buckets", (size_t)nbuckets * sizeof(g1_xyzz29_t), buckets);
+  WS("msm.buckets", (size_t)nbuckets * set_count * sizeof(g1_xyzz29_t), buckets);
+  buckets += (size_t)nbuckets * set_index;
   WS("msm.part", (size_t)tn * 2 * sizeof(g1_xyzz29_t), part);
   WS("msm.part_id", (size_t)tn * 2 * 4, part_id);
   const uint32_t big_cap = tn / FIXUP_SERIAL_MAX + 2;
@@ -247,11 +357,6 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   uint32_t *huge_list, *huge_count; g1_xyzz29_t *huge_part;
   WS("msm.huge_list", ((size_t)huge_cap * 3 + 1) * 4, huge_list); huge_count = huge_list + (size_t)huge_cap * 3;
   WS("msm.huge_part", (size_t)huge_cap * FIXUP_SLICES * sizeof(g1_xyzz29_t), huge_part);
-  WS("msm.chunk_out", (size_t)nchunks * sizeof(g1_xyzz29_t), chunk_out);   // 144 B: large enough for either record form
-  g1_xyzz29_t *tree_a, *tree_b;
-  { const size_t lvl = (size_t)ceil_div(chunks_per_window, 256 * TREE_PER_THREAD) * red_windows + 1;
-    WS("msm.tree_a", lvl * sizeof(g1_xyzz29_t), tree_a); WS("msm.tree_b", lvl * sizeof(g1_xyzz29_t), tree_b); }
-  WS("msm.window_sums", (size_t)red_windows * sizeof(g1_xyzz29_t), window_sums);
 #undef WS
 
   const int grid_stream = g.prop.multiProcessorCount * 8;
@@ -305,31 +410,18 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
     hipStream_t s = st.c;
     Scope sc("msm_reduce", s);
     HIPCHK(hipMemsetAsync(big_count, 0, 4, s));
-    MsmPlan PR = P; PR.windows = red_windows;
     // the whole tail runs on the 29-bit field (g1_xyzz29_add / _dbl): records are never converted to the saturated form on the way
     HIPCHK(hipMemsetAsync(huge_count, 0, 4, s));
     hipLaunchKernelGGL(k_msm_fixup, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap, huge_list, huge_count, huge_cap);
     hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
     hipLaunchKernelGGL(k_msm_fixup_huge, dim3(huge_cap * FIXUP_SLICES), dim3(256), 0, s, part, part_id, huge_list, huge_count, huge_part);
     hipLaunchKernelGGL(k_msm_fixup_huge_fold, dim3(huge_cap), dim3(64), 0, s, buckets, huge_list, huge_count, (const g1_xyzz29_t *)huge_part);
-    hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
-    {
-      // tree-sum the chunk results per window, ping-ponging between two small buffers
-      const g1_xyzz29_t *cur = chunk_out; uint32_t cnt = chunks_per_window; g1_xyzz29_t *bufs[2] = {tree_a, tree_b}; int which = 0;
-      while (true) {
-        const uint32_t outn = ceil_div(cnt, 256 * TREE_PER_THREAD);
-        g1_xyzz29_t *dst = outn == 1 ? window_sums : bufs[which];
-        hipLaunchKernelGGL(k_msm_tree_sum29, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
-        if (outn == 1) break;
-        cur = dst; cnt = outn; which ^= 1;
-      }
-    }
-    hipLaunchKernelGGL(k_msm_final29, dim3(M), dim3(64), 0, s, (const g1_xyzz29_t *)window_sums, red_wpp, shared ? 0u : P.c, out_dev, normalise ? 1 : 0);
+    if (!skip_tail) CHK(msm_reduce_tail(sh, M, buckets, out_dev, normalise, s, sfx));
   }
   if (piped) HIPCHK(hipEventRecord(slot.red_done, st.c));
   slot.used = true;
   HIPCHK(hipGetLastError());
-  g.last_c = (int)P.c; g.last_w = (int)P.windows; g.last_entries += emax;
+  g.last_c = (int)P.c; g.last_w = (int)P.windows; g.last_entries += emax; g.last_shared = shared;
   return MI355_OK;
 }
 
@@ -344,8 +436,9 @@ uint32_t msm_chunks_for(uint32_t M, uint64_t n) {
   return k;
 }
 
-// out_dev_user (M = 1 only): the result stays in device memory and the call returns without waiting for the stream.
-int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre, void *out_dev_user) {
+// out_dev_user: the M results stay in device memory and the call returns without waiting for the stream.  accumulate_plan: second half of
+// a split batch (mi355_msm_last_plan reports the entries of the whole batch).
+int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre, void *out_dev_user, bool accumulate_plan) {
   if (M == 0) return MI355_OK;
   if (n == 0) {
     if (out_dev_user) { HIPCHK(hipMemsetAsync(out_dev_user, 0, (size_t)M * sizeof(g1_jac_t), g.stream)); return MI355_OK; }
@@ -353,22 +446,19 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
   }
   if (n >= (1ull << 31)) return fail(MI355_EBADARG, "msm: n must be < 2^31");
   if (M > 1) {
-    // a batch that would overflow the 32-bit entry index, the coarse histogram's LDS or a sensible workspace (16 B per entry) is
-    // processed as two half batches
-    uint32_t c = (uint32_t)choose_c(n);
-    const bool shared = pre && pre->table && !g.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)c, false) && ((uint64_t)pre->w << log2_ceil(n)) < (1ull << 31);
-    if (shared) c = (uint32_t)pre->c;
-    const uint32_t W = (255 + c - 1) / c, kb = c - 1, cbits = kb <= 11 ? 0 : (kb - 11 > 10 ? 10 : kb - 11);
-    const uint64_t emax = (uint64_t)M * n * W, regions = (uint64_t)M * (shared ? 1 : W) << cbits, bk = (uint64_t)M * (shared ? 1 : W) << kb;
-    if (emax > (1ull << 29) || regions * 4 > 48 * 1024 || bk >= (1ull << 28)) {
+    // a batch that would overflow the 32-bit entry index, the coarse histogram's LDS or 8 GiB of bucket records is processed as two
+    // half batches (the same shape computation as the launch code: msm_shape)
+    MsmShape sh; const int rc0 = msm_shape(n, M, pre, sh);
+    if (rc0 != MI355_OK || sh.emax > (1ull << 29) || sh.nbuckets * sizeof(g1_xyzz29_t) > (8ull << 30)) {
       const uint32_t h = M / 2;
-      int rc = msm_batch_impl(bases, polys_host, h, n, out_host, pre);
+      int rc = msm_batch_impl(bases, polys_host, h, n, out_host, pre, out_dev_user, accumulate_plan);
       if (rc != MI355_OK) return rc;
-      return msm_batch_impl(bases, polys_host + h, M - h, n, (char *)out_host + (size_t)h * sizeof(g1_jac_t), pre);
+      return msm_batch_impl(bases, polys_host + h, M - h, n, out_host ? (char *)out_host + (size_t)h * sizeof(g1_jac_t) : nullptr, pre,
+                            out_dev_user ? (char *)out_dev_user + (size_t)h * sizeof(g1_jac_t) : nullptr, true);
     }
   }
   const uint32_t K = msm_chunks_for(M, n);
-  g.last_entries = 0;
+  if (!accumulate_plan) { g.last_entries = 0; g.last_host_slices = 1; }
   CallTrace tr("msm_g1", (uint64_t)M * n, 96.0);
   g1_jac_t *out_dev; const fe_t **polys_dev = nullptr;
   CHK(ws_get("msm.out", (size_t)(K + 1) * M * sizeof(g1_jac_t), (void **)&out_dev));
@@ -385,7 +475,7 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
       HIPCHK(hipStreamSynchronize(s));
     }
     MsmStreams st{s, s, s};
-    CHK(msm_enqueue(bases, inl, polys_dev, M, n, out_dev, pre, g.msm_slot[0], st, g.normalise));
+    CHK(msm_enqueue(bases, inl, polys_dev, M, n, out_dev, pre, g.msm_slot[0], st, t_opts.normalise));
   } else {
     std::vector<uint64_t> lo(K + 1);
     for (uint32_t k = 0; k <= K; k++) lo[k] = n * k / K;
@@ -401,7 +491,7 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
     }
     HIPCHK(hipStreamWaitEvent(s, g.msm_slot[0].red_done, 0)); HIPCHK(hipStreamWaitEvent(s, g.msm_slot[1].red_done, 0));
     HIPCHK(hipEventRecord(g.ev_fork, st.a)); HIPCHK(hipStreamWaitEvent(s, g.ev_fork, 0));   // join the sort stream too
-    hipLaunchKernelGGL(k_g1_sum_strided, dim3(M), dim3(64), 0, s, out_dev + M, K, M, out_dev, g.normalise ? 1 : 0);
+    hipLaunchKernelGGL(k_g1_sum_strided, dim3(M), dim3(64), 0, s, out_dev + M, K, M, out_dev, t_opts.normalise ? 1 : 0);
   }
   HIPCHK(hipGetLastError());
   total.close();
@@ -417,6 +507,67 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
   HIPCHK(hipStreamSynchronize(s));
   resolve_spans();
   { char buf[64]; snprintf(buf, sizeof buf, " batch=%u c=%d W=%d", M, g.last_c, g.last_w); tr.done(buf); }
+  return MI355_OK;
+}
+
+// mi355_msm_g1_host on one device.  Big single MSMs are cut into K point-range slices: slice k + 1 crosses PCIe on the copy stream while
+// slice k is sorted and accumulated; every slice fills its OWN bucket set with the common layout (c, W, table rows), the K sets are
+// added bucket by bucket and the latency-bound reduction tail runs once.  (The pipelined device-resident schedule above pays a tail
+// per slice; here the slices only differ from the one-pass MSM by K - 1 extra bucket records per bucket.)  Everything else -- batches,
+// small sizes -- is one copy followed by the device-resident path.
+int msm_host_single(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre, void *out_dev_user = nullptr) {
+  fe_t *sc; CHK(ws_get("io.scalars", (size_t)M * n * sizeof(fe_t), (void **)&sc));
+  hipStream_t s = g.stream;
+  uint32_t K = (M == 1 && n >= (1ull << 22)) ? g.host_chunks : 1;
+  while (K > 1 && n / K < (1ull << 20)) K >>= 1;
+  MsmShape shape;
+  if (K > 1 && (msm_shape((n + K - 1) / K, 1, pre, shape) != MI355_OK || shape.nbuckets * K * sizeof(g1_xyzz29_t) > (8ull << 30))) K = 1;
+  if (K <= 1) {
+    std::vector<const fe_t *> ptrs(M);
+    for (uint32_t m = 0; m < M; m++) { ptrs[m] = sc + (size_t)m * n; HIPCHK(hipMemcpyAsync(sc + (size_t)m * n, polys_host[m], n * sizeof(fe_t), hipMemcpyHostToDevice, s)); }
+    return msm_batch_impl(bases, ptrs.data(), M, n, out_host, pre, out_dev_user);
+  }
+  if (!g.copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[i], hipEventDisableTiming));
+  }
+  g.last_entries = 0;
+  CallTrace tr("msm_g1_host", n, 96.0);
+  g1_jac_t *out_dev; CHK(ws_get("msm.out", 2 * sizeof(g1_jac_t), (void **)&out_dev));
+  Scope total("msm_total", s);
+  // the staging buffer may still be read by work queued earlier on the compute stream
+  HIPCHK(hipEventRecord(g.ev_fork, s)); HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_fork, 0));
+  PolyPtrs inl; for (int i = 0; i < 8; i++) inl.p[i] = nullptr;
+  MsmStreams st{s, s, s};
+  for (uint32_t k = 0; k < K; k++) {
+    const uint64_t lo = n * k / K, hi = n * (k + 1) / K;
+    // pageable source: the call blocks this thread while the DMA runs, which is exactly when the GPU works on the slices queued before
+    HIPCHK(hipMemcpyAsync(sc + lo, polys_host[0] + lo, (hi - lo) * sizeof(fe_t), hipMemcpyHostToDevice, g.copy_stream));
+    HIPCHK(hipEventRecord(g.ev_copy[k & 3], g.copy_stream));
+    HIPCHK(hipStreamWaitEvent(s, g.ev_copy[k & 3], 0));
+    PreTable pk; const PreTable *pp = nullptr;
+    if (pre) { pk = *pre; if (pk.table) pk.table += lo; pp = &pk; }
+    inl.p[0] = sc + lo;
+    CHK(msm_enqueue(bases + lo, inl, nullptr, 1, hi - lo, out_dev, pp, g.msm_slot[0], st, t_opts.normalise, &shape, k, K, true));
+  }
+  g.msm_slot[0].used = false;
+  g1_xyzz29_t *buckets; CHK(ws_get("msm.buckets", (size_t)shape.nbuckets * K * sizeof(g1_xyzz29_t), (void **)&buckets));
+  {
+    Scope sc2("msm_reduce", s);
+    hipLaunchKernelGGL(k_msm_bucket_fold, dim3(ceil_div(shape.nbuckets, 256)), dim3(256), 0, s, buckets, (uint32_t)shape.nbuckets, K);
+    CHK(msm_reduce_tail(shape, 1, buckets, out_dev, t_opts.normalise, s, std::string()));
+  }
+  total.close();
+  g.last_chunks = (int)K; g.last_host_slices = (int)K;
+  if (out_dev_user) {   // sharded MSM: the partial stays on the device, in stream order
+    HIPCHK(hipMemcpyAsync(out_dev_user, out_dev, sizeof(g1_jac_t), hipMemcpyDeviceToDevice, s));
+    if (g.profiling) resolve_spans();
+    return MI355_OK;
+  }
+  HIPCHK(hipMemcpyAsync(out_host, out_dev, sizeof(g1_jac_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  resolve_spans();
+  { char buf[64]; snprintf(buf, sizeof buf, " host slices=%u c=%d W=%d", K, g.last_c, g.last_w); tr.done(buf); }
   return MI355_OK;
 }
 
@@ -544,19 +695,18 @@ int finish_async() { if (g.profiling) resolve_spans(); return MI355_OK; }
 // DFT over G1 points (g1fft.cuh).  in: n x (96 B Jacobian | 64 B affine), out likewise (may alias in); scale: optional Fr (Montgomery).
 int g1fft_impl(const void *in, int in_jac, void *out, int out_jac, uint32_t log_n, const void *omega, const void *scale_host) {
   const uint32_t n = 1u << log_n, half = std::max(1u, n / 2);
-  g1_xyzz_t *work; fe_t *tw, *scale = nullptr;
+  g1_xyzz_t *work; fe_t *tw; fe_t scale = Fr::zero(); if (scale_host) memcpy(&scale, scale_host, 32);
   CHK(ws_get("g1fft.work", (size_t)n * sizeof(g1_xyzz_t), (void **)&work));
   CHK(ws_get("g1fft.tw", (size_t)half * sizeof(fe_t), (void **)&tw));
   hipStream_t s = g.stream;
   fe_t w; memcpy(&w, omega, 32);
   Scope total("g1_fft");
   hipLaunchKernelGGL(k_pow_table, dim3(ceil_div(half, 256)), dim3(256), 0, s, tw, w, (uint64_t)1, half);
-  if (scale_host) { CHK(ws_get("g1fft.scale", sizeof(fe_t), (void **)&scale)); HIPCHK(hipMemcpyAsync(scale, scale_host, sizeof(fe_t), hipMemcpyHostToDevice, s)); }
   if (in_jac) hipLaunchKernelGGL(k_g1fft_load<1>, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, work, log_n);
   else hipLaunchKernelGGL(k_g1fft_load<0>, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, work, log_n);
   for (uint32_t st = 0; st < log_n; st++) hipLaunchKernelGGL(k_g1fft_stage, dim3(ceil_div(n / 2, 256)), dim3(256), 0, s, work, tw, log_n, st);
-  if (out_jac) hipLaunchKernelGGL(k_g1fft_store<1>, dim3(ceil_div(n, 256)), dim3(256), 0, s, work, out, log_n, scale);
-  else hipLaunchKernelGGL(k_g1fft_store<0>, dim3(ceil_div(n, 256)), dim3(256), 0, s, work, out, log_n, scale);
+  if (out_jac) hipLaunchKernelGGL(k_g1fft_store<1>, dim3(ceil_div(n, 256)), dim3(256), 0, s, work, out, log_n, scale, scale_host ? 1 : 0);
+  else hipLaunchKernelGGL(k_g1fft_store<0>, dim3(ceil_div(n, 256)), dim3(256), 0, s, work, out, log_n, scale, scale_host ? 1 : 0);
   HIPCHK(hipGetLastError());
   return MI355_OK;
 }
@@ -615,13 +765,39 @@ extern "C" {
 const char *mi355_last_error(void) { return g_err.c_str(); }
 const char *mi355_version(void) { return "mi355zk 0.1.0 (gfx950; BN254 G1 MSM + Fr NTT)"; }
 
-int mi355_init(int device_id) {
-  return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (g.inited) return g.device == device_id ? MI355_OK : fail(MI355_EBADARG, "already bound to another device (one device per process)");
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); return fail(MI355_ENODEVICE, "no HIP device visible"); }
-  if (device_id < 0 || device_id >= count) return fail(MI355_EBADARG, "device_id out of range");
+// ---- RCCL, bound lazily: librccl.so.1 is dlopen()ed by mi355_init_multi only when it needs a communicator, so single-device users (and the
+// CPU-only symbol checks) carry no RCCL dependency; a process that imported torch first gets torch's copy (same SONAME), as with libamdhip64.
+struct Rccl {
+  void *lib = nullptr;
+  int (*CommInitAll)(void **, int, const int *) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+} g_rccl;
+static int rccl_fail(const char *what, int rc) { return fail(MI355_ERCCL, std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?")); }
+static int rccl_load() {
+  if (g_rccl.lib) return MI355_OK;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail(MI355_ERCCL, std::string("cannot load librccl.so.1: ") + dlerror());
+  g_rccl.CommInitAll = (int (*)(void **, int, const int *))dlsym(h, "ncclCommInitAll");
+  g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+  g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+  g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+  g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GroupStart || !g_rccl.GroupEnd) { dlclose(h); return fail(MI355_ERCCL, "librccl.so.1 lacks the expected nccl* symbols"); }
+  g_rccl.lib = h;
+  return MI355_OK;
+}
+
+// everything mi355_init does for ONE device slot (the calling thread ends up bound to that device)
+static int init_ctx(int slot, int device_id) {
+  use_ctx(slot);
+  g = Ctx();
+  g.slot = slot;
   HIPCHK(hipSetDevice(device_id));
   HIPCHK(hipGetDeviceProperties(&g.prop, device_id));
   if (strncmp(g.prop.gcnArchName, "gfx950", 6) != 0) return fail(MI355_ENODEVICE, std::string("device is ") + g.prop.gcnArchName + ", this library is built for gfx950 only");
@@ -634,7 +810,9 @@ int mi355_init(int device_id) {
     HIPCHK(hipEventCreateWithFlags(&g.msm_slot[i].sorted, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&g.msm_slot[i].acc_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&g.msm_slot[i].red_done, hipEventDisableTiming));
   }
   HIPCHK(hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&g.ev_xchg, hipEventDisableTiming));
   { const char *e = getenv("MI355_MSM_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 16) g.msm_chunks = (uint32_t)v; } }
+  // dynamic-LDS limits are per device
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -653,7 +831,9 @@ int mi355_init(int device_id) {
   HIPCHK(hipFuncSetAttribute((const void *)k_fr_linrec<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   { const char *e = getenv("MI355_TRACE"); g.trace = e && e[0] == '1'; }
   { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
+#ifdef MI355_DEBUG_KNOBS
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
+#endif
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 3; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_FB"); if (e) { int v = atoi(e); if (v >= 9 && v <= 12) g.sort_fb = (uint32_t)v; } }
@@ -662,37 +842,103 @@ int mi355_init(int device_id) {
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
   { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
+  { const char *e = getenv("MI355_HOST_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64) g.host_chunks = (uint32_t)v; } }
   g.inited = true;
+  return MI355_OK;
+}
+static void destroy_ctx(int slot) {
+  use_ctx(slot);
+  if (!g.inited) return;
+  (void)hipSetDevice(g.device);
+  (void)hipStreamSynchronize(g.stream);
+  for (auto &kv : g.ws) if (kv.second.p) (void)hipFree(kv.second.p);
+  g.ws.clear();
+  for (auto &kv : g.ntt_plans) { for (void *q : kv.second.owned) (void)hipFree(q); for (int i = 0; i < 3; i++) if (kv.second.tw_m[i]) (void)hipFree(kv.second.tw_m[i]); for (int i = 0; i < 2; i++) { if (kv.second.tw_s_lo[i]) (void)hipFree(kv.second.tw_s_lo[i]); if (kv.second.tw_s_hi[i]) (void)hipFree(kv.second.tw_s_hi[i]); } }
+  g.ntt_plans.clear();
+  if (g.fixed_base_table) { (void)hipFree(g.fixed_base_table); g.fixed_base_table = nullptr; }
+  if (g.pin_ring) { (void)hipHostFree(g.pin_ring); g.pin_ring = nullptr; g.pin_ring_bytes = 0; }
+  if (g.comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(g.comm); g.comm = nullptr; }
+  if (g.own_stream) (void)hipStreamDestroy(g.own_stream);
+  for (int i = 0; i < 2; i++) {
+    if (g.aux_stream[i]) { (void)hipStreamDestroy(g.aux_stream[i]); g.aux_stream[i] = nullptr; }
+    if (g.msm_slot[i].sorted) { (void)hipEventDestroy(g.msm_slot[i].sorted); (void)hipEventDestroy(g.msm_slot[i].acc_done); (void)hipEventDestroy(g.msm_slot[i].red_done); g.msm_slot[i] = MsmSlot(); }
+  }
+  if (g.ev_fork) { (void)hipEventDestroy(g.ev_fork); g.ev_fork = nullptr; }
+  if (g.ev_xchg) { (void)hipEventDestroy(g.ev_xchg); g.ev_xchg = nullptr; }
+  for (int i = 0; i < 4; i++) if (g.ev_copy[i]) { (void)hipEventDestroy(g.ev_copy[i]); g.ev_copy[i] = nullptr; }
+  if (g.copy_stream) { (void)hipStreamDestroy(g.copy_stream); g.copy_stream = nullptr; }
+  g.own_stream = g.stream = nullptr; g.inited = false; g.device = -1;
+}
+static void shutdown_all() {
+  for (auto &kv : g_srs) { kv.second.tab.reset(); kv.second.mem.reset(); }   // the destructors bind each shard's device and free
+  g_srs.clear();
+  for (int s = g_ndev - 1; s >= 0; s--) destroy_ctx(s);
+  g_ndev = 0; g_dup_devices = false; g_force_exchange = false;
+  use_ctx(0);
+}
+
+int mi355_init_multi(const int *device_ids, int n_devices) {
+  return guarded([&]() -> int {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!device_ids || n_devices < 1 || n_devices > MAX_DEV) return fail(MI355_EBADARG, "init_multi: need 1..16 device ids");
+  if (g_ndev) {
+    bool same = g_ndev == n_devices;
+    for (int i = 0; same && i < n_devices; i++) same = g_ctx[i].device == device_ids[i];
+    use_ctx(0);
+    return same ? MI355_OK : fail(MI355_EBADARG, "already bound to a different device list (mi355_shutdown first)");
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); return fail(MI355_ENODEVICE, "no HIP device visible"); }
+  bool dup = false;
+  for (int i = 0; i < n_devices; i++) {
+    if (device_ids[i] < 0 || device_ids[i] >= count) return fail(MI355_EBADARG, "device_id out of range");
+    for (int j = 0; j < i; j++) if (device_ids[j] == device_ids[i]) dup = true;
+  }
+  if (dup) { const char *e = getenv("MI355_ALLOW_DUP_DEVICES"); if (!(e && e[0] == '1')) return fail(MI355_EBADARG, "init_multi: the same device listed twice (test mode needs MI355_ALLOW_DUP_DEVICES=1)"); }
+  int rc = MI355_OK;
+  for (int s = 0; s < n_devices && rc == MI355_OK; s++) { rc = init_ctx(s, device_ids[s]); if (rc == MI355_OK) g_ndev = s + 1; else { g_ndev = s + 1; } }
+  if (rc != MI355_OK) { const std::string keep = g_err; shutdown_all(); g_err = keep; return rc; }
+  g_dup_devices = dup;
+  { const char *e = getenv("MI355_MULTI_FORCE"); g_force_exchange = e && e[0] == '1'; }
+  if (n_devices > 1 || g_force_exchange) {
+    // one communicator per process over the bound devices: ncclCommInitAll.  Duplicate devices (test mode) cannot form a
+    // communicator; their exchange is a device-to-device copy.
+    if (!dup) {
+      rc = rccl_load();
+      if (rc == MI355_OK) {
+        void *comms[MAX_DEV] = {nullptr};
+        const int r = g_rccl.CommInitAll(comms, n_devices, device_ids);
+        if (r != 0) rc = rccl_fail("ncclCommInitAll", r);
+        else for (int s = 0; s < n_devices; s++) g_ctx[s].comm = comms[s];
+      }
+    }
+    for (int s = 0; s < n_devices && rc == MI355_OK; s++) {
+      use_ctx(s);
+      if (hipSetDevice(g.device) != hipSuccess) { rc = fail(MI355_EHIP, "hipSetDevice failed"); break; }
+      if (!dup) for (int t = 0; t < n_devices; t++) if (t != s) { int can = 0; if (hipDeviceCanAccessPeer(&can, g.device, g_ctx[t].device) == hipSuccess && can) { if (hipDeviceEnablePeerAccess(g_ctx[t].device, 0) != hipSuccess) (void)hipGetLastError(); } }
+    }
+    if (rc != MI355_OK) { const std::string keep = g_err; shutdown_all(); g_err = keep; return rc; }
+  }
+  use_ctx(0);
+  (void)hipSetDevice(g.device);
   return MI355_OK;
   });
 }
+int mi355_init(int device_id) { return mi355_init_multi(&device_id, 1); }
+int mi355_device_count(int *n_out) { std::lock_guard<std::mutex> lk(g_mu); if (!n_out) return fail(MI355_EBADARG, "device_count: null pointer"); *n_out = g_ndev; return MI355_OK; }
 
 int mi355_shutdown(void) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (!g.inited) return MI355_OK;
-  hipStreamSynchronize(g.stream);
-  for (auto &kv : g.ws) if (kv.second.p) hipFree(kv.second.p);
-  g.ws.clear();
-  for (auto &kv : g.srs) { if (kv.second.owned && kv.second.dev) hipFree(kv.second.dev); if (kv.second.pre) hipFree(kv.second.pre); }
-  g.srs.clear();
-  for (auto &kv : g.ntt_plans) { for (void *q : kv.second.owned) hipFree(q); for (int i = 0; i < 3; i++) if (kv.second.tw_m[i]) hipFree(kv.second.tw_m[i]); for (int i = 0; i < 2; i++) { if (kv.second.tw_s_lo[i]) hipFree(kv.second.tw_s_lo[i]); if (kv.second.tw_s_hi[i]) hipFree(kv.second.tw_s_hi[i]); } }
-  g.ntt_plans.clear();
-  if (g.fixed_base_table) { hipFree(g.fixed_base_table); g.fixed_base_table = nullptr; }
-  if (g.own_stream) hipStreamDestroy(g.own_stream);
-  for (int i = 0; i < 2; i++) {
-    if (g.aux_stream[i]) { hipStreamDestroy(g.aux_stream[i]); g.aux_stream[i] = nullptr; }
-    if (g.msm_slot[i].sorted) { hipEventDestroy(g.msm_slot[i].sorted); hipEventDestroy(g.msm_slot[i].acc_done); hipEventDestroy(g.msm_slot[i].red_done); g.msm_slot[i] = MsmSlot(); }
-  }
-  if (g.ev_fork) { hipEventDestroy(g.ev_fork); g.ev_fork = nullptr; }
-  g.own_stream = g.stream = nullptr; g.inited = false; g.device = -1;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ndev) return MI355_OK;
+  shutdown_all();
   return MI355_OK;
   });
 }
 
 int mi355_set_stream(void *hip_stream) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   HIPCHK(hipStreamSynchronize(g.stream));
   g.stream = (hipStream_t)hip_stream;   // NULL = the HIP null (legacy default) stream, which is torch's default stream
@@ -701,51 +947,88 @@ int mi355_set_stream(void *hip_stream) {
 }
 int mi355_reset_stream(void) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   HIPCHK(hipStreamSynchronize(g.stream));
   g.stream = g.own_stream;
   return MI355_OK;
   });
 }
-int mi355_synchronize(void) { std::lock_guard<std::mutex> lk(g.mu); CHK(need_init()); HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans(); return MI355_OK; }
+int mi355_synchronize(void) {
+  return guarded([&]() -> int {
+  std::lock_guard<std::mutex> lk(g_mu);
+  CHK(need_init());
+  for (int s = g_ndev - 1; s >= 0; s--) { CHK(bind_ctx(s)); HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans(); }
+  return MI355_OK;
+  });
+}
 
 // ---- SRS
+// shard plan of a basis of n points: D equal point ranges, or everything on the primary device when the basis is too small to be worth
+// spreading (a 2^14-point shard is already latency-bound)
+static std::vector<Shard> plan_shards(uint64_t n) {
+  std::vector<Shard> v;
+  int D = g_ndev;
+  if (D > 1 && n / (uint64_t)D < (1ull << 14)) D = 1;
+  for (int d = 0; d < D; d++) { Shard s; s.slot = d; s.lo = n * d / D; s.n = n * (d + 1) / D - s.lo; if (s.n) v.push_back(s); }
+  return v;
+}
+static int srs_find(uint64_t handle, Srs **out, const char *who) {
+  auto it = g_srs.find(handle);
+  if (it == g_srs.end() || !it->second.mem) return fail(MI355_EBADARG, std::string(who) + ": unknown SRS handle");
+  *out = &it->second; return MI355_OK;
+}
+static uint64_t srs_insert(const Srs &s) { const uint64_t h = g_next_handle++; g_srs[h] = s; return h; }
+// allocate the shards of `mem` on their devices (leaves the primary bound)
+static int srs_alloc(SrsMem &mem, uint64_t n) {
+  mem.sh = plan_shards(n);
+  for (auto &sh : mem.sh) {
+    CHK(bind_ctx(sh.slot));
+    HIPCHK(hipMalloc((void **)&sh.dev, sh.n * sizeof(g1_affine_t))); sh.owned = true;
+  }
+  return bind_ctx(0);
+}
 int mi355_srs_register_host(const void *bases, uint64_t n, uint64_t *handle_out) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!bases || !handle_out || n == 0) return fail(MI355_EBADARG, "srs_register: null pointer or n == 0");
-  Srs s; s.n = n; s.owned = true;
-  HIPCHK(hipMalloc((void **)&s.dev, n * sizeof(g1_affine_t)));
-  hipError_t e = hipMemcpy(s.dev, bases, n * sizeof(g1_affine_t), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { hipFree(s.dev); return fail(MI355_EHIP, std::string("srs upload: ") + hipGetErrorString(e)); }
-  *handle_out = g.next_handle++; g.srs[*handle_out] = s; return MI355_OK;
+  Srs s; s.n = n; s.mem = std::make_shared<SrsMem>();
+  CHK(srs_alloc(*s.mem, n));
+  for (auto &sh : s.mem->sh) {
+    CHK(bind_ctx(sh.slot));
+    HIPCHK(hipMemcpy(sh.dev, (const g1_affine_t *)bases + sh.lo, sh.n * sizeof(g1_affine_t), hipMemcpyHostToDevice));
+  }
+  CHK(bind_ctx(0));
+  *handle_out = srs_insert(s); return MI355_OK;
   });
 }
 // Prover::load_params for one degree: stream a RawBytes params file into device memory (two pinned staging buffers: the read of chunk
 // i + 1 overlaps the DMA of chunk i), optionally validate every point on the device, register both bases as library-owned handles.
-static int stream_file_to_device(FILE *f, void *dev, size_t bytes, void *pinned[2], hipEvent_t ev[2], size_t chunk) {
-  size_t done = 0; int which = 0;
-  while (done < bytes) {
+static int stream_file_to_device(FILE *f, void *dev, size_t bytes, void *pinned[2], size_t chunk) {
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)); HIPCHK(hipEventRecord(ev[i], g.stream)); }
+  size_t done = 0; int which = 0; int rc = MI355_OK;
+  while (done < bytes && rc == MI355_OK) {
     const size_t len = std::min(chunk, bytes - done);
-    HIPCHK(hipEventSynchronize(ev[which]));                       // the previous copy out of this staging buffer has finished
-    if (fread(pinned[which], 1, len, f) != len) return fail(MI355_EBADARG, "srs_load_params_file: short read");
-    HIPCHK(hipMemcpyAsync((char *)dev + done, pinned[which], len, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipEventRecord(ev[which], g.stream));
+    if (hipEventSynchronize(ev[which]) != hipSuccess) { rc = fail(MI355_EHIP, "srs_load_params_file: event wait failed"); break; }   // the previous copy out of this staging buffer has finished
+    if (fread(pinned[which], 1, len, f) != len) { rc = fail(MI355_EBADARG, "srs_load_params_file: short read"); break; }
+    if (hipMemcpyAsync((char *)dev + done, pinned[which], len, hipMemcpyHostToDevice, g.stream) != hipSuccess || hipEventRecord(ev[which], g.stream) != hipSuccess) { (void)hipGetLastError(); rc = fail(MI355_EHIP, "srs_load_params_file: copy failed"); break; }
     done += len; which ^= 1;
   }
-  return MI355_OK;
+  (void)hipStreamSynchronize(g.stream);
+  for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev[i]);
+  return rc;
 }
 int mi355_srs_load_params_file(const char *path, uint32_t flags, uint32_t *k_out, uint64_t *g_handle_out, uint64_t *g_lagrange_handle_out, void *g2_out, void *s_g2_out) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!path || !k_out || !g_handle_out || !g_lagrange_handle_out) return fail(MI355_EBADARG, "srs_load_params_file: null pointer");
   FILE *f = fopen(path, "rb");
   if (!f) return fail(MI355_EBADARG, std::string("srs_load_params_file: cannot open ") + path);
   uint8_t hdr[4];
-  int rc = MI355_OK; Srs sg, sl; void *pinned[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; uint32_t *bad = nullptr;
+  int rc = MI355_OK; Srs sg, sl; void *pinned[2] = {nullptr, nullptr};
   do {
     if (fread(hdr, 1, 4, f) != 4) { rc = fail(MI355_EBADARG, "srs_load_params_file: empty file"); break; }
     const uint32_t k = (uint32_t)hdr[0] | ((uint32_t)hdr[1] << 8) | ((uint32_t)hdr[2] << 16) | ((uint32_t)hdr[3] << 24);
@@ -754,139 +1037,307 @@ int mi355_srs_load_params_file(const char *path, uint32_t flags, uint32_t *k_out
     if (fseek(f, 0, SEEK_END) != 0 || (uint64_t)ftell(f) != want) { rc = fail(MI355_EBADARG, "srs_load_params_file: file length does not match 4 + 2 * 2^k * 64 + 256 (load_params rejects it too)"); break; }
     fseek(f, 4, SEEK_SET);
     const size_t chunk = std::min<uint64_t>(64ull << 20, n * sizeof(g1_affine_t));
-    sg.n = sl.n = n; sg.owned = sl.owned = true;
-    if (hipMalloc((void **)&sg.dev, n * sizeof(g1_affine_t)) != hipSuccess || hipMalloc((void **)&sl.dev, n * sizeof(g1_affine_t)) != hipSuccess) { (void)hipGetLastError(); rc = fail(MI355_EOOM, "srs_load_params_file: device allocation failed"); break; }
+    sg.n = sl.n = n; sg.mem = std::make_shared<SrsMem>(); sl.mem = std::make_shared<SrsMem>();
+    if (srs_alloc(*sg.mem, n) != MI355_OK || srs_alloc(*sl.mem, n) != MI355_OK) { (void)hipGetLastError(); rc = fail(MI355_EOOM, "srs_load_params_file: device allocation failed"); break; }
     bool okp = true;
-    for (int i = 0; i < 2; i++) okp = okp && hipHostMalloc(&pinned[i], chunk, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess && hipEventRecord(ev[i], g.stream) == hipSuccess;
+    for (int i = 0; i < 2; i++) okp = okp && hipHostMalloc(&pinned[i], chunk, hipHostMallocPortable) == hipSuccess;
     if (!okp) { rc = fail(MI355_EOOM, "srs_load_params_file: pinned staging allocation failed"); break; }
-    if ((rc = stream_file_to_device(f, sg.dev, n * sizeof(g1_affine_t), pinned, ev, chunk)) != MI355_OK) break;
-    if ((rc = stream_file_to_device(f, sl.dev, n * sizeof(g1_affine_t), pinned, ev, chunk)) != MI355_OK) break;
+    for (Srs *b : {&sg, &sl}) for (auto &sh : b->mem->sh) {   // the file holds g then g_lagrange, each in point order = shard order
+      if (rc != MI355_OK) break;
+      if ((rc = bind_ctx(sh.slot)) != MI355_OK) break;
+      rc = stream_file_to_device(f, sh.dev, sh.n * sizeof(g1_affine_t), pinned, chunk);
+    }
+    if (rc != MI355_OK) break;
     uint8_t tail[256];
     if (fread(tail, 1, 256, f) != 256) { rc = fail(MI355_EBADARG, "srs_load_params_file: short read (g2 / s_g2)"); break; }
     if (g2_out) memcpy(g2_out, tail, 128);
     if (s_g2_out) memcpy(s_g2_out, tail + 128, 128);
     if (flags & 1u) {
-      if (ws_get("io.validate", 4, (void **)&bad) != MI355_OK) { rc = MI355_EHIP; break; }
-      (void)hipMemsetAsync(bad, 0, 4, g.stream);
-      hipLaunchKernelGGL(k_g1_validate, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, sg.dev, n, bad);
-      hipLaunchKernelGGL(k_g1_validate, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, sl.dev, n, bad);
-      uint32_t nbad = 0;
-      if (hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) { rc = fail(MI355_EHIP, "srs_load_params_file: validation failed to run"); break; }
-      if (nbad) { rc = fail(MI355_EBADARG, "srs_load_params_file: " + std::to_string(nbad) + " point(s) are not on the curve"); break; }
+      uint64_t nbad_total = 0;
+      for (Srs *b : {&sg, &sl}) for (auto &sh : b->mem->sh) {
+        if ((rc = bind_ctx(sh.slot)) != MI355_OK) break;
+        uint32_t *bad = nullptr;
+        if (ws_get("io.validate", 4, (void **)&bad) != MI355_OK) { rc = MI355_EHIP; break; }
+        (void)hipMemsetAsync(bad, 0, 4, g.stream);
+        hipLaunchKernelGGL(k_g1_validate, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, sh.dev, sh.n, bad);
+        uint32_t nbad = 0;
+        if (hipMemcpyAsync(&nbad, bad, 4, hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipStreamSynchronize(g.stream) != hipSuccess) { rc = fail(MI355_EHIP, "srs_load_params_file: validation failed to run"); break; }
+        nbad_total += nbad;
+      }
+      if (rc != MI355_OK) break;
+      if (nbad_total) { rc = fail(MI355_EBADARG, "srs_load_params_file: " + std::to_string(nbad_total) + " point(s) are not on the curve"); break; }
     }
-    if (hipStreamSynchronize(g.stream) != hipSuccess) { rc = fail(MI355_EHIP, "srs_load_params_file: copy failed"); break; }
     *k_out = k;
-    *g_handle_out = g.next_handle++; g.srs[*g_handle_out] = sg;
-    *g_lagrange_handle_out = g.next_handle++; g.srs[*g_lagrange_handle_out] = sl;
+    *g_handle_out = srs_insert(sg);
+    *g_lagrange_handle_out = srs_insert(sl);
   } while (false);
   fclose(f);
-  if (rc != MI355_OK) (void)hipStreamSynchronize(g.stream);
-  for (int i = 0; i < 2; i++) { if (ev[i]) hipEventDestroy(ev[i]); if (pinned[i]) (void)hipHostFree(pinned[i]); }
-  if (rc != MI355_OK) { if (sg.dev) (void)hipFree(sg.dev); if (sl.dev) (void)hipFree(sl.dev); }
-  return rc;
+  for (int i = 0; i < 2; i++) if (pinned[i]) (void)hipHostFree(pinned[i]);
+  const std::string keep = g_err;
+  (void)bind_ctx(0);
+  if (rc != MI355_OK) g_err = keep;
+  return rc;   // on failure the shared_ptrs in sg / sl free whatever was allocated
   });
+}
+// copy a basis that sits contiguously on the primary device into freshly allocated shards
+static int srs_scatter_from_primary(SrsMem &mem, const g1_affine_t *src_dev, uint64_t n, bool alias_shard0) {
+  mem.sh = plan_shards(n);
+  for (auto &sh : mem.sh) {
+    if (sh.slot == 0 && alias_shard0) { sh.dev = const_cast<g1_affine_t *>(src_dev) + sh.lo; sh.owned = false; continue; }
+    CHK(bind_ctx(sh.slot));
+    HIPCHK(hipMalloc((void **)&sh.dev, sh.n * sizeof(g1_affine_t))); sh.owned = true;
+    if (sh.slot == 0 || g_ctx[sh.slot].device == g_ctx[0].device) HIPCHK(hipMemcpyAsync(sh.dev, src_dev + sh.lo, sh.n * sizeof(g1_affine_t), hipMemcpyDeviceToDevice, g.stream));
+    else HIPCHK(hipMemcpyPeerAsync(sh.dev, g.device, src_dev + sh.lo, g_ctx[0].device, sh.n * sizeof(g1_affine_t), g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+  }
+  return bind_ctx(0);
 }
 int mi355_srs_register_dev(const void *bases_dev, uint64_t n, int copy, uint64_t *handle_out) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!bases_dev || !handle_out || n == 0) return fail(MI355_EBADARG, "srs_register_dev: null pointer or n == 0");
-  Srs s; s.n = n;
-  if (copy) { s.owned = true; HIPCHK(hipMalloc((void **)&s.dev, n * sizeof(g1_affine_t))); HIPCHK(hipMemcpyAsync(s.dev, bases_dev, n * sizeof(g1_affine_t), hipMemcpyDeviceToDevice, g.stream)); HIPCHK(hipStreamSynchronize(g.stream)); }
-  else { s.owned = false; s.dev = (g1_affine_t *)bases_dev; }
-  *handle_out = g.next_handle++; g.srs[*handle_out] = s; return MI355_OK;
+  HIPCHK(hipStreamSynchronize(g.stream));   // the producer of bases_dev may have run on the library stream
+  Srs s; s.n = n; s.mem = std::make_shared<SrsMem>();
+  CHK(srs_scatter_from_primary(*s.mem, (const g1_affine_t *)bases_dev, n, copy == 0));
+  *handle_out = srs_insert(s); return MI355_OK;
+  });
+}
+// ParamsKZG::downsize / `&params.g[..n]` as a handle of its own: the first n points of a registered basis, sharing its device memory AND
+// its window tables (the clone + downsize of load_params_map [REF integration/tests/integration.rs:17-22] must not double-allocate 48 GiB
+// tables).  The memory is freed when the last handle that shares it is released, in any order.
+int mi355_srs_register_prefix(uint64_t parent_handle, uint64_t n, uint64_t *handle_out) {
+  return guarded([&]() -> int {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Srs *p; CHK(srs_find(parent_handle, &p, "srs_register_prefix"));
+  if (!handle_out || n == 0 || n > p->n) return fail(MI355_EBADARG, "srs_register_prefix: n must be in [1, len(parent)]");
+  Srs s; s.n = n; s.mem = p->mem; s.tab = p->tab;
+  *handle_out = srs_insert(s); return MI355_OK;
   });
 }
 int mi355_srs_release(uint64_t handle) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  auto it = g.srs.find(handle);
-  if (it == g.srs.end()) return fail(MI355_EBADARG, "srs_release: unknown handle");
-  if (g.inited) hipStreamSynchronize(g.stream);
-  if (it->second.owned) hipFree(it->second.dev);
-  if (it->second.pre) hipFree(it->second.pre);
-  g.srs.erase(it); return MI355_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_srs.find(handle);
+  if (it == g_srs.end()) return fail(MI355_EBADARG, "srs_release: unknown handle");
+  for (int s = 0; s < g_ndev; s++) if (g_ctx[s].inited) { (void)hipSetDevice(g_ctx[s].device); (void)hipStreamSynchronize(g_ctx[s].stream); }
+  g_srs.erase(it);   // the last handle sharing the memory frees it (SrsMem::~SrsMem)
+  if (g_ndev) (void)hipSetDevice(g_ctx[0].device);
+  return MI355_OK;
   });
 }
 int mi355_srs_precompute(uint64_t handle, uint64_t n_hint, int c) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
-  auto it = g.srs.find(handle);
-  if (it == g.srs.end()) return fail(MI355_EBADARG, "srs_precompute: unknown handle");
-  Srs &sr = it->second;
-  if (n_hint == 0 || n_hint > sr.n) n_hint = sr.n;
-  if (c == 0) {   // best shared-bucket window for n_hint, within the sorter's key range (c - 1 <= 21 bits)
+  Srs *sp; CHK(srs_find(handle, &sp, "srs_precompute"));
+  SrsMem &mem = *sp->mem;
+  if (n_hint == 0 || n_hint > sp->n) n_hint = sp->n;
+  size_t live = 0; for (const auto &sh : mem.sh) if (sh.lo < sp->n) live++;
+  const uint64_t per_shard = std::max<uint64_t>(1, n_hint / std::max<size_t>(1, live));
+  const bool automatic = c == 0;
+  if (automatic) {   // best shared-bucket window for MSMs of n_hint points (per shard), within the sorter's key range
     double best = 1e300;
-    for (int cc = 4; cc <= 22; cc++) { const double co = msm_cost(n_hint, cc, true); if (co < best) { best = co; c = cc; } }
+    for (int cc = 4; cc <= MSM_MAX_C; cc++) { const double co = msm_cost(per_shard, cc, true); if (co < best) { best = co; c = cc; } }
   }
-  if (c < 2 || c > 22) return fail(MI355_EBADARG, "srs_precompute: window bits must be in [2, 22]");
-  const int W = (255 + c - 1) / c;
-  if (sr.pre) { HIPCHK(hipStreamSynchronize(g.stream)); HIPCHK(hipFree(sr.pre)); sr.pre = nullptr; }
-  HIPCHK(hipMalloc((void **)&sr.pre, (size_t)W * sr.n * sizeof(g1_affine_t)));
-  hipLaunchKernelGGL(k_srs_precompute, dim3(ceil_div(sr.n, 256)), dim3(256), 0, g.stream, sr.dev, sr.pre, sr.n, (uint32_t)W, (uint32_t)c);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(g.stream));
-  sr.pre_c = c; sr.pre_w = W;
-  return MI355_OK;
+  if (c < 2 || c > MSM_MAX_C) return fail(MI355_EBADARG, "srs_precompute: window bits out of range");
+  if (sp->tab) {
+    if (sp->tab->c == c) return MI355_OK;
+    // tables inherited from the parent basis (or built earlier with another width) stay when they are within 10 % of the best schedule
+    if (automatic && msm_cost(per_shard, sp->tab->c, true) <= 1.10 * msm_cost(per_shard, c, true)) return MI355_OK;
+  }
+  const int W = (MSM_SCALAR_BITS + c - 1) / c;
+  auto tab = std::make_shared<SrsTables>();
+  tab->c = c; tab->w = W;
+  tab->pre.assign(mem.sh.size(), nullptr); tab->stride.assign(mem.sh.size(), 0); tab->slot.assign(mem.sh.size(), 0);
+  for (size_t i = 0; i < mem.sh.size(); i++) {
+    const Shard &sh = mem.sh[i];
+    tab->slot[i] = sh.slot;
+    if (sh.lo >= sp->n) continue;
+    const uint64_t cnt = std::min(sh.n, sp->n - sh.lo);   // a prefix view tabulates only its own points
+    CHK(bind_ctx(sh.slot));
+    HIPCHK(hipMalloc((void **)&tab->pre[i], (size_t)W * cnt * sizeof(g1_affine_t)));
+    tab->stride[i] = cnt;
+    hipLaunchKernelGGL(k_srs_precompute, dim3(ceil_div(cnt, 256)), dim3(256), 0, g.stream, sh.dev, tab->pre[i], cnt, (uint32_t)W, (uint32_t)c);
+    HIPCHK(hipGetLastError());
+  }
+  for (const auto &sh : mem.sh) { CHK(bind_ctx(sh.slot)); HIPCHK(hipStreamSynchronize(g.stream)); }
+  sp->tab = tab;   // the previous tables (if any) are freed here unless another handle still shares them
+  return bind_ctx(0);
   });
 }
 int mi355_srs_pre_dev_ptr(uint64_t handle, void **dev_ptr_out, int *c_out, int *windows_out) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  auto it = g.srs.find(handle);
-  if (it == g.srs.end() || !dev_ptr_out) return fail(MI355_EBADARG, "srs_pre_dev_ptr: unknown handle");
-  *dev_ptr_out = it->second.pre; if (c_out) *c_out = it->second.pre_c; if (windows_out) *windows_out = it->second.pre_w; return MI355_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Srs *sp; CHK(srs_find(handle, &sp, "srs_pre_dev_ptr"));
+  if (!dev_ptr_out) return fail(MI355_EBADARG, "srs_pre_dev_ptr: null pointer");
+  *dev_ptr_out = sp->tab && !sp->tab->pre.empty() ? sp->tab->pre[0] : nullptr; if (c_out) *c_out = sp->tab ? sp->tab->c : 0; if (windows_out) *windows_out = sp->tab ? sp->tab->w : 0; return MI355_OK;
   });
 }
 int mi355_srs_len(uint64_t handle, uint64_t *n_out) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  auto it = g.srs.find(handle);
-  if (it == g.srs.end() || !n_out) return fail(MI355_EBADARG, "srs_len: unknown handle");
-  *n_out = it->second.n; return MI355_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Srs *sp; CHK(srs_find(handle, &sp, "srs_len"));
+  if (!n_out) return fail(MI355_EBADARG, "srs_len: null pointer");
+  *n_out = sp->n; return MI355_OK;
   });
 }
 int mi355_srs_dev_ptr(uint64_t handle, void **dev_ptr_out) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  auto it = g.srs.find(handle);
-  if (it == g.srs.end() || !dev_ptr_out) return fail(MI355_EBADARG, "srs_dev_ptr: unknown handle");
-  *dev_ptr_out = it->second.dev; return MI355_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Srs *sp; CHK(srs_find(handle, &sp, "srs_dev_ptr"));
+  if (!dev_ptr_out) return fail(MI355_EBADARG, "srs_dev_ptr: null pointer");
+  *dev_ptr_out = sp->mem->sh.empty() ? nullptr : sp->mem->sh[0].dev; return MI355_OK;   // primary shard (all points with one device)
   });
 }
 
 // ---- MSM
-static int srs_slice(uint64_t handle, uint64_t off, uint64_t n, const g1_affine_t **out, PreTable *pre) {
-  auto it = g.srs.find(handle);
-  if (it == g.srs.end()) return fail(MI355_EBADARG, "msm: unknown SRS handle");
-  if (off > it->second.n || n > it->second.n - off) return fail(MI355_EBADARG, "msm: base_offset + n exceeds the registered basis (best_multiexp panics on length mismatch)");
-  *out = it->second.dev + off;
-  if (it->second.pre) { pre->table = it->second.pre + off; pre->row_stride = it->second.n; pre->c = it->second.pre_c; pre->w = it->second.pre_w; }
+// the pieces of [off, off + n) of a registered basis, one per shard that intersects it
+struct Piece { int slot; const g1_affine_t *bases; PreTable pre; uint64_t a /* first scalar of the call */, cnt; };
+static int srs_pieces(uint64_t handle, uint64_t off, uint64_t n, std::vector<Piece> &out) {
+  Srs *sp; CHK(srs_find(handle, &sp, "msm"));
+  if (off > sp->n || n > sp->n - off) return fail(MI355_EBADARG, "msm: base_offset + n exceeds the registered basis (best_multiexp panics on length mismatch)");
+  const SrsMem &mem = *sp->mem;
+  for (size_t i = 0; i < mem.sh.size(); i++) {
+    const Shard &sh = mem.sh[i];
+    const uint64_t lo = std::max(off, sh.lo), hi = std::min(off + n, sh.lo + sh.n);
+    if (hi <= lo) continue;
+    Piece p; p.slot = sh.slot; p.bases = sh.dev + (lo - sh.lo); p.a = lo - off; p.cnt = hi - lo;
+    if (sp->tab && sp->tab->pre[i] && hi - sh.lo <= sp->tab->stride[i]) { p.pre.table = sp->tab->pre[i] + (lo - sh.lo); p.pre.row_stride = sp->tab->stride[i]; p.pre.c = sp->tab->c; p.pre.w = sp->tab->w; }
+    out.push_back(p);
+  }
+  if (out.empty()) { Piece p; p.slot = 0; p.bases = nullptr; p.a = 0; p.cnt = 0; out.push_back(p); }   // n == 0
   return MI355_OK;
 }
+
+enum ScalarLoc { SCALARS_HOST = 0, SCALARS_DEV = 1 };
+// Sharded MSM: every device that owns part of the point range computes the partial sum over its shard on its own stream, driven by
+// its own host thread (copies from pageable memory block the issuing thread, so one thread per device keeps the PCIe links busy in parallel);
+// the M x 96-byte partials are exchanged with ONE ncclAllGather per device (grouped) and folded + normalised on the primary device.
+// polys: M pointers to n scalars each, host memory or primary-device memory.
+static int msm_multi(const std::vector<Piece> &pieces, const fe_t *const *polys, ScalarLoc loc, uint32_t M, uint64_t n, void *out_host) {
+  (void)n;
+  const int D = g_ndev;
+  const MsmOpts opts = t_opts;
+  std::vector<int> rcs(D, MI355_OK); std::vector<std::string> errs(D);
+  std::vector<const Piece *> by_slot(D, nullptr);
+  for (const auto &p : pieces) by_slot[p.slot] = &p;
+  auto work = [&](int slot) {
+    t_opts = opts; t_opts.normalise = false;            // partials are folded (and normalised once) after the exchange
+    auto body = [&]() -> int {
+      CHK(bind_ctx(slot));
+      g1_jac_t *send; CHK(ws_get("xchg.send", (size_t)M * sizeof(g1_jac_t), (void **)&send));
+      const Piece *p = by_slot[slot];
+      if (!p || p->cnt == 0) { HIPCHK(hipMemsetAsync(send, 0, (size_t)M * sizeof(g1_jac_t), g.stream)); return MI355_OK; }
+      std::vector<const fe_t *> ptrs(M);
+      if (loc == SCALARS_HOST) {   // this device's slice of every polynomial crosses its own PCIe link, chunk-overlapped with the compute
+        for (uint32_t m = 0; m < M; m++) ptrs[m] = polys[m] + p->a;
+        return msm_host_single(p->bases, ptrs.data(), M, p->cnt, nullptr, &p->pre, send);
+      }
+      if (slot == 0 || g.device == g_ctx[0].device) for (uint32_t m = 0; m < M; m++) ptrs[m] = polys[m] + p->a;
+      else {
+        fe_t *sc; CHK(ws_get("io.scalars", (size_t)M * p->cnt * sizeof(fe_t), (void **)&sc));
+        for (uint32_t m = 0; m < M; m++) {
+          ptrs[m] = sc + (size_t)m * p->cnt;
+          HIPCHK(hipMemcpyPeerAsync(sc + (size_t)m * p->cnt, g.device, polys[m] + p->a, g_ctx[0].device, p->cnt * sizeof(fe_t), g.stream));   // over xGMI
+        }
+      }
+      return msm_batch_impl(p->bases, ptrs.data(), M, p->cnt, nullptr, &p->pre, send);
+    };
+    rcs[slot] = guarded(body);
+    if (rcs[slot] != MI355_OK) errs[slot] = g_err;
+  };
+  // scalars on the primary device may still be in flight on the primary stream: the peers' copies must wait for it
+  if (loc == SCALARS_DEV && D > 1) { CHK(bind_ctx(0)); HIPCHK(hipStreamSynchronize(g.stream)); }
+  {
+    std::vector<std::thread> th;
+    for (int s = 1; s < D; s++) th.emplace_back(work, s);
+    work(0);
+    for (auto &t : th) t.join();
+  }
+  t_opts = opts;
+  CHK(bind_ctx(0));
+  for (int s = 0; s < D; s++) if (rcs[s] != MI355_OK) return fail(rcs[s], "device slot " + std::to_string(s) + ": " + errs[s]);
+  // ---- exchange: D x M x 96 bytes
+  const size_t part_bytes = (size_t)M * sizeof(g1_jac_t);
+  std::vector<g1_jac_t *> send(D), recv(D);
+  for (int s = 0; s < D; s++) { CHK(bind_ctx(s)); CHK(ws_get("xchg.send", part_bytes, (void **)&send[s])); CHK(ws_get("xchg.recv", part_bytes * D, (void **)&recv[s])); }
+  if (g_ctx[0].comm) {
+    int r = g_rccl.GroupStart(); if (r != 0) return rccl_fail("ncclGroupStart", r);
+    for (int s = 0; s < D; s++) {
+      CHK(bind_ctx(s));
+      r = g_rccl.AllGather(send[s], recv[s], part_bytes, /* ncclUint8 */ 1, g_ctx[s].comm, g_ctx[s].stream);
+      if (r != 0) { (void)g_rccl.GroupEnd(); return rccl_fail("ncclAllGather", r); }
+    }
+    r = g_rccl.GroupEnd(); if (r != 0) return rccl_fail("ncclGroupEnd", r);
+    g_last_exchange = "rccl_allgather";
+  } else {
+    // several slots on one physical device (test mode): no communicator can exist; the partials are copied device-to-device
+    for (int s = 0; s < D; s++) {
+      CHK(bind_ctx(s)); HIPCHK(hipEventRecord(g.ev_xchg, g.stream));
+      CHK(bind_ctx(0)); HIPCHK(hipStreamWaitEvent(g.stream, g_ctx[s].ev_xchg, 0));
+      HIPCHK(hipMemcpyAsync((char *)recv[0] + part_bytes * s, send[s], part_bytes, hipMemcpyDeviceToDevice, g.stream));
+    }
+    g_last_exchange = "device_copy";
+  }
+  CHK(bind_ctx(0));
+  g1_jac_t *res; CHK(ws_get("xchg.result", part_bytes, (void **)&res));
+  hipLaunchKernelGGL(k_g1_sum_strided, dim3(M), dim3(64), 0, g.stream, (const g1_jac_t *)recv[0], (uint32_t)D, M, res, opts.normalise ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_host, res, part_bytes, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  for (int s = D - 1; s >= 0; s--) { CHK(bind_ctx(s)); if (s) HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans(); }
+  g_last_devices = D;
+  return MI355_OK;
+}
+static bool single_device_call(const std::vector<Piece> &pieces) { return pieces.size() == 1 && pieces[0].slot == 0 && !g_force_exchange; }
+
+// host scalars, one device: mi355_msm_g1_host.  The copy is cut into chunks on a second stream; the digit extraction of chunk j runs while
+// chunk j + 1 crosses PCIe (msm_host_single in the MSM section above).
+static int msm_host_dispatch(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_host, uint32_t M, uint64_t n, void *out_g1_host) {
+  std::vector<Piece> pieces; CHK(srs_pieces(srs_handle, base_offset, n, pieces));
+  if (M == 0 || n == 0) { if (M) memset(out_g1_host, 0, (size_t)M * sizeof(g1_jac_t)); return MI355_OK; }
+  if (!single_device_call(pieces)) return msm_multi(pieces, (const fe_t *const *)scalars_host, SCALARS_HOST, M, n, out_g1_host);
+  const Piece &p = pieces[0];
+  g_last_devices = 1; g_last_exchange = "none";
+  // staged in groups of at most 4 GiB of scalars
+  const uint32_t group_max = (uint32_t)std::max<uint64_t>(1, (4ull << 30) / (n * sizeof(fe_t)));
+  for (uint32_t m0 = 0; m0 < M; m0 += group_max) {
+    const uint32_t mg = std::min(group_max, M - m0);
+    CHK(msm_host_single(p.bases, (const fe_t *const *)scalars_host + m0, mg, n, (char *)out_g1_host + (size_t)m0 * sizeof(g1_jac_t), &p.pre));
+  }
+  return MI355_OK;
+}
+static int msm_dev_dispatch(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_dev, uint32_t M, uint64_t n, void *out_g1_host) {
+  std::vector<Piece> pieces; CHK(srs_pieces(srs_handle, base_offset, n, pieces));
+  if (M == 0 || n == 0) { if (M) memset(out_g1_host, 0, (size_t)M * sizeof(g1_jac_t)); return MI355_OK; }
+  if (!single_device_call(pieces)) return msm_multi(pieces, (const fe_t *const *)scalars_dev, SCALARS_DEV, M, n, out_g1_host);
+  g_last_devices = 1; g_last_exchange = "none";
+  return msm_batch_impl(pieces[0].bases, (const fe_t *const *)scalars_dev, M, n, out_g1_host, &pieces[0].pre);
+}
+
 int mi355_msm_g1_dev(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_host) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!out_g1_host || (n && !scalars_dev)) return fail(MI355_EBADARG, "msm: null pointer");
-  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
-  return msm_dev_impl(bases, (const fe_t *)scalars_dev, n, out_g1_host, &pre);
+  return msm_dev_dispatch(srs_handle, base_offset, &scalars_dev, 1, n, out_g1_host);
   });
 }
 int mi355_msm_g1_dev_async(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_dev) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!out_g1_dev || (n && !scalars_dev)) return fail(MI355_EBADARG, "msm: null pointer");
-  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
+  std::vector<Piece> pieces; CHK(srs_pieces(srs_handle, base_offset, n, pieces));
+  if (pieces.size() != 1 || pieces[0].slot != 0) return fail(MI355_EBADARG, "msm_g1_dev_async: the range must lie on the primary device (one process per GPU drives its own shard)");
   const fe_t *sc = (const fe_t *)scalars_dev;
-  return msm_batch_impl(bases, &sc, 1, n, nullptr, &pre, out_g1_dev);
+  return msm_batch_impl(pieces[0].bases, &sc, 1, n, nullptr, &pieces[0].pre, out_g1_dev);
   });
 }
 int mi355_g1_sum_dev(const void *pts_dev, uint64_t n, void *out_g1_host) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!out_g1_host || (n && !pts_dev) || n > (1u << 20)) return fail(MI355_EBADARG, "g1_sum: bad argument");
   g1_jac_t *dev; CHK(ws_get("io.g1sum", sizeof(g1_jac_t), (void **)&dev));
@@ -899,59 +1350,41 @@ int mi355_g1_sum_dev(const void *pts_dev, uint64_t n, void *out_g1_host) {
 }
 int mi355_msm_g1_host(uint64_t srs_handle, uint64_t base_offset, const void *scalars_host, uint64_t n, void *out_g1_host) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!out_g1_host || (n && !scalars_host)) return fail(MI355_EBADARG, "msm: null pointer");
-  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
-  fe_t *sc = nullptr;
-  if (n) { CHK(ws_get("io.scalars", n * sizeof(fe_t), (void **)&sc)); HIPCHK(hipMemcpyAsync(sc, scalars_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
-  return msm_dev_impl(bases, sc, n, out_g1_host, &pre);
+  return msm_host_dispatch(srs_handle, base_offset, &scalars_host, 1, n, out_g1_host);
   });
 }
 int mi355_msm_g1_batch_dev(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_dev, uint32_t batch, uint64_t n, void *out_g1_host) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!out_g1_host || (batch && !scalars_dev)) return fail(MI355_EBADARG, "msm_batch: null pointer");
   for (uint32_t m = 0; m < batch; m++) if (n && !scalars_dev[m]) return fail(MI355_EBADARG, "msm_batch: null polynomial pointer");
-  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
-  return msm_batch_impl(bases, (const fe_t *const *)scalars_dev, batch, n, out_g1_host, &pre);
+  return msm_dev_dispatch(srs_handle, base_offset, scalars_dev, batch, n, out_g1_host);
   });
 }
 int mi355_msm_g1_batch_host(uint64_t srs_handle, uint64_t base_offset, const void *const *scalars_host, uint32_t batch, uint64_t n, void *out_g1_host) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!out_g1_host || (batch && !scalars_host)) return fail(MI355_EBADARG, "msm_batch: null pointer");
   for (uint32_t m = 0; m < batch; m++) if (n && !scalars_host[m]) return fail(MI355_EBADARG, "msm_batch: null polynomial pointer");
-  const g1_affine_t *bases; PreTable pre; CHK(srs_slice(srs_handle, base_offset, n, &bases, &pre));
-  if (batch == 0 || n == 0) return msm_batch_impl(bases, nullptr, batch, n, out_g1_host, &pre);
-  // staged in groups of at most 4 GiB of scalars
-  const uint32_t group_max = (uint32_t)std::max<uint64_t>(1, (4ull << 30) / (n * sizeof(fe_t)));
-  for (uint32_t m0 = 0; m0 < batch; m0 += group_max) {
-    const uint32_t mg = std::min(group_max, batch - m0);
-    fe_t *sc; CHK(ws_get("io.scalars", (size_t)mg * n * sizeof(fe_t), (void **)&sc));
-    std::vector<const fe_t *> ptrs(mg);
-    for (uint32_t m = 0; m < mg; m++) {
-      ptrs[m] = sc + (size_t)m * n;
-      HIPCHK(hipMemcpyAsync(sc + (size_t)m * n, scalars_host[m0 + m], n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream));
-    }
-    CHK(msm_batch_impl(bases, ptrs.data(), mg, n, (char *)out_g1_host + (size_t)m0 * sizeof(g1_jac_t), &pre));
-  }
-  return MI355_OK;
+  return msm_host_dispatch(srs_handle, base_offset, scalars_host, batch, n, out_g1_host);
   });
 }
 int mi355_msm_set_pipeline(uint32_t chunks, uint32_t min_log_n) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   if (chunks > 16 || min_log_n > 31) return fail(MI355_EBADARG, "msm_set_pipeline: chunks <= 16, min_log_n <= 31");
-  g.msm_chunks = chunks ? chunks : 1; g.msm_chunk_min_log = chunks ? min_log_n : 23;
+  for (int s = 0; s < std::max(1, g_ndev); s++) { g_ctx[s].msm_chunks = chunks ? chunks : 1; g_ctx[s].msm_chunk_min_log = chunks ? min_log_n : 23; }
   return MI355_OK;
   });
 }
 int mi355_msm_g1_adhoc_host(const void *bases_host, const void *scalars_host, uint64_t n, void *out_g1_host) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!out_g1_host || (n && (!scalars_host || !bases_host))) return fail(MI355_EBADARG, "msm: null pointer");
   fe_t *sc = nullptr; g1_affine_t *bs = nullptr;
@@ -960,12 +1393,13 @@ int mi355_msm_g1_adhoc_host(const void *bases_host, const void *scalars_host, ui
     HIPCHK(hipMemcpyAsync(sc, scalars_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(bs, bases_host, n * sizeof(g1_affine_t), hipMemcpyHostToDevice, g.stream));
   }
+  g_last_devices = 1; g_last_exchange = "none";
   return msm_dev_impl(bs, sc, n, out_g1_host);
   });
 }
 int mi355_g1_sum_host(const void *pts_host, uint64_t n, void *out_g1_host) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!out_g1_host || (n && !pts_host) || n > (1u << 20)) return fail(MI355_EBADARG, "g1_sum: bad argument");
   g1_jac_t *dev; CHK(ws_get("io.g1sum", (n + 1) * sizeof(g1_jac_t), (void **)&dev));
@@ -977,19 +1411,28 @@ int mi355_g1_sum_host(const void *pts_host, uint64_t n, void *out_g1_host) {
   return MI355_OK;
   });
 }
+// The two setters below act on the CALLING THREAD only (thread-local options): concurrent callers never see each other's settings.
 int mi355_msm_set_window_bits(int c) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (c != 0 && (c < 2 || c > 24)) return fail(MI355_EBADARG, "window bits must be 0 (auto) or in [2, 24]");
-  g.force_c = c; return MI355_OK;
+  if (c != 0 && (c < 2 || c > MSM_MAX_C)) return fail(MI355_EBADARG, "window bits must be 0 (auto) or in [2, 24]");
+  t_opts.force_c = c; return MI355_OK;
   });
 }
-int mi355_msm_set_normalise(int on) { std::lock_guard<std::mutex> lk(g.mu); g.normalise = on != 0; return MI355_OK; }
+int mi355_msm_set_normalise(int on) { t_opts.normalise = on != 0; return MI355_OK; }
 int mi355_msm_last_plan(int *c_out, int *windows_out, uint64_t *entries_out) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  if (c_out) *c_out = g.last_c; if (windows_out) *windows_out = g.last_w; if (entries_out) *entries_out = g.last_entries; return MI355_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const Ctx &p = g_ctx[0];
+  if (c_out) *c_out = p.last_c; if (windows_out) *windows_out = p.last_w; if (entries_out) *entries_out = p.last_entries; return MI355_OK;
   });
+}
+// how the last MSM ran: device slots that took part, the exchange ("none" | "rccl_allgather" | "device_copy"), whether the window tables
+// (one shared bucket set) were used, and the number of point-range slices of the host-pointer path
+int mi355_msm_last_run(int *devices_out, const char **exchange_out, int *shared_tables_out, int *host_slices_out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (devices_out) *devices_out = g_last_devices; if (exchange_out) *exchange_out = g_last_exchange;
+  if (shared_tables_out) *shared_tables_out = g_ctx[0].last_shared ? 1 : 0; if (host_slices_out) *host_slices_out = g_ctx[0].last_host_slices;
+  return MI355_OK;
 }
 
 // ---- NTT
@@ -1000,7 +1443,7 @@ static int check_ntt_args(const void *data, uint32_t log_n, const void *omega) {
 }
 int mi355_ntt_fr_dev(void *data_dev, uint32_t log_n, const void *omega) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init()); CHK(check_ntt_args(data_dev, log_n, omega));
   CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_n, (fe_t *)data_dev, log_n, omega, nullptr, nullptr));
   return finish_async();
@@ -1008,7 +1451,7 @@ int mi355_ntt_fr_dev(void *data_dev, uint32_t log_n, const void *omega) {
 }
 int mi355_intt_fr_dev(void *data_dev, uint32_t log_n, const void *omega_inv, const void *divisor) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init()); CHK(check_ntt_args(data_dev, log_n, omega_inv));
   if (!divisor) return fail(MI355_EBADARG, "intt: null divisor");
   fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], divisor, 32);
@@ -1018,7 +1461,7 @@ int mi355_intt_fr_dev(void *data_dev, uint32_t log_n, const void *omega_inv, con
 }
 int mi355_coeff_to_extended_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init()); CHK(check_ntt_args(dst_dev, log_ext, extended_omega));
   if (!coeffs_dev || !g_coset || !g_coset_inv || log_n > log_ext) return fail(MI355_EBADARG, "coeff_to_extended: bad argument");
   fe_t pre[3]; pre[0] = Fr::one(); memcpy(&pre[1], g_coset, 32); memcpy(&pre[2], g_coset_inv, 32);
@@ -1026,15 +1469,12 @@ int mi355_coeff_to_extended_dev(void *dst_dev, const void *coeffs_dev, uint32_t 
   return finish_async();
   });
 }
+static int extended_to_coeff_locked(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor);
 int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  CHK(need_init()); CHK(check_ntt_args(data_dev, log_ext, extended_omega_inv));
-  if (!g_coset || !g_coset_inv || !extended_ifft_divisor) return fail(MI355_EBADARG, "extended_to_coeff: null pointer");
-  // post-scale table {d, d * g_coset_inv, d * g_coset}: three constant products formed on the host (setup, not data path)
-  fe_t d, gc, gci, post[3]; memcpy(&d, extended_ifft_divisor, 32); memcpy(&gc, g_coset, 32); memcpy(&gci, g_coset_inv, 32);
-  post[0] = d; post[1] = Fr::mul(d, gci); post[2] = Fr::mul(d, gc);
-  CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_ext, (fe_t *)data_dev, log_ext, extended_omega_inv, nullptr, post));
+  std::lock_guard<std::mutex> lk(g_mu);
+  CHK(need_init());
+  CHK(extended_to_coeff_locked(data_dev, log_ext, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor));
   return finish_async();
   });
 }
@@ -1042,7 +1482,7 @@ int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_
 struct NttHostArgs { uint32_t log_n; const void *omega; const void *divisor; };
 int mi355_ntt_fr_host(void *data_host, uint32_t log_n, const void *omega) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init()); CHK(check_ntt_args(data_host, log_n, omega));
   NttHostArgs a{log_n, omega, nullptr};
   const size_t bytes = sizeof(fe_t) << log_n;
@@ -1051,7 +1491,7 @@ int mi355_ntt_fr_host(void *data_host, uint32_t log_n, const void *omega) {
 }
 int mi355_intt_fr_host(void *data_host, uint32_t log_n, const void *omega_inv, const void *divisor) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init()); CHK(check_ntt_args(data_host, log_n, omega_inv));
   if (!divisor) return fail(MI355_EBADARG, "intt: null divisor");
   NttHostArgs a{log_n, omega_inv, divisor};
@@ -1064,7 +1504,7 @@ int mi355_intt_fr_host(void *data_host, uint32_t log_n, const void *omega_inv, c
 // ---- DFT over G1 points (best_fft::<Fr, G1>, g_to_lagrange)
 int mi355_g1_fft_dev(void *points_jac_dev, uint32_t log_n, const void *omega) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init()); CHK(check_ntt_args(points_jac_dev, log_n, omega));
   CHK(g1fft_impl(points_jac_dev, 1, points_jac_dev, 1, log_n, omega, nullptr));
   return finish_async();
@@ -1072,7 +1512,7 @@ int mi355_g1_fft_dev(void *points_jac_dev, uint32_t log_n, const void *omega) {
 }
 int mi355_g1_fft_host(void *points_jac_host, uint32_t log_n, const void *omega) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init()); CHK(check_ntt_args(points_jac_host, log_n, omega));
   NttHostArgs a{log_n, omega, nullptr};
   const size_t bytes = sizeof(g1_jac_t) << log_n;
@@ -1081,44 +1521,73 @@ int mi355_g1_fft_host(void *points_jac_host, uint32_t log_n, const void *omega) 
 }
 int mi355_g_to_lagrange_dev(const void *g_affine_dev, void *g_lagrange_affine_dev, uint32_t log_n, const void *omega_inv, const void *n_inv) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init()); CHK(check_ntt_args(g_affine_dev, log_n, omega_inv));
   if (!g_lagrange_affine_dev || !n_inv) return fail(MI355_EBADARG, "g_to_lagrange: null pointer");
   CHK(g1fft_impl(g_affine_dev, 0, g_lagrange_affine_dev, 0, log_n, omega_inv, n_inv));
   return finish_async();
   });
 }
+// the first n points of a registered basis as ONE contiguous array on the primary device: the primary shard itself when it covers them,
+// otherwise a temporary assembled from the shards (xGMI peer copies)
+static int srs_gather_to_primary(const Srs &sr, uint64_t n, const g1_affine_t **out) {
+  const SrsMem &mem = *sr.mem;
+  if (!mem.sh.empty() && mem.sh[0].slot == 0 && mem.sh[0].lo == 0 && mem.sh[0].n >= n) { *out = mem.sh[0].dev; return MI355_OK; }
+  CHK(bind_ctx(0));
+  g1_affine_t *tmp; CHK(ws_get("srs.gather", n * sizeof(g1_affine_t), (void **)&tmp));
+  for (const auto &sh : mem.sh) {
+    if (sh.lo >= n) continue;
+    const uint64_t cnt = std::min(sh.n, n - sh.lo);
+    if (g_ctx[sh.slot].device == g.device) HIPCHK(hipMemcpyAsync(tmp + sh.lo, sh.dev, cnt * sizeof(g1_affine_t), hipMemcpyDeviceToDevice, g.stream));
+    else HIPCHK(hipMemcpyPeerAsync(tmp + sh.lo, g.device, sh.dev, g_ctx[sh.slot].device, cnt * sizeof(g1_affine_t), g.stream));
+  }
+  *out = tmp; return MI355_OK;
+}
 int mi355_srs_downsize(uint64_t g_handle, uint32_t k, const void *omega_inv, const void *n_inv, uint64_t *g_lagrange_handle_out) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
-  auto it = g.srs.find(g_handle);
-  if (it == g.srs.end()) return fail(MI355_EBADARG, "srs_downsize: unknown handle");
-  if (!omega_inv || !n_inv || !g_lagrange_handle_out || k > 28 || (1ull << k) > it->second.n) return fail(MI355_EBADARG, "srs_downsize: bad argument (2^k must not exceed the registered basis)");
-  Srs s; s.n = 1ull << k; s.owned = true;
-  HIPCHK(hipMalloc((void **)&s.dev, s.n * sizeof(g1_affine_t)));
-  int rc = g1fft_impl(it->second.dev, 0, s.dev, 0, k, omega_inv, n_inv);
+  Srs *sp; CHK(srs_find(g_handle, &sp, "srs_downsize"));
+  if (!omega_inv || !n_inv || !g_lagrange_handle_out || k > 28 || (1ull << k) > sp->n) return fail(MI355_EBADARG, "srs_downsize: bad argument (2^k must not exceed the registered basis)");
+  const uint64_t n = 1ull << k;
+  for (int sl = 1; sl < g_ndev; sl++) { CHK(bind_ctx(sl)); HIPCHK(hipStreamSynchronize(g.stream)); }
+  CHK(bind_ctx(0));
+  const g1_affine_t *src; CHK(srs_gather_to_primary(*sp, n, &src));
+  g1_affine_t *res; HIPCHK(hipMalloc((void **)&res, n * sizeof(g1_affine_t)));
+  int rc = g1fft_impl(src, 0, res, 0, k, omega_inv, n_inv);
   if (rc == MI355_OK) rc = finish_async();
   if (rc == MI355_OK && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MI355_EHIP, "srs_downsize: stream synchronize failed");
-  if (rc != MI355_OK) { (void)hipFree(s.dev); return rc; }
-  *g_lagrange_handle_out = g.next_handle++; g.srs[*g_lagrange_handle_out] = s; return MI355_OK;
+  Srs s; s.n = n; s.mem = std::make_shared<SrsMem>();
+  if (rc == MI355_OK) {
+    if (plan_shards(n).size() == 1) { Shard one; one.slot = 0; one.lo = 0; one.n = n; one.dev = res; one.owned = true; s.mem->sh.push_back(one); res = nullptr; }
+    else rc = srs_scatter_from_primary(*s.mem, res, n, false);
+  }
+  if (res) { (void)bind_ctx(0); (void)hipFree(res); }
+  if (rc != MI355_OK) return rc;
+  *g_lagrange_handle_out = srs_insert(s); return MI355_OK;
   });
 }
 int mi355_srs_read_host(uint64_t handle, uint64_t offset, uint64_t n, void *out_affine_host) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
-  auto it = g.srs.find(handle);
-  if (it == g.srs.end() || (n && !out_affine_host)) return fail(MI355_EBADARG, "srs_read_host: unknown handle or null pointer");
-  if (offset > it->second.n || n > it->second.n - offset) return fail(MI355_EBADARG, "srs_read_host: range exceeds the registered basis");
-  if (n) { HIPCHK(hipMemcpyAsync(out_affine_host, it->second.dev + offset, n * sizeof(g1_affine_t), hipMemcpyDeviceToHost, g.stream)); HIPCHK(hipStreamSynchronize(g.stream)); }
-  return MI355_OK;
+  Srs *sp; CHK(srs_find(handle, &sp, "srs_read_host"));
+  if (n && !out_affine_host) return fail(MI355_EBADARG, "srs_read_host: null pointer");
+  if (offset > sp->n || n > sp->n - offset) return fail(MI355_EBADARG, "srs_read_host: range exceeds the registered basis");
+  for (const auto &sh : sp->mem->sh) {
+    const uint64_t lo = std::max(offset, sh.lo), hi = std::min(offset + n, sh.lo + sh.n);
+    if (hi <= lo) continue;
+    CHK(bind_ctx(sh.slot));
+    HIPCHK(hipMemcpyAsync((g1_affine_t *)out_affine_host + (lo - offset), sh.dev + (lo - sh.lo), (hi - lo) * sizeof(g1_affine_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+  }
+  return bind_ctx(0);
   });
 }
 int mi355_coeff_to_extended_host(void *dst_host, const void *coeffs_host, uint32_t log_n, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega) {
   return guarded([&]() -> int {
   {
-    std::lock_guard<std::mutex> lk(g.mu);
+    std::lock_guard<std::mutex> lk(g_mu);
     CHK(need_init()); CHK(check_ntt_args(dst_host, log_ext, extended_omega));
     if (!coeffs_host || !g_coset || !g_coset_inv || log_n > log_ext) return fail(MI355_EBADARG, "coeff_to_extended: bad argument");
     void *src, *dst; CHK(ws_get("io.ntt_src", sizeof(fe_t) << log_n, &src)); CHK(ws_get("io.ntt", sizeof(fe_t) << log_ext, &dst));
@@ -1131,55 +1600,60 @@ int mi355_coeff_to_extended_host(void *dst_host, const void *coeffs_host, uint32
   return MI355_OK;
   });
 }
+// body of mi355_extended_to_coeff_dev, to be called with g_mu held
+static int extended_to_coeff_locked(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
+  CHK(check_ntt_args(data_dev, log_ext, extended_omega_inv));
+  if (!g_coset || !g_coset_inv || !extended_ifft_divisor) return fail(MI355_EBADARG, "extended_to_coeff: null pointer");
+  // post-scale table {d, d * g_coset_inv, d * g_coset}: three constant products formed on the host (setup, not data path)
+  fe_t d, gc, gci, post[3]; memcpy(&d, extended_ifft_divisor, 32); memcpy(&gc, g_coset, 32); memcpy(&gci, g_coset_inv, 32);
+  post[0] = d; post[1] = Fr::mul(d, gci); post[2] = Fr::mul(d, gc);
+  return ntt_dev_impl((const fe_t *)data_dev, 1ull << log_ext, (fe_t *)data_dev, log_ext, extended_omega_inv, nullptr, post);
+}
 int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
   return guarded([&]() -> int {
-  void *dev;
-  {
-    std::lock_guard<std::mutex> lk(g.mu);
-    CHK(need_init()); CHK(check_ntt_args(data_host, log_ext, extended_omega_inv));
-    CHK(ws_get("io.ntt", sizeof(fe_t) << log_ext, &dev));
-    HIPCHK(hipMemcpyAsync(dev, data_host, sizeof(fe_t) << log_ext, hipMemcpyHostToDevice, g.stream));
-  }
-  CHK(mi355_extended_to_coeff_dev(dev, log_ext, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor));
-  {
-    std::lock_guard<std::mutex> lk(g.mu);
-    HIPCHK(hipMemcpyAsync(data_host, dev, sizeof(fe_t) << log_ext, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans();
-  }
+  std::lock_guard<std::mutex> lk(g_mu);   // held across stage, compute and copy-back: the staging buffer is shared between the host entry points
+  CHK(need_init()); CHK(check_ntt_args(data_host, log_ext, extended_omega_inv));
+  void *dev; CHK(ws_get("io.ntt", sizeof(fe_t) << log_ext, &dev));
+  HIPCHK(hipMemcpyAsync(dev, data_host, sizeof(fe_t) << log_ext, hipMemcpyHostToDevice, g.stream));
+  CHK(extended_to_coeff_locked(dev, log_ext, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor));
+  HIPCHK(hipMemcpyAsync(data_host, dev, sizeof(fe_t) << log_ext, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans();
   return MI355_OK;
   });
 }
 
 // ---- distribute_powers / coset NTT
-int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *factor) {
-  return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  CHK(need_init());
+static int distribute_powers_locked(void *data_dev, uint64_t n, const void *factor) {
   if (!factor || (n && !data_dev)) return fail(MI355_EBADARG, "distribute_powers: null pointer");
   if (n == 0) return MI355_OK;
   fe_t f; memcpy(&f, factor, 32);
   hipLaunchKernelGGL(k_distribute_powers, dim3(ceil_div(n, (uint64_t)EVAL_RUN * 256)), dim3(256), 0, g.stream, (fe_t *)data_dev, n, f);
   HIPCHK(hipGetLastError());
   return MI355_OK;
+}
+int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *factor) {
+  return guarded([&]() -> int {
+  std::lock_guard<std::mutex> lk(g_mu);
+  CHK(need_init());
+  return distribute_powers_locked(data_dev, n, factor);
   });
 }
 int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, const void *coset_factor, const void *omega) {
   return guarded([&]() -> int {
-  {
-    std::lock_guard<std::mutex> lk(g.mu);
-    CHK(need_init()); CHK(check_ntt_args(dst_dev, log_n, omega));
-    if (!coeffs_dev || !coset_factor) return fail(MI355_EBADARG, "coset_ntt: null pointer");
-    if (dst_dev != coeffs_dev) HIPCHK(hipMemcpyAsync(dst_dev, coeffs_dev, sizeof(fe_t) << log_n, hipMemcpyDeviceToDevice, g.stream));
-  }
-  CHK(mi355_distribute_powers_fr_dev(dst_dev, 1ull << log_n, coset_factor));
-  return mi355_ntt_fr_dev(dst_dev, log_n, omega);
+  std::lock_guard<std::mutex> lk(g_mu);   // one critical section: copy, coset scaling and transform are queued back to back
+  CHK(need_init()); CHK(check_ntt_args(dst_dev, log_n, omega));
+  if (!coeffs_dev || !coset_factor) return fail(MI355_EBADARG, "coset_ntt: null pointer");
+  if (dst_dev != coeffs_dev) HIPCHK(hipMemcpyAsync(dst_dev, coeffs_dev, sizeof(fe_t) << log_n, hipMemcpyDeviceToDevice, g.stream));
+  CHK(distribute_powers_locked(dst_dev, 1ull << log_n, coset_factor));
+  CHK(ntt_dev_impl((const fe_t *)dst_dev, 1ull << log_n, (fe_t *)dst_dev, log_n, omega, nullptr, nullptr));
+  return finish_async();
   });
 }
 
 // ---- element-wise vector operations on resident polynomials
 int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_dev, uint64_t n) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (op < 0 || op > 2 || (n && (!dst_dev || !a_dev || !b_dev))) return fail(MI355_EBADARG, "fr_vec_op: bad argument");
   if (n == 0) return MI355_OK;
@@ -1190,7 +1664,7 @@ int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_
 }
 int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, const void *scalar, uint64_t n) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!scalar || (n && (!dst_dev || !b_dev))) return fail(MI355_EBADARG, "fr_vec_axpy: null pointer");
   if (n == 0) return MI355_OK;
@@ -1202,7 +1676,7 @@ int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, c
 }
 int mi355_fr_kate_division_dev(void *dst_dev, const void *poly_dev, uint64_t n, const void *z) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!z || n == 0 || !poly_dev || (n > 1 && !dst_dev)) return fail(MI355_EBADARG, "fr_kate_division: null pointer or empty polynomial");
   if (n >= (1ull << 40)) return fail(MI355_EBADARG, "fr_kate_division: n too large");
@@ -1215,7 +1689,7 @@ int mi355_fr_kate_division_dev(void *dst_dev, const void *poly_dev, uint64_t n, 
 }
 int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (n && !data_dev) return fail(MI355_EBADARG, "fr_batch_invert: null pointer");
   if (n >= (1ull << 40)) return fail(MI355_EBADARG, "fr_batch_invert: n too large");
@@ -1227,7 +1701,7 @@ int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n) {
 }
 int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (n && (!dst_dev || !src_dev)) return fail(MI355_EBADARG, "fr_prefix_product: null pointer");
   if (n >= (1ull << 40)) return fail(MI355_EBADARG, "fr_prefix_product: n too large");
@@ -1248,7 +1722,7 @@ int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, 
 }
 int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_host, uint32_t period) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!table_host || period == 0 || (period & (period - 1)) || period > 4096 || (n && !data_dev)) return fail(MI355_EBADARG, "fr_vec_mul_periodic: period must be a power of two <= 4096");
   if (n == 0) return MI355_OK;
@@ -1262,10 +1736,7 @@ int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_
 }
 
 // ---- eval_polynomial
-int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host) {
-  return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
-  CHK(need_init());
+static int eval_polynomial_locked(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host) {
   if (!out_fr_host || !point || (n && !poly_dev)) return fail(MI355_EBADARG, "eval_polynomial: null pointer");
   fe_t res = Fr::zero();
   if (n == 0) { memcpy(out_fr_host, &res, 32); return MI355_OK; }
@@ -1283,18 +1754,22 @@ int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *poin
   resolve_spans();
   memcpy(out_fr_host, &res, 32);
   return MI355_OK;
+}
+int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host) {
+  return guarded([&]() -> int {
+  std::lock_guard<std::mutex> lk(g_mu);
+  CHK(need_init());
+  return eval_polynomial_locked(poly_dev, n, point, out_fr_host);
   });
 }
 int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *point, void *out_fr_host) {
   return guarded([&]() -> int {
+  std::lock_guard<std::mutex> lk(g_mu);   // held across staging and evaluation (the staging buffer is shared between the host entry points)
+  CHK(need_init());
+  if (n && !poly_host) return fail(MI355_EBADARG, "eval_polynomial: null pointer");
   void *dev = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(g.mu);
-    CHK(need_init());
-    if (n && !poly_host) return fail(MI355_EBADARG, "eval_polynomial: null pointer");
-    if (n) { CHK(ws_get("io.ntt", n * sizeof(fe_t), &dev)); HIPCHK(hipMemcpyAsync(dev, poly_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
-  }
-  return mi355_eval_polynomial_dev(dev, n, point, out_fr_host);
+  if (n) { CHK(ws_get("io.ntt", n * sizeof(fe_t), &dev)); HIPCHK(hipMemcpyAsync(dev, poly_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
+  return eval_polynomial_locked(dev, n, point, out_fr_host);
   });
 }
 
@@ -1308,7 +1783,7 @@ static int ensure_fixed_base_table() {
 }
 int mi355_g1_fixed_base_mul_dev(void *points_dev, const void *scalars_dev, uint64_t n) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!points_dev || !scalars_dev) return fail(MI355_EBADARG, "fixed_base_mul: null pointer");
   CHK(ensure_fixed_base_table());
@@ -1319,7 +1794,7 @@ int mi355_g1_fixed_base_mul_dev(void *points_dev, const void *scalars_dev, uint6
 }
 int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const void *tau, const void *omega) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   if (!g_dev || !g_lagrange_dev || !tau || !omega || k > 28) return fail(MI355_EBADARG, "srs_setup: bad argument");
   CHK(ensure_fixed_base_table());
@@ -1341,7 +1816,7 @@ int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const voi
 // ---- test hook: read back a workspace buffer ("msm.sorted", "msm.offsets", ...) after a call
 int mi355_debug_ws_read(const char *role, uint64_t offset, void *dst_host, uint64_t bytes) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   CHK(need_init());
   auto it = g.ws.find(role ? role : "");
   if (it == g.ws.end() || !dst_host || offset + bytes > it->second.cap) return fail(MI355_EBADARG, "debug_ws_read: unknown role or range");
@@ -1352,13 +1827,14 @@ int mi355_debug_ws_read(const char *role, uint64_t offset, void *dst_host, uint6
 }
 
 // ---- profiling
-int mi355_profile_enable(int on) { std::lock_guard<std::mutex> lk(g.mu); g.profiling = on != 0; return MI355_OK; }
-int mi355_profile_reset(void) { std::lock_guard<std::mutex> lk(g.mu); if (g.inited) resolve_spans(); g.prof.clear(); return MI355_OK; }
+int mi355_profile_enable(int on) { std::lock_guard<std::mutex> lk(g_mu); for (int s = 0; s < MAX_DEV; s++) g_ctx[s].profiling = on != 0; return MI355_OK; }
+int mi355_profile_reset(void) { std::lock_guard<std::mutex> lk(g_mu); for (int s = g_ndev - 1; s >= 0; s--) { if (bind_ctx(s) == MI355_OK) resolve_spans(); g.prof.clear(); } use_ctx(0); return MI355_OK; }
 int mi355_profile_get(const char *name, double *ms_out, uint64_t *launches_out) {
   return guarded([&]() -> int {
-  std::lock_guard<std::mutex> lk(g.mu);
+  std::lock_guard<std::mutex> lk(g_mu);
   if (!name) return fail(MI355_EBADARG, "profile_get: null name");
-  if (g.inited) resolve_spans();
+  use_ctx(0);   // the primary device's record (a sharded MSM runs the same kernels on every device)
+  if (g_ndev && g.inited && bind_ctx(0) == MI355_OK) resolve_spans();
   auto it = g.prof.find(name);
   if (ms_out) *ms_out = it == g.prof.end() ? 0.0 : it->second.ms;
   if (launches_out) *launches_out = it == g.prof.end() ? 0 : it->second.launches;

@@ -83,14 +83,14 @@ __global__ void __launch_bounds__(256) k_g1fft_stage(g1_xyzz_t *__restrict__ wor
 }
 
 // out[i] = scale * work[i], normalised.  JAC = 1: Jacobian (x, y, R) / all-zero identity; JAC = 0: affine, identity (0, 0).
-// scale == nullptr: no scalar multiple.
-template <int JAC> __global__ void __launch_bounds__(256) k_g1fft_store(const g1_xyzz_t *__restrict__ work, void *__restrict__ out, uint32_t log_n, const fe_t *__restrict__ scale) {
+// has_scale == 0: no scalar multiple.  The scale travels by value (a kernel argument is copied at launch: the caller's host copy may be a temporary).
+template <int JAC> __global__ void __launch_bounds__(256) k_g1fft_store(const g1_xyzz_t *__restrict__ work, void *__restrict__ out, uint32_t log_n, fe_t scale, int has_scale) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (1u << log_n)) return;
   g1_xyzz_t v = g1fft_load_xyzz(&work[i]);
-  if (scale) {
+  if (has_scale) {
     fe_t one_c = Fr::zero(); one_c.l[0] = 1;
-    v = g1_xyzz_mul_fr(v, fr_mul_ps(g_load(scale), one_c));
+    v = g1_xyzz_mul_fr(v, fr_mul_ps(scale, one_c));
   }
   const g1_jac_t r = g1_xyzz_to_jac_normalised(v);
   if (JAC) { g1_jac_t *dst = static_cast<g1_jac_t *>(out) + i; g_store(&dst->x, r.x); g_store(&dst->y, r.y); g_store(&dst->z, r.z); }

@@ -464,6 +464,15 @@ __global__ void __launch_bounds__(64) k_msm_fixup_huge_fold(g1_xyzz29_t *__restr
   if (threadIdx.x == 0) store_xyzz29(&bucket_sums[huge_list[3 * idx]], acc);
 }
 
+// host-chunked MSM: every slice of the point range fills its own bucket set (same layout); buckets[b] += sum_k buckets[k * nbuckets + b]
+__global__ void __launch_bounds__(256) k_msm_bucket_fold(g1_xyzz29_t *__restrict__ buckets, uint32_t nbuckets, uint32_t sets) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  g1_xyzz29_t acc = load_xyzz29(&buckets[b]);
+  for (uint32_t k = 1; k < sets; k++) g1_xyzz29_add(acc, load_xyzz29(&buckets[(uint64_t)k * nbuckets + b]));
+  store_xyzz29(&buckets[b], acc);
+}
+
 // ---- 6a. chunked running sums: thread j of window w covers buckets [j*K, (j+1)*K) and emits
 //          T + (j*K) * S  where S = sum B_i, T = sum (i_local + 1) B_i
 __global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {

@@ -53,7 +53,8 @@ def sharded_multiexp_device(capi, srs_handle: int, scalars_dev, n: int, base_off
     """the production form of the exchange (backend "nccl" = RCCL): this rank's partial sum never leaves the GPU --
     mi355_msm_g1_dev_async leaves 96 bytes in device memory in stream order, ONE all_gather_into_tensor moves world x 96 bytes over
     xGMI, mi355_g1_sum_dev folds and normalises them on the device; the only host synchronisation is the final 96-byte read-back.
-    Call mi355_msm_set_normalise(0) first so that the per-rank Horner tail skips its inversion.  Same result on every rank."""
+    The per-rank Horner tail skips its inversion (the partial is requested un-normalised for this call only: the option is per calling
+    thread and is restored before returning).  Same result on every rank."""
     import torch
     import torch.distributed as dist
     grouped = dist.is_available() and dist.is_initialized()
@@ -63,7 +64,11 @@ def sharded_multiexp_device(capi, srs_handle: int, scalars_dev, n: int, base_off
         _BUFFERS[key] = (torch.empty(96, dtype=torch.uint8, device=scalars_dev.device), torch.empty(world * 96, dtype=torch.uint8, device=scalars_dev.device))
     mine, out = _BUFFERS[key]
     lib = capi.lib()
-    capi.check(lib.mi355_msm_g1_dev_async(srs_handle, base_offset, capi.ptr(scalars_dev), n, capi.ptr(mine)))
+    capi.check(lib.mi355_msm_set_normalise(0))
+    try:
+        capi.check(lib.mi355_msm_g1_dev_async(srs_handle, base_offset, capi.ptr(scalars_dev), n, capi.ptr(mine)))
+    finally:
+        capi.check(lib.mi355_msm_set_normalise(1))
     if grouped:
         dist.all_gather_into_tensor(out, mine)     # also with one rank: the same RCCL call, so a 1-GPU box exercises the real path
     else:

@@ -77,6 +77,14 @@ def test_no_gpu_means_loud_failure_not_fallback(zk):
         lib.mi355_srs_register_host(ptr(bs), 4, C.byref(h)),
     ]
     assert all(rc == capi.ENODEVICE for rc in calls), calls
+    # several devices behind one process: the same loud failure; the bookkeeping entry points work without a device
+    ids = (C.c_int * 2)(0, 1)
+    assert lib.mi355_init_multi(ids, 2) == capi.ENODEVICE
+    nd = C.c_int(-1)
+    assert lib.mi355_device_count(C.byref(nd)) == capi.OK and nd.value == 0
+    assert lib.mi355_srs_register_prefix(12345, 4, C.byref(h)) == capi.EBADARG
+    dv, ex, shd, sl = C.c_int(), C.c_char_p(), C.c_int(), C.c_int()
+    assert lib.mi355_msm_last_run(C.byref(dv), C.byref(ex), C.byref(shd), C.byref(sl)) == capi.OK and ex.value in (b"none", b"rccl_allgather", b"device_copy")
 
 
 def test_missing_library_raises(zk, monkeypatch):

@@ -12,13 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "test_halo2_mirror")
 
 
-def build_exe():
+def build_exe(name="test_halo2_mirror"):
     ge.build()
-    src = os.path.join(ROOT, "tests", "cpp", "test_halo2_mirror.cpp")
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", name)
     pkg = os.path.join(ROOT, "scroll-prover_amd"); orc = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                            "-L", pkg, "-lmi355zk", "-L", orc, "-loracle_bn254", f"-Wl,-rpath,{pkg}", f"-Wl,-rpath,{orc}", "-Wl,-rpath,/opt/rocm/lib"])
-    return EXE
+    return exe
 
 
 def test_cpp_mirror_host_only():
@@ -32,5 +33,25 @@ def test_cpp_mirror_host_only():
 def test_cpp_mirror_on_gpu():
     exe = build_exe()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout
+
+
+def test_shim_replay_compiles_and_fails_loudly_without_a_gpu():
+    """tests/cpp/test_shim_replay.cpp = what rust_shim/mi355zk.rs does, compiled: here it must build and stop at mi355_init (exit 2)."""
+    import torch
+    exe = build_exe("test_shim_replay")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the full replay runs under -m gpu")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "mi355_init" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_shim_replay_on_gpu():
+    """register by struct-owned handles, clone + downsize as load_params_map does, commits on sub-slices, freed-and-reused addresses,
+    8 concurrent committing threads with per-thread options, release in any order."""
+    exe = build_exe("test_shim_replay")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
