@@ -73,6 +73,81 @@ def witness_like_scalars(n: int, seed: int, device, h2) -> torch.Tensor:
     return a.contiguous()
 
 
+def proof_mix(zk, lib, check, ptr, h2, dev, k, g, g_handle, tau, args, rand_scalars):
+    """one layer-4 proof's call mix (see the call site); returns wall-clock ms device-resident and through the host-pointer API."""
+    n = 1 << k
+    dom = h2.EvaluationDomain(5, k)                   # quotient degree 4 -> extended_k = k + 2, four cosets of size 2^k
+    out = np.zeros(12, dtype=np.uint64)
+    # the Lagrange basis of the same SRS, registered with its window tables like g (registration-time work, outside the timing)
+    gl = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+    w_k = pow(h2.FR_ROOT_OF_UNITY, 1 << (h2.FR_S - k), h2.R_MOD)
+    check(lib.mi355_srs_setup_dev(ptr(scratch), ptr(gl), k, ptr(h2.fr(tau)), ptr(h2.fr(w_k))))
+    del scratch
+    hl = C.c_uint64(); check(lib.mi355_srs_register_dev(ptr(gl), n, 0, C.byref(hl)))
+    tables = not args.no_precompute and not args.window_bits
+    if tables:
+        check(lib.mi355_srs_precompute(hl.value, 0, 0))
+    NW, Q = 8, 4
+    polys = [rand_scalars(n, 7000 + i, dev) for i in range(NW)]
+    part = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    acc = torch.zeros((Q * n, 4), dtype=torch.int64, device=dev)          # the quotient on the extended domain, part by part
+    pt = h2.fr(0x1234567890ABCDEF)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for p_ in polys:                                                        # witness commitments (Lagrange basis)
+        check(lib.mi355_msm_g1_dev(hl.value, 0, ptr(p_), n, ptr(out)))
+    for i in (0, 1):                                                        # permutation / lookup products: batch inversion + running product
+        h2.batch_invert(polys[i]); h2.prefix_product(polys[i], dst=part)
+    for p_ in polys:
+        dom.lagrange_to_coeff(p_)
+    for q in range(Q):
+        hq = acc[q * n:(q + 1) * n]
+        for i, p_ in enumerate(polys):
+            dom.coeff_to_extended_part(p_, q, part)
+            h2.fr_vec_op("mul" if i % 2 else "add", hq, hq, part)         # stand-in for the gate / permutation / lookup expressions of evaluate_h
+    dom.divide_by_vanishing_poly(acc)
+    dom.extended_to_coeff(acc)
+    for q in range(Q):                                                      # quotient pieces (coefficient basis)
+        check(lib.mi355_msm_g1_dev(g_handle.value, 0, ptr(acc[q * n:(q + 1) * n]), n, ptr(out)))
+    for i in range(27):
+        h2.eval_polynomial(polys[i % NW], pt)
+    for i in range(NW):                                                     # multi-open: linear combination, two quotients, two commitments
+        h2.fr_vec_axpy(part, part if i else None, polys[i], pt)
+    for _ in range(2):
+        h2.kate_division(part, pt, dst=acc[: n - 1])
+        check(lib.mi355_msm_g1_dev(g_handle.value, 0, ptr(acc[:n]), n, ptr(out)))
+    check(lib.mi355_synchronize()); torch.cuda.synchronize()
+    dev_ms = (time.perf_counter() - t0) * 1e3
+    res = {"layer": "4 (batch compression, k = %d)" % k, "device_resident_ms": dev_ms,
+           "calls": "14 MSM 2^%d (8 Lagrange + 6 coefficient basis), 8 iNTT + 32 coset NTT 2^%d, 1 extended_to_coeff 2^%d, 2 batch_invert + 2 prefix_product, 27 eval_polynomial, 8 axpy, 2 kate_division, 40 pointwise" % (k, k, k + 2),
+           "window_tables": tables, "excludes": "witness synthesis, the gate arithmetic of evaluate_h, transcript hashing (CPU side of create_proof)"}
+    del acc, part
+    if not args.no_host_api:
+        # the same MSM / NTT calls through the host-pointer entry points the Rust shim binds (every operand crosses PCIe both ways;
+        # the pointwise steps and scans stay on the CPU in that integration and are not part of this leg)
+        hp = polys[0].cpu().numpy().view(np.uint64)
+        hext = np.zeros((Q * n, 4), dtype=np.uint64)
+        t1 = time.perf_counter()
+        for _ in range(8):
+            check(lib.mi355_msm_g1_host(hl.value, 0, ptr(hp), n, ptr(out)))
+        for _ in range(6):
+            check(lib.mi355_msm_g1_host(g_handle.value, 0, ptr(hp), n, ptr(out)))
+        for _ in range(8):
+            dom.lagrange_to_coeff(hp)
+        for _ in range(32):
+            h2.best_fft(hp, dom.omega, k)
+        check(lib.mi355_extended_to_coeff_host(ptr(hext), dom.extended_k, ptr(dom.g_coset), ptr(dom.g_coset_inv), ptr(dom.extended_omega_inv), ptr(dom.extended_ifft_divisor)))
+        for _ in range(27):
+            h2.eval_polynomial(hp, pt)
+        res["host_api_ms"] = (time.perf_counter() - t1) * 1e3
+        res["host_api_calls"] = "14 mi355_msm_g1_host, 8 mi355_intt_fr_host, 32 mi355_ntt_fr_host, 1 mi355_extended_to_coeff_host (2^%d), 27 mi355_eval_polynomial_host; pageable numpy buffers" % (k + 2)
+        del hp, hext
+    check(lib.mi355_srs_release(hl.value))
+    del polys, gl
+    torch.cuda.empty_cache()
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,14 +158,20 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="skip the registration-time window tables (mi355_srs_precompute)")
-    ap.add_argument("--proxy-chunk-proof", action="store_true", help="also replay the layer-2 (k=25) call mix of one chunk proof on synthetic data (SURVEY 3.3): 11 MSM + NTT mix")
-    ap.add_argument("--host-api", action="store_true", help="also time the host-pointer entry point (scalars cross PCIe) -- never the headline value")
+    ap.add_argument("--no-proof-mix", action="store_true", help="skip the replay of one layer-4 (k = 26) proof's MSM / NTT call mix (device-resident and through the host API)")
+    ap.add_argument("--proxy-chunk-proof", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--single-process", action="store_true", help="N GPUs behind ONE process (mi355_init_multi: shards, worker threads, ncclAllGather inside the library) instead of one rank per GPU")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer leg (mi355_msm_g1_host: scalars cross PCIe inside the call; reported next to, never as, the headline value)")
+    ap.add_argument("--no-table-free", action="store_true", help="skip the leg without window tables")
+    ap.add_argument("--host-api", action="store_true", help=argparse.SUPPRESS)   # accepted for older command lines: the leg is on by default now
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    single = args.single_process          # N GPUs behind this one process (the reference's shape: one prover process, one params_map)
+    assert single or world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or pass --single-process)"
+    assert not (single and world > 1), "--single-process is launched without torchrun"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     # one rank per GPU.  MI355_BENCH_SHARE_GPU=1 (test only) lets several ranks share the visible GPUs and moves the
     # collective to gloo, so the N > 1 control flow can be exercised on a one-GPU box; the driver never sets it.
@@ -108,7 +189,12 @@ def main() -> None:
 
     zk = ge.load_package()
     lib, check, ptr, h2 = zk._capi.lib(), zk._capi.check, zk._capi.ptr, zk.halo2
-    zk.init(dev_index)
+    if single:
+        # device ids 0..N-1; on a box with fewer GPUs the same device may be listed twice when MI355_ALLOW_DUP_DEVICES=1 (test mode)
+        cnt = torch.cuda.device_count()
+        zk.init([i % cnt for i in range(args.gpus)] if os.environ.get("MI355_ALLOW_DUP_DEVICES") == "1" else list(range(args.gpus)))
+    else:
+        zk.init(dev_index)
     check(lib.mi355_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     check(lib.mi355_msm_set_window_bits(args.window_bits))
 
@@ -216,7 +302,8 @@ def main() -> None:
     pairs_per_s = n_total * args.steps / dt
     shared_buckets = pre_ms is not None
     # N*W bucket additions + 2 * 2^(c-1) running-sum additions per bucket set (W sets per shard, or ONE with precomputed window tables)
-    adds_per_msm = n_total * W + world * (1 if shared_buckets else W) * (1 << c)
+    devs = args.gpus if single else world
+    adds_per_msm = n_total * W + devs * (1 if shared_buckets else W) * (1 << c)
     value = adds_per_msm * args.steps / dt
 
     # ---- secondary: NTT fwd + inv at 2^k on this rank (replica), device resident
@@ -253,39 +340,58 @@ def main() -> None:
         dt_ev = (time.perf_counter() - t5) / 5
         ntt["eval_polynomial"] = {"log_n": k, "ms": dt_ev * 1e3, "roofline": {"bound": "hbm", "achieved": 32.0 * (1 << k) / dt_ev / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": 32.0 * (1 << k) / dt_ev / 1e9 / HBM_PEAK_GBS, "note": "algorithmic bytes = 32 B per coefficient, host wall time incl. the 32-byte result copy"}}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # CPU baseline of the transform (rank 0, N = 1): the oracle's restatement of best_fft (bit-reverse + radix-2 layers, thread
+            # split) on a bounded sample: 2^22 coefficients of the same data, all host threads
+            from oracle import cref
+            cores = os.cpu_count() or 1
+            ks_ = min(k, 22)
+            sample = poly[: 1 << ks_].cpu().numpy().view(np.uint64).reshape(1 << ks_, 4).copy()
+            dom_s = h2.EvaluationDomain(2, ks_)
+            t8 = time.perf_counter(); cref.best_fft(sample, dom_s.omega, ks_, threads=cores); dt_c = time.perf_counter() - t8
+            ntt["cpu_baseline"] = {"value": (1 << ks_) // 2 * ks_ / dt_c, "unit": "butterflies/s", "cores": cores, "kind": "port",
+                                   "sample": f"best_fft restatement (oracle/bn254_oracle.c, pthreads) on 2^{ks_} coefficients of the same data, {dt_c:.2f} s wall"}
         del poly
 
     extra = {}
-    if args.host_api and world == 1:
+    if world == 1 and not args.no_host_api:
+        # the entry point the Rust shim calls: scalars in ordinary (pageable) host memory cross PCIe inside the call.  Never `value`.
         sc_host = scalars.cpu().numpy().view(np.uint64)
         check(lib.mi355_msm_g1_host(handle.value, 0, ptr(sc_host), n, ptr(out)))   # warm-up (allocates the staging buffer)
+        host_ok = bool((out == result).all())
+        check(lib.mi355_profile_reset()); check(lib.mi355_profile_enable(1))
         t3 = time.perf_counter()
         for _ in range(3):
             check(lib.mi355_msm_g1_host(handle.value, 0, ptr(sc_host), n, ptr(out)))
-        extra["host_api_ms_per_commit_pcie_inclusive"] = (time.perf_counter() - t3) / 3 * 1e3
+        host_ms = (time.perf_counter() - t3) / 3 * 1e3
+        check(lib.mi355_profile_enable(0))
+        dv, ex, shd, sl = C.c_int(), C.c_char_p(), C.c_int(), C.c_int()
+        check(lib.mi355_msm_last_run(C.byref(dv), C.byref(ex), C.byref(shd), C.byref(sl)))
+        extra["host_api"] = {"ms_per_commit_pcie_inclusive": host_ms, "vs_resident": host_ms / ms_per_step, "point_range_slices": sl.value,
+                             "same_result_as_resident": host_ok, "scalars": "pageable host memory (numpy), 32 B x 2^%d" % k,
+                             "phase_ms_sum_over_slices": {p_: prof(p_)[0] / 3 for p_ in ("msm_digits", "msm_sort", "msm_accumulate", "msm_reduce", "msm_total")}}
         del sc_host
-    if args.proxy_chunk_proof and world == 1:
-        # layer-2 compression circuit, k = 25 (SURVEY 3.3 / BASELINE.md): 11 commitments (1+1+3 witness, 4 quotient pieces, 2 SHPLONK),
-        # 5 witness polys -> coefficient form (iNTT) and 4 coset extensions each, one extended inverse; synthetic data, device resident
-        kk = min(25, k)
-        domp = h2.EvaluationDomain(5, kk)
-        polys = [rand_scalars(1 << kk, 900 + i, dev) for i in range(5)]
-        ext = torch.empty((1 << domp.extended_k, 4), dtype=torch.int64, device=dev)
-        hh = C.c_uint64(); check(lib.mi355_srs_register_dev(ptr(g), 1 << kk, 0, C.byref(hh)))
-        if not args.no_precompute and not args.window_bits:
-            check(lib.mi355_srs_precompute(hh.value, 0, 0))      # registration-time work, as for the headline basis
-        torch.cuda.synchronize(); t4 = time.perf_counter()
-        for i in range(11):
-            check(lib.mi355_msm_g1_dev(hh.value, 0, ptr(polys[i % 5]), 1 << kk, ptr(out)))
-        for pl in polys:
-            domp.lagrange_to_coeff(pl)
-            domp.coeff_to_extended(pl, out=ext)
-        domp.extended_to_coeff(ext)
-        check(lib.mi355_synchronize()); torch.cuda.synchronize()
-        extra["proxy_chunk_proof_layer2_ms"] = (time.perf_counter() - t4) * 1e3
-        extra["proxy_chunk_proof_note"] = "11 MSM(2^%d) + 5 iNTT(2^%d) + 5 coeff_to_extended(2^%d->2^%d) + 1 extended_to_coeff; synthetic; excludes witness synthesis, evaluate_h, transcript (CPU side of create_proof)" % (kk, kk, kk, domp.extended_k)
-        check(lib.mi355_srs_release(hh.value)); del polys, ext
-
+    if world == 1 and pre_ms is not None and not args.no_table_free:
+        # the memory-lean configuration: no window tables (W x the basis of HBM saved), per-window bucket sets and the Horner tail
+        check(lib.mi355_msm_set_window_bits(-1))
+        check(lib.mi355_msm_g1_dev(handle.value, 0, ptr(scalars), n, ptr(out)))
+        nt_ok = bool((out == result).all())
+        torch.cuda.synchronize(); t7 = time.perf_counter()
+        for _ in range(2):
+            check(lib.mi355_msm_g1_dev(handle.value, 0, ptr(scalars), n, ptr(out)))
+        nt_ms = (time.perf_counter() - t7) / 2 * 1e3
+        c2, w2, e2 = C.c_int(), C.c_int(), C.c_uint64()
+        check(lib.mi355_msm_last_plan(C.byref(c2), C.byref(w2), C.byref(e2)))
+        check(lib.mi355_msm_set_window_bits(0))
+        extra["without_window_tables"] = {"ms_per_commit": nt_ms, "window_bits": c2.value, "windows": w2.value, "same_result": nt_ok}
+    if world == 1 and not args.no_proof_mix:
+        # ---- proxy for "chunk-proof wall-clock" (BASELINE metric, third part): the MSM / NTT / scan call mix of ONE layer-4 compression
+        # proof (k = 26: the batch proof; fixture counts [3, 1, 4] witness columns, Q = 4, 27 evaluations) replayed on synthetic
+        # data -- the GPU side of create_proof only (witness synthesis, evaluate_h's gate arithmetic and the transcript stay on the CPU).
+        #   8 commit_lagrange (advice 3, lookup 1, permutation / lookup / random 4) | 8 lagrange_to_coeff | 8 x 4 coset NTTs of 2^k (the scroll
+        #   fork's coeff_to_extended_part) with the pointwise accumulation between them | extended_to_coeff on 2^(k+2) | 4 quotient-piece commits
+        #   | 2 batch inversions + 2 grand products (permutation / lookup z) | 27 evaluations | multi-open: 8 axpy + 2 kate_division + 2 commits
+        extra["proof_mix"] = proof_mix(zk, lib, check, ptr, h2, dev, k, g, handle, tau, args, rand_scalars)
     if world == 1 and k <= 26:
         # the second scalar distribution the survey asks for: mostly zeros / tiny values (giant buckets, few entries)
         wl = witness_like_scalars(n, 0x5343524F4C4C0004, dev, h2)
@@ -326,7 +432,7 @@ def main() -> None:
 
     if rank == 0:
         acc_avg_ms = acc_ms / max(1, acc_cnt)
-        pairs_per_launch = n / chunks          # one accumulate launch processes one chunk of the point range, all windows
+        pairs_per_launch = n / chunks / (args.gpus if single else 1)   # one accumulate launch processes one chunk of this device's point range, all windows
         achieved = 96.0 * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -336,12 +442,12 @@ def main() -> None:
             except Exception:
                 traffic = None
         line = {
-            "metric": "BN254 MSM G1-adds/sec at k=%d" % k, "value": value, "unit": "G1-adds/s", "n_gpus": world, "steps": args.steps,
+            "metric": "BN254 MSM G1-adds/sec at k=%d" % k, "value": value, "unit": "G1-adds/s", "n_gpus": args.gpus if single else world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32 limbs (254-bit Montgomery integers: 9x29-bit unsaturated compute form, 8x32 storage; v_mad_u64_u32)", "data": "synthetic",
             "config": {"workload": f"BN254 G1 Pippenger MSM, 2^{k} uniform random scalars x synthetic SRS points, inputs resident in HBM; "
                                    f"point-range shards over {world} GPU(s), RCCL all-gather of 96-B partials",
-                       "log_n": k, "window_bits": c, "windows": W, "parallelism": f"point-range x{world}",
+                       "log_n": k, "window_bits": c, "windows": W, "parallelism": (f"point-range x{args.gpus} inside one process (mi355_init_multi: per-device shards, ncclAllGather of the partials in the library)" if single else f"point-range x{world}, one rank per GPU"),
                        "srs_window_tables": shared_buckets, "srs_precompute_ms_once": pre_ms},
             "pairs_per_s": pairs_per_s, "g1_adds_per_msm": adds_per_msm, "verified_against_field_check": verified,
             "msm_phase_ms": phases, "msm_pipeline_chunks": chunks,

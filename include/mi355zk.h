@@ -120,7 +120,8 @@ int mi355_g1_sum_host(const void *g1_points_host, uint64_t n, void *out_g1_host)
 /* (per calling thread) normalise = 0: subsequent MSM results are SOME Jacobian representative of the sum (as best_multiexp's C::Curve is) instead of the
  * normalised one; saves the serial field inversion (~0.4 ms) where the result is folded again anyway (per-GPU partial sums).      */
 int mi355_msm_set_normalise(int on);
-/* tuning (per calling thread): window bits c for subsequent MSMs (0 = automatic from n)                        */
+/* tuning (per calling thread): window bits c for subsequent MSMs: 0 = automatic from n (window tables used when registered and cheaper),
+ * -1 = automatic but ignoring window tables (the memory-lean schedule: per-window bucket sets + Horner), 2..22 = fixed, no tables       */
 int mi355_msm_set_window_bits(int c);
 /* pipelined schedule of a large single MSM: the point range is cut into `chunks` slices and the (memory-bound) sort of slice k + 1
  * runs under the (ALU-bound) accumulation of slice k on separate HIP streams; results are identical.  Off by default (measured
@@ -182,6 +183,13 @@ int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *po
 int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const void *tau, const void *omega);
 /* points[i] = scalars[i] * G (fixed-base, batch-normalised); building block of the above                      */
 int mi355_g1_fixed_base_mul_dev(void *points_affine_dev, const void *scalars_dev, uint64_t n);
+
+/* ---- G2: out = scalar * p on the twist y^2 = x^3 + 3 / (9 + u) over Fq2.  Points are 128-byte halo2curves G2Affine values
+ * (x.c0 | x.c1 | y.c0 | y.c1, Montgomery limbs; identity = all zero) -- the layout of `g2` / `s_g2` in a RawBytes params file.  The one G2
+ * operation on the path: ParamsKZG::setup's s_g2 = tau * G2 [EXT-recalled poly/kzg/commitment.rs]; a G2 MSM does not exist in create_proof
+ * (SURVEY 8a a7).  MI355_EBADARG when p is not on the twist.  The generator constant is halo2curves' G2 generator, pinned by the
+ * pairing input of the released verifier [REF release-v0.13.1/evm_verifier.yul:1230-1233].                                             */
+int mi355_g2_mul_host(const void *p_g2affine_host, const void *scalar_fr, void *out_g2affine_host);
 
 /* ---- best_fft::<Fr, G1> -- the same DFT over G1 points, a'[i] = sum_j omega^(ij) a[j] -- and its one caller, g_to_lagrange, which
  * ParamsKZG::downsize(k) [REF integration/tests/integration.rs:17-22] and ParamsKZG::setup run to rebuild g_lagrange from

@@ -226,6 +226,87 @@ int orc_g1_decompress(g1a *o, const uint8_t in[32]) {
   o->x = xm; o->y = y; return 1;
 }
 
+/* ------------------------------------------------------------------ G2 ------- */
+/* Fq2 = Fq[u] / (u^2 + 1); G2 = the sextic twist y^2 = x^3 + 3 / (9 + u) over Fq2 [EXT-recalled halo2curves src/bn256/fq2.rs, curve.rs].
+ * G2Affine = {x: {c0, c1}, y: {c0, c1}} = 128 B of Montgomery limbs, identity = all zero; this is the layout of `g2` / `s_g2` in a
+ * RawBytes params file.  The only G2 work on this path is ParamsKZG::setup's s_g2 = tau * G2.
+ * Pinned by the fixture [REF release-v0.13.1/evm_verifier.yul:1230-1239]: the generator below equals the words of the pairing input,
+ * both fixture points satisfy the twist equation and are annihilated by r (tests/test_oracle_golden.py). */
+typedef struct { fe c0, c1; } fe2;
+typedef struct { fe2 x, y; } g2a;
+typedef struct { fe2 x, y, z; } g2j;
+static void f2_add(fe2 *o, const fe2 *a, const fe2 *b) { fe_add(&o->c0, &a->c0, &b->c0, &FQ); fe_add(&o->c1, &a->c1, &b->c1, &FQ); }
+static void f2_sub(fe2 *o, const fe2 *a, const fe2 *b) { fe_sub(&o->c0, &a->c0, &b->c0, &FQ); fe_sub(&o->c1, &a->c1, &b->c1, &FQ); }
+static void f2_dbl(fe2 *o, const fe2 *a) { f2_add(o, a, a); }
+static void f2_mul(fe2 *o, const fe2 *a, const fe2 *b) {
+  fe t0, t1, t2, t3; fe_mul(&t0, &a->c0, &b->c0, &FQ); fe_mul(&t1, &a->c1, &b->c1, &FQ); fe_mul(&t2, &a->c0, &b->c1, &FQ); fe_mul(&t3, &a->c1, &b->c0, &FQ);
+  fe_sub(&o->c0, &t0, &t1, &FQ); fe_add(&o->c1, &t2, &t3, &FQ);
+}
+static void f2_sqr(fe2 *o, const fe2 *a) { fe2 t = *a; f2_mul(o, &t, &t); }
+static int f2_is_zero(const fe2 *a) { return fe_is_zero(&a->c0) && fe_is_zero(&a->c1); }
+static int f2_eq(const fe2 *a, const fe2 *b) { return fe_eq(&a->c0, &b->c0) && fe_eq(&a->c1, &b->c1); }
+static void f2_inv(fe2 *o, const fe2 *a) {   /* conj(a) / (c0^2 + c1^2) */
+  fe n, t; fe_sqr(&n, &a->c0, &FQ); fe_sqr(&t, &a->c1, &FQ); fe_add(&n, &n, &t, &FQ); fe_inv(&n, &n, &FQ);
+  fe_mul(&o->c0, &a->c0, &n, &FQ); fe_neg(&t, &a->c1, &FQ); fe_mul(&o->c1, &t, &n, &FQ);
+}
+static void f2_from_u64(fe2 *o, uint64_t c0, uint64_t c1) { fe a = {{c0, 0, 0, 0}}, b = {{c1, 0, 0, 0}}; fe_from_canonical(&o->c0, &a, &FQ); fe_from_canonical(&o->c1, &b, &FQ); }
+static void g2_b(fe2 *o) { fe2 three, nine_u, inv; f2_from_u64(&three, 3, 0); f2_from_u64(&nine_u, 9, 1); f2_inv(&inv, &nine_u); f2_mul(o, &three, &inv); }   /* 3 / (9 + u) */
+static int g2a_is_identity(const g2a *p) { return f2_is_zero(&p->x) && f2_is_zero(&p->y); }
+static int g2j_is_identity(const g2j *p) { return f2_is_zero(&p->z); }
+int orc_g2_is_on_curve(const g2a *p) {
+  if (g2a_is_identity(p)) return 1;
+  fe2 y2, x3, b; g2_b(&b); f2_sqr(&y2, &p->y); f2_sqr(&x3, &p->x); f2_mul(&x3, &x3, &p->x); f2_add(&x3, &x3, &b);
+  return f2_eq(&y2, &x3);
+}
+/* the same Jacobian formulas as G1 (dbl-2009-l, madd-2007-bl), over Fq2 */
+static void g2j_double(g2j *o, const g2j *p) {
+  if (g2j_is_identity(p)) { *o = *p; return; }
+  fe2 a, b, c, d, e, f, t, x3, y3, z3;
+  f2_sqr(&a, &p->x); f2_sqr(&b, &p->y); f2_sqr(&c, &b);
+  f2_add(&d, &p->x, &b); f2_sqr(&d, &d); f2_sub(&d, &d, &a); f2_sub(&d, &d, &c); f2_dbl(&d, &d);
+  f2_dbl(&e, &a); f2_add(&e, &e, &a); f2_sqr(&f, &e);
+  f2_mul(&z3, &p->y, &p->z); f2_dbl(&z3, &z3);
+  f2_dbl(&t, &d); f2_sub(&x3, &f, &t);
+  f2_sub(&t, &d, &x3); f2_mul(&y3, &e, &t); f2_dbl(&c, &c); f2_dbl(&c, &c); f2_dbl(&c, &c); f2_sub(&y3, &y3, &c);
+  o->x = x3; o->y = y3; o->z = z3;
+}
+static void g2j_add_affine(g2j *o, const g2j *p, const g2a *q) {
+  if (g2a_is_identity(q)) { *o = *p; return; }
+  if (g2j_is_identity(p)) { o->x = q->x; o->y = q->y; o->z.c0 = FQ.r; memset(&o->z.c1, 0, sizeof(fe)); return; }
+  fe2 z1z1, u2, s2, h, hh, i, j, r, v, t, x3, y3, z3;
+  f2_sqr(&z1z1, &p->z); f2_mul(&u2, &q->x, &z1z1);
+  f2_mul(&s2, &q->y, &p->z); f2_mul(&s2, &s2, &z1z1);
+  if (f2_eq(&p->x, &u2)) { if (f2_eq(&p->y, &s2)) { g2j_double(o, p); } else { memset(o, 0, sizeof *o); } return; }
+  f2_sub(&h, &u2, &p->x); f2_sqr(&hh, &h); f2_dbl(&i, &hh); f2_dbl(&i, &i); f2_mul(&j, &h, &i);
+  f2_sub(&r, &s2, &p->y); f2_dbl(&r, &r); f2_mul(&v, &p->x, &i);
+  f2_sqr(&x3, &r); f2_sub(&x3, &x3, &j); f2_sub(&x3, &x3, &v); f2_sub(&x3, &x3, &v);
+  f2_sub(&t, &v, &x3); f2_mul(&y3, &r, &t); f2_mul(&t, &p->y, &j); f2_dbl(&t, &t); f2_sub(&y3, &y3, &t);
+  f2_add(&z3, &p->z, &h); f2_sqr(&z3, &z3); f2_sub(&z3, &z3, &z1z1); f2_sub(&z3, &z3, &hh);
+  o->x = x3; o->y = y3; o->z = z3;
+}
+static void g2j_to_affine(g2a *o, const g2j *p) {
+  if (g2j_is_identity(p)) { memset(o, 0, sizeof *o); return; }
+  fe2 zi, zi2, zi3; f2_inv(&zi, &p->z); f2_sqr(&zi2, &zi); f2_mul(&zi3, &zi2, &zi);
+  f2_mul(&o->x, &p->x, &zi2); f2_mul(&o->y, &p->y, &zi3);
+}
+/* out = k * p, k canonical limbs; double-and-add (the definitional oracle).  Returns affine. */
+static void g2_mul_canonical(g2a *o, const g2a *p, const uint64_t k[4]) {
+  g2j acc; memset(&acc, 0, sizeof acc);
+  for (int i = 255; i >= 0; i--) { g2j_double(&acc, &acc); if ((k[i >> 6] >> (i & 63)) & 1) g2j_add_affine(&acc, &acc, p); }
+  g2j_to_affine(o, &acc);
+}
+void orc_g2_mul(g2a *o, const g2a *p, const fe *scalar_mont) { fe k; fe_to_canonical(&k, scalar_mont, &FR); g2a r; g2_mul_canonical(&r, p, k.l); *o = r; }
+/* r * p == identity (subgroup membership; r is taken as a plain integer, not reduced mod r) */
+int orc_g2_in_subgroup(const g2a *p) { g2a r; g2_mul_canonical(&r, p, FR.m.l); return g2a_is_identity(&r); }
+/* halo2curves G2 generator [EXT-recalled src/bn256/curve.rs G2_GENERATOR_X/Y]; equality with the fixture words is a golden test */
+void orc_g2_generator(g2a *o) {
+  const fe xc0 = {{0x46debd5cd992f6edULL, 0x674322d4f75edaddULL, 0x426a00665e5c4479ULL, 0x1800deef121f1e76ULL}};
+  const fe xc1 = {{0x97e485b7aef312c2ULL, 0xf1aa493335a9e712ULL, 0x7260bfb731fb5d25ULL, 0x198e9393920d483aULL}};
+  const fe yc0 = {{0x4ce6cc0166fa7daaULL, 0xe3d1e7690c43d37bULL, 0x4aab71808dcb408fULL, 0x12c85ea5db8c6debULL}};
+  const fe yc1 = {{0x55acdadcd122975bULL, 0xbc4b313370b38ef3ULL, 0xec9e99ad690c3395ULL, 0x090689d0585ff075ULL}};
+  fe_from_canonical(&o->x.c0, &xc0, &FQ); fe_from_canonical(&o->x.c1, &xc1, &FQ); fe_from_canonical(&o->y.c0, &yc0, &FQ); fe_from_canonical(&o->y.c1, &yc1, &FQ);
+}
+
 /* ------------------------------------------------------------------ MSM ------ */
 /* definitional oracle: sum_i s_i * P_i by double-and-add */
 void orc_msm_naive(g1j *out, const fe *scalars_mont, const g1a *bases, uint64_t n) {

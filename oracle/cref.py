@@ -144,6 +144,31 @@ def g1_decompress(b: bytes):
     ok = lib().orc_g1_decompress(_p(o), buf); return o if ok else None
 
 
+def g2_generator():
+    o = np.zeros(16, dtype=np.uint64); lib().orc_g2_generator(_p(o)); return o
+
+
+def g2_is_on_curve(p) -> bool:
+    return bool(lib().orc_g2_is_on_curve(_p(np.ascontiguousarray(p, dtype=np.uint64))))
+
+
+def g2_in_subgroup(p) -> bool:
+    return bool(lib().orc_g2_in_subgroup(_p(np.ascontiguousarray(p, dtype=np.uint64))))
+
+
+def g2_mul(p, s_mont):
+    """s * p on the twist: G2Affine (16 limbs: x.c0, x.c1, y.c0, y.c1) in, G2Affine out."""
+    o = np.zeros(16, dtype=np.uint64)
+    lib().orc_g2_mul(_p(o), _p(np.ascontiguousarray(p, dtype=np.uint64)), _p(np.ascontiguousarray(s_mont))); return o
+
+
+def g2_from_words(words):
+    """the four 32-byte big-endian words of an EVM pairing input (x.c1, x.c0, y.c1, y.c0) -> G2Affine Montgomery limbs"""
+    w = [int(x, 16) if isinstance(x, str) else int(x) for x in words]
+    q = [w[1], w[0], w[3], w[2]]
+    return np.concatenate([f_from_canonical_vec(FQ, np.array([int_to_limbs(v)], dtype=np.uint64))[0] for v in q])
+
+
 def msm_naive(scalars, bases):
     o = np.zeros(12, dtype=np.uint64); s = np.ascontiguousarray(scalars); b = np.ascontiguousarray(bases)
     lib().orc_msm_naive(_p(o), _p(s), _p(b), C.c_uint64(s.shape[0])); return o

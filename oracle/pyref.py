@@ -201,3 +201,77 @@ def lagrange_scalars(k: int, tau: int):
         out.append(wi * tn1 % R_MOD * ninv % R_MOD * pow((tau - wi) % R_MOD, -1, R_MOD) % R_MOD)
         wi = wi * w % R_MOD
     return out
+
+
+# ----------------------------------------------------------------- G2 (affine over Fq2 = Fq[u]/(u^2+1), canonical ints; None = identity)
+# Second, independent statement of the twist arithmetic (affine chord-and-tangent with explicit Fq2 inversions; the C oracle uses
+# Jacobian coordinates).  G2 appears on this path only as g2 / s_g2 = tau * G2 of ParamsKZG.
+def f2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P_MOD, (a[0] * b[1] + a[1] * b[0]) % P_MOD)
+
+
+def f2_add(a, b):
+    return ((a[0] + b[0]) % P_MOD, (a[1] + b[1]) % P_MOD)
+
+
+def f2_sub(a, b):
+    return ((a[0] - b[0]) % P_MOD, (a[1] - b[1]) % P_MOD)
+
+
+def f2_inv(a):
+    n = pow((a[0] * a[0] + a[1] * a[1]) % P_MOD, -1, P_MOD)
+    return (a[0] * n % P_MOD, (-a[1]) * n % P_MOD)
+
+
+G2_B = f2_mul((3, 0), f2_inv((9, 1)))          # 3 / (9 + u)
+G2_GEN = ((0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED, 0x198E9393920D483A7260BFB731FB5D25F1AA493335A9E71297E485B7AEF312C2),
+          (0x12C85EA5DB8C6DEB4AAB71808DCB408FE3D1E7690C43D37B4CE6CC0166FA7DAA, 0x090689D0585FF075EC9E99AD690C3395BC4B313370B38EF355ACDADCD122975B))
+
+
+def g2_is_on_curve(Q) -> bool:
+    if Q is None:
+        return True
+    x, y = Q
+    return f2_mul(y, y) == f2_add(f2_mul(f2_mul(x, x), x), G2_B)
+
+
+def g2_add(P, Q):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    (x1, y1), (x2, y2) = P, Q
+    if x1 == x2:
+        if f2_add(y1, y2) == (0, 0):
+            return None
+        lam = f2_mul(f2_mul((3, 0), f2_mul(x1, x1)), f2_inv(f2_add(y1, y1)))
+    else:
+        lam = f2_mul(f2_sub(y2, y1), f2_inv(f2_sub(x2, x1)))
+    x3 = f2_sub(f2_sub(f2_mul(lam, lam), x1), x2)
+    return (x3, f2_sub(f2_mul(lam, f2_sub(x1, x3)), y1))
+
+
+def g2_mul(P, k: int):
+    acc, add = None, P
+    while k:
+        if k & 1:
+            acc = g2_add(acc, add)
+        add = g2_add(add, add)
+        k >>= 1
+    return acc
+
+
+def g2_to_limbs(Q):
+    """G2Affine as 16 u64 limbs (x.c0, x.c1, y.c0, y.c1, Montgomery): the 128 bytes of g2 / s_g2 in a RawBytes params file."""
+    if Q is None:
+        return [0] * 16
+    out = []
+    for c in (Q[0][0], Q[0][1], Q[1][0], Q[1][1]):
+        out += mont_limbs(c, P_MOD)
+    return out
+
+
+def g2_from_evm_words(words):
+    """(x.c1, x.c0, y.c1, y.c0) big-endian words of a pairing-precompile input -> ((x.c0, x.c1), (y.c0, y.c1))"""
+    w = [int(x, 16) if isinstance(x, str) else int(x) for x in words]
+    return ((w[1], w[0]), (w[3], w[2]))

@@ -2,16 +2,26 @@
 //! the crate scroll-prover's GPU images already replace wholesale [REF docker/chain-prover/gpu/Dockerfile:7-8]) as
 //! `halo2_proofs/src/mi355zk.rs`, with `build.rs` emitting `cargo:rustc-link-lib=dylib=mi355zk`.
 //!
-//! NOT compiled in this repository's container (no rustc/cargo): this is the binding a
-//! maintainer adds; every `extern "C"` item mirrors include/mi355zk.h one-to-one.
+//! NOT compiled in this repository's container (no rustc/cargo).  Its behaviour -- who owns a handle, when it
+//! is released, what clone / downsize do, which slices are never registered -- is replayed call for call through the same C-ABI by
+//! the compiled test `tests/cpp/test_shim_replay.cpp` (`pytest -m gpu tests/test_cpp_mirror.py`).
+//!
+//! Ownership model (round 2; the round-1 address-keyed map is gone -- a freed and re-used Vec address could select a stale basis):
+//!   * a registration is a `GpuBasis(u64)`; `Drop` releases it (`mi355_srs_release`);
+//!   * `ParamsKZG` carries `gpu_g` / `gpu_g_lagrange: Option<Arc<GpuBasis>>`, filled by `setup` / `read_custom`; `clone()` shares
+//!     the Arcs (no second upload, no second 48 GiB window table);
+//!   * `downsize(k)`: `g.truncate(n)` -> `mi355_srs_register_prefix` (a view that shares memory and tables), `g_lagrange` is rebuilt
+//!     on the device (`mi355_srs_downsize` + `mi355_srs_read_host`) -- the `load_params_map` pattern
+//!     [REF integration/tests/integration.rs:12-22], [REF bin/src/trace_prover.rs:35-36];
+//!   * `commit` / `commit_lagrange` use the handle of `self`; the generic `best_multiexp(coeffs, bases)` only sees slices and
+//!     therefore goes through `mi355_msm_g1_adhoc_host` -- nothing is ever registered by address.
 //!
 //! Layout contract asserted at start-up: size_of::<Fr>() == 32, size_of::<G1Affine>() == 64,
 //! size_of::<G1>() == 96 and Fr::one() serialises to R = 2^256 mod r in little-endian u64 limbs (fixture KAT A1).
 #![allow(non_camel_case_types)]
 use std::any::TypeId;
-use std::collections::HashMap;
 use std::os::raw::{c_char, c_int, c_void};
-use std::sync::{Mutex, Once};
+use std::sync::{Arc, Once};
 
 use halo2curves::bn256::{Fr, G1Affine, G1};
 
@@ -19,8 +29,10 @@ pub const MI355_OK: c_int = 0;
 
 extern "C" {
     pub fn mi355_init(device_id: c_int) -> c_int;
+    pub fn mi355_init_multi(device_ids: *const c_int, n_devices: c_int) -> c_int;
     pub fn mi355_last_error() -> *const c_char;
     pub fn mi355_srs_register_host(bases_affine_host: *const c_void, n: u64, handle_out: *mut u64) -> c_int;
+    pub fn mi355_srs_register_prefix(parent_handle: u64, n: u64, handle_out: *mut u64) -> c_int;
     pub fn mi355_srs_release(handle: u64) -> c_int;
     pub fn mi355_srs_precompute(handle: u64, n_hint: u64, c: c_int) -> c_int;
     pub fn mi355_srs_downsize(g_handle: u64, k: u32, omega_inv: *const c_void, n_inv: *const c_void, g_lagrange_handle_out: *mut u64) -> c_int;
@@ -43,7 +55,9 @@ fn min_log(var: &str, default: u32) -> u32 { std::env::var(var).ok().and_then(|v
 static INIT: Once = Once::new();
 static mut AVAILABLE: bool = false;
 
-/// One device per process; MI355_DEVICE selects it (default 0).  Never panics: on any failure the caller keeps the CPU path.
+/// MI355_DEVICES="0,1,2,3,4,5,6,7" binds several GPUs to this one prover process (bases are sharded by point range, every MSM fans
+/// out behind the same call, partial sums meet in one ncclAllGather); MI355_DEVICE / default 0 binds one.  Never panics: on any
+/// failure the caller keeps the CPU path.
 pub fn available() -> bool {
     INIT.call_once(|| unsafe {
         assert_eq!(std::mem::size_of::<Fr>(), 32);
@@ -51,85 +65,86 @@ pub fn available() -> bool {
         assert_eq!(std::mem::size_of::<G1>(), 96);
         let one: [u64; 4] = std::mem::transmute(Fr::one());
         assert_eq!(one, [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f]);
-        let dev = std::env::var("MI355_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0);
-        AVAILABLE = mi355_init(dev) == MI355_OK;
+        let rc = match std::env::var("MI355_DEVICES") {
+            Ok(list) => {
+                let ids: Vec<c_int> = list.split(',').filter_map(|s| s.trim().parse().ok()).collect();
+                if ids.is_empty() { mi355_init(0) } else { mi355_init_multi(ids.as_ptr(), ids.len() as c_int) }
+            }
+            Err(_) => mi355_init(std::env::var("MI355_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0)),
+        };
+        AVAILABLE = rc == MI355_OK;
         if !AVAILABLE { log::warn!("mi355zk unavailable: {:?}; using the CPU path", std::ffi::CStr::from_ptr(mi355_last_error())); }
     });
     unsafe { AVAILABLE }
 }
 
-lazy_static::lazy_static! {
-    /// (pointer, len) of a `Vec<G1Affine>` basis inside a long-lived ParamsKZG -> registered handle.  The reference keeps
-    /// params in a process-wide map borrowed by every prover [REF integration/src/prove.rs:11-17], so pointer identity is stable.
-    static ref SRS: Mutex<HashMap<(usize, usize), u64>> = Mutex::new(HashMap::new());
+/// One registered basis in HBM.  Owned through `Arc` by every `ParamsKZG` that shares it; released when the last owner drops.
+#[derive(Debug)]
+pub struct GpuBasis(pub u64);
+impl Drop for GpuBasis {
+    fn drop(&mut self) { unsafe { let _ = mi355_srs_release(self.0); } }
 }
 
-fn srs_handle(bases: &[G1Affine]) -> Option<(u64, u64)> {
-    // a slice `&params.g[..n]` of a registered basis resolves to (handle, offset)
-    let mut map = SRS.lock().unwrap();
-    let (p, l) = (bases.as_ptr() as usize, bases.len());
-    for (&(bp, bl), &h) in map.iter() {
-        if p >= bp && p + l * 64 <= bp + bl * 64 { return Some((h, ((p - bp) / 64) as u64)); }
+impl GpuBasis {
+    /// Called by ParamsKZG::{setup, read_custom} once `g` / `g_lagrange` are final.
+    pub fn register(bases: &[G1Affine]) -> Option<Arc<GpuBasis>> {
+        if !available() || bases.is_empty() { return None; }
+        let mut h = 0u64;
+        if unsafe { mi355_srs_register_host(bases.as_ptr() as *const c_void, bases.len() as u64, &mut h) } != MI355_OK { return None; }
+        // registration-time window tables (W x the basis in HBM; MI355_SRS_PRECOMPUTE=0 disables): all windows share one bucket set
+        if std::env::var("MI355_SRS_PRECOMPUTE").map(|v| v != "0").unwrap_or(true) { unsafe { let _ = mi355_srs_precompute(h, 0, 0); } }
+        Some(Arc::new(GpuBasis(h)))
     }
-    let mut h = 0u64;
-    let rc = unsafe { mi355_srs_register_host(bases.as_ptr() as *const c_void, l as u64, &mut h) };
-    if rc != MI355_OK { return None; }
-    // registration-time window tables (W x the basis in HBM; MI355_SRS_PRECOMPUTE=0 disables): all windows share one bucket set
-    if std::env::var("MI355_SRS_PRECOMPUTE").map(|v| v != "0").unwrap_or(true) { unsafe { let _ = mi355_srs_precompute(h, 0, 0); } }
-    map.insert((p, l), h);
-    Some((h, 0))
+    /// `&g[..n]` after `g.truncate(n)`: a view that shares device memory and window tables with `self`.
+    pub fn prefix(self: &Arc<Self>, n: usize) -> Option<Arc<GpuBasis>> {
+        let mut h = 0u64;
+        if unsafe { mi355_srs_register_prefix(self.0, n as u64, &mut h) } != MI355_OK { return None; }
+        Some(Arc::new(GpuBasis(h)))
+    }
+    /// best_multiexp(coeffs, &basis[..coeffs.len()]) on the registered basis.
+    pub fn multiexp(&self, coeffs: &[Fr]) -> Option<G1> {
+        if (coeffs.len() as u64) < (1u64 << min_log("MI355_MSM_MIN_LOGN", 14)) { return None; }
+        let mut out = std::mem::MaybeUninit::<G1>::uninit();
+        let rc = unsafe { mi355_msm_g1_host(self.0, 0, coeffs.as_ptr() as *const c_void, coeffs.len() as u64, out.as_mut_ptr() as *mut c_void) };
+        if rc == MI355_OK { Some(unsafe { out.assume_init() }) } else { None }
+    }
+    /// One call for the `polys.iter().map(|p| params.commit_lagrange(p, blind))` loops of create_proof (advice / instance / lookup /
+    /// permutation columns of one phase): equal-length polynomials over this basis.  None -> caller runs the per-polynomial loop.
+    pub fn multiexp_many(&self, polys: &[&[Fr]]) -> Option<Vec<G1>> {
+        if polys.is_empty() { return Some(vec![]); }
+        let n = polys[0].len();
+        assert!(polys.iter().all(|p| p.len() == n));
+        if (n as u64) < (1u64 << min_log("MI355_MSM_MIN_LOGN", 14)) { return None; }
+        let ptrs: Vec<*const c_void> = polys.iter().map(|p| p.as_ptr() as *const c_void).collect();
+        let mut out: Vec<G1> = Vec::with_capacity(polys.len());
+        let rc = unsafe { mi355_msm_g1_batch_host(self.0, 0, ptrs.as_ptr(), polys.len() as u32, n as u64, out.as_mut_ptr() as *mut c_void) };
+        if rc != MI355_OK { return None; }
+        unsafe { out.set_len(polys.len()); }
+        Some(out)
+    }
+    /// `g_to_lagrange(&g[..2^k], k)` for `ParamsKZG::downsize` / `setup`: a size-2^k inverse FFT over curve points (minutes on the
+    /// CPU).  Returns the new `g_lagrange` Vec and its registration.  None -> run the CPU code.
+    pub fn g_to_lagrange(&self, k: u32, omega_inv: &Fr, n_inv: &Fr) -> Option<(Vec<G1Affine>, Arc<GpuBasis>)> {
+        let n = 1usize << k;
+        let mut hl = 0u64;
+        if unsafe { mi355_srs_downsize(self.0, k, omega_inv as *const Fr as *const c_void, n_inv as *const Fr as *const c_void, &mut hl) } != MI355_OK { return None; }
+        let gl = Arc::new(GpuBasis(hl));
+        let mut out: Vec<G1Affine> = Vec::with_capacity(n);
+        if unsafe { mi355_srs_read_host(hl, 0, n as u64, out.as_mut_ptr() as *mut c_void) } != MI355_OK { return None; }
+        unsafe { out.set_len(n); }
+        if std::env::var("MI355_SRS_PRECOMPUTE").map(|v| v != "0").unwrap_or(true) { unsafe { let _ = mi355_srs_precompute(hl, 0, 0); } }
+        Some((out, gl))
+    }
 }
 
-/// Called by ParamsKZG::{setup, read_custom, downsize} right after `g` / `g_lagrange` are final (register the FULL vectors).
-pub fn register_basis(bases: &[G1Affine]) { if available() { let _ = srs_handle(bases); } }
-
-/// Replacement body of `best_multiexp` for C = G1Affine.  Returns None -> caller runs the original CPU code.
+/// Replacement body of the generic `best_multiexp` for C = G1Affine when the bases are just a slice (not `self.g` of a ParamsKZG):
+/// ad-hoc upload, nothing registered, nothing cached.  Returns None -> caller runs the original CPU code.
 pub fn multiexp_g1(coeffs: &[Fr], bases: &[G1Affine]) -> Option<G1> {
     assert_eq!(coeffs.len(), bases.len());            // same panic as the reference
     if !available() || (coeffs.len() as u64) < (1u64 << min_log("MI355_MSM_MIN_LOGN", 14)) { return None; }
     let mut out = std::mem::MaybeUninit::<G1>::uninit();
-    let rc = unsafe {
-        match srs_handle(bases) {
-            Some((h, off)) => mi355_msm_g1_host(h, off, coeffs.as_ptr() as *const c_void, coeffs.len() as u64, out.as_mut_ptr() as *mut c_void),
-            None => mi355_msm_g1_adhoc_host(bases.as_ptr() as *const c_void, coeffs.as_ptr() as *const c_void, coeffs.len() as u64, out.as_mut_ptr() as *mut c_void),
-        }
-    };
+    let rc = unsafe { mi355_msm_g1_adhoc_host(bases.as_ptr() as *const c_void, coeffs.as_ptr() as *const c_void, coeffs.len() as u64, out.as_mut_ptr() as *mut c_void) };
     if rc == MI355_OK { Some(unsafe { out.assume_init() }) } else { None }
-}
-
-/// One call for the `polys.iter().map(|p| params.commit_lagrange(p, blind))` loops of create_proof (advice / instance / lookup /
-/// permutation columns of one phase): equal-length polynomials over one registered basis.  The blinding term is added by the caller as
-/// in the reference.  None -> caller runs the original per-polynomial loop.
-pub fn multiexp_g1_many(polys: &[&[Fr]], bases: &[G1Affine]) -> Option<Vec<G1>> {
-    if polys.is_empty() { return Some(vec![]); }
-    let n = polys[0].len();
-    assert!(polys.iter().all(|p| p.len() == n) && n <= bases.len());
-    if !available() || (n as u64) < (1u64 << min_log("MI355_MSM_MIN_LOGN", 14)) { return None; }
-    let (h, off) = srs_handle(&bases[..n])?;
-    let ptrs: Vec<*const c_void> = polys.iter().map(|p| p.as_ptr() as *const c_void).collect();
-    let mut out: Vec<G1> = Vec::with_capacity(polys.len());
-    let rc = unsafe { mi355_msm_g1_batch_host(h, off, ptrs.as_ptr(), polys.len() as u32, n as u64, out.as_mut_ptr() as *mut c_void) };
-    if rc != MI355_OK { return None; }
-    unsafe { out.set_len(polys.len()); }
-    Some(out)
-}
-
-/// `g_to_lagrange(g, k)` for `ParamsKZG::downsize` / `setup`: a size-2^k inverse FFT over curve points, minutes on the CPU.
-/// `g` must be (a prefix of) a registered basis; returns the new `g_lagrange` (and registers it).  None -> run the CPU code.
-pub fn g_to_lagrange(g: &[G1Affine], k: u32, omega_inv: &Fr, n_inv: &Fr) -> Option<Vec<G1Affine>> {
-    if !available() { return None; }
-    let n = 1usize << k;
-    let (h, off) = srs_handle(&g[..n])?;
-    if off != 0 { return None; }
-    let mut hl = 0u64;
-    let rc = unsafe { mi355_srs_downsize(h, k, omega_inv as *const Fr as *const c_void, n_inv as *const Fr as *const c_void, &mut hl) };
-    if rc != MI355_OK { return None; }
-    let mut out: Vec<G1Affine> = Vec::with_capacity(n);
-    let rc = unsafe { mi355_srs_read_host(hl, 0, n as u64, out.as_mut_ptr() as *mut c_void) };
-    unsafe { let _ = mi355_srs_release(hl); }          // the caller's Vec is registered by address on first use, like every basis
-    if rc != MI355_OK { return None; }
-    unsafe { out.set_len(n); }
-    Some(out)
 }
 
 /// Replacement body of `best_fft` for G = Scalar = Fr (the G = curve-point instantiation keeps the CPU code).

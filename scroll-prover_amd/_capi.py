@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi355zk.so")
+# MI355ZK_LIB: another build of the same library (A/B experiments with compile-time switches, tools/build_variant.py); never a fallback
+LIB_PATH = os.environ.get("MI355ZK_LIB") or os.path.join(HERE, "libmi355zk.so")
 
 OK, EBADARG, ENODEVICE, EOOM, EHIP, ERCCL = 0, 1, 2, 3, 4, 5
 _vp, _u64, _u32, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
@@ -66,6 +67,7 @@ SIGNATURES = {
     "mi355_eval_polynomial_host": (_int, [_vp, _u64, _vp, _vp]),
     "mi355_srs_setup_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
     "mi355_g1_fixed_base_mul_dev": (_int, [_vp, _vp, _u64]),
+    "mi355_g2_mul_host": (_int, [_vp, _vp, _vp]),
     "mi355_profile_enable": (_int, [_int]),
     "mi355_profile_get": (_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "mi355_profile_reset": (_int, []),

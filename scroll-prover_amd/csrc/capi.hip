@@ -23,11 +23,13 @@
 #include "ntt29.cuh"
 #include "g1fft.cuh"
 #include "frscan.cuh"
+#include "g2.cuh"
 
 using namespace zk;
 
 // the ABI is plain bytes: these sizes are what the Rust / C++ / Python bindings assume (halo2curves Fr 32 B, G1Affine 64 B, G1 96 B)
 static_assert(sizeof(fe_t) == 32 && sizeof(g1_affine_t) == 64 && sizeof(g1_jac_t) == 96, "ABI element sizes");
+static_assert(sizeof(g2_affine_t) == 128, "G2Affine is 128 bytes (x.c0, x.c1, y.c0, y.c1)");
 static_assert(sizeof(g1_xyzz_t) == 128 && sizeof(g1_xyzz29_t) == 144, "device record sizes (workspace layout, 16-byte vector accesses)");
 
 namespace {
@@ -81,7 +83,7 @@ struct Ctx {
   // host-pointer MSM: chunked copy on its own stream, overlapped with the digit extraction (msm_host_single)
   hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr};
   void *pin_ring = nullptr; size_t pin_ring_bytes = 0;
-  uint32_t host_chunks = 8;     // MI355_HOST_CHUNKS
+  uint32_t host_chunks = 8;     // MI355_HOST_CHUNKS: upper bound on the point-range slices of the host-pointer MSM (1 = one copy, then compute)
   int device = -1;
   hipDeviceProp_t prop;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -97,7 +99,7 @@ struct Ctx {
   g1_affine_t *fixed_base_table = nullptr;
   uint32_t sort_t2 = 0;         // MI355_SORT_T2 = 8192 | 16384 (0: by size)
   uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
-  uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): bit 0 nontemporal gathers, bit 1 prefetched bucket ends -- neither measurably helps
+  uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): 4 = limb products as explicitly chained v_mad (measured 58.4 vs 59.3 ms at 2^26: within box noise, off)
   uint32_t seg_factor = 16;
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
@@ -128,7 +130,7 @@ int g_last_devices = 1; const char *g_last_exchange = "none";
 
 // per-THREAD MSM options (mi355_msm_set_normalise / _set_window_bits): a rayon worker that asks for un-normalised partial sums must not
 // change what another worker's commit returns (SURVEY 8b "Threading")
-struct MsmOpts { bool normalise = true; int force_c = 0; };
+struct MsmOpts { bool normalise = true; int force_c = 0; bool no_tables = false; };
 thread_local MsmOpts t_opts;
 
 void use_ctx(int slot) { g_cur = &g_ctx[slot]; }
@@ -238,7 +240,7 @@ int msm_shape(uint64_t n, uint32_t M, const PreTable *pre, MsmShape &o, const Ms
   else {
     o.c = (uint32_t)choose_c(n);
     // precomputed rows 2^(c w) P available and cheaper than the per-window schedule at this n -> all windows share one bucket set
-    o.shared = pre && pre->table && !t_opts.force_c && msm_cost(n, pre->c, true) <= msm_cost(n, (int)o.c, false) && ((uint64_t)pre->w << log2_ceil(n)) < (1ull << 31);
+    o.shared = pre && pre->table && !t_opts.force_c && !t_opts.no_tables && msm_cost(n, pre->c, true) <= msm_cost(n, (int)o.c, false) && ((uint64_t)pre->w << log2_ceil(n)) < (1ull << 31);
     if (o.shared) o.c = (uint32_t)pre->c;
   }
   o.W = (MSM_SCALAR_BITS + o.c - 1) / o.c;
@@ -401,7 +403,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
       Scope sc("msm_accumulate", s);
       HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
 #define ACC_LAUNCH(V) hipLaunchKernelGGL(k_msm_accumulate<V>, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, S.nshift, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask)
-      switch (g.acc_variant) { case 0: ACC_LAUNCH(0); break; case 1: ACC_LAUNCH(1); break; case 2: ACC_LAUNCH(2); break; default: ACC_LAUNCH(3); break; }
+      if (g.acc_variant & 4) ACC_LAUNCH(4); else ACC_LAUNCH(0);   // 4: limb products as explicitly chained v_mad (fp29.cuh mac_*); the older A/B variants (index stream further ahead, prefetched bucket ends) did not help and are no longer instantiated
 #undef ACC_LAUNCH
     }
     if (piped) { HIPCHK(hipEventRecord(slot.acc_done, s)); HIPCHK(hipStreamWaitEvent(st.c, slot.acc_done, 0)); }
@@ -518,10 +520,24 @@ int msm_batch_impl(const g1_affine_t *bases, const fe_t *const *polys_host, uint
 int msm_host_single(const g1_affine_t *bases, const fe_t *const *polys_host, uint32_t M, uint64_t n, void *out_host, const PreTable *pre, void *out_dev_user = nullptr) {
   fe_t *sc; CHK(ws_get("io.scalars", (size_t)M * n * sizeof(fe_t), (void **)&sc));
   hipStream_t s = g.stream;
-  uint32_t K = (M == 1 && n >= (1ull << 22)) ? g.host_chunks : 1;
-  while (K > 1 && n / K < (1ull << 20)) K >>= 1;
+  // Slice plan: the copy of slice k + 1 must fit under the compute of slice k.  PCIe moves a pair's 32 bytes ~1.7x faster than the GPU
+  // consumes them, so slices may GROW by that factor: a small first slice (its copy is the only exposed one), then x1.7 each -- 5 slices
+  // for 2^26 pairs instead of 8 equal ones.  Every extra slice costs bucket crossings in the accumulation (each bucket is visited once
+  // per slice) and a fix-up pass, which is why fewer, growing slices win (measured: 8 equal slices 86.7 ms).
+  std::vector<uint64_t> cut;   // slice k = [cut[k], cut[k + 1])
+  if (M == 1 && n >= (1ull << 22) && g.host_chunks > 1) {
+    double w = 1.0, tot = 0; std::vector<double> ws;
+    const double first = 1.0 / 16.0;
+    for (double rem = 1.0; rem > 1e-9 && ws.size() + 1 < g.host_chunks;) { const double take = std::min(rem, first * w); ws.push_back(take); rem -= take; w *= 1.7; tot += take; }
+    if (tot < 1.0 - 1e-9) ws.push_back(1.0 - tot);
+    cut.push_back(0); double acc = 0;
+    for (size_t i = 0; i + 1 < ws.size(); i++) { acc += ws[i]; cut.push_back(std::min<uint64_t>(n, (uint64_t)(acc * (double)n) & ~1023ull)); }
+    cut.push_back(n);
+  }
+  uint32_t K = cut.empty() ? 1 : (uint32_t)cut.size() - 1;
+  uint64_t biggest = 0; for (uint32_t k = 0; k < K && !cut.empty(); k++) biggest = std::max(biggest, cut[k + 1] - cut[k]);
   MsmShape shape;
-  if (K > 1 && (msm_shape((n + K - 1) / K, 1, pre, shape) != MI355_OK || shape.nbuckets * K * sizeof(g1_xyzz29_t) > (8ull << 30))) K = 1;
+  if (K > 1 && (msm_shape(biggest, 1, pre, shape) != MI355_OK || shape.nbuckets * K * sizeof(g1_xyzz29_t) > (8ull << 30))) K = 1;
   if (K <= 1) {
     std::vector<const fe_t *> ptrs(M);
     for (uint32_t m = 0; m < M; m++) { ptrs[m] = sc + (size_t)m * n; HIPCHK(hipMemcpyAsync(sc + (size_t)m * n, polys_host[m], n * sizeof(fe_t), hipMemcpyHostToDevice, s)); }
@@ -540,7 +556,7 @@ int msm_host_single(const g1_affine_t *bases, const fe_t *const *polys_host, uin
   PolyPtrs inl; for (int i = 0; i < 8; i++) inl.p[i] = nullptr;
   MsmStreams st{s, s, s};
   for (uint32_t k = 0; k < K; k++) {
-    const uint64_t lo = n * k / K, hi = n * (k + 1) / K;
+    const uint64_t lo = cut[k], hi = cut[k + 1];
     // pageable source: the call blocks this thread while the DMA runs, which is exactly when the GPU works on the slices queued before
     HIPCHK(hipMemcpyAsync(sc + lo, polys_host[0] + lo, (hi - lo) * sizeof(fe_t), hipMemcpyHostToDevice, g.copy_stream));
     HIPCHK(hipEventRecord(g.ev_copy[k & 3], g.copy_stream));
@@ -572,6 +588,7 @@ int msm_host_single(const g1_affine_t *bases, const fe_t *const *polys_host, uin
 }
 
 // ------------------------------------------------------------------------------------------------ NTT
+constexpr uint32_t NTT_DIRECT_TW_MAX_LOG = 20;   // 2^20 x 36 B = 38 MB per table at most
 std::string plan_key(uint32_t log_n, const void *omega) { std::string k((const char *)omega, 32); k.push_back((char)log_n); return k; }
 
 int pow_table(fe_t **out, const fe_t &base, uint64_t step, uint32_t count) {
@@ -608,7 +625,9 @@ int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
     if (lm >= 1) CHK(pow_table(&p.tw_m[l], w, N >> lm, std::max(1u, 1u << (lm - 1))));
     CHK(pow_table29(p, &p.tw29_m[l], w, N >> lm, std::max(1u, (1u << lm) >> 1)));
     if (l + 1 < p.levels) {
-      p.split[l] = (log_s + 1) / 2;
+      // inter-level twiddles w_S^e, e < 2^log_s: ONE table when it is small enough to live in L2 (no lo x hi product per element),
+      // otherwise the usual two half-size tables
+      p.split[l] = log_s <= NTT_DIRECT_TW_MAX_LOG ? log_s : (log_s + 1) / 2;
       CHK(pow_table(&p.tw_s_lo[l], w, N >> log_s, 1u << p.split[l]));
       CHK(pow_table(&p.tw_s_hi[l], w, (N >> log_s) << p.split[l], 1u << (log_s - p.split[l])));
       CHK(pow_table29(p, &p.tw29_s_lo[l], w, N >> log_s, 1u << p.split[l]));
@@ -669,7 +688,7 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
       const uint64_t blocks = (N >> log_s) << (L.log_t - lc);
       Scope sc("ntt_pass");
       if (g.ntt29) {
-        Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l];
+        Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l]; L9.direct = (p->split[l] == log_s) ? 1u : 0u;
         NTT29_LAUNCH(k_ntt29_strided, (uint32_t)blocks, tile, (size_t)36 * tile, cur, scratch, L9, lc, cur_len, cur_pre);
       } else
       hipLaunchKernelGGL(k_ntt_strided, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, scratch, L, lc, cur_len, cur_pre);
@@ -834,7 +853,7 @@ static int init_ctx(int slot, int device_id) {
 #ifdef MI355_DEBUG_KNOBS
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
 #endif
-  { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 3; }
+  { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 7; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_FB"); if (e) { int v = atoi(e); if (v >= 9 && v <= 12) g.sort_fb = (uint32_t)v; } }
   { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
@@ -1414,8 +1433,9 @@ int mi355_g1_sum_host(const void *pts_host, uint64_t n, void *out_g1_host) {
 // The two setters below act on the CALLING THREAD only (thread-local options): concurrent callers never see each other's settings.
 int mi355_msm_set_window_bits(int c) {
   return guarded([&]() -> int {
-  if (c != 0 && (c < 2 || c > MSM_MAX_C)) return fail(MI355_EBADARG, "window bits must be 0 (auto) or in [2, 24]");
-  t_opts.force_c = c; return MI355_OK;
+  if (c == -1) { t_opts.force_c = 0; t_opts.no_tables = true; return MI355_OK; }   // automatic window, window tables ignored
+  if (c != 0 && (c < 2 || c > MSM_MAX_C)) return fail(MI355_EBADARG, "window bits must be 0 (auto), -1 (auto, no window tables) or in [2, 22]");
+  t_opts.force_c = c; t_opts.no_tables = false; return MI355_OK;
   });
 }
 int mi355_msm_set_normalise(int on) { t_opts.normalise = on != 0; return MI355_OK; }
@@ -1809,6 +1829,28 @@ int mi355_srs_setup_dev(void *g_dev, void *g_lagrange_dev, uint32_t k, const voi
   hipLaunchKernelGGL(k_fixed_base_mul, dim3(ceil_div(n, 256)), dim3(256), 0, g.stream, g.fixed_base_table, sc + n, (g1_affine_t *)g_lagrange_dev, n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(g.stream));
+  return MI355_OK;
+  });
+}
+
+// ---- G2: s_g2 = tau * G2 of ParamsKZG::setup (the only G2 arithmetic on the path)
+int mi355_g2_mul_host(const void *p_affine_host, const void *scalar, void *out_affine_host) {
+  return guarded([&]() -> int {
+  std::lock_guard<std::mutex> lk(g_mu);
+  CHK(need_init());
+  if (!p_affine_host || !scalar || !out_affine_host) return fail(MI355_EBADARG, "g2_mul: null pointer");
+  g2_affine_t *dev; CHK(ws_get("g2.io", 2 * sizeof(g2_affine_t) + 16, (void **)&dev));
+  uint32_t *flag = reinterpret_cast<uint32_t *>(dev + 2);
+  fe_t k; memcpy(&k, scalar, 32);
+  HIPCHK(hipMemcpyAsync(dev, p_affine_host, sizeof(g2_affine_t), hipMemcpyHostToDevice, g.stream));
+  hipLaunchKernelGGL(k_g2_mul, dim3(1), dim3(64), 0, g.stream, (const g2_affine_t *)dev, k, dev + 1, flag);
+  HIPCHK(hipGetLastError());
+  uint32_t ok = 0; g2_affine_t res;
+  HIPCHK(hipMemcpyAsync(&res, dev + 1, sizeof res, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipMemcpyAsync(&ok, flag, 4, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  if (!ok) return fail(MI355_EBADARG, "g2_mul: the point is not on the twist y^2 = x^3 + 3 / (9 + u)");
+  memcpy(out_affine_host, &res, sizeof res);
   return MI355_OK;
   });
 }

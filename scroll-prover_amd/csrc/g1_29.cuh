@@ -39,8 +39,11 @@ ZK_HD g1_xyzz29_t g1_xyzz29_dbl_affine(const fe29_t &xt, const fe29_t &yt) {
   return r;
 }
 
-// acc += (+-) q, q in the ABI form.  madd-2008-s.
-template <bool FUSED_Y3 = true> ZK_HD void g1_xyzz29_madd(g1_xyzz29_t &acc, const g1_affine_t &q, bool negate) {
+// acc += (+-) q, q in the ABI form.  madd-2008-s.  CHAIN: limb products as explicitly chained v_mad (fp29.cuh mac_*), bit-identical.
+#ifndef ZK_MADD_CHAIN_DEFAULT
+#define ZK_MADD_CHAIN_DEFAULT false
+#endif
+template <bool FUSED_Y3 = true, bool CHAIN = ZK_MADD_CHAIN_DEFAULT> ZK_HD void g1_xyzz29_madd(g1_xyzz29_t &acc, const g1_affine_t &q, bool negate) {
   if (g1_affine_is_identity(q)) return;
   const fe29_t x2 = Fq29::from_sat(q.x);
   fe29_t y2 = Fq29::from_sat(q.y);
@@ -51,11 +54,11 @@ template <bool FUSED_Y3 = true> ZK_HD void g1_xyzz29_madd(g1_xyzz29_t &acc, cons
     acc.zz = Fq29::one(); acc.zzz = Fq29::one();
     return;
   }
-  const fe29_t U2 = Fq29::mul(x2, acc.zz), S2 = Fq29::mul(y2, acc.zzz);      // tight, < 1.2 p
+  const fe29_t U2 = Fq29::mul_t<CHAIN>(x2, acc.zz), S2 = Fq29::mul_t<CHAIN>(y2, acc.zzz);      // tight, < 1.2 p
   const fe29_t Pd = Fq29::sub16(U2, acc.x);                                    // < 18 p
   const fe29_t Rd = Fq29::sub8(S2, acc.y);                                     // < 10 p
-  const fe29_t PP = Fq29::sqr(Pd);                                             // < 3 p
-  const fe29_t ZZ3 = Fq29::mul(acc.zz, PP);                                    // < 1.1 p : zero iff Pd == 0 (acc.zz != 0)
+  const fe29_t PP = Fq29::sqr_t<CHAIN>(Pd);                                    // < 3 p
+  const fe29_t ZZ3 = Fq29::mul_t<CHAIN>(acc.zz, PP);                           // < 1.1 p : zero iff Pd == 0 (acc.zz != 0)
   if (Fq29::is_zero_tight(ZZ3)) {
     // q == +-acc: doubling or annihilation (rare; taken by repeated / opposite points inside one bucket)
     const fe29_t one = Fq29::one();
@@ -63,13 +66,13 @@ template <bool FUSED_Y3 = true> ZK_HD void g1_xyzz29_madd(g1_xyzz29_t &acc, cons
     else acc = g1_xyzz29_identity();
     return;
   }
-  const fe29_t PPP = Fq29::mul(Pd, PP);                                        // < 1.4 p
-  const fe29_t Q = Fq29::mul(acc.x, PP);                                       // < 1.3 p
-  const fe29_t X3 = Fq29::sub8(Fq29::sub4(Fq29::sqr(Rd), PPP), Fq29::dbl(Q)); // (1.6 + 4) p + 8 p = 13.6 p
+  const fe29_t PPP = Fq29::mul_t<CHAIN>(Pd, PP);                               // < 1.4 p
+  const fe29_t Q = Fq29::mul_t<CHAIN>(acc.x, PP);                              // < 1.3 p
+  const fe29_t X3 = Fq29::sub8(Fq29::sub4(Fq29::sqr_t<CHAIN>(Rd), PPP), Fq29::dbl(Q)); // (1.6 + 4) p + 8 p = 13.6 p
   // Y3 = Rd (Q - X3) - Y1 PPP: both products under ONE Montgomery reduction (signed column accumulator): (1.02 - 0.05 .. ) p + p + [0, p) < 3.1 p
-  const fe29_t Y3 = FUSED_Y3 ? Fq29::mul_sub(Rd, Fq29::sub16(Q, X3), acc.y, PPP)
-                             : Fq29::sub4(Fq29::mul(Rd, Fq29::sub16(Q, X3)), Fq29::mul(acc.y, PPP));   // unfused form: < 2.1 p + 4 p
-  acc.x = X3; acc.y = Y3; acc.zz = ZZ3; acc.zzz = Fq29::mul(acc.zzz, PPP);
+  const fe29_t Y3 = FUSED_Y3 ? Fq29::mul_sub_t<CHAIN>(Rd, Fq29::sub16(Q, X3), acc.y, PPP)
+                             : Fq29::sub4(Fq29::mul_t<CHAIN>(Rd, Fq29::sub16(Q, X3)), Fq29::mul_t<CHAIN>(acc.y, PPP));   // unfused form: < 2.1 p + 4 p
+  acc.x = X3; acc.y = Y3; acc.zz = ZZ3; acc.zzz = Fq29::mul_t<CHAIN>(acc.zzz, PPP);
 }
 
 // 2 * acc for an accumulator under the invariants above (dbl-2008-s-1).  Output: x < 9.1 p (limbs <= 2^29 + 8), y < 5.4 p

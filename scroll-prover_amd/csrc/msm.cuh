@@ -376,7 +376,7 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
       }
       if (VARIANT & 2) next_end = (b + 2 <= nbuckets) ? offsets[b + 2] : b_end;
     }
-    g1_xyzz29_madd(acc, p, (ent >> 31) != 0);
+    g1_xyzz29_madd<true, (VARIANT & 4) != 0>(acc, p, (ent >> 31) != 0);
     ent = ent_next; if (VARIANT & 1) ent_next = ent_next2; p = p_next;
   }
   // bucket b is still open at `end`

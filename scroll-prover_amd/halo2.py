@@ -143,6 +143,29 @@ def prefix_product(src, dst=None, want_total: bool = False):
     return (dst, total) if want_total else dst
 
 
+# halo2curves bn256 G2 generator (x.c0, x.c1, y.c0, y.c1) [EXT-recalled src/bn256/curve.rs]; the same four words are the first pairing
+# input of the released verifier [REF release-v0.13.1/evm_verifier.yul:1230-1233] (tests/test_oracle_golden.py)
+G2_GENERATOR = (0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED, 0x198E9393920D483A7260BFB731FB5D25F1AA493335A9E71297E485B7AEF312C2,
+                0x12C85EA5DB8C6DEB4AAB71808DCB408FE3D1E7690C43D37B4CE6CC0166FA7DAA, 0x090689D0585FF075EC9E99AD690C3395BC4B313370B38EF355ACDADCD122975B)
+
+
+def fq(x: int) -> np.ndarray:
+    v = (x % P_MOD) * (1 << 256) % P_MOD
+    return np.array([(v >> (64 * i)) & _M64 for i in range(4)], dtype=np.uint64)
+
+
+def g2_generator() -> np.ndarray:
+    """G2Affine (16 u64: x.c0 | x.c1 | y.c0 | y.c1, Montgomery) of the generator: the `g2` field of every ParamsKZG."""
+    return np.concatenate([fq(c) for c in G2_GENERATOR])
+
+
+def g2_mul(point: np.ndarray, scalar: np.ndarray) -> np.ndarray:
+    """scalar * point on the twist (mi355_g2_mul_host): ParamsKZG::setup's s_g2 = tau * G2."""
+    out = np.zeros(16, dtype=np.uint64)
+    check(lib().mi355_g2_mul_host(ptr(np.ascontiguousarray(point, dtype=np.uint64)), ptr(scalar), ptr(out)))
+    return out
+
+
 def g1_sum(points: np.ndarray) -> np.ndarray:
     """fold of per-GPU partial results: results.iter().fold(identity, |a, b| a + b)."""
     points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
@@ -239,6 +262,7 @@ class ParamsKZG:
     def __init__(self, k: int, g_handle: int, gl_handle: int, owner=None):
         self.k, self.n = k, 1 << k
         self._g, self._gl, self._owner = g_handle, gl_handle, owner
+        self.g2, self.s_g2 = bytes(128), bytes(128)   # G2Affine bytes as in the params file; setup() / params_from_file() fill them
 
     @classmethod
     def from_host(cls, k: int, g: np.ndarray, g_lagrange: np.ndarray) -> "ParamsKZG":
@@ -266,7 +290,24 @@ class ParamsKZG:
             h = C.c_uint64()
             check(lib().mi355_srs_register_dev(ptr(t), n, 0, C.byref(h)))
             hs.append(h.value)
-        return cls(k, hs[0], hs[1], owner=(g, gl))
+        p = cls(k, hs[0], hs[1], owner=(g, gl))
+        p.g2 = g2_generator().tobytes()                               # g2 = G2 generator, s_g2 = tau * g2 [EXT-recalled ParamsKZG::setup]
+        p.s_g2 = g2_mul(g2_generator(), fr(tau)).tobytes()
+        return p
+
+    def clone_downsized(self, k: int) -> "ParamsKZG":
+        """`let mut p = params.clone(); p.downsize(k)` of load_params_map [REF integration/tests/integration.rs:12-22]: the clone's g is a
+        PREFIX VIEW of this object's registration (mi355_srs_register_prefix: same device memory, same window tables), its g_lagrange is
+        rebuilt on the device.  Either object may be released first."""
+        assert k <= self.k
+        h = C.c_uint64()
+        check(lib().mi355_srs_register_prefix(self._g, 1 << k, C.byref(h)))
+        w_inv = pow(pow(FR_ROOT_OF_UNITY, 1 << (FR_S - k), R_MOD), R_MOD - 2, R_MOD)
+        hl = C.c_uint64()
+        check(lib().mi355_srs_downsize(h.value, k, ptr(fr(w_inv)), ptr(fr(pow(1 << k, R_MOD - 2, R_MOD))), C.byref(hl)))
+        p = ParamsKZG(k, h.value, hl.value, owner=self._owner)
+        p.g2, p.s_g2 = getattr(self, "g2", bytes(128)), getattr(self, "s_g2", bytes(128))
+        return p
 
     def commit(self, poly_coeff) -> np.ndarray:
         """commit(&self, poly: &Polynomial<_, Coeff>, _: Blind) = best_multiexp(poly, &self.g[..poly.len()])"""
@@ -334,6 +375,10 @@ class ParamsKZG:
 
     def g_lagrange_slice(self, offset: int, n: int) -> SrsSlice:
         return SrsSlice(self._gl, offset, n)
+
+    def write(self, path: str) -> None:
+        """ParamsKZG::write (SerdeFormat::RawBytes): a file prover::load_params / params_from_file accepts."""
+        write_params(path, self.k, self.read_g(), self.read_g(lagrange=True), self.g2, self.s_g2)
 
     def release(self) -> None:
         for h in (self._g, self._gl):

@@ -102,7 +102,7 @@ int main(int argc, char **argv) {
   int dev = 0; if (argc > 1) dev = std::atoi(argv[1]);
   if (mi355_init(dev) != MI355_OK) { std::printf("mi355_init: %s\n", mi355_last_error()); return 2; }
   std::mt19937_64 rng(2024);
-  const uint32_t K = 15; const uint64_t N = uint64_t(1) << K;
+  const uint32_t K = 14; const uint64_t N = uint64_t(1) << K;
   // "params15": g = random independent points (what a real SRS looks like to the MSM), g_lagrange = g_to_lagrange(g) by the oracle
   std::vector<Fr> ks(N); for (auto &x : ks) x = rand_fr(rng);
   std::vector<G1Affine> g(N), gl(N);
@@ -115,7 +115,7 @@ int main(int argc, char **argv) {
   EXPECT(params_map[K].gpu_g && params_map[K].gpu_gl);
   void *tab_parent = nullptr; int c_parent = 0, w_parent = 0;
   EXPECT(mi355_srs_pre_dev_ptr(params_map[K].gpu_g->handle, &tab_parent, &c_parent, &w_parent) == MI355_OK && tab_parent);
-  for (uint32_t k : {14u, 12u}) {
+  for (uint32_t k : {13u, 11u}) {
     ParamsKZG p = params_map[K];                      // clone: host Vecs copied, registrations shared
     EXPECT(p.gpu_g.get() == params_map[K].gpu_g.get());
     Fr wi, ni; domain_consts(k, wi, ni);
@@ -143,11 +143,11 @@ int main(int argc, char **argv) {
 
   // ---- drop order: the parent params go away first, the downsized clones keep working (memory lives until the last sharer drops)
   params_map.erase(K);
-  { const ParamsKZG &p = params_map[14]; G1 out; EXPECT(p.commit(poly.data(), 1 << 14, out) && to_affine(out) == oracle_msm(poly.data(), p.g.data(), 1 << 14)); }
+  { const ParamsKZG &p = params_map[13]; G1 out; EXPECT(p.commit(poly.data(), 1 << 13, out) && to_affine(out) == oracle_msm(poly.data(), p.g.data(), 1 << 13)); }
 
   // ---- a temporary basis is freed and its address re-used with other contents: must never resolve to a stale registration
   {
-    const uint64_t n = 1 << 14;
+    const uint64_t n = 1 << 13;
     auto *tmp = new std::vector<G1Affine>(g.begin(), g.begin() + n);
     const G1Affine *addr = tmp->data();
     G1 out; EXPECT(best_multiexp(poly.data(), tmp->data(), n, out) && to_affine(out) == oracle_msm(poly.data(), g.data(), n));
@@ -159,7 +159,7 @@ int main(int argc, char **argv) {
 
   // ---- 8 worker threads commit concurrently; odd threads ask for un-normalised results (per-thread option must not leak)
   {
-    const ParamsKZG &p = params_map[14]; const uint64_t n = 1 << 14;
+    const ParamsKZG &p = params_map[13]; const uint64_t n = 1 << 13;
     std::vector<std::vector<Fr>> polys(8, std::vector<Fr>(n));
     std::vector<G1Affine> want(8);
     for (int t = 0; t < 8; t++) { for (auto &x : polys[t]) x = rand_fr(rng); want[t] = oracle_msm(polys[t].data(), p.g.data(), n); }
@@ -180,7 +180,7 @@ int main(int argc, char **argv) {
 
   // ---- released handles are gone
   {
-    uint64_t h = params_map[12].gpu_g->handle;
+    uint64_t h = params_map[11].gpu_g->handle;
     params_map.clear();
     uint64_t len = 0; EXPECT(mi355_srs_len(h, &len) == MI355_EBADARG);
   }

@@ -127,7 +127,7 @@ def test_host_pointer_path_sliced(zk, k):
     got = affine_of(params.commit(sc_host))
     run = last_run(zk)
     assert (got == want).all()
-    assert run["host_slices"] == (1 if k < 22 else 8), run
+    assert (run["host_slices"] == 1) if k < 22 else (2 <= run["host_slices"] <= 8), run
     assert (affine_of(params.commit(sc)) == want).all()
     # witness-like scalars (giant buckets straddle slices) and a ragged length through a prefix slice
     wl = dev_scalars(n, 6000 + k, "witness")

@@ -840,3 +840,63 @@ def test_shutdown_releases_everything_and_reinit_works():
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "LIFECYCLE-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+
+
+# ------------------------------------------------------------------------------------------------ G2 (ParamsKZG::setup: s_g2 = tau * G2)
+def test_g2_scalar_multiplication_matches_both_oracles(zk, kat):
+    h2 = zk.halo2
+    gen = h2.g2_generator()
+    for tau in (1, 2, 3, 0x5343524F4C4C0001, R - 1, (1 << 253) + 7):
+        got = h2.g2_mul(gen, h2.fr(tau))
+        assert (got == cref.g2_mul(gen, cref.fr_mont(tau))).all()
+        assert list(got) == pyref.g2_to_limbs(pyref.g2_mul(pyref.G2_GEN, tau))
+    assert (h2.g2_mul(gen, h2.fr(0)) == 0).all()                                     # 0 * G2 = identity (all-zero G2Affine)
+    assert (h2.g2_mul(np.zeros(16, dtype=np.uint64), h2.fr(5)) == 0).all()           # k * identity
+    # the production SRS's s_g2 (fixture, [REF release-v0.13.1/evm_verifier.yul:1236-1239]) as the base point
+    s_g2 = cref.g2_from_words(kat["yul"]["s_g2_words"])
+    assert (h2.g2_mul(s_g2, h2.fr(12345)) == cref.g2_mul(s_g2, cref.fr_mont(12345))).all()
+    off = gen.copy(); off[0] ^= np.uint64(1)
+    with pytest.raises(zk.Mi355Error):
+        h2.g2_mul(off, h2.fr(3))                                                     # not on the twist
+
+
+def test_setup_writes_a_loadable_params_file_with_real_g2_points(zk, tmp_path):
+    """ParamsKZG::setup -> write (RawBytes) -> load_params: g2 = G2 generator, s_g2 = tau * G2 (no longer 128 zero bytes), both bases intact."""
+    h2 = zk.halo2
+    k, tau = 9, 0xABCDEF0123456789
+    p = h2.ParamsKZG.setup(k, tau)
+    assert p.g2 == h2.g2_generator().tobytes()
+    assert p.s_g2 == cref.g2_mul(cref.g2_generator(), cref.fr_mont(tau)).tobytes()
+    path = str(tmp_path / f"params{k}")
+    p.write(path)
+    assert os.path.getsize(path) == h2.params_file_size(k)
+    q = h2.params_from_file(path, validate=True)
+    assert q.k == k and q.g2 == p.g2 and q.s_g2 == p.s_g2
+    assert (q.read_g() == p.read_g()).all() and (q.read_g(lagrange=True) == p.read_g(lagrange=True)).all()
+    g_or, gl_or, _, _ = cref.srs_setup(k, cref.fr_mont(tau), h2.fr(pyref.omega(k)))
+    assert (q.read_g() == g_or).all() and (q.read_g(lagrange=True) == gl_or).all()
+    p.release(); q.release()
+
+
+def test_clone_downsized_shares_the_parent_registration(zk):
+    """load_params_map's clone + downsize [REF integration/tests/integration.rs:12-22]: prefix view of g (same memory, same tables),
+    g_lagrange rebuilt; parent released first, the clone keeps working."""
+    h2 = zk.halo2
+    lib, check = zk._capi.lib(), zk._capi.check
+    big = h2.ParamsKZG.setup(13, 0x77)
+    big.precompute(lagrange=False)
+    small = big.clone_downsized(11)
+    ref = h2.ParamsKZG.setup(11, 0x77)
+    pa, pb = C.c_void_p(), C.c_void_p(); ca, cb = C.c_int(), C.c_int()
+    check(lib.mi355_srs_pre_dev_ptr(big._g, C.byref(pa), C.byref(ca), None)); check(lib.mi355_srs_pre_dev_ptr(small._g, C.byref(pb), C.byref(cb), None))
+    assert pa.value == pb.value and pa.value and ca.value == cb.value                  # ONE window table
+    assert (small.read_g() == ref.read_g()).all() and (small.read_g(lagrange=True) == ref.read_g(lagrange=True)).all()
+    rng = np.random.default_rng(5)
+    sc = rand_fr(rng, 1 << 11)
+    want = affine_of(ref.commit(sc))
+    assert (affine_of(small.commit(sc)) == want).all() and (affine_of(small.commit_lagrange(sc)) == affine_of(ref.commit_lagrange(sc))).all()
+    check(lib.mi355_srs_release(big._g)); check(lib.mi355_srs_release(big._gl))        # parent first
+    assert (affine_of(small.commit(sc)) == want).all()
+    n_out = C.c_uint64()
+    assert lib.mi355_srs_len(big._g, C.byref(n_out)) == zk._capi.EBADARG
+    small.release(); ref.release()

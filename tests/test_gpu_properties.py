@@ -38,12 +38,18 @@ def dev_scalars(n, seed, kind="uniform"):
     a[:, 3] = torch.where(top >= 0x30644E72E131A029, top >> 1, top)
     if kind == "witness":
         # 60 % zero, 20 % tiny, 10 % 64-bit, 10 % uniform: as raw Montgomery limbs this is NOT "small canonical values",
-        # so build the small values through the table of Montgomery forms of 0..255 / one-limb values times R
-        u = torch.rand(n, device="cuda", generator=g)
+        # so build the small values through the table of Montgomery forms of 0..255 / one-limb values times R.
+        # Built in chunks: one index / where launch over 2^26 x 4 elements exceeds torch's launch configuration limits.
         small = torch.from_numpy(np.stack([cref.fr_mont(v) for v in range(256)]).view(np.int64)).cuda()
-        pick = torch.randint(1, 256, (n,), device="cuda", generator=g)
-        a = torch.where((u < 0.8).unsqueeze(1), small[pick], a)
-        a = torch.where((u < 0.6).unsqueeze(1), torch.zeros_like(a), a)
+        step = 1 << 22
+        for lo in range(0, n, step):
+            m = min(step, n - lo)
+            u = torch.rand(m, device="cuda", generator=g)
+            pick = torch.randint(1, 256, (m,), device="cuda", generator=g)
+            blk = a[lo:lo + m]
+            blk = torch.where((u < 0.8).unsqueeze(1), torch.index_select(small, 0, pick), blk)
+            blk = torch.where((u < 0.6).unsqueeze(1), torch.zeros_like(blk), blk)
+            a[lo:lo + m] = blk
     return a.contiguous()
 
 

@@ -114,3 +114,32 @@ def test_constants_rederived():
     assert pyref.FR_ROOT_OF_UNITY == 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
     assert pyref.omega(24) == 0x1951441010B2B95A6E47A6075066A50A036F5BA978C050F2821DF86636C0FACB
     assert pyref.omega(20) == 0x2A14464F1FF42DE3856402B62520E670745E39FADA049D5B2F0E1E3182673378
+
+
+def test_g2_fixture_pins_the_twist_arithmetic(kat):
+    """KAT A8 [REF release-v0.13.1/evm_verifier.yul:1230-1239]: the pairing inputs g2 and s_g2 of the production SRS.
+    * the G2 generator constant of both oracles (and of the host mirror) equals the fixture words, in the (x.c1, x.c0, y.c1, y.c0) order
+      of the EVM precompile;
+    * both fixture points satisfy y^2 = x^3 + 3 / (9 + u) over Fq2 (pins Fq2 multiplication and the twist constant);
+    * both are annihilated by r (pins the G2 addition / doubling formulas: a wrong formula leaves the order-r subgroup);
+    * the C oracle (Jacobian) and the Python oracle (affine) agree on a scalar multiple."""
+    import numpy as np
+    import __graft_entry__ as ge
+    g2w, s2w = kat["yul"]["g2_words"], kat["yul"]["s_g2_words"]
+    gen_c = cref.g2_generator()
+    assert (gen_c == cref.g2_from_words(g2w)).all()
+    assert pyref.g2_from_evm_words(g2w) == pyref.G2_GEN
+    assert list(gen_c) == pyref.g2_to_limbs(pyref.G2_GEN)
+    h2 = ge.load_package().halo2
+    assert (h2.g2_generator() == gen_c).all()                       # the product's constant (host mirror)
+    s_c = cref.g2_from_words(s2w)
+    s_py = pyref.g2_from_evm_words(s2w)
+    for pt_c, pt_py in ((gen_c, pyref.G2_GEN), (s_c, s_py)):
+        assert cref.g2_is_on_curve(pt_c) and pyref.g2_is_on_curve(pt_py)
+        assert cref.g2_in_subgroup(pt_c)
+    assert pyref.g2_mul(s_py, R) is None and pyref.g2_mul(pyref.G2_GEN, R) is None
+    off = gen_c.copy(); off[0] ^= np.uint64(1)
+    assert not cref.g2_is_on_curve(off)
+    for tau in (1, 2, 0x5343524F4C4C0001, R - 1):
+        assert list(cref.g2_mul(gen_c, cref.fr_mont(tau))) == pyref.g2_to_limbs(pyref.g2_mul(pyref.G2_GEN, tau))
+    assert (cref.g2_mul(s_c, cref.fr_mont(0)) == 0).all()

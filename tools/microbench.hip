@@ -84,17 +84,19 @@ template <int VARIANT> __global__ void k_fq29mul(fe_t *io) {
     if (VARIANT == 1) { a = Fq29::sqr(a); a = Fq29::mul(a, b); }
     if (VARIANT == 2) { a = Fq29::mul(Fq29::sub4(a, b), b); b = Fq29::mul(Fq29::add(b, a), a); }   // with lazy add/sub in the chain
     if (VARIANT == 3) { a = Fq29::mul2(a, b); b = Fq29::mul2(b, a); }
+    if (VARIANT == 4) { a = Fq29::mul_c(a, b); b = Fq29::mul_c(b, a); }       // chained v_mad (inline asm), no per-column 64-bit add
+    if (VARIANT == 5) { a = Fq29::sqr_c(a); a = Fq29::mul_c(a, b); }
   }
   io[2 * t] = Fq29::to_sat(a); io[2 * t + 1] = Fq29::to_sat(b);
 }
 // madd chain on the 29-bit accumulator, to see the ALU ceiling of k_msm_accumulate at its real occupancy
 #include "../scroll-prover_amd/csrc/g1_29.cuh"
-template <bool FUSED> __global__ void __launch_bounds__(256) k_madd29(g1_xyzz_t *accs, const g1_affine_t *pts, int npts, int iters) {
+template <bool FUSED, bool CHAIN = false> __global__ void __launch_bounds__(256) k_madd29(g1_xyzz_t *accs, const g1_affine_t *pts, int npts, int iters) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   g1_xyzz29_t acc = g1_xyzz29_identity();
   for (int i = 0; i < iters; i++) {
     g1_affine_t p = pts[(t * 31 + i) % npts];
-    g1_xyzz29_madd<FUSED>(acc, p, (i & 1) != 0);
+    g1_xyzz29_madd<FUSED, CHAIN>(acc, p, (i & 1) != 0);
   }
   accs[t] = g1_xyzz29_to_sat(acc);
 }
@@ -165,6 +167,14 @@ int main() {
     printf("Fq29::mul chain vs Fq::mul chain mismatches (inputs must be < p for equality; random inputs here are < 2^253): %zu of %zu\n", bad29, nfe);
   }
   RUN_MUL29(0, "Fq29::mul (9x29)") RUN_MUL29(1, "Fq29 sqr+mul") RUN_MUL29(2, "Fq29 mul + lazy add/sub") RUN_MUL29(3, "Fq29::mul2 (dual acc)")
+  RUN_MUL29(4, "Fq29::mul_c (chained mad)") RUN_MUL29(5, "Fq29 sqr_c+mul_c")
+  {
+    CK(hipMemcpy(d1, h.data(), nfe * 32, hipMemcpyHostToDevice)); CK(hipMemcpy(d2, h.data(), nfe * 32, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fq29mul<4>, dim3(blocks), dim3(threads), 0, 0, d1); hipLaunchKernelGGL(k_fq29mul<0>, dim3(blocks), dim3(threads), 0, 0, d2); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(r1.data(), d1, nfe * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r0.data(), d2, nfe * 32, hipMemcpyDeviceToHost));
+    size_t badc = 0; for (size_t i = 0; i < nfe; i++) if (memcmp(&r0[i], &r1[i], 32)) badc++;
+    printf("Fq29::mul_c chain vs Fq29::mul chain mismatches: %zu of %zu\n", badc, nfe);
+  }
   for (int bpc : {1, 2, 4}) {
     int b2 = prop.multiProcessorCount * bpc;
     float m0 = time_kernel([&] { hipLaunchKernelGGL(k_fq29mul<0>, dim3(b2), dim3(threads), 0, 0, d2); });
@@ -194,7 +204,8 @@ int main() {
       int b2 = prop.multiProcessorCount * bpc;
       float ms = time_kernel([&] { hipLaunchKernelGGL(k_madd29<true>, dim3(b2), dim3(threads), 0, 0, da, dp, npts, iters); });
       float ms0 = time_kernel([&] { hipLaunchKernelGGL(k_madd29<false>, dim3(b2), dim3(threads), 0, 0, da, dp, npts, iters); });
-      printf("xyzz29 madd chain %d waves/SIMD: fused-Y3 %8.2f G madd/s   unfused %8.2f G madd/s\n", bpc, (double)b2 * threads * iters / ms * 1e-6, (double)b2 * threads * iters / ms0 * 1e-6);
+      float msc = time_kernel([&] { hipLaunchKernelGGL((k_madd29<true, true>), dim3(b2), dim3(threads), 0, 0, db, dp, npts, iters); });
+      printf("xyzz29 madd chain %d waves/SIMD: fused-Y3 %8.2f G madd/s   unfused %8.2f G madd/s   fused + chained mads %8.2f G madd/s\n", bpc, (double)b2 * threads * iters / ms * 1e-6, (double)b2 * threads * iters / ms0 * 1e-6, (double)b2 * threads * iters / msc * 1e-6);
     }
     for (int v = 0; v < 2; v++) {
       float ms = time_kernel([&] { if (v == 0) hipLaunchKernelGGL(k_madd<0>, dim3(blocks), dim3(threads), 0, 0, da, dp, npts, iters); else hipLaunchKernelGGL(k_madd<1>, dim3(blocks), dim3(threads), 0, 0, db, dp, npts, iters); });
