@@ -43,14 +43,19 @@ ZK_HD g1_xyzz29_t g1_xyzz29_dbl_affine(const fe29_t &xt, const fe29_t &yt) {
 #ifndef ZK_MADD_CHAIN_DEFAULT
 #define ZK_MADD_CHAIN_DEFAULT false
 #endif
+template <bool FUSED_Y3 = true, bool CHAIN = ZK_MADD_CHAIN_DEFAULT> ZK_HD void g1_xyzz29_madd_core(g1_xyzz29_t &acc, const fe29_t &x2, const fe29_t &y2, bool y2_needs_normalise);
 template <bool FUSED_Y3 = true, bool CHAIN = ZK_MADD_CHAIN_DEFAULT> ZK_HD void g1_xyzz29_madd(g1_xyzz29_t &acc, const g1_affine_t &q, bool negate) {
   if (g1_affine_is_identity(q)) return;
   const fe29_t x2 = Fq29::from_sat(q.x);
   fe29_t y2 = Fq29::from_sat(q.y);
   if (negate) y2 = fq29_neg_loaded(y2);                    // limbs < 2^30, value < 64 p: multiplication operand only
+  g1_xyzz29_madd_core<FUSED_Y3, CHAIN>(acc, x2, y2, negate);
+}
+// the same addition for an addend that already sits in 29-bit limbs (x2, y2: limbs < 2^30, value < 64 p, not the identity)
+template <bool FUSED_Y3, bool CHAIN> ZK_HD void g1_xyzz29_madd_core(g1_xyzz29_t &acc, const fe29_t &x2, const fe29_t &y2, bool y2_needs_normalise) {
   if (g1_xyzz29_is_identity(acc)) {
     // first point of a bucket: taken by every lane at a different iteration (divergent), so keep it multiplication-free
-    acc.x = Fq29::reduce_small(x2); acc.y = Fq29::reduce_small(negate ? Fq29::normalise(y2) : y2);   // tight, < 2p
+    acc.x = Fq29::reduce_small(x2); acc.y = Fq29::reduce_small(y2_needs_normalise ? Fq29::normalise(y2) : y2);   // tight, < 2p
     acc.zz = Fq29::one(); acc.zzz = Fq29::one();
     return;
   }

@@ -169,11 +169,13 @@ def test_xyzz29_bucket_accumulator(hs):
 
 
 def test_reduce_small_boundaries(hs):
-    """quotient estimate of Fp29::reduce_small: exact multiples of p, one below/above, and random values below 64p."""
+    """quotient estimate of Fp29::reduce_small: exact multiples of p, one below/above, and random values -- over the whole range the
+    9-limb form can hold (v < 2^261 = 168 p): the NTT's unit-twiddle butterflies reduce u - v + 64 r < 103 r this way."""
     rng = random.Random(64)
     M = (1 << 29) - 1
     for w, m in ((0, P), (1, R)):
-        vals = [k * m + d for k in range(64) for d in (0, 1, m - 1, m // 2) if k * m + d < 64 * m] + [rng.randrange(64 * m) for _ in range(3000)]
+        top = (1 << 261) // m
+        vals = [k * m + d for k in range(top + 1) for d in (0, 1, m - 1, m // 2) if k * m + d < (1 << 261)] + [rng.randrange(1 << 261) for _ in range(6000)] + [(1 << 261) - 1]
         for v in vals:
             inp = (C.c_uint32 * 9)(*[(v >> (29 * i)) & M if i < 8 else v >> 232 for i in range(9)])
             out = (C.c_uint32 * 9)()

@@ -100,6 +100,45 @@ template <bool FUSED, bool CHAIN = false> __global__ void __launch_bounds__(256)
   }
   accs[t] = g1_xyzz29_to_sat(acc);
 }
+// ---- batched-affine candidate ("pairs, then madd"): entries are taken two at a time, the pair is added in AFFINE coordinates with one
+// shared inversion per batch of B pairs (Montgomery's trick: prefix products kept in LDS, points gathered again in the backward pass, as
+// the real kernel would have to -- B x 4 coordinates do not fit in registers or LDS), and the affine sum enters the XYZZ accumulator by
+// a mixed addition.  INV = 0: the inversion is skipped (results are wrong; the time is a LOWER bound for any inversion algorithm);
+// INV = 1: a Fermat-sized ladder (254 squarings + ~127 multiplications on the 29-bit field; timing only, the exponent is not p - 2).  Compare entries/s with the plain madd chain.
+template <int B, int INV> __global__ void __launch_bounds__(256) k_affine_pairs(g1_xyzz_t *accs, const g1_affine_t *pts, int npts, int iters) {
+  extern __shared__ uint32_t lds_pref[];                 // [B][9][256]: prefix products, lane-interleaved (conflict-free)
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  auto pref_put = [&](int i, const fe29_t &v) { for (int k = 0; k < 9; k++) lds_pref[(i * 9 + k) * 256 + lane] = v.l[k]; };
+  auto pref_get = [&](int i) { fe29_t v; for (int k = 0; k < 9; k++) v.l[k] = lds_pref[(i * 9 + k) * 256 + lane]; return v; };
+  for (int it = 0; it < iters; it += 2 * B) {
+    fe29_t run = Fq29::one();
+    for (int i = 0; i < B; i++) {                        // forward: d_i = x2 - x1, running product
+      const g1_affine_t p = pts[(t * 31 + it + 2 * i) % npts], q = pts[(t * 31 + it + 2 * i + 1) % npts];
+      const fe29_t d = Fq29::sub16(Fq29::from_sat(q.x), Fq29::reduce_small(Fq29::from_sat(p.x)));
+      pref_put(i, run);
+      run = Fq29::mul(run, d);
+    }
+    fe29_t inv = run;
+    if (INV == 1) {                                       // run^(p-2): square-and-multiply over the fixed exponent
+      fe29_t r = Fq29::one();
+      for (int bit = 253; bit >= 0; bit--) { r = Fq29::sqr(r); if (((uint32_t)bit * 2654435761u) >> 31) r = Fq29::mul(r, run); }   // timing only: ~half the exponent bits set, as in p - 2
+      inv = r;
+    }
+    for (int i = B - 1; i >= 0; i--) {                   // backward: inverse of d_i, the affine sum, its mixed addition into the accumulator
+      const g1_affine_t p = pts[(t * 31 + it + 2 * i) % npts], q = pts[(t * 31 + it + 2 * i + 1) % npts];
+      const fe29_t x1 = Fq29::reduce_small(Fq29::from_sat(p.x)), y1 = Fq29::reduce_small(Fq29::from_sat(p.y)), x2 = Fq29::from_sat(q.x), y2 = Fq29::from_sat(q.y);
+      const fe29_t d = Fq29::sub16(x2, x1);
+      const fe29_t inv_i = Fq29::mul(inv, pref_get(i));
+      inv = Fq29::mul(inv, d);
+      const fe29_t lam = Fq29::mul(Fq29::sub16(y2, y1), inv_i);
+      const fe29_t x3 = Fq29::sub8(Fq29::sub4(Fq29::sqr(lam), x1), Fq29::carry(x2));
+      const fe29_t y3 = Fq29::sub4(Fq29::mul(lam, Fq29::sub16(x1, x3)), y1);
+      g1_xyzz29_madd_core<true, false>(acc, x3, y3, false);
+    }
+  }
+  accs[t] = g1_xyzz29_to_sat(acc);
+}
 // XYZZ mixed-add chain: the real MSM inner loop without memory traffic
 template <int VARIANT> __global__ void k_madd(g1_xyzz_t *accs, const g1_affine_t *pts, int npts, int iters) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,6 +245,19 @@ int main() {
       float ms0 = time_kernel([&] { hipLaunchKernelGGL(k_madd29<false>, dim3(b2), dim3(threads), 0, 0, da, dp, npts, iters); });
       float msc = time_kernel([&] { hipLaunchKernelGGL((k_madd29<true, true>), dim3(b2), dim3(threads), 0, 0, db, dp, npts, iters); });
       printf("xyzz29 madd chain %d waves/SIMD: fused-Y3 %8.2f G madd/s   unfused %8.2f G madd/s   fused + chained mads %8.2f G madd/s\n", bpc, (double)b2 * threads * iters / ms * 1e-6, (double)b2 * threads * iters / ms0 * 1e-6, (double)b2 * threads * iters / msc * 1e-6);
+    }
+    // batched-affine candidate: entries per second (2 per pair) against the madd chain's, at the occupancy its LDS use allows
+    {
+      const int it2 = 512;
+#define RUN_AFF(B, INV, bpc)                                                                                                              \
+      { int b2 = prop.multiProcessorCount * (bpc); size_t ldsb = (size_t)(B) * 9 * 256 * 4;                                                 \
+        CK(hipFuncSetAttribute((const void *)k_affine_pairs<B, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
+        float ms = time_kernel([&] { hipLaunchKernelGGL((k_affine_pairs<B, INV>), dim3(b2), dim3(threads), ldsb, 0, db, dp, npts, it2); });   \
+        printf("affine pairs + madd  B=%2d inv=%s  %d blocks/CU (LDS %3zu KB/block): %8.2f G entries/s\n", B, INV ? "fermat" : "none  ", bpc, ldsb >> 10, (double)b2 * threads * it2 / ms * 1e-6); }
+      RUN_AFF(4, 0, 2) RUN_AFF(8, 0, 2) RUN_AFF(16, 0, 1) RUN_AFF(8, 0, 1)
+      RUN_AFF(8, 1, 2) RUN_AFF(16, 1, 1)
+      for (int bpc : {1, 2, 3}) { int b2 = prop.multiProcessorCount * bpc; float ms = time_kernel([&] { hipLaunchKernelGGL((k_madd29<true, false>), dim3(b2), dim3(threads), 0, 0, da, dp, npts, it2); });
+        printf("plain madd chain (same table, same loop) %d blocks/CU: %8.2f G entries/s\n", bpc, (double)b2 * threads * it2 / ms * 1e-6); }
     }
     for (int v = 0; v < 2; v++) {
       float ms = time_kernel([&] { if (v == 0) hipLaunchKernelGGL(k_madd<0>, dim3(blocks), dim3(threads), 0, 0, da, dp, npts, iters); else hipLaunchKernelGGL(k_madd<1>, dim3(blocks), dim3(threads), 0, 0, db, dp, npts, iters); });
