@@ -136,3 +136,56 @@ def test_rccl_allgather_leg_with_one_rank():
         params.release()
     finally:
         _reinit(pkg, [0, 0], {"MI355_ALLOW_DUP_DEVICES": "1"})
+
+
+def test_three_slots_ragged_length_and_params_file(tmp_path):
+    """three device slots, a length that does not divide evenly, bases uploaded from the host and streamed from a params file."""
+    pkg = ge.load_package()
+    _reinit(pkg, [0, 0, 0], {"MI355_ALLOW_DUP_DEVICES": "1"})
+    try:
+        h2 = pkg.halo2
+        k = 17
+        src = h2.ParamsKZG.setup(k, TAU + 3)
+        g, gl = src.read_g(), src.read_g(lagrange=True)
+        n = (1 << k) - 77
+        sc = dev_scalars(n, 41).cpu().numpy().view(np.uint64).reshape(n, 4)
+        want = cref.g1_to_affine(cref.best_multiexp(sc, g[:n], threads=8))
+        assert (affine_of(h2.best_multiexp(sc.copy(), src.g_slice(0, n))) == want).all()
+        run = last_run(pkg)
+        assert run["devices"] == 3 and run["exchange"] == "device_copy", run
+        up = h2.ParamsKZG.from_host(k, g, gl)                         # mi355_srs_register_host: three uploads
+        assert (affine_of(h2.best_multiexp(sc.copy(), up.g_slice(0, n))) == want).all()
+        path = str(tmp_path / "params17")
+        src.write(path)
+        ld = h2.params_from_file(path, validate=True)                 # streamed shard by shard
+        assert (ld.read_g() == g).all() and (ld.read_g(lagrange=True) == gl).all()
+        assert (affine_of(h2.best_multiexp(sc.copy(), ld.g_slice(0, n))) == want).all()
+        assert ld.s_g2 == src.s_g2
+        for p in (src, up, ld):
+            p.release()
+    finally:
+        _reinit(pkg, [0, 0], {"MI355_ALLOW_DUP_DEVICES": "1"})
+
+
+def test_prefix_view_gets_private_tables_when_much_smaller(zk2):
+    """a 2^12 prefix of a 2^20 basis: the inherited table (built for 2^19-point shards) is far from the best width for 2^12 points, so
+    mi355_srs_precompute builds a private one for the view; the parent keeps its own."""
+    h2 = zk2.halo2
+    lib, check = zk2._capi.lib(), zk2._capi.check
+    big = h2.ParamsKZG.setup(20, TAU + 4)
+    big.precompute(lagrange=False)
+    view = big.clone_downsized(12)
+    pa, pb = C.c_void_p(), C.c_void_p(); ca, cb = C.c_int(), C.c_int()
+    check(lib.mi355_srs_pre_dev_ptr(big._g, C.byref(pa), C.byref(ca), None))
+    check(lib.mi355_srs_pre_dev_ptr(view._g, C.byref(pb), C.byref(cb), None))
+    assert pa.value == pb.value                                       # inherited
+    check(lib.mi355_srs_precompute(view._g, 0, 0))
+    check(lib.mi355_srs_pre_dev_ptr(view._g, C.byref(pb), C.byref(cb), None))
+    assert pb.value != pa.value and cb.value < ca.value               # private, narrower windows
+    sc = dev_scalars(1 << 12, 5)
+    assert (affine_of(view.commit(sc)) == field_commit(sc, TAU + 4)).all()
+    sc_big = dev_scalars(1 << 20, 6)
+    assert (affine_of(big.commit(sc_big)) == field_commit(sc_big, TAU + 4)).all()
+    check(lib.mi355_srs_pre_dev_ptr(big._g, C.byref(pb), C.byref(cb), None))
+    assert pb.value == pa.value and cb.value == ca.value
+    view.release(); big.release()
