@@ -155,6 +155,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--logn", type=int, default=26, help="log2 of the MSM / NTT size (BASELINE metric: 26)")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--table-bits", type=int, default=0, help="window bits of the registration-time tables (mi355_srs_precompute; 0 = automatic, up to 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="skip the registration-time window tables (mi355_srs_precompute)")
@@ -218,7 +219,7 @@ def main() -> None:
     if not args.no_precompute and not args.window_bits:
         # registration-time work, outside the timed region: T[w][i] = 2^(c w) P_i (W x the basis in HBM: 48 GiB at 2^26, c = 22)
         tp = time.perf_counter()
-        check(lib.mi355_srs_precompute(handle.value, 0, 0))
+        check(lib.mi355_srs_precompute(handle.value, 0, args.table_bits))
         pre_ms = (time.perf_counter() - tp) * 1e3
     scalars = rand_scalars(n, 0x5343524F4C4C0002 + rank, dev)
     torch.cuda.synchronize()

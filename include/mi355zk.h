@@ -121,7 +121,7 @@ int mi355_g1_sum_host(const void *g1_points_host, uint64_t n, void *out_g1_host)
  * normalised one; saves the serial field inversion (~0.4 ms) where the result is folded again anyway (per-GPU partial sums).      */
 int mi355_msm_set_normalise(int on);
 /* tuning (per calling thread): window bits c for subsequent MSMs: 0 = automatic from n (window tables used when registered and cheaper),
- * -1 = automatic but ignoring window tables (the memory-lean schedule: per-window bucket sets + Horner), 2..22 = fixed, no tables       */
+ * -1 = automatic but ignoring window tables (the memory-lean schedule: per-window bucket sets + Horner), 2..24 = fixed, no tables       */
 int mi355_msm_set_window_bits(int c);
 /* pipelined schedule of a large single MSM: the point range is cut into `chunks` slices and the (memory-bound) sort of slice k + 1
  * runs under the (ALU-bound) accumulation of slice k on separate HIP streams; results are identical.  Off by default (measured

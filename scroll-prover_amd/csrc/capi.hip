@@ -83,6 +83,7 @@ struct Ctx {
   // host-pointer MSM: chunked copy on its own stream, overlapped with the digit extraction (msm_host_single)
   hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr};
   void *pin_ring = nullptr; size_t pin_ring_bytes = 0;
+  uint32_t host_slice_min_log = 22;   // MI355_HOST_SLICE_MIN_LOG: smallest log2(n) the host-pointer MSM cuts into slices (tests lower it)
   uint32_t host_chunks = 8;     // MI355_HOST_CHUNKS: upper bound on the point-range slices of the host-pointer MSM (1 = one copy, then compute)
   int device = -1;
   hipDeviceProp_t prop;
@@ -121,6 +122,7 @@ std::mutex g_mu;
 Ctx g_ctx[MAX_DEV];
 int g_ndev = 0;
 bool g_dup_devices = false;     // test mode: the same physical device bound to several slots (exchange by device copies instead of RCCL)
+uint32_t g_shard_min_log = 14;  // MI355_SHARD_MIN_LOG: a basis with fewer than 2^this points per device stays on the primary device (tests lower it)
 bool g_force_exchange = false;  // MI355_MULTI_FORCE=1: take the sharded path (partials + exchange + fold) even with one device
 thread_local Ctx *g_cur = &g_ctx[0];
 #define g (*g_cur)
@@ -150,7 +152,9 @@ SrsTables::~SrsTables() {
 }
 // signed-digit recoding of min(k, r - k) < 2^253: W = ceil(254 / c) windows always absorb the carry of the top digit (253 bits of
 // magnitude + 1); c <= 24 is the sorter's key range (23 bucket bits = 12 fine + 11 coarse)
-constexpr int MSM_SCALAR_BITS = 255, MSM_MAX_C = 22;
+constexpr int MSM_SCALAR_BITS = 255, MSM_MAX_C = 24;   // hard limit of the sorter (23 key bits); the automatic choices stop at g_auto_max_c
+int g_auto_max_c = 22;          // MI355_MSM_AUTO_MAX_C (22..24): widest window the automatic choices may take.  c = 24 (W = 11) trades 8 % fewer
+                                // bucket additions for a 4x larger bucket reduction; explicit requests (mi355_srs_precompute(c), _set_window_bits) may always use 23 / 24
 
 // Every compute entry point starts here.  The HIP current device is per host thread and calls arrive from whichever thread runs
 // create_proof (rayon workers included, SURVEY 8b "Threading"), so the bound device is re-selected on the calling thread each time.
@@ -215,7 +219,7 @@ double msm_cost(uint64_t n, int c, bool shared) { const double W = (MSM_SCALAR_B
 int choose_c(uint64_t n) {
   if (t_opts.force_c) return t_opts.force_c;
   double best = 1e300; int best_c = 8;
-  for (int c = 4; c <= MSM_MAX_C; c++) {
+  for (int c = 4; c <= g_auto_max_c; c++) {
     const double W = (MSM_SCALAR_BITS + c - 1) / c, nb = (double)(1ull << (c - 1));
     if (W * nb * sizeof(g1_xyzz29_t) > 6.0e9) continue;
     const double cost = msm_cost(n, c, false);
@@ -525,13 +529,14 @@ int msm_host_single(const g1_affine_t *bases, const fe_t *const *polys_host, uin
   // for 2^26 pairs instead of 8 equal ones.  Every extra slice costs bucket crossings in the accumulation (each bucket is visited once
   // per slice) and a fix-up pass, which is why fewer, growing slices win (measured: 8 equal slices 86.7 ms).
   std::vector<uint64_t> cut;   // slice k = [cut[k], cut[k + 1])
-  if (M == 1 && n >= (1ull << 22) && g.host_chunks > 1) {
+  if (M == 1 && n >= (1ull << g.host_slice_min_log) && g.host_chunks > 1) {
     double w = 1.0, tot = 0; std::vector<double> ws;
     const double first = 1.0 / 16.0;
     for (double rem = 1.0; rem > 1e-9 && ws.size() + 1 < g.host_chunks;) { const double take = std::min(rem, first * w); ws.push_back(take); rem -= take; w *= 1.7; tot += take; }
     if (tot < 1.0 - 1e-9) ws.push_back(1.0 - tot);
     cut.push_back(0); double acc = 0;
-    for (size_t i = 0; i + 1 < ws.size(); i++) { acc += ws[i]; cut.push_back(std::min<uint64_t>(n, (uint64_t)(acc * (double)n) & ~1023ull)); }
+    const uint64_t align = n >= (1ull << 20) ? ~1023ull : ~0ull;
+    for (size_t i = 0; i + 1 < ws.size(); i++) { acc += ws[i]; const uint64_t c = std::min<uint64_t>(n, (uint64_t)(acc * (double)n) & align); if (c > cut.back() && c < n) cut.push_back(c); }
     cut.push_back(n);
   }
   uint32_t K = cut.empty() ? 1 : (uint32_t)cut.size() - 1;
@@ -818,10 +823,11 @@ static int init_ctx(int slot, int device_id) {
   g = Ctx();
   g.slot = slot;
   HIPCHK(hipSetDevice(device_id));
+  g.device = device_id;                     // from here on destroy_ctx() releases whatever the steps below created
   HIPCHK(hipGetDeviceProperties(&g.prop, device_id));
   if (strncmp(g.prop.gcnArchName, "gfx950", 6) != 0) return fail(MI355_ENODEVICE, std::string("device is ") + g.prop.gcnArchName + ", this library is built for gfx950 only");
   HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
-  g.stream = g.own_stream; g.device = device_id;
+  g.stream = g.own_stream;
   for (int i = 0; i < 2; i++) {
     { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); const char *e = getenv("MI355_AUX_PRIO"); const bool high = !(e && e[0] == '0');
       HIPCHK(hipStreamCreateWithPriority(&g.aux_stream[i], hipStreamNonBlocking, high ? hi : lo)); }   // the side streams outrank the accumulation
@@ -862,14 +868,15 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_HOST_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64) g.host_chunks = (uint32_t)v; } }
+  { const char *e = getenv("MI355_HOST_SLICE_MIN_LOG"); if (e) { int v = atoi(e); if (v >= 4 && v <= 31) g.host_slice_min_log = (uint32_t)v; } }
   g.inited = true;
   return MI355_OK;
 }
 static void destroy_ctx(int slot) {
   use_ctx(slot);
-  if (!g.inited) return;
+  if (g.device < 0) return;                 // never reached hipSetDevice: nothing was created
   (void)hipSetDevice(g.device);
-  (void)hipStreamSynchronize(g.stream);
+  if (g.stream) (void)hipStreamSynchronize(g.stream);
   for (auto &kv : g.ws) if (kv.second.p) (void)hipFree(kv.second.p);
   g.ws.clear();
   for (auto &kv : g.ntt_plans) { for (void *q : kv.second.owned) (void)hipFree(q); for (int i = 0; i < 3; i++) if (kv.second.tw_m[i]) (void)hipFree(kv.second.tw_m[i]); for (int i = 0; i < 2; i++) { if (kv.second.tw_s_lo[i]) (void)hipFree(kv.second.tw_s_lo[i]); if (kv.second.tw_s_hi[i]) (void)hipFree(kv.second.tw_s_hi[i]); } }
@@ -919,6 +926,8 @@ int mi355_init_multi(const int *device_ids, int n_devices) {
   if (rc != MI355_OK) { const std::string keep = g_err; shutdown_all(); g_err = keep; return rc; }
   g_dup_devices = dup;
   { const char *e = getenv("MI355_MULTI_FORCE"); g_force_exchange = e && e[0] == '1'; }
+  { const char *e = getenv("MI355_MSM_AUTO_MAX_C"); g_auto_max_c = 22; if (e) { int v = atoi(e); if (v >= 16 && v <= MSM_MAX_C) g_auto_max_c = v; } }
+  { const char *e = getenv("MI355_SHARD_MIN_LOG"); g_shard_min_log = 14; if (e) { int v = atoi(e); if (v >= 0 && v <= 30) g_shard_min_log = (uint32_t)v; } }
   if (n_devices > 1 || g_force_exchange) {
     // one communicator per process over the bound devices: ncclCommInitAll.  Duplicate devices (test mode) cannot form a
     // communicator; their exchange is a device-to-device copy.
@@ -988,7 +997,7 @@ int mi355_synchronize(void) {
 static std::vector<Shard> plan_shards(uint64_t n) {
   std::vector<Shard> v;
   int D = g_ndev;
-  if (D > 1 && n / (uint64_t)D < (1ull << 14)) D = 1;
+  if (D > 1 && n / (uint64_t)D < (1ull << g_shard_min_log)) D = 1;
   for (int d = 0; d < D; d++) { Shard s; s.slot = d; s.lo = n * d / D; s.n = n * (d + 1) / D - s.lo; if (s.n) v.push_back(s); }
   return v;
 }
@@ -1157,7 +1166,7 @@ int mi355_srs_precompute(uint64_t handle, uint64_t n_hint, int c) {
   const bool automatic = c == 0;
   if (automatic) {   // best shared-bucket window for MSMs of n_hint points (per shard), within the sorter's key range
     double best = 1e300;
-    for (int cc = 4; cc <= MSM_MAX_C; cc++) { const double co = msm_cost(per_shard, cc, true); if (co < best) { best = co; c = cc; } }
+    for (int cc = 4; cc <= g_auto_max_c; cc++) { const double co = msm_cost(per_shard, cc, true); if (co < best) { best = co; c = cc; } }
   }
   if (c < 2 || c > MSM_MAX_C) return fail(MI355_EBADARG, "srs_precompute: window bits out of range");
   if (sp->tab) {
@@ -1269,10 +1278,11 @@ static int msm_multi(const std::vector<Piece> &pieces, const fe_t *const *polys,
   // scalars on the primary device may still be in flight on the primary stream: the peers' copies must wait for it
   if (loc == SCALARS_DEV && D > 1) { CHK(bind_ctx(0)); HIPCHK(hipStreamSynchronize(g.stream)); }
   {
-    std::vector<std::thread> th;
-    for (int s = 1; s < D; s++) th.emplace_back(work, s);
+    // every started worker is joined on every path (a std::thread that is destroyed while joinable terminates the process)
+    struct Joiner { std::vector<std::thread> th; ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); } } workers;
+    workers.th.reserve(D);
+    for (int s = 1; s < D; s++) workers.th.emplace_back(work, s);
     work(0);
-    for (auto &t : th) t.join();
   }
   t_opts = opts;
   CHK(bind_ctx(0));
@@ -1434,7 +1444,7 @@ int mi355_g1_sum_host(const void *pts_host, uint64_t n, void *out_g1_host) {
 int mi355_msm_set_window_bits(int c) {
   return guarded([&]() -> int {
   if (c == -1) { t_opts.force_c = 0; t_opts.no_tables = true; return MI355_OK; }   // automatic window, window tables ignored
-  if (c != 0 && (c < 2 || c > MSM_MAX_C)) return fail(MI355_EBADARG, "window bits must be 0 (auto), -1 (auto, no window tables) or in [2, 22]");
+  if (c != 0 && (c < 2 || c > MSM_MAX_C)) return fail(MI355_EBADARG, "window bits must be 0 (auto), -1 (auto, no window tables) or in [2, 24]");
   t_opts.force_c = c; t_opts.no_tables = false; return MI355_OK;
   });
 }

@@ -17,7 +17,10 @@ R = pyref.R_MOD
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-zk = ge.load_package(); zk.init(0); h2 = zk.halo2
+# FUZZ_DEVICES=0,0 (with MI355_ALLOW_DUP_DEVICES=1): several device slots behind the process -> sharded bases, worker threads, exchange;
+# MI355_HOST_SLICE_MIN_LOG=6: even small host-pointer MSMs are cut into point-range slices (bucket-set fold + one reduction tail)
+_devs = os.environ.get("FUZZ_DEVICES")
+zk = ge.load_package(); zk.init([int(x) for x in _devs.split(",")] if _devs else 0); h2 = zk.halo2
 lib, check, ptr = zk._capi.lib(), zk._capi.check, zk._capi.ptr
 
 G = cref.g1_generator()
