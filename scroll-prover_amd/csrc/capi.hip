@@ -100,7 +100,7 @@ struct Ctx {
   g1_affine_t *fixed_base_table = nullptr;
   uint32_t sort_t2 = 0;         // MI355_SORT_T2 = 8192 | 16384 (0: by size)
   uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
-  uint32_t acc_variant = 0;     // MI355_ACC_VARIANT (A/B knob): 4 = limb products as explicitly chained v_mad (measured 58.4 vs 59.3 ms at 2^26: within box noise, off)
+  uint32_t acc_variant = 4;     // MI355_ACC_VARIANT: 4 = limb products of k_msm_accumulate as column blocks of chained v_mad (fp29_asm_gen.inc): 57.1 vs 59.5 ms at 2^26, bit-identical; 0 = the plain C++ multiplier
   uint32_t seg_factor = 16;
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction

@@ -39,22 +39,15 @@ struct Fr29P {
   ZK_HD static constexpr uint32_t fat30_16p(int i) { constexpr uint32_t m[9] = {0x40000010u, 0x50fac9f6u, 0x45c2450du, 0x5d090f35u, 0x585d2831u, 0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x30644e5u}; return m[i]; }
 };
 
-// acc += a * b as ONE v_mad_u64_u32 in a fixed dependency chain.  Written as plain C++ the compiler sums every column's products in
-// a fresh accumulator and joins it to the carried one with a 64-bit add (shorter dependency chain, but one more 4-cycle instruction per
-// column: 16 per multiplication, ~7 % of its issue slots); with three waves per SIMD the chain latency is hidden anyway, so the kernels
-// that are VALU-bound use the chained form (MI355_FP29_CHAIN, A/B'ed in tools/microbench.hip).
+// Chained multiplier (A/B experiment).  Written as plain C++ the compiler sums every column's products in a fresh
+// accumulator and joins it to the carried one with a 64-bit add (a shorter dependency chain, but one more 4-cycle instruction per column:
+// 16 per multiplication, ~7 % of its issue slots).  mul_c / sqr_c / mul_sub_c issue the products of a column as one inline-asm block of
+// chained v_mad instead; with three waves per SIMD the chain latency is hidden anyway.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MI355_FP29_NO_CHAIN)
 #define ZK_FP29_CHAIN 1
-__device__ __forceinline__ void mac_vv(uint64_t &acc, uint32_t a, uint32_t b) { uint64_t co; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(co) : "v"(a), "v"(b)); }
-__device__ __forceinline__ void mac_vs(uint64_t &acc, uint32_t a, uint32_t b_uniform) { uint64_t co; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(co) : "v"(a), "s"(b_uniform)); }
-__device__ __forceinline__ void smac_vv(int64_t &acc, int32_t a, int32_t b) { uint64_t co; asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(co) : "v"(a), "v"(b)); }
-__device__ __forceinline__ void smac_vs(int64_t &acc, int32_t a, int32_t b_uniform) { uint64_t co; asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(co) : "v"(a), "s"(b_uniform)); }
+#include "fp29_asm_gen.inc"
 #else
 #define ZK_FP29_CHAIN 0
-ZK_HD void mac_vv(uint64_t &acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
-ZK_HD void mac_vs(uint64_t &acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
-ZK_HD void smac_vv(int64_t &acc, int32_t a, int32_t b) { acc += (int64_t)a * b; }
-ZK_HD void smac_vs(int64_t &acc, int32_t a, int32_t b) { acc += (int64_t)a * b; }
 #endif
 
 template <class P> struct Fp29 {
@@ -116,86 +109,43 @@ template <class P> struct Fp29 {
     r.l[8] = (uint32_t)((int32_t)acc + (int32_t)P::mod(8));
     return r;
   }
-  // the same three routines with every limb product issued as one chained v_mad (mac_*): bit-identical results
+  // the same three routines with the limb products of every column issued as ONE inline-asm block of chained v_mad (fp29_asm_gen.inc,
+  // written by tools/gen_fp29_asm.py): bit-identical results; on the host they are the plain C++ routines
   ZK_HD static fe29_t mul_c(const fe29_t &a, const fe29_t &b) {
-    uint64_t acc = 0; uint32_t m[9]; fe29_t r;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-      for (int i = 0; i <= k; i++) mac_vv(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-      for (int i = 0; i < k; i++) mac_vs(acc, m[i], P::mod(k - i));
-      m[k] = ((uint32_t)acc * P::INV) & M29;
-      mac_vs(acc, m[k], P::mod(0));
-      acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-      for (int i = k - 8; i < 9; i++) mac_vv(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-      for (int i = k - 8; i < 9; i++) mac_vs(acc, m[i], P::mod(k - i));
-      r.l[k - 9] = (uint32_t)acc & M29;
-      acc >>= 29;
-    }
-    r.l[8] = (uint32_t)acc;
+#if ZK_FP29_CHAIN
+    uint64_t acc = 0, co; uint32_t m[9]; fe29_t r;
+    ZK_FP29_MUL_COLUMNS
+    (void)co;
     return r;
+#else
+    return mul(a, b);
+#endif
   }
   ZK_HD static fe29_t sqr_c(const fe29_t &a) {
-    uint64_t acc = 0; uint32_t m[9]; fe29_t r;
+#if ZK_FP29_CHAIN
+    uint64_t acc = 0, co; uint32_t m[9]; fe29_t r;
     uint32_t a2[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-      for (int i = 0; 2 * i < k; i++) mac_vv(acc, a.l[i], a2[k - i]);
-      if ((k & 1) == 0) mac_vv(acc, a.l[k / 2], a.l[k / 2]);
-#pragma unroll
-      for (int i = 0; i < k; i++) mac_vs(acc, m[i], P::mod(k - i));
-      m[k] = ((uint32_t)acc * P::INV) & M29;
-      mac_vs(acc, m[k], P::mod(0));
-      acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-      for (int i = k - 8; 2 * i < k; i++) mac_vv(acc, a.l[i], a2[k - i]);
-      if ((k & 1) == 0) mac_vv(acc, a.l[k / 2], a.l[k / 2]);
-#pragma unroll
-      for (int i = k - 8; i < 9; i++) mac_vs(acc, m[i], P::mod(k - i));
-      r.l[k - 9] = (uint32_t)acc & M29;
-      acc >>= 29;
-    }
-    r.l[8] = (uint32_t)acc;
+    ZK_FP29_SQR_COLUMNS
+    (void)co;
     return r;
+#else
+    return sqr(a);
+#endif
   }
   ZK_HD static fe29_t mul_sub_c(const fe29_t &a, const fe29_t &b, const fe29_t &c, const fe29_t &d) {
-    int64_t acc = 0; uint32_t m[9]; fe29_t r;
+#if ZK_FP29_CHAIN
+    int64_t acc = 0; uint64_t co; uint32_t m[9]; fe29_t r;
     int32_t nc[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) nc[i] = -(int32_t)c.l[i];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-      for (int i = 0; i <= k; i++) { smac_vv(acc, (int32_t)a.l[i], (int32_t)b.l[k - i]); smac_vv(acc, nc[i], (int32_t)d.l[k - i]); }
-#pragma unroll
-      for (int i = 0; i < k; i++) smac_vs(acc, (int32_t)m[i], (int32_t)P::mod(k - i));
-      m[k] = ((uint32_t)acc * P::INV) & M29;
-      smac_vs(acc, (int32_t)m[k], (int32_t)P::mod(0));
-      acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-      for (int i = k - 8; i < 9; i++) { smac_vv(acc, (int32_t)a.l[i], (int32_t)b.l[k - i]); smac_vv(acc, nc[i], (int32_t)d.l[k - i]); }
-#pragma unroll
-      for (int i = k - 8; i < 9; i++) smac_vs(acc, (int32_t)m[i], (int32_t)P::mod(k - i));
-      r.l[k - 9] = ((uint32_t)acc & M29) + P::mod(k - 9);
-      acc >>= 29;
-    }
-    r.l[8] = (uint32_t)((int32_t)acc + (int32_t)P::mod(8));
+    ZK_FP29_MULSUB_COLUMNS
+    (void)co;
     return r;
+#else
+    return mul_sub(a, b, c, d);
+#endif
   }
   template <bool C> ZK_HD static fe29_t mul_t(const fe29_t &a, const fe29_t &b) { return C ? mul_c(a, b) : mul(a, b); }
   template <bool C> ZK_HD static fe29_t sqr_t(const fe29_t &a) { return C ? sqr_c(a) : sqr(a); }
@@ -283,6 +233,14 @@ template <class P> struct Fp29 {
     for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + P::fat30_8p(i) - b.l[i];
     return carry(r);
   }
+  // a - b - c + 12p in ONE pass and ONE carry (X3 = R^2 - PPP - 2Q of the point additions): b TIGHT as for sub4, c as for sub8; a limbs <= 2^29 + 8.
+  // Limb-wise a + (4p + 8p fat limbs, < 2^31.3) - b - c < 2^31.5: no 32-bit overflow, never negative; after the carry limbs <= 2^29 + 8.
+  ZK_HD static fe29_t sub4_8(const fe29_t &a, const fe29_t &b, const fe29_t &c) {
+    fe29_t r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (P::fat29_4p(i) + P::fat30_8p(i)) - b.l[i] - c.l[i];
+    return carry(r);
+  }
   // a - b + 16p: b limbs <= 2^30 - 2, value(b) < 15.9 p
   ZK_HD static fe29_t sub16(const fe29_t &a, const fe29_t &b) {
     fe29_t r;
@@ -321,6 +279,9 @@ template <class P> struct Fp29 {
   }
   // value == 0 mod p, for a TIGHT mul/sqr output (value < 2p, limbs exact): value is 0 or p
   ZK_HD static bool is_zero_tight(const fe29_t &a) {
+    // the low limb decides almost always (it is 0 or p's low limb with probability 2^-28 for a non-zero value): the full comparison
+    // sits behind a branch that a wavefront practically never takes
+    if (a.l[0] != 0 && a.l[0] != P::mod(0)) return false;
     uint32_t z = 0, q = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) { z |= a.l[i]; q |= a.l[i] ^ P::mod(i); }

@@ -73,7 +73,7 @@ template <bool FUSED_Y3, bool CHAIN> ZK_HD void g1_xyzz29_madd_core(g1_xyzz29_t 
   }
   const fe29_t PPP = Fq29::mul_t<CHAIN>(Pd, PP);                               // < 1.4 p
   const fe29_t Q = Fq29::mul_t<CHAIN>(acc.x, PP);                              // < 1.3 p
-  const fe29_t X3 = Fq29::sub8(Fq29::sub4(Fq29::sqr_t<CHAIN>(Rd), PPP), Fq29::dbl(Q)); // (1.6 + 4) p + 8 p = 13.6 p
+  const fe29_t X3 = Fq29::sub4_8(Fq29::sqr_t<CHAIN>(Rd), PPP, Fq29::dbl(Q));          // (1.6 + 4 + 8) p = 13.6 p, one carry
   // Y3 = Rd (Q - X3) - Y1 PPP: both products under ONE Montgomery reduction (signed column accumulator): (1.02 - 0.05 .. ) p + p + [0, p) < 3.1 p
   const fe29_t Y3 = FUSED_Y3 ? Fq29::mul_sub_t<CHAIN>(Rd, Fq29::sub16(Q, X3), acc.y, PPP)
                              : Fq29::sub4(Fq29::mul_t<CHAIN>(Rd, Fq29::sub16(Q, X3)), Fq29::mul_t<CHAIN>(acc.y, PPP));   // unfused form: < 2.1 p + 4 p
@@ -118,7 +118,7 @@ ZK_HD void g1_xyzz29_add(g1_xyzz29_t &acc, const g1_xyzz29_t &q) {
   }
   const fe29_t PPP = Fq29::mul(Pd, PP);                                        // < 1.1 p
   const fe29_t Q = Fq29::mul(U1, PP);                                          // < 1.1 p
-  const fe29_t X3 = Fq29::sub8(Fq29::sub4(Fq29::sqr(Rd), PPP), Fq29::dbl(Q)); // (1.2 + 4) p + 8 p = 13.2 p
+  const fe29_t X3 = Fq29::sub4_8(Fq29::sqr(Rd), PPP, Fq29::dbl(Q));          // (1.2 + 4 + 8) p = 13.2 p, one carry
   const fe29_t Y3 = Fq29::mul_sub(Rd, Fq29::sub16(Q, X3), S1, PPP);           // as in the mixed addition, with the tight S1 for Y1
   acc.x = X3; acc.y = Y3;
   acc.zz = Fq29::mul(ZZt, q.zz); acc.zzz = Fq29::mul(Fq29::mul(acc.zzz, PPP), q.zzz);
