@@ -25,16 +25,23 @@ ZK_HD fe29_t fq29_neg_loaded(const fe29_t &y) {
   return r;   // limbs < 2^30, value < 64 p
 }
 
+// the full addition / doubling below (reduction tail of the MSM, DFT over G1 points) take the chained multiplier on the device as well
+#ifndef ZK_G1_29_CHAIN
+#define ZK_G1_29_CHAIN true
+#endif
+#define FQ29_MUL(a, b) Fq29::mul_t<ZK_G1_29_CHAIN>(a, b)
+#define FQ29_SQR(a) Fq29::sqr_t<ZK_G1_29_CHAIN>(a)
+
 // 2 * (affine point) for tight coordinates xt, yt (< 1.1 p): mdbl-2008-s
 ZK_HD g1_xyzz29_t g1_xyzz29_dbl_affine(const fe29_t &xt, const fe29_t &yt) {
   const fe29_t U = Fq29::dbl(yt);                         // limbs <= 2^30 - 2, < 2.2 p
-  const fe29_t V = Fq29::sqr(U), W = Fq29::mul(U, V), S = Fq29::mul(xt, V);   // tight, < 1.1 p
-  const fe29_t xx = Fq29::sqr(xt);
+  const fe29_t V = FQ29_SQR(U), W = FQ29_MUL(U, V), S = FQ29_MUL(xt, V);   // tight, < 1.1 p
+  const fe29_t xx = FQ29_SQR(xt);
   const fe29_t M = Fq29::carry(Fq29::add(Fq29::dbl(xx), xx));                  // 3 x^2, limbs <= 2^29 + 8, < 3.3 p
   g1_xyzz29_t r;
-  r.x = Fq29::sub8(Fq29::sqr(M), Fq29::dbl(S));           // < 1.1 p + 8 p
+  r.x = Fq29::sub8(FQ29_SQR(M), Fq29::dbl(S));           // < 1.1 p + 8 p
   const fe29_t t = Fq29::sub16(S, r.x);                    // < 17.1 p
-  r.y = Fq29::sub4(Fq29::mul(M, t), Fq29::mul(W, yt));     // < 1.4 p + 4 p
+  r.y = Fq29::sub4(FQ29_MUL(M, t), FQ29_MUL(W, yt));     // < 1.4 p + 4 p
   r.zz = V; r.zzz = W;
   return r;
 }
@@ -87,14 +94,14 @@ ZK_HD g1_xyzz29_t g1_xyzz29_dbl(const g1_xyzz29_t &a) {
   const fe29_t xt = Fq29::reduce_small(Fq29::normalise(a.x));   // tight, < 2 p (x^2 of a 14 p value would leave the < 2 p output range)
   const fe29_t yc = Fq29::carry(a.y);                           // limbs <= 2^29 + 2, value < 6.1 p
   const fe29_t U = Fq29::dbl(yc);                               // limbs <= 2^30 + 4, < 12.2 p   (U^2 = 149 p^2 < 2^261 p = 168 p^2)
-  const fe29_t V = Fq29::sqr(U), W = Fq29::mul(U, V), S = Fq29::mul(xt, V);   // tight, < 1.9 p / 1.2 p / 1.1 p
-  const fe29_t xx = Fq29::sqr(xt);
+  const fe29_t V = FQ29_SQR(U), W = FQ29_MUL(U, V), S = FQ29_MUL(xt, V);   // tight, < 1.9 p / 1.2 p / 1.1 p
+  const fe29_t xx = FQ29_SQR(xt);
   const fe29_t M = Fq29::carry(Fq29::add(Fq29::dbl(xx), xx));                  // 3 x^2, limbs <= 2^29 + 8, < 3.3 p
   g1_xyzz29_t r;
-  r.x = Fq29::sub8(Fq29::sqr(M), Fq29::dbl(S));                 // < 1.1 p + 8 p
+  r.x = Fq29::sub8(FQ29_SQR(M), Fq29::dbl(S));                 // < 1.1 p + 8 p
   const fe29_t t = Fq29::sub16(S, r.x);                          // < 17.1 p
-  r.y = Fq29::sub4(Fq29::mul(M, t), Fq29::mul(W, yc));           // < 1.4 p + 4 p
-  r.zz = Fq29::mul(V, a.zz); r.zzz = Fq29::mul(W, a.zzz);
+  r.y = Fq29::sub4(FQ29_MUL(M, t), FQ29_MUL(W, yc));           // < 1.4 p + 4 p
+  r.zz = FQ29_MUL(V, a.zz); r.zzz = FQ29_MUL(W, a.zzz);
   return r;
 }
 
@@ -104,24 +111,24 @@ ZK_HD g1_xyzz29_t g1_xyzz29_dbl(const g1_xyzz29_t &a) {
 ZK_HD void g1_xyzz29_add(g1_xyzz29_t &acc, const g1_xyzz29_t &q) {
   if (g1_xyzz29_is_identity(q)) return;
   if (g1_xyzz29_is_identity(acc)) { acc = q; return; }
-  const fe29_t U1 = Fq29::mul(acc.x, q.zz), S1 = Fq29::mul(acc.y, q.zzz);      // tight, < 1.1 p
-  const fe29_t U2 = Fq29::mul(q.x, acc.zz), S2 = Fq29::mul(q.y, acc.zzz);      // tight, < 1.1 p
+  const fe29_t U1 = FQ29_MUL(acc.x, q.zz), S1 = FQ29_MUL(acc.y, q.zzz);      // tight, < 1.1 p
+  const fe29_t U2 = FQ29_MUL(q.x, acc.zz), S2 = FQ29_MUL(q.y, acc.zzz);      // tight, < 1.1 p
   const fe29_t Pd = Fq29::sub4(U2, U1);                                        // < 5.1 p
   const fe29_t Rd = Fq29::sub4(S2, S1);                                        // < 5.1 p
-  const fe29_t PP = Fq29::sqr(Pd);                                             // < 1.2 p
-  const fe29_t ZZt = Fq29::mul(acc.zz, PP);                                    // zero iff Pd == 0 (both zz != 0)
+  const fe29_t PP = FQ29_SQR(Pd);                                             // < 1.2 p
+  const fe29_t ZZt = FQ29_MUL(acc.zz, PP);                                    // zero iff Pd == 0 (both zz != 0)
   if (Fq29::is_zero_tight(ZZt)) {
     // q == +-acc: doubling or annihilation
-    if (Fq29::is_zero_tight(Fq29::mul(Rd, Fq29::one()))) acc = g1_xyzz29_dbl(acc);
+    if (Fq29::is_zero_tight(FQ29_MUL(Rd, Fq29::one()))) acc = g1_xyzz29_dbl(acc);
     else acc = g1_xyzz29_identity();
     return;
   }
-  const fe29_t PPP = Fq29::mul(Pd, PP);                                        // < 1.1 p
-  const fe29_t Q = Fq29::mul(U1, PP);                                          // < 1.1 p
-  const fe29_t X3 = Fq29::sub4_8(Fq29::sqr(Rd), PPP, Fq29::dbl(Q));          // (1.2 + 4 + 8) p = 13.2 p, one carry
-  const fe29_t Y3 = Fq29::mul_sub(Rd, Fq29::sub16(Q, X3), S1, PPP);           // as in the mixed addition, with the tight S1 for Y1
+  const fe29_t PPP = FQ29_MUL(Pd, PP);                                        // < 1.1 p
+  const fe29_t Q = FQ29_MUL(U1, PP);                                          // < 1.1 p
+  const fe29_t X3 = Fq29::sub4_8(FQ29_SQR(Rd), PPP, Fq29::dbl(Q));          // (1.2 + 4 + 8) p = 13.2 p, one carry
+  const fe29_t Y3 = Fq29::mul_sub_t<ZK_G1_29_CHAIN>(Rd, Fq29::sub16(Q, X3), S1, PPP);           // as in the mixed addition, with the tight S1 for Y1
   acc.x = X3; acc.y = Y3;
-  acc.zz = Fq29::mul(ZZt, q.zz); acc.zzz = Fq29::mul(Fq29::mul(acc.zzz, PPP), q.zzz);
+  acc.zz = FQ29_MUL(ZZt, q.zz); acc.zzz = FQ29_MUL(FQ29_MUL(acc.zzz, PPP), q.zzz);
 }
 
 // accumulator -> the saturated XYZZ record the reduction kernels consume (R = 2^256 Montgomery, fully reduced)

@@ -2,6 +2,8 @@
 // g_to_lagrange / ParamsKZG::downsize [REF integration/tests/integration.rs:12-22; SURVEY 8a row a3, 8f-2]:
 //     a'[i] = sum_j omega^(ij) a[j]      (natural order in, natural order out, no scaling)
 //
+// Round 2: the butterflies run on the 9 x 29-bit field with the chained multiplier (g1_xyzz29_mul_fr below); the work array keeps the
+// saturated XYZZ records.
 // Every butterfly costs one 254-bit scalar multiple of a point (~4000 field multiplications) against 192 B of traffic, so the kernels are
 // plain radix-2 stages over a work array of XYZZ points in HBM -- there is nothing for LDS tiling to win.  The points are permuted into
 // bit-reversed order on load, the stages then run decimation-in-time exactly like the serial reference:
@@ -10,6 +12,7 @@
 #pragma once
 #include "fp_asm.cuh"
 #include "g1.cuh"
+#include "g1_29.cuh"
 
 namespace zk {
 #ifdef __HIPCC__
@@ -34,6 +37,55 @@ __device__ __noinline__ g1_xyzz_t g1_xyzz_mul_fr(const g1_xyzz_t &p, const fe_t 
         sel.zzz.l[j] = d == 1 ? p.zzz.l[j] : d == 2 ? p2.zzz.l[j] : p3.zzz.l[j];
       }
       g1_xyzz_add_ps(acc, sel);
+    }
+  }
+  return acc;
+}
+
+// The same scalar multiple on the 9 x 29-bit field with the chained multiplier (1.4x the saturated multiplier's rate): signed 2-bit
+// digits {-1, 0, 1, 2} (a digit 3 becomes -1 with a carry into the next one), so the table is {p, 2p} plus a negated y -- 72 registers
+// less than {p, 2p, 3p}.  p: valid accumulator with TIGHT coordinates (from g1_xyzz29_from_sat); result: valid accumulator.
+__device__ __forceinline__ g1_xyzz29_t g1_xyzz29_from_sat(const g1_xyzz_t &p) {
+  g1_xyzz29_t r;
+  if (g1_xyzz_is_identity(p)) return g1_xyzz29_identity();
+  r.x = Fq29::reduce_small(Fq29::from_sat(p.x)); r.y = Fq29::reduce_small(Fq29::from_sat(p.y));
+  r.zz = Fq29::reduce_small(Fq29::from_sat(p.zz)); r.zzz = Fq29::reduce_small(Fq29::from_sat(p.zzz));
+  return r;
+}
+__device__ __noinline__ g1_xyzz29_t g1_xyzz29_mul_fr(const g1_xyzz29_t &p, const fe_t &k) {
+  if (g1_xyzz29_is_identity(p)) return p;
+  uint32_t code[8]; uint32_t carry = 0;   // 16 digits per word, 2 bits each: 0, 1, 2, or 3 meaning -1
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    uint32_t out = 0;
+    for (int j = 0; j < 16; j++) {
+      uint32_t d = ((k.l[w] >> (2 * j)) & 3u) + carry;
+      carry = d >= 3 ? 1u : 0u;
+      d = d == 4 ? 0u : d;               // 3 stays 3 (= -1, carry 1), 4 = 0 with carry 1
+      out |= d << (2 * j);
+    }
+    code[w] = out;
+  }
+  // k < r < 2^254: digit 127 is 0 or (after a carry) 1, never a carry out of the top
+  const g1_xyzz29_t p2 = g1_xyzz29_dbl(p);
+  fe29_t yneg = Fq29::sub4(Fq29::zero(), p.y);           // 4p - y: limbs <= 2^29 + 8, value < 4p (p.y tight)
+  g1_xyzz29_t acc = g1_xyzz29_identity();
+  for (int i = 127; i >= 0; i--) {
+    acc = g1_xyzz29_dbl(g1_xyzz29_dbl(acc));
+    uint32_t word = code[0];               // static indices + selects: a runtime-indexed register array would live in scratch memory
+#pragma unroll
+    for (int w = 1; w < 8; w++) word = (i >> 4) == w ? code[w] : word;
+    const uint32_t d = (word >> ((i & 15) * 2)) & 3u;
+    if (d) {
+      g1_xyzz29_t sel;
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        sel.x.l[j] = d == 2 ? p2.x.l[j] : p.x.l[j];
+        sel.y.l[j] = d == 2 ? p2.y.l[j] : (d == 3 ? yneg.l[j] : p.y.l[j]);
+        sel.zz.l[j] = d == 2 ? p2.zz.l[j] : p.zz.l[j];
+        sel.zzz.l[j] = d == 2 ? p2.zzz.l[j] : p.zzz.l[j];
+      }
+      g1_xyzz29_add(acc, sel);
     }
   }
   return acc;
@@ -70,16 +122,18 @@ __global__ void __launch_bounds__(256) k_g1fft_stage(g1_xyzz_t *__restrict__ wor
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (1u << log_n) / 2) return;
   const uint32_t m = 1u << s, j = t & (m - 1), ia = ((t >> s) << (s + 1)) + j, ib = ia + m;
-  g1_xyzz_t a = g1fft_load_xyzz(&work[ia]), b = g1fft_load_xyzz(&work[ib]);
+  const g1_xyzz_t a = g1fft_load_xyzz(&work[ia]), b = g1fft_load_xyzz(&work[ib]);
+  g1_xyzz29_t wb = g1_xyzz29_from_sat(b);
   if (j) {
     fe_t one_c = Fr::zero(); one_c.l[0] = 1;
     const fe_t k = fr_mul_ps(g_load(&tw[(uint64_t)j << (log_n - 1 - s)]), one_c);   // Montgomery -> canonical
-    b = g1_xyzz_mul_fr(b, k);
+    wb = g1_xyzz29_mul_fr(wb, k);
   }
-  g1_xyzz_t lo = a; g1_xyzz_add_ps(lo, b);
-  b.y = Fq::neg(b.y);
-  g1_xyzz_add_ps(a, b);
-  g1fft_store_xyzz(&work[ia], lo); g1fft_store_xyzz(&work[ib], a);
+  g1_xyzz29_t lo = g1_xyzz29_from_sat(a), hi = lo;
+  g1_xyzz29_add(lo, wb);
+  if (!g1_xyzz29_is_identity(wb)) wb.y = Fq29::sub8(Fq29::zero(), wb.y);   // -w b: 8p - y (accumulator invariant: y < 6.1 p, limbs <= 2^30 - 2); only ever a multiplication operand below
+  g1_xyzz29_add(hi, wb);
+  g1fft_store_xyzz(&work[ia], g1_xyzz29_to_sat(lo)); g1fft_store_xyzz(&work[ib], g1_xyzz29_to_sat(hi));
 }
 
 // out[i] = scale * work[i], normalised.  JAC = 1: Jacobian (x, y, R) / all-zero identity; JAC = 0: affine, identity (0, 0).
@@ -90,7 +144,7 @@ template <int JAC> __global__ void __launch_bounds__(256) k_g1fft_store(const g1
   g1_xyzz_t v = g1fft_load_xyzz(&work[i]);
   if (has_scale) {
     fe_t one_c = Fr::zero(); one_c.l[0] = 1;
-    v = g1_xyzz_mul_fr(v, fr_mul_ps(scale, one_c));
+    v = g1_xyzz29_to_sat(g1_xyzz29_mul_fr(g1_xyzz29_from_sat(v), fr_mul_ps(scale, one_c)));
   }
   const g1_jac_t r = g1_xyzz_to_jac_normalised(v);
   if (JAC) { g1_jac_t *dst = static_cast<g1_jac_t *>(out) + i; g_store(&dst->x, r.x); g_store(&dst->y, r.y); g_store(&dst->z, r.z); }

@@ -485,7 +485,7 @@ def _affine_to_jac(a):
     return j
 
 
-@pytest.mark.parametrize("k", [0, 1, 2, 3, 5, 7])
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 5, 7, 10])
 def test_g1_fft_matches_oracle(zk, points, k):
     """best_fft::<Fr, G1> (mi355_g1_fft_host / _dev) against the oracle's serial restatement; inputs include the identity, repeated
     points (the doubling branch of the butterfly) and a non-normalised Jacobian representative."""
