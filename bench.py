@@ -164,6 +164,7 @@ def main() -> None:
     ap.add_argument("--single-process", action="store_true", help="N GPUs behind ONE process (mi355_init_multi: shards, worker threads, ncclAllGather inside the library) instead of one rank per GPU")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer leg (mi355_msm_g1_host: scalars cross PCIe inside the call; reported next to, never as, the headline value)")
     ap.add_argument("--no-table-free", action="store_true", help="skip the leg without window tables")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the k = 20 / 24 legs (MSM on prefix views of the basis + NTT)")
     ap.add_argument("--host-api", action="store_true", help=argparse.SUPPRESS)   # accepted for older command lines: the leg is on by default now
     args = ap.parse_args()
 
@@ -408,6 +409,50 @@ def main() -> None:
         extra["witness_like"] = {"ms_per_commit": dt_w * 1e3, "pairs_per_s": n / dt_w, "verified_against_field_check": ok_w,
                                  "distribution": "60% zero, 20% in 1..255, 10% 64-bit, 10% uniform"}
         del wl
+
+    if world == 1 and not args.no_sizes:
+        # north_star asks for k = 20 / 24 / 26: the two smaller sizes on PREFIX VIEWS of the same registered basis (what load_params_map's
+        # clone + downsize amounts to), each with the tables mi355_srs_precompute picks for its length; same scalars, same checks
+        from oracle import cref
+        sizes = {}
+        for ks in (20, 24):
+            if ks >= k:
+                continue
+            ns = 1 << ks
+            hp = C.c_uint64()
+            check(lib.mi355_srs_register_prefix(handle.value, ns, C.byref(hp)))
+            if pre_ms is not None:
+                check(lib.mi355_srs_precompute(hp.value, 0, 0))
+            sc_s = scalars[:ns]
+            check(lib.mi355_msm_g1_dev(hp.value, 0, ptr(sc_s), ns, ptr(out)))
+            reps_s = 20 if ks <= 20 else 5
+            torch.cuda.synchronize(); t9 = time.perf_counter()
+            for _ in range(reps_s):
+                check(lib.mi355_msm_g1_dev(hp.value, 0, ptr(sc_s), ns, ptr(out)))
+            dt_s = (time.perf_counter() - t9) / reps_s
+            cs, ws, es = C.c_int(), C.c_int(), C.c_uint64()
+            check(lib.mi355_msm_last_plan(C.byref(cs), C.byref(ws), C.byref(es)))
+            dv, ex, shd, sl = C.c_int(), C.c_char_p(), C.c_int(), C.c_int()
+            check(lib.mi355_msm_last_run(C.byref(dv), C.byref(ex), C.byref(shd), C.byref(sl)))
+            ok_s = bool((np.asarray(out)[:8] == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(sc_s.cpu().numpy().view(np.uint64), tau_m)))).all())
+            adds_s = ns * ws.value + (1 if shd.value else ws.value) * (1 << cs.value)
+            rec = {"msm_ms_per_commit": dt_s * 1e3, "pairs_per_s": ns / dt_s, "g1_adds_per_s": adds_s / dt_s, "window_bits": cs.value, "windows": ws.value,
+                   "srs_window_tables": bool(shd.value), "verified_against_field_check": ok_s,
+                   "msm_roofline_frac_hbm": 96.0 * ns / dt_s / 1e9 / HBM_PEAK_GBS}
+            check(lib.mi355_srs_release(hp.value))
+            if not args.no_ntt:
+                dom_s = h2.EvaluationDomain(2, ks)
+                poly_s = rand_scalars(ns, 0x5343524F4C4C0003, dev)
+                dom_s.coeff_to_lagrange(poly_s); dom_s.lagrange_to_coeff(poly_s)
+                torch.cuda.synchronize(); t10 = time.perf_counter()
+                for _ in range(reps_s):
+                    dom_s.coeff_to_lagrange(poly_s); dom_s.lagrange_to_coeff(poly_s)
+                check(lib.mi355_synchronize()); torch.cuda.synchronize()
+                dt_n = (time.perf_counter() - t10) / (2 * reps_s)
+                rec.update({"ntt_ms_per_transform": dt_n * 1e3, "butterflies_per_s": ns // 2 * ks / dt_n, "ntt_roofline_frac_hbm": 64.0 * ns / dt_n / 1e9 / HBM_PEAK_GBS})
+                del poly_s
+            sizes["k%d" % ks] = rec
+        extra["sizes"] = sizes
 
     # ---- CPU baseline (rank 0, N = 1 only): the restated reference algorithm on a bounded sample of the same workload
     cpu = None

@@ -117,6 +117,12 @@ int mi355_msm_g1_adhoc_host(const void *bases_affine_host, const void *scalars_h
 /* sum of `n` G1 (Jacobian, any representative) points: the fold `results.iter().fold(identity, |a, b| a + b)` of
  * best_multiexp, used to combine per-GPU partial sums after the RCCL all-gather.                  */
 int mi355_g1_sum_host(const void *g1_points_host, uint64_t n, void *out_g1_host);
+/* group::Curve::batch_normalize(p: &[G1], q: &mut [G1Affine]) [EXT-recalled halo2curves bn256 / group crate; create_proof normalises each
+ * vector of projective commitments with it before they enter the transcript]: n Jacobian points (96 B, any representative) -> n affine
+ * points (64 B), the identity (Z = 0) becomes (0, 0).  One shared inversion per 256 points (Montgomery's trick).  Input and output
+ * must not overlap; the _dev variant is asynchronous on the library stream.                                                          */
+int mi355_g1_batch_normalize_dev(const void *g1_points_dev, void *affine_out_dev, uint64_t n);
+int mi355_g1_batch_normalize_host(const void *g1_points_host, void *affine_out_host, uint64_t n);
 /* (per calling thread) normalise = 0: subsequent MSM results are SOME Jacobian representative of the sum (as best_multiexp's C::Curve is) instead of the
  * normalised one; saves the serial field inversion (~0.4 ms) where the result is folded again anyway (per-GPU partial sums).      */
 int mi355_msm_set_normalise(int on);

@@ -80,6 +80,11 @@ inline void best_fft(std::vector<G1> &a, const Fr &omega, uint32_t log_n) {
   if (a.size() != (size_t(1) << log_n)) throw std::invalid_argument("best_fft: a.len() != 1 << log_n");
   check(mi355_g1_fft_host(a.data(), log_n, omega.data()));
 }
+// group::Curve::batch_normalize(p, q): Jacobian -> affine with one shared inversion per 256 points; panics on unequal lengths like the original
+inline void batch_normalize(const std::vector<G1> &p, std::vector<G1Affine> &q) {
+  if (p.size() != q.size()) throw std::invalid_argument("batch_normalize: p.len() != q.len()");
+  check(mi355_g1_batch_normalize_host(p.data(), q.data(), p.size()));
+}
 inline Fr eval_polynomial(const std::vector<Fr> &poly, const Fr &point) {
   Fr out;
   check(mi355_eval_polynomial_host(poly.data(), poly.size(), point.data(), out.data()));

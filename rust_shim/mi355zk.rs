@@ -41,6 +41,7 @@ extern "C" {
     pub fn mi355_msm_g1_host(srs: u64, base_offset: u64, scalars_host: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_msm_g1_batch_host(srs: u64, base_offset: u64, scalars_host: *const *const c_void, batch: u32, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_msm_g1_adhoc_host(bases: *const c_void, scalars: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
+    pub fn mi355_g1_batch_normalize_host(g1_points_host: *const c_void, affine_out_host: *mut c_void, n: u64) -> c_int;
     pub fn mi355_ntt_fr_host(data_host: *mut c_void, log_n: u32, omega: *const c_void) -> c_int;
     pub fn mi355_intt_fr_host(data_host: *mut c_void, log_n: u32, omega_inv: *const c_void, divisor: *const c_void) -> c_int;
     pub fn mi355_coeff_to_extended_host(dst: *mut c_void, coeffs: *const c_void, log_n: u32, log_ext: u32,
@@ -145,6 +146,14 @@ pub fn multiexp_g1(coeffs: &[Fr], bases: &[G1Affine]) -> Option<G1> {
     let mut out = std::mem::MaybeUninit::<G1>::uninit();
     let rc = unsafe { mi355_msm_g1_adhoc_host(bases.as_ptr() as *const c_void, coeffs.as_ptr() as *const c_void, coeffs.len() as u64, out.as_mut_ptr() as *mut c_void) };
     if rc == MI355_OK { Some(unsafe { out.assume_init() }) } else { None }
+}
+
+/// `G1::batch_normalize(p, q)` for long vectors (g_to_lagrange / setup outputs; the dozen commitments of a proof stay on the CPU).
+/// Returns false -> caller runs the original CPU code.
+pub fn batch_normalize_g1(p: &[G1], q: &mut [G1Affine]) -> bool {
+    assert_eq!(p.len(), q.len());                     // same panic as the reference
+    if !available() || (p.len() as u64) < (1u64 << min_log("MI355_NORMALIZE_MIN_LOGN", 12)) { return false; }
+    unsafe { mi355_g1_batch_normalize_host(p.as_ptr() as *const c_void, q.as_mut_ptr() as *mut c_void, p.len() as u64) == MI355_OK }
 }
 
 /// Replacement body of `best_fft` for G = Scalar = Fr (the G = curve-point instantiation keeps the CPU code).

@@ -39,6 +39,8 @@ SIGNATURES = {
     "mi355_msm_set_pipeline": (_int, [_u32, _u32]),
     "mi355_msm_g1_adhoc_host": (_int, [_vp, _vp, _u64, _vp]),
     "mi355_g1_sum_host": (_int, [_vp, _u64, _vp]),
+    "mi355_g1_batch_normalize_dev": (_int, [_vp, _vp, _u64]),
+    "mi355_g1_batch_normalize_host": (_int, [_vp, _vp, _u64]),
     "mi355_msm_set_normalise": (_int, [_int]),
     "mi355_msm_set_window_bits": (_int, [_int]),
     "mi355_ntt_fr_host": (_int, [_vp, _u32, _vp]),

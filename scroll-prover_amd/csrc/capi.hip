@@ -1440,6 +1440,39 @@ int mi355_g1_sum_host(const void *pts_host, uint64_t n, void *out_g1_host) {
   return MI355_OK;
   });
 }
+// Curve::batch_normalize: n Jacobian points (96 B, any representative) -> n affine points (64 B); k_g1_batch_normalize (frscan.cuh)
+int mi355_g1_batch_normalize_dev(const void *jac_dev, void *affine_dev, uint64_t n) {
+  return guarded([&]() -> int {
+  std::lock_guard<std::mutex> lk(g_mu);
+  CHK(need_init());
+  if (n && (!jac_dev || !affine_dev)) return fail(MI355_EBADARG, "g1_batch_normalize: null pointer");
+  if (n >= (1ull << 31)) return fail(MI355_EBADARG, "g1_batch_normalize: n must be < 2^31");
+  if (n) {
+    const char *a = (const char *)jac_dev, *b = (const char *)affine_dev;
+    if (a < b + n * sizeof(g1_affine_t) && b < a + n * sizeof(g1_jac_t)) return fail(MI355_EBADARG, "g1_batch_normalize: input and output must not overlap");
+    hipLaunchKernelGGL(k_g1_batch_normalize, dim3(ceil_div(n, FRSCAN_THREADS)), dim3(FRSCAN_THREADS), 0, g.stream, (const g1_jac_t *)jac_dev, (g1_affine_t *)affine_dev, n);
+    HIPCHK(hipGetLastError());
+  }
+  return finish_async();
+  });
+}
+int mi355_g1_batch_normalize_host(const void *jac_host, void *affine_host, uint64_t n) {
+  return guarded([&]() -> int {
+  std::lock_guard<std::mutex> lk(g_mu);
+  CHK(need_init());
+  if (n && (!jac_host || !affine_host)) return fail(MI355_EBADARG, "g1_batch_normalize: null pointer");
+  if (n >= (1ull << 31)) return fail(MI355_EBADARG, "g1_batch_normalize: n must be < 2^31");
+  if (!n) return MI355_OK;
+  char *dev; CHK(ws_get("io.g1norm", n * (sizeof(g1_jac_t) + sizeof(g1_affine_t)), (void **)&dev));
+  g1_jac_t *in = (g1_jac_t *)dev; g1_affine_t *out = (g1_affine_t *)(dev + n * sizeof(g1_jac_t));
+  HIPCHK(hipMemcpyAsync(in, jac_host, n * sizeof(g1_jac_t), hipMemcpyHostToDevice, g.stream));
+  hipLaunchKernelGGL(k_g1_batch_normalize, dim3(ceil_div(n, FRSCAN_THREADS)), dim3(FRSCAN_THREADS), 0, g.stream, (const g1_jac_t *)in, out, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(affine_host, out, n * sizeof(g1_affine_t), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return MI355_OK;
+  });
+}
 // The two setters below act on the CALLING THREAD only (thread-local options): concurrent callers never see each other's settings.
 int mi355_msm_set_window_bits(int c) {
   return guarded([&]() -> int {

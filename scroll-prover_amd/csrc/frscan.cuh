@@ -32,20 +32,21 @@ __device__ __forceinline__ fe_t lds_get(const uint32_t *p) {
 
 // exclusive multiplicative scan of one value per thread across the workgroup (Hillis-Steele through LDS, 9 dwords per slot).
 // buf: 2 * 256 * 9 dwords.  Returns prod_{t' < t} x_t'; total = product of all 256 values.  REVERSE scans from the other end.
-template <bool REVERSE> __device__ fe_t block_exclusive_mul_scan(const fe_t &x, uint32_t *buf, fe_t &total) {
+// FQ: the same scan in the base field (k_g1_batch_normalize multiplies Z coordinates).
+template <bool REVERSE, bool FQ = false> __device__ fe_t block_exclusive_mul_scan(const fe_t &x, uint32_t *buf, fe_t &total) {
   const uint32_t t = REVERSE ? FRSCAN_THREADS - 1 - threadIdx.x : threadIdx.x;
   uint32_t *cur = buf, *nxt = buf + FRSCAN_THREADS * 9;
   lds_put(cur + t * 9, x);
   __syncthreads();
   fe_t v = x;
   for (uint32_t o = 1; o < FRSCAN_THREADS; o <<= 1) {
-    if (t >= o) v = fr_mul_ps(lds_get(cur + (t - o) * 9), v);
+    if (t >= o) v = FQ ? fq_mul_ps(lds_get(cur + (t - o) * 9), v) : fr_mul_ps(lds_get(cur + (t - o) * 9), v);
     lds_put(nxt + t * 9, v);
     __syncthreads();
     uint32_t *tmp = cur; cur = nxt; nxt = tmp;
   }
   total = lds_get(cur + (FRSCAN_THREADS - 1) * 9);
-  fe_t ex = t ? lds_get(cur + (t - 1) * 9) : Fr::one();
+  fe_t ex = t ? lds_get(cur + (t - 1) * 9) : (FQ ? Fq::one() : Fr::one());
   __syncthreads();
   return ex;
 }
@@ -209,6 +210,31 @@ template <int FINAL> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_linr
     const uint64_t jj = base + e;
     if (jj < n) g_store(&dst[reverse ? n - 1 - jj : jj], lds_get(tile + (e >> 3) * 65 + (e & 7) * 8));
   }
+}
+
+// ---- group::Curve::batch_normalize(&[G1], &mut [G1Affine]) [EXT-recalled halo2curves / group crate; create_proof turns each vector of
+// projective commitments into affine points with it before they enter the transcript, SURVEY 8f-3]: out[i] = (X / Z^2, Y / Z^3), the
+// identity (Z = 0) becomes (0, 0).  Montgomery's trick per 256-point tile: the Z coordinates are scanned from both ends through LDS
+// (zeros replaced by one), lane 0 inverts the tile product once (Euclidean inverse), every thread finishes with two multiplications.
+__global__ void __launch_bounds__(FRSCAN_THREADS) k_g1_batch_normalize(const g1_jac_t *__restrict__ in, g1_affine_t *__restrict__ out, uint64_t n) {
+  __shared__ uint32_t buf[2 * FRSCAN_THREADS * 9];
+  __shared__ uint32_t inv_total[8];
+  const uint64_t i = (uint64_t)blockIdx.x * FRSCAN_THREADS + threadIdx.x;
+  fe_t z = i < n ? g_load(&in[i].z) : Fq::one();
+  const bool ident = Fq::is_zero(z);
+  if (ident) z = Fq::one();
+  fe_t total, total_r;
+  const fe_t left = block_exclusive_mul_scan<false, true>(z, buf, total);
+  const fe_t right = block_exclusive_mul_scan<true, true>(z, buf, total_r);
+  if (threadIdx.x == 0) lds_put(inv_total, Fq::inv_bgcd(total));
+  __syncthreads();
+  if (i >= n) return;
+  g1_affine_t r; r.x = Fq::zero(); r.y = Fq::zero();
+  if (!ident) {
+    const fe_t zi = fq_mul_ps(fq_mul_ps(lds_get(inv_total), left), right), zi2 = fq_sqr_ps(zi);
+    r.x = fq_mul_ps(g_load(&in[i].x), zi2); r.y = fq_mul_ps(g_load(&in[i].y), fq_mul_ps(zi2, zi));
+  }
+  g_store(&out[i].x, r.x); g_store(&out[i].y, r.y);
 }
 
 #endif  // __HIPCC__

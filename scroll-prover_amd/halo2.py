@@ -174,6 +174,20 @@ def g1_sum(points: np.ndarray) -> np.ndarray:
     return out
 
 
+def batch_normalize(points, out=None):
+    """group::Curve::batch_normalize: n Jacobian G1 (any representative, [n,12] u64) -> n affine points ([n,8] u64, identity = (0, 0)).
+    Host arrays go through mi355_g1_batch_normalize_host; device tensors (96 n bytes in, 64 n bytes out, `out` required) stay in HBM."""
+    if _is_device(points):
+        n = points.numel() * points.element_size() // 96
+        assert out is not None and out.numel() * out.element_size() == 64 * n, "batch_normalize: device output tensor of 64 n bytes required"
+        check(lib().mi355_g1_batch_normalize_dev(ptr(points), ptr(out), n))
+        return out
+    points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+    res = np.zeros((points.shape[0], 8), dtype=np.uint64)
+    check(lib().mi355_g1_batch_normalize_host(ptr(points), ptr(res), points.shape[0]))
+    return res
+
+
 # ------------------------------------------------------------------------------------------ poly/domain.rs
 class EvaluationDomain:
     """EvaluationDomain::new(j, k): n = 2^k, quotient_poly_degree = j - 1, extended_k minimal with 2^extended_k >= n * (j - 1)."""

@@ -129,6 +129,11 @@ int main(int argc, char **argv) {
     wj = jac; orc_best_fft_g1(wj.data(), d5.omega.data(), k5);
     best_fft(jac, d5.omega, k5);
     for (uint64_t i = 0; i < n5; i++) { G1Affine w; orc_g1_to_affine(w.data(), wj[i].data()); EXPECT(std::memcmp(jac[i].data(), w.data(), 64) == 0 && std::memcmp(jac[i].data() + 8, one_q.data(), 32) == 0); }
+    // Curve::batch_normalize on the oracle's un-normalised DFT output (z != 1) plus an identity
+    { std::vector<G1> pj = wj; pj[3] = G1{}; std::vector<G1Affine> qa(n5), wa(n5); batch_normalize(pj, qa);
+      for (uint64_t i = 0; i < n5; i++) orc_g1_to_affine(wa[i].data(), pj[i].data());
+      EXPECT(qa == wa); EXPECT(qa[3] == G1Affine{});
+      threw = false; try { std::vector<G1Affine> shorter(n5 - 1); batch_normalize(pj, shorter); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw); }
     std::vector<G1Affine> rev(bases.rbegin(), bases.rend());
     ParamsKZG params(k, bases, rev);
     params.downsize(k5);

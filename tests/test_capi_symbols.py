@@ -64,6 +64,8 @@ def test_no_gpu_means_loud_failure_not_fallback(zk):
         lib.mi355_msm_g1_batch_dev(1, 0, arr, 1, 4, ptr(out)),
         lib.mi355_msm_g1_dev_async(1, 0, ptr(sc), 4, ptr(out)),
         lib.mi355_g1_sum_dev(ptr(jac), 4, ptr(out)),
+        lib.mi355_g1_batch_normalize_host(ptr(jac), ptr(bs), 4),
+        lib.mi355_g1_batch_normalize_dev(ptr(jac), ptr(bs), 4),
         lib.mi355_g1_fft_host(ptr(jac), 2, ptr(sc[0])),
         lib.mi355_g_to_lagrange_dev(ptr(bs), ptr(bs), 2, ptr(sc[0]), ptr(sc[1])),
         lib.mi355_srs_downsize(1, 1, ptr(sc[0]), ptr(sc[1]), C.byref(h)),

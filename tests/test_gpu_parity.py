@@ -193,6 +193,39 @@ def test_g1_sum_and_errors(zk, points):
     _ = G
 
 
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 2048])
+def test_batch_normalize_matches_oracle(zk, points, n):
+    """group::Curve::batch_normalize: random Jacobian representatives (x z^2, y z^3, z), identities in between, ragged tile sizes;
+    host pointers and device-resident buffers against the oracle's per-point to_affine."""
+    import torch
+    h2 = zk.halo2
+    rng = np.random.default_rng(900 + n)
+    zs = rand_fr(rng, max(n, 1), full=False)[:n]
+    jac = np.zeros((n, 12), dtype=np.uint64)
+    for i in range(n):
+        z = cref.f_mul(cref.FQ, zs[i], zs[i]) if i % 3 else zs[i]          # any non-zero field element (read as an Fq Montgomery residue)
+        z2 = cref.f_mul(cref.FQ, z, z)
+        jac[i, 0:4] = cref.f_mul(cref.FQ, points[i, 0:4], z2)
+        jac[i, 4:8] = cref.f_mul(cref.FQ, points[i, 4:8], cref.f_mul(cref.FQ, z2, z))
+        jac[i, 8:12] = z
+    for i in range(0, n, 7):
+        jac[i, 8:12] = 0                                                    # identity: z = 0 with arbitrary x, y
+    if n > 300:
+        jac[256:300, 8:12] = 0                                              # a run of identities across a tile boundary
+    want = cref.g1_to_affine(jac) if n else np.zeros((0, 8), dtype=np.uint64)
+    got = h2.batch_normalize(jac)
+    assert got.shape == (n, 8) and (got == want).all()
+    if n:
+        assert (got[0] == 0).all()
+        d_in = torch.from_numpy(jac.view(np.int64)).cuda()
+        d_out = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+        h2.batch_normalize(d_in, d_out)
+        zk._capi.check(zk._capi.lib().mi355_synchronize())
+        assert (d_out.cpu().numpy().view(np.uint64) == want).all()
+        with pytest.raises(zk.Mi355Error):                                  # overlapping buffers are refused
+            zk._capi.check(zk._capi.lib().mi355_g1_batch_normalize_dev(zk._capi.ptr(d_in), zk._capi.ptr(d_in), n))
+
+
 def test_registered_srs_offsets(zk, points):
     h2 = zk.halo2
     params = h2.ParamsKZG.from_host(11, points, points[::-1].copy())
