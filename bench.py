@@ -430,6 +430,12 @@ def main() -> None:
             for _ in range(reps_s):
                 check(lib.mi355_msm_g1_dev(hp.value, 0, ptr(sc_s), ns, ptr(out)))
             dt_s = (time.perf_counter() - t9) / reps_s
+            # phase breakdown from a separate short pass (the HIP events of the profiler cost a few microseconds per phase: kept out of the timing)
+            check(lib.mi355_profile_reset()); check(lib.mi355_profile_enable(1))
+            for _ in range(3):
+                check(lib.mi355_msm_g1_dev(hp.value, 0, ptr(sc_s), ns, ptr(out)))
+            check(lib.mi355_profile_enable(0))
+            ph_s = {p_: prof(p_)[0] / 3 for p_ in ("msm_digits", "msm_sort", "msm_accumulate", "msm_reduce", "msm_total")}
             cs, ws, es = C.c_int(), C.c_int(), C.c_uint64()
             check(lib.mi355_msm_last_plan(C.byref(cs), C.byref(ws), C.byref(es)))
             dv, ex, shd, sl = C.c_int(), C.c_char_p(), C.c_int(), C.c_int()
@@ -437,7 +443,7 @@ def main() -> None:
             ok_s = bool((np.asarray(out)[:8] == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(sc_s.cpu().numpy().view(np.uint64), tau_m)))).all())
             adds_s = ns * ws.value + (1 if shd.value else ws.value) * (1 << cs.value)
             rec = {"msm_ms_per_commit": dt_s * 1e3, "pairs_per_s": ns / dt_s, "g1_adds_per_s": adds_s / dt_s, "window_bits": cs.value, "windows": ws.value,
-                   "srs_window_tables": bool(shd.value), "verified_against_field_check": ok_s,
+                   "srs_window_tables": bool(shd.value), "verified_against_field_check": ok_s, "msm_phase_ms": ph_s,
                    "msm_roofline_frac_hbm": 96.0 * ns / dt_s / 1e9 / HBM_PEAK_GBS}
             check(lib.mi355_srs_release(hp.value))
             if not args.no_ntt:

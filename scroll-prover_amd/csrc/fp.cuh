@@ -164,6 +164,115 @@ template <class P> struct Fp {
     // r = (a_plain R)^-1 as a plain residue; two Montgomery products with R^2 give a_plain^-1 * R
     return mul(mul(r, r2), r2);
   }
+
+  // a^-1 by Bernstein-Yang division steps ("safegcd", as published by Bernstein and Yang, CHES 2019, in the batched form with 30-bit
+  // signed limbs and a 2x2 transition matrix per 30 steps).  Montgomery form in and out; 0 -> 0.  The instruction stream does not depend on
+  // the data -- 20 batches of 30 steps cover every 256-bit input (bound 590) -- so a whole wavefront can invert 64 different values
+  // without divergence, and the dependent chains are 32-bit shifts / adds instead of multiword borrow chains: about a quarter of the
+  // binary Euclid's latency in the one-lane normalisations (k_msm_final29, the tile inversions of the scans).
+  // State: f = m, g = a, d = 0, e = 1 with d * a = f, e * a = g (mod m) up to the running power of two, which update_de divides out.
+  static constexpr int32_t SG_M30 = 0x3fffffff;
+  ZK_HD static constexpr uint32_t sg_mod(int i) {   // bits [30 i, 30 i + 30) of the modulus
+    const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+    uint32_t v = P::mod(w) >> sh;
+    if (sh > 2 && w + 1 < 8) v |= P::mod(w + 1) << (32 - sh);
+    return v & (uint32_t)SG_M30;
+  }
+  ZK_HD static constexpr uint32_t sg_mod_inv30() {   // m^-1 mod 2^30 (Newton iteration on the odd low limb)
+    uint32_t m = P::mod(0), x = m;
+    for (int i = 0; i < 5; i++) x *= 2u - m * x;
+    return x & (uint32_t)SG_M30;
+  }
+  struct sg_t { int32_t v[9]; };
+  // 30 division steps on the low limbs; t = (u, v, q, r) with 2^30 (f', g') = t (f, g)
+  ZK_HD static int32_t sg_divsteps30(int32_t zeta, uint32_t f0, uint32_t g0, int32_t (&t)[4]) {
+    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+#pragma unroll
+    for (int i = 0; i < 30; i++) {
+      uint32_t c1 = (uint32_t)(zeta >> 31);           // all ones iff zeta < 0
+      const uint32_t c2 = 0u - (g & 1u);              // all ones iff g is odd
+      const uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;   // (f, u, v), negated when zeta < 0
+      g += x & c2; q += y & c2; r += z & c2;
+      c1 &= c2;                                       // swap: zeta < 0 and g odd
+      zeta = (int32_t)(((uint32_t)zeta ^ c1) - 1u);   // -zeta - 2, or zeta - 1
+      f += g & c1; u += q & c1; v += r & c1;
+      g >>= 1; u <<= 1; v <<= 1;
+    }
+    t[0] = (int32_t)u; t[1] = (int32_t)v; t[2] = (int32_t)q; t[3] = (int32_t)r;
+    return zeta;
+  }
+  // (d, e) <- t (d, e) / 2^30 mod m: a multiple of m makes the low 30 bits vanish before they are shifted out
+  ZK_HD static void sg_update_de(sg_t &d, sg_t &e, const int32_t (&t)[4]) {
+    const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
+    const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+    int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+    int64_t cd = (int64_t)u * d.v[0] + (int64_t)v * e.v[0], ce = (int64_t)q * d.v[0] + (int64_t)r * e.v[0];
+    md -= (int32_t)((sg_mod_inv30() * (uint32_t)cd + (uint32_t)md) & (uint32_t)SG_M30);
+    me -= (int32_t)((sg_mod_inv30() * (uint32_t)ce + (uint32_t)me) & (uint32_t)SG_M30);
+    cd += (int64_t)sg_mod(0) * md; ce += (int64_t)sg_mod(0) * me;
+    cd >>= 30; ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+      cd += (int64_t)u * d.v[i] + (int64_t)v * e.v[i]; ce += (int64_t)q * d.v[i] + (int64_t)r * e.v[i];
+      cd += (int64_t)sg_mod(i) * md; ce += (int64_t)sg_mod(i) * me;
+      d.v[i - 1] = (int32_t)cd & SG_M30; cd >>= 30;
+      e.v[i - 1] = (int32_t)ce & SG_M30; ce >>= 30;
+    }
+    d.v[8] = (int32_t)cd; e.v[8] = (int32_t)ce;
+  }
+  // (f, g) <- t (f, g) / 2^30 (exact)
+  ZK_HD static void sg_update_fg(sg_t &f, sg_t &g, const int32_t (&t)[4]) {
+    const int32_t u = t[0], v = t[1], q = t[2], r = t[3];
+    int64_t cf = (int64_t)u * f.v[0] + (int64_t)v * g.v[0], cg = (int64_t)q * f.v[0] + (int64_t)r * g.v[0];
+    cf >>= 30; cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+      cf += (int64_t)u * f.v[i] + (int64_t)v * g.v[i]; cg += (int64_t)q * f.v[i] + (int64_t)r * g.v[i];
+      f.v[i - 1] = (int32_t)cf & SG_M30; cf >>= 30;
+      g.v[i - 1] = (int32_t)cg & SG_M30; cg >>= 30;
+    }
+    f.v[8] = (int32_t)cf; g.v[8] = (int32_t)cg;
+  }
+  ZK_HD static fe_t inv_sgcd(const fe_t &a) {
+    sg_t f, g, d, e;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+      uint32_t x = a.l[w] >> sh;
+      if (sh > 2 && w + 1 < 8) x |= a.l[w + 1] << (32 - sh);
+      g.v[i] = (int32_t)(x & (uint32_t)SG_M30); f.v[i] = (int32_t)sg_mod(i); d.v[i] = 0; e.v[i] = i == 0;
+    }
+    int32_t zeta = -1;
+    for (int it = 0; it < 20; it++) {
+      int32_t t[4];
+      zeta = sg_divsteps30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+      sg_update_de(d, e, t);
+      sg_update_fg(f, g, t);
+    }
+    // g = 0 and f = +-1 now (f = +-m for a = 0, where d stays 0): d = sign(f) a^-1 in (-2m, m); bring it to [0, m)
+    int32_t r[9];
+    const int32_t add1 = d.v[8] >> 31, neg = f.v[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r[i] = d.v[i] + ((int32_t)sg_mod(i) & add1); r[i] = (r[i] ^ neg) - neg; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { r[i + 1] += r[i] >> 30; r[i] &= SG_M30; }
+    const int32_t add2 = r[8] >> 31;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r[i] += (int32_t)sg_mod(i) & add2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { r[i + 1] += r[i] >> 30; r[i] &= SG_M30; }
+    fe_t o, r2;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      const int bit = 32 * w, i = bit / 30, sh = bit - 30 * i;
+      uint64_t x = (uint64_t)(uint32_t)r[i] >> sh;
+      x |= (uint64_t)(uint32_t)r[i + 1] << (30 - sh);
+      if (i + 2 < 9) x |= (uint64_t)(uint32_t)r[i + 2] << (60 - sh);
+      o.l[w] = (uint32_t)x; r2.l[w] = P::r2(w);
+    }
+    // o = (a_plain R)^-1 as a plain residue; two Montgomery products with R^2 give a_plain^-1 * R
+    return mul(mul(o, r2), r2);
+  }
 };
 
 #if defined(__HIPCC__)

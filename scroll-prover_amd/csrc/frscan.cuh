@@ -5,7 +5,7 @@
 //   k_fr_batch_invert     data[i] = data[i]^-1, zeros stay zero (ff::BatchInvert semantics).  A thread multiplies its 8 (strided,
 //                         coalesced) elements, the 256 thread products are scanned from both ends through LDS; the products of the
 //                         2048-element tiles are themselves batch-inverted (recursion on the host side), so the whole vector costs a
-//                         handful of Fermat inversions.
+//                         handful of one-lane inversions (division steps, fp.cuh inv_sgcd).
 //   k_fr_prefix_product   dst[i] = prod_{j < i} src[j]  (dst[0] = 1): tile products -> scan of the tile products -> tile-local rescan
 //                         with the carried-in prefix.  Order matters here, so tiles go through LDS to turn coalesced 16-byte-per-lane
 //                         global accesses into 8 consecutive elements per thread (chunk stride 65 dwords: conflict-free).
@@ -51,20 +51,9 @@ template <bool REVERSE, bool FQ = false> __device__ fe_t block_exclusive_mul_sca
   return ex;
 }
 
-// a^(r-2) with the assembly multiplier (left-to-right square-and-multiply over the fixed exponent)
-__device__ __noinline__ fe_t fr_inv_ps(const fe_t &a) {
-  constexpr uint32_t e[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};   // r - 2
-  fe_t acc = a;   // top bit of r - 2 is bit 253
-  for (int i = 252; i >= 0; i--) {
-    acc = fr_sqr_ps(acc);
-    if ((e[i >> 5] >> (i & 31)) & 1u) acc = fr_mul_ps(acc, a);
-  }
-  return acc;
-}
-
-// MODE 0: self-contained (the tile product is inverted by one wavefront of the workgroup) -- for short vectors and the last level;
+// MODE 0: self-contained (the tile product is inverted by lane 0) -- for short vectors and the last level;
 // MODE 1: tile_prod[b] = product of the tile's non-zero elements;  MODE 2: invert with tile_prod[b] already holding the INVERSE of the
-// tile product (the host recursion inverts the tile products with the same three steps, so a 2^26 vector costs 17 Fermat inversions).
+// tile product (the host recursion inverts the tile products with the same three steps, so a 2^26 vector costs 17 one-lane inversions).
 template <int MODE> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_batch_invert(fe_t *__restrict__ data, uint64_t n, fe_t *__restrict__ tile_prod) {
   __shared__ uint32_t buf[2 * FRSCAN_THREADS * 9];
   __shared__ uint32_t inv_total[8];
@@ -86,10 +75,7 @@ template <int MODE> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_batch
   const fe_t right = block_exclusive_mul_scan<true>(run, buf, total_r);
   fe_t inv_t;
   if (MODE == 0) {
-    if (threadIdx.x < 64) {   // one wavefront inverts the tile product (every lane the same value: no divergence, one result kept)
-      const fe_t inv = fr_inv_ps(total);
-      if (threadIdx.x == 0) lds_put(inv_total, inv);
-    }
+    if (threadIdx.x == 0) lds_put(inv_total, Fr::inv_sgcd(total));   // division-step inverse (fp.cuh): a fraction of the Fermat ladder's latency
     __syncthreads();
     inv_t = lds_get(inv_total);
   } else inv_t = g_load(&tile_prod[blockIdx.x]);
@@ -226,7 +212,7 @@ __global__ void __launch_bounds__(FRSCAN_THREADS) k_g1_batch_normalize(const g1_
   fe_t total, total_r;
   const fe_t left = block_exclusive_mul_scan<false, true>(z, buf, total);
   const fe_t right = block_exclusive_mul_scan<true, true>(z, buf, total_r);
-  if (threadIdx.x == 0) lds_put(inv_total, Fq::inv_bgcd(total));
+  if (threadIdx.x == 0) lds_put(inv_total, Fq::inv_sgcd(total));
   __syncthreads();
   if (i >= n) return;
   g1_affine_t r; r.x = Fq::zero(); r.y = Fq::zero();

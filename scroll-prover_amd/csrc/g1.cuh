@@ -83,7 +83,7 @@ ZK_HD g1_affine_t g1_xyzz_to_affine(const g1_xyzz_t &p) {
   g1_affine_t r;
   if (g1_xyzz_is_identity(p)) { r.x = Fq::zero(); r.y = Fq::zero(); return r; }
   // 1/ZZZ, then 1/ZZ = ZZZ^-1 * ZZZ / ZZ ... cheaper: i = (ZZ*ZZZ)^-1; 1/ZZ = i*ZZZ; 1/ZZZ = i*ZZ
-  fe_t i = Fq::inv_bgcd(Fq::mul(p.zz, p.zzz));   // one lane per result: the Euclidean inverse beats the ladder ~5x here
+  fe_t i = Fq::inv_sgcd(Fq::mul(p.zz, p.zzz));   // division-step inverse (fp.cuh): no multiword borrow chains, no divergence when every lane converts a point
   r.x = Fq::mul(p.x, Fq::mul(i, p.zzz));
   r.y = Fq::mul(p.y, Fq::mul(i, p.zz));
   return r;

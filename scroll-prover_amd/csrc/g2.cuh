@@ -27,7 +27,7 @@ struct Fq2 {
   // (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u
   ZK_HD static fe2_t sqr(const fe2_t &a) { fe2_t r; r.c0 = Fq::mul(Fq::add(a.c0, a.c1), Fq::sub(a.c0, a.c1)); r.c1 = Fq::dbl(Fq::mul(a.c0, a.c1)); return r; }
   ZK_HD static fe2_t inv(const fe2_t &a) {   // conj(a) / (a0^2 + a1^2); 0 -> 0
-    const fe_t n = Fq::inv(Fq::add(Fq::sqr(a.c0), Fq::sqr(a.c1)));
+    const fe_t n = Fq::inv_sgcd(Fq::add(Fq::sqr(a.c0), Fq::sqr(a.c1)));
     fe2_t r; r.c0 = Fq::mul(a.c0, n); r.c1 = Fq::mul(Fq::neg(a.c1), n); return r;
   }
 };

@@ -56,6 +56,14 @@ def test_field_ops_bit_exact(hs):
             assert (op(hs, w, 3, mont[i]) == cref.f_inv(w, mont[i])).all()
         for i in range(len(vals)):                                        # binary-Euclid inverse used by the one-lane normalisations
             assert (op(hs, w, 9, mont[i]) == cref.f_inv(w, mont[i])).all(), vals[i]
+        # division-step ("safegcd") inverse: constant instruction stream, every edge value plus a long random run; 0 -> 0
+        more = [rng.randrange(m) for _ in range(3000)] + [(1 << k) % m for k in range(0, 256, 5)] + [m - (1 << k) for k in range(0, 250, 7)]
+        mont2 = cref.f_from_canonical_vec(w, np.array([pyref.to_limbs(v) for v in more], dtype=np.uint64))
+        for i in range(len(vals)):
+            assert (op(hs, w, 10, mont[i]) == cref.f_inv(w, mont[i])).all(), vals[i]
+        for i in range(len(more)):
+            got = pyref.from_limbs(op(hs, w, 10, mont2[i]))
+            assert got == pow(more[i], -1, m) * pyref.MONT_R % m, more[i]
 
 
 def _pt(Pt):

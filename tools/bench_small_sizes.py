@@ -4,7 +4,11 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 import __graft_entry__ as ge
 zk = ge.load_package(); zk.init(0); h2 = zk.halo2
-for k in (10, 12, 14, 16, 18):
+import ctypes as C
+lib = zk._capi.lib()
+def prof(name):
+    ms, cnt = C.c_double(), C.c_uint64(); zk._capi.check(lib.mi355_profile_get(name.encode(), C.byref(ms), C.byref(cnt))); return ms.value
+for k in [int(x) for x in (sys.argv[1:] or (10, 12, 14, 16, 18, 20, 22))]:
     n = 1 << k
     p = h2.ParamsKZG.setup(k, 0x5343524f4c4c0001); p.precompute()
     sc = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device="cuda"); sc[:, 3] &= (1 << 59) - 1
@@ -16,5 +20,9 @@ for k in (10, 12, 14, 16, 18):
         fn(); torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(10): fn()
         torch.cuda.synchronize(); res[name] = (time.perf_counter() - t) / 10 * 1e3
-    print(f"k={k}: " + "  ".join(f"{a_}={b_:.3f} ms" for a_, b_ in res.items()), flush=True)
+    zk._capi.check(lib.mi355_profile_reset()); zk._capi.check(lib.mi355_profile_enable(1))
+    for _ in range(5): p.commit(sc)
+    zk._capi.check(lib.mi355_profile_enable(0))
+    ph = " ".join(f"{q[4:]}={prof(q) / 5:.3f}" for q in ("msm_digits", "msm_sort", "msm_accumulate", "msm_reduce"))
+    print(f"k={k}: " + "  ".join(f"{a_}={b_:.3f} ms" for a_, b_ in res.items()) + "  | phases ms: " + ph, flush=True)
     p.release()
