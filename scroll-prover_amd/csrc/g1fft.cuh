@@ -2,8 +2,8 @@
 // g_to_lagrange / ParamsKZG::downsize [REF integration/tests/integration.rs:12-22; SURVEY 8a row a3, 8f-2]:
 //     a'[i] = sum_j omega^(ij) a[j]      (natural order in, natural order out, no scaling)
 //
-// Round 2: the butterflies run on the 9 x 29-bit field with the chained multiplier (g1_xyzz29_mul_fr below); the work array keeps the
-// saturated XYZZ records.
+// Round 2: the butterflies run on the 9 x 29-bit field with the chained multiplier and the GLV endomorphism (g1_xyzz29_mul_scalar below:
+// k P = k1 P + k2 phi(P) with 127-bit k1, k2); the work array keeps the saturated XYZZ records.
 // Every butterfly costs one 254-bit scalar multiple of a point (~4000 field multiplications) against 192 B of traffic, so the kernels are
 // plain radix-2 stages over a work array of XYZZ points in HBM -- there is nothing for LDS tiling to win.  The points are permuted into
 // bit-reversed order on load, the stages then run decimation-in-time exactly like the serial reference:
@@ -13,6 +13,7 @@
 #include "fp_asm.cuh"
 #include "g1.cuh"
 #include "g1_29.cuh"
+#include "glv.cuh"
 
 namespace zk {
 #ifdef __HIPCC__
@@ -91,6 +92,14 @@ __device__ __noinline__ g1_xyzz29_t g1_xyzz29_mul_fr(const g1_xyzz29_t &p, const
   return acc;
 }
 
+// GLV form of the same multiple (glv.cuh): k = k1 + lambda k2, one joint double-and-add over 64 signed 2-bit digits with the tables
+// {P, 2P} and their images under phi(x, y) = (beta x, y) -- 128 doublings + ~96 additions instead of 256 + ~96 (-31 % of the field
+// multiplications).  ZK_G1FFT_GLV=false keeps the plain ladder for A/B runs.
+#ifndef ZK_G1FFT_GLV
+#define ZK_G1FFT_GLV true
+#endif
+__device__ __noinline__ g1_xyzz29_t g1_xyzz29_mul_scalar(const g1_xyzz29_t &p, const fe_t &k) { return ZK_G1FFT_GLV ? g1_xyzz29_mul_glv(p, k) : g1_xyzz29_mul_fr(p, k); }
+
 __device__ __forceinline__ g1_xyzz_t g1fft_load_xyzz(const g1_xyzz_t *p) {
   g1_xyzz_t r; r.x = g_load(&p->x); r.y = g_load(&p->y); r.zz = g_load(&p->zz); r.zzz = g_load(&p->zzz); return r;
 }
@@ -127,7 +136,7 @@ __global__ void __launch_bounds__(256) k_g1fft_stage(g1_xyzz_t *__restrict__ wor
   if (j) {
     fe_t one_c = Fr::zero(); one_c.l[0] = 1;
     const fe_t k = fr_mul_ps(g_load(&tw[(uint64_t)j << (log_n - 1 - s)]), one_c);   // Montgomery -> canonical
-    wb = g1_xyzz29_mul_fr(wb, k);
+    wb = g1_xyzz29_mul_scalar(wb, k);
   }
   g1_xyzz29_t lo = g1_xyzz29_from_sat(a), hi = lo;
   g1_xyzz29_add(lo, wb);
@@ -144,7 +153,7 @@ template <int JAC> __global__ void __launch_bounds__(256) k_g1fft_store(const g1
   g1_xyzz_t v = g1fft_load_xyzz(&work[i]);
   if (has_scale) {
     fe_t one_c = Fr::zero(); one_c.l[0] = 1;
-    v = g1_xyzz29_to_sat(g1_xyzz29_mul_fr(g1_xyzz29_from_sat(v), fr_mul_ps(scale, one_c)));
+    v = g1_xyzz29_to_sat(g1_xyzz29_mul_scalar(g1_xyzz29_from_sat(v), fr_mul_ps(scale, one_c)));
   }
   const g1_jac_t r = g1_xyzz_to_jac_normalised(v);
   if (JAC) { g1_jac_t *dst = static_cast<g1_jac_t *>(out) + i; g_store(&dst->x, r.x); g_store(&dst->y, r.y); g_store(&dst->z, r.z); }

@@ -6,6 +6,7 @@
 #include "../../scroll-prover_amd/csrc/fp_asm.cuh"
 #include "../../scroll-prover_amd/csrc/fp29.cuh"
 #include "../../scroll-prover_amd/csrc/g1_29.cuh"
+#include "../../scroll-prover_amd/csrc/glv.cuh"
 #include <string.h>
 using namespace zk;
 
@@ -105,4 +106,18 @@ extern "C" void hs_xyzz29_ladder(void *out_xyzz, const void *affine, const uint8
   g1_xyzz29_t acc = g1_xyzz29_identity();
   for (int bit = 31; bit >= 0; bit--) { acc = g1_xyzz29_dbl(acc); if ((k >> bit) & 1) g1_xyzz29_add(acc, base); }
   *(g1_xyzz_t *)out_xyzz = g1_xyzz29_to_sat(acc);
+}
+
+// ---- GLV (glv.cuh): decomposition of a canonical scalar and the joint scalar multiple k * P on the 29-bit field
+extern "C" void hs_glv_decompose(const void *k_canonical, uint32_t *k1, int *neg1, uint32_t *k2, int *neg2) {
+  uint32_t a[4], b[4]; bool n1, n2;
+  glv_decompose(*(const fe_t *)k_canonical, a, n1, b, n2);
+  for (int i = 0; i < 4; i++) { k1[i] = a[i]; k2[i] = b[i]; }
+  *neg1 = n1; *neg2 = n2;
+}
+extern "C" void hs_g1_mul_glv(void *out_xyzz, const void *affine, const void *k_canonical) {
+  const g1_affine_t *q = (const g1_affine_t *)affine;
+  g1_xyzz29_t base = g1_xyzz29_identity();
+  g1_xyzz29_madd(base, *q, false);                              // tight coordinates, zz = zzz = one (what g1_xyzz29_from_sat hands over)
+  *(g1_xyzz_t *)out_xyzz = g1_xyzz29_to_sat(g1_xyzz29_mul_glv(base, *(const fe_t *)k_canonical));
 }

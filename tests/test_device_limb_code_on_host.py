@@ -237,3 +237,33 @@ def test_xyzz29_full_addition_and_doubling(hs):
         hs.hs_xyzz29_ladder(p_(out), p_(pts), signs, C.c_uint64(len(seq)), C.c_uint32(k))
         base = total(seq)
         assert as_point(out) == (pyref.g1_mul(base, k) if (base is not None and k) else None), (seq, k)
+
+
+def test_glv_decomposition_and_joint_scalar_multiple(hs):
+    """glv.cuh: k = k1 + lambda k2 (mod r) with |k_i| < 2^127 for random and extreme scalars, and k * P by the joint double-and-add
+    (phi(P) = (beta x, y), signed 2-bit digits) against the big-integer oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_glv", os.path.join(os.path.dirname(HERE), "tools", "gen_glv_constants.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    c = gen.derive()
+    lam = c["lam"]
+    assert lam == pyref.FR_ZETA and (lam * lam + lam + 1) % R == 0 and pow(c["beta"], 3, P) == 1 and c["beta"] != 1
+    rng = random.Random(2024)
+    ks = [0, 1, 2, 3, R - 1, R - 2, R // 2, R // 2 + 1, lam, R - lam, (1 << 253), (1 << 127), (1 << 127) - 1, (1 << 128) + 5] + [rng.randrange(R) for _ in range(4000)]
+    for k in ks:
+        kc = np.array(pyref.to_limbs(k), dtype=np.uint64)
+        k1 = (C.c_uint32 * 4)(); k2 = (C.c_uint32 * 4)(); n1 = C.c_int(); n2 = C.c_int()
+        hs.hs_glv_decompose(p_(kc), k1, C.byref(n1), k2, C.byref(n2))
+        a = sum(int(v) << (32 * i) for i, v in enumerate(k1)) * (-1 if n1.value else 1)
+        b = sum(int(v) << (32 * i) for i, v in enumerate(k2)) * (-1 if n2.value else 1)
+        assert (a, b) == gen.decompose(k, c), k                                     # the same integers as the generator's formulas
+        assert (a + lam * b - k) % R == 0 and abs(a) < (1 << 127) and abs(b) < (1 << 127), k
+    G = pyref.G1_GEN
+    pts = [G, pyref.g1_mul(G, 5), pyref.g1_mul(G, rng.randrange(1, R)), pyref.g1_mul(G, rng.randrange(1, R))]
+    for k in ks[:14] + ks[14:14 + 40]:
+        for Pt in pts[: 2 if k in ks[:14] else 4]:
+            out = np.zeros(16, dtype=np.uint64)
+            hs.hs_g1_mul_glv(p_(out), p_(_pt(Pt)), p_(np.array(pyref.to_limbs(k), dtype=np.uint64)))
+            jac = np.zeros(12, dtype=np.uint64); hs.hs_xyzz_to_jac(p_(jac), p_(out))
+            got = pyref.g1_jacobian_from_limbs(jac[:4], jac[4:8], jac[8:])
+            assert got == (pyref.g1_mul(Pt, k) if k % R else None), (k, Pt)
