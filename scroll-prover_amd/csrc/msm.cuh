@@ -403,29 +403,50 @@ __device__ __forceinline__ g1_xyzz29_t shfl_down_xyzz29(const g1_xyzz29_t &v, ui
   for (int i = 0; i < 36; i++) d[i] = __shfl_down(s[i], o);
   return r;
 }
-__global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
+__device__ __forceinline__ g1_xyzz29_t shfl_xor_xyzz29(const g1_xyzz29_t &v, uint32_t o) {
+  g1_xyzz29_t r; const uint32_t *s = reinterpret_cast<const uint32_t *>(&v); uint32_t *d = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+  for (int i = 0; i < 36; i++) d[i] = __shfl_xor(s[i], o);
+  return r;
+}
+// FIXUP_LANES lanes per bucket: a bucket of a mid-size MSM straddles ~15 accumulate threads (2^20 pairs: 240 entries per bucket, 16 per
+// thread), and one lane summing them serially left the kernel at one wavefront per SIMD on a 15-addition chain (184 us of a 2 ms MSM).
+// Each lane of the group sums every FIXUP_LANES-th partial and two shuffle steps combine them; launch = nbuckets * FIXUP_LANES threads
+// (0.60 -> 0.45 ms of tail at 2^14 pairs, 0.73 -> 0.67 ms at 2^20).
+// FIXUP_LANES = 1 (big bucket sets: 2^21 buckets of which few straddle more than two threads) is the plain one-lane-per-bucket kernel.
+template <uint32_t FIXUP_LANES> __global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
                                                    const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg,
                                                    uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
                                                    uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, uint32_t huge_cap) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbuckets) return;
-  const uint32_t s = offsets[b], e = offsets[b + 1];
-  if (e == s) return;
-  const uint32_t t0 = s / seg, t1 = (e - 1) / seg;
-  if (t0 == t1) return;  // sole owner wrote it
-  if (t1 - t0 > FIXUP_SERIAL_MAX) {
-    if (huge_cap && t1 - t0 >= FIXUP_HUGE_MIN) {   // thousands of partials: several workgroups (k_msm_fixup_huge)
-      const uint32_t idx = atomicAdd(huge_count, 1u);
-      if (idx < huge_cap) { huge_list[3 * idx] = b; huge_list[3 * idx + 1] = t0; huge_list[3 * idx + 2] = t1; }
-      return;
-    }
-    const uint32_t idx = atomicAdd(big_count, 1u);
-    if (idx < big_cap) { big_list[3 * idx] = b; big_list[3 * idx + 1] = t0; big_list[3 * idx + 2] = t1; }
-    return;
-  }
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid / FIXUP_LANES, sub = gid % FIXUP_LANES;
   g1_xyzz29_t acc = g1_xyzz29_identity();
-  for (uint32_t t = t0; t <= t1; t++) fixup_take29(acc, part, part_id, t, b);
-  store_xyzz29(&bucket_sums[b], acc);
+  bool mine = false;   // this group sums a straddling bucket of moderate span
+  if (b < nbuckets) {
+    const uint32_t s = offsets[b], e = offsets[b + 1];
+    if (e != s) {
+      const uint32_t t0 = s / seg, t1 = (e - 1) / seg;
+      if (t0 != t1) {   // t0 == t1: the sole owner wrote it
+        if (t1 - t0 > FIXUP_SERIAL_MAX) {
+          if (sub == 0) {
+            if (huge_cap && t1 - t0 >= FIXUP_HUGE_MIN) {   // thousands of partials: several workgroups (k_msm_fixup_huge)
+              const uint32_t idx = atomicAdd(huge_count, 1u);
+              if (idx < huge_cap) { huge_list[3 * idx] = b; huge_list[3 * idx + 1] = t0; huge_list[3 * idx + 2] = t1; }
+            } else {
+              const uint32_t idx = atomicAdd(big_count, 1u);
+              if (idx < big_cap) { big_list[3 * idx] = b; big_list[3 * idx + 1] = t0; big_list[3 * idx + 2] = t1; }
+            }
+          }
+        } else {
+          mine = true;
+          for (uint32_t t = t0 + sub; t <= t1; t += FIXUP_LANES) fixup_take29(acc, part, part_id, t, b);
+        }
+      }
+    }
+  }
+  // every lane of the wavefront reaches the shuffles; groups with nothing to do carry identities (the addition returns at once)
+#pragma unroll
+  for (uint32_t o = 1; o < FIXUP_LANES; o <<= 1) { const g1_xyzz29_t other = shfl_xor_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
+  if (mine && sub == 0) store_xyzz29(&bucket_sums[b], acc);
 }
 __global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyzz29_t *__restrict__ bucket_sums, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id,
                                                        const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count) {
