@@ -402,11 +402,17 @@ def main() -> None:
         for _ in range(3):
             check(lib.mi355_msm_g1_dev(handle.value, 0, ptr(wl), n, ptr(out)))
         dt_w = (time.perf_counter() - t6) / 3
+        check(lib.mi355_profile_reset()); check(lib.mi355_profile_enable(1))
+        check(lib.mi355_msm_g1_dev(handle.value, 0, ptr(wl), n, ptr(out)))
+        check(lib.mi355_profile_enable(0))
+        ph_w = {p_: prof(p_)[0] for p_ in ("msm_digits", "msm_sort", "msm_accumulate", "msm_reduce", "msm_total")}
+        cw, ww, ew = C.c_int(), C.c_int(), C.c_uint64()
+        check(lib.mi355_msm_last_plan(C.byref(cw), C.byref(ww), C.byref(ew)))
         ok_w = None
         if k <= 24:
             from oracle import cref
             ok_w = bool((np.asarray(out)[:8] == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(wl.cpu().numpy().view(np.uint64), tau_m)))).all())
-        extra["witness_like"] = {"ms_per_commit": dt_w * 1e3, "pairs_per_s": n / dt_w, "verified_against_field_check": ok_w,
+        extra["witness_like"] = {"ms_per_commit": dt_w * 1e3, "pairs_per_s": n / dt_w, "verified_against_field_check": ok_w, "msm_phase_ms": ph_w,
                                  "distribution": "60% zero, 20% in 1..255, 10% 64-bit, 10% uniform"}
         del wl
 

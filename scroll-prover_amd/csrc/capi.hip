@@ -104,6 +104,9 @@ struct Ctx {
   uint32_t seg_factor = 16;
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
+  uint32_t seg_min = 16;             // MI355_SEG_MIN: shortest accumulate segment (entries per thread) when few digits are non-zero
+  uint32_t fixup_huge_min = 2048;    // MI355_FIXUP_HUGE_MIN (>= 2048): bucket spans from this many accumulate threads on are summed by several workgroups
+  uint32_t fixup_serial_max = 32;    // MI355_FIXUP_SERIAL_MAX: bucket spans (in accumulate threads) above this go to the workgroup-per-bucket fix-up
   uint32_t fixup_lanes_max_log = 17;  // MI355_FIXUP_LANES_MAX_LOG: bucket sets up to 2^this records take the four-lanes-per-bucket fix-up
   uint32_t reduce_min_chunk = 4;     // MI355_REDUCE_MIN_CHUNK: shortest running-sum chain (buckets per reduce thread) small bucket sets are cut into
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
@@ -321,6 +324,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   const uint64_t want_threads = (uint64_t)g.prop.multiProcessorCount * 256 * g.seg_factor;   // segments per lane slot (MI355_SEG_FACTOR)
   uint64_t seg = (emax + want_threads - 1) / want_threads; if (seg < 16) seg = 16; if (seg > 4096) seg = 4096;
   P.seg = (uint32_t)seg;
+  const uint32_t seg_arg = P.seg | (std::min(g.seg_min, P.seg) << 16);   // worst-case segment (<= 4096) | minimum: the kernels derive the segment from the actual entry count
   const uint32_t red_wpp = shared ? 1 : P.windows;        // bucket sets per polynomial
   const uint32_t red_windows = M * red_wpp;               // bucket sets to reduce
   const uint32_t nbuckets = (uint32_t)sh.nbuckets;
@@ -359,7 +363,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   buckets += (size_t)nbuckets * set_index;
   WS("msm.part", (size_t)tn * 2 * sizeof(g1_xyzz29_t), part);
   WS("msm.part_id", (size_t)tn * 2 * 4, part_id);
-  const uint32_t big_cap = tn / FIXUP_SERIAL_MAX + 2;
+  const uint32_t big_cap = tn / g.fixup_serial_max + 2;
   uint32_t *big_list; WS("msm.big_list", ((size_t)big_cap * 3 + 1) * 4, big_list);
   uint32_t *big_count = big_list + (size_t)big_cap * 3;
   // buckets that span >= FIXUP_HUGE_MIN accumulate threads (at most tn / FIXUP_HUGE_MIN of them) get FIXUP_SLICES workgroups each
@@ -410,7 +414,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
     {
       Scope sc("msm_accumulate", s);
       HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
-#define ACC_LAUNCH(V) hipLaunchKernelGGL(k_msm_accumulate<V>, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, P.seg, S.nshift, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask)
+#define ACC_LAUNCH(V) hipLaunchKernelGGL(k_msm_accumulate<V>, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, seg_arg, S.nshift, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask)
       if (g.acc_variant & 4) ACC_LAUNCH(4); else ACC_LAUNCH(0);   // 4: limb products as explicitly chained v_mad (fp29.cuh mac_*); the older A/B variants (index stream further ahead, prefetched bucket ends) did not help and are no longer instantiated
 #undef ACC_LAUNCH
     }
@@ -424,10 +428,10 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
     HIPCHK(hipMemsetAsync(huge_count, 0, 4, s));
     // four lanes per bucket where buckets straddle many short segments (small and mid-size MSMs); with 2^19 buckets and more the extra
     // threads cost more than the shorter chains save (measured: +0.15 ms at 2^18, +0.5 ms at 2^21 buckets)
-    if (nbuckets <= (1u << g.fixup_lanes_max_log)) hipLaunchKernelGGL(k_msm_fixup<4>, dim3(ceil_div((uint64_t)nbuckets * 4, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap, huge_list, huge_count, huge_cap);
-    else hipLaunchKernelGGL(k_msm_fixup<1>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, P.seg, big_list, big_count, big_cap, huge_list, huge_count, huge_cap);
+    if (nbuckets <= (1u << g.fixup_lanes_max_log)) hipLaunchKernelGGL(k_msm_fixup<4>, dim3(ceil_div((uint64_t)nbuckets * 4, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, seg_arg, tn, big_list, big_count, big_cap, huge_list, huge_count, huge_cap, g.fixup_serial_max, g.fixup_huge_min);
+    else hipLaunchKernelGGL(k_msm_fixup<1>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, seg_arg, tn, big_list, big_count, big_cap, huge_list, huge_count, huge_cap, g.fixup_serial_max, g.fixup_huge_min);
     hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
-    hipLaunchKernelGGL(k_msm_fixup_huge, dim3(huge_cap * FIXUP_SLICES), dim3(256), 0, s, part, part_id, huge_list, huge_count, huge_part);
+    hipLaunchKernelGGL(k_msm_fixup_huge, dim3(huge_cap * FIXUP_SLICES), dim3(256), 0, s, part, part_id, huge_list, huge_count, huge_part, huge_cap);
     hipLaunchKernelGGL(k_msm_fixup_huge_fold, dim3(huge_cap), dim3(64), 0, s, buckets, huge_list, huge_count, (const g1_xyzz29_t *)huge_part);
     if (!skip_tail) CHK(msm_reduce_tail(sh, M, buckets, out_dev, normalise, s, sfx));
   }
@@ -868,6 +872,9 @@ static int init_ctx(int slot, int device_id) {
 #endif
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 7; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
+  { const char *e = getenv("MI355_SEG_MIN"); if (e) { int v = atoi(e); if (v >= 1 && v <= 4096) g.seg_min = (uint32_t)v; } }
+  { const char *e = getenv("MI355_FIXUP_HUGE_MIN"); if (e) { long v = atol(e); if (v >= 2048 && v <= 0x7fffffffL) g.fixup_huge_min = (uint32_t)v; } }
+  { const char *e = getenv("MI355_FIXUP_SERIAL_MAX"); if (e) { int v = atoi(e); if (v >= 1 && v <= 1024) g.fixup_serial_max = (uint32_t)v; } }
   { const char *e = getenv("MI355_FIXUP_LANES_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 0 && v <= 31) g.fixup_lanes_max_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_REDUCE_MIN_CHUNK"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) g.reduce_min_chunk = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_FB"); if (e) { int v = atoi(e); if (v >= 9 && v <= 12) g.sort_fb = (uint32_t)v; } }

@@ -321,10 +321,24 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
 // ---- 4. segmented accumulation
 // offsets[b] .. offsets[b+1] = entries of global bucket b (b = w * nb + bucket); offsets has nbuckets+1 entries.
 // bucket_sums must be zero-filled (all-zero XYZZ = identity) before launch.
+// Segment length: the launch is sized for the worst case (every digit non-zero: n * W entries, `seg_max` per thread); the actual count is
+// only known on the device (offsets[nbuckets]).  Witness-like columns (mostly zero / one-window scalars) leave 14 % of the entries, and
+// with the worst-case segment 86 % of the launched threads had nothing to do while the rest ran at ~2 wavefronts per SIMD (11.6 ms for
+// 1.1e8 entries at 2^26).  Every kernel that maps entries to threads therefore derives the segment from the actual total.
+// The segment is chosen so that the entries fill ~40 % of the launched threads (about two rounds of resident wavefronts: enough to keep
+// every SIMD at its three waves, while every further thread only adds partial sums for the fix-up to merge -- calibrated on witness-like,
+// byte-valued and all-ones columns at 2^26, profiles/r02b_segment_calibration.log).
+__device__ __forceinline__ uint32_t msm_seg_eff(uint32_t total, uint32_t threads, uint32_t seg_max, uint32_t seg_min) {
+  const uint64_t target = ((uint64_t)threads * 2 + 4) / 5;
+  uint32_t sg = (uint32_t)(((uint64_t)total + target - 1) / (target ? target : 1));
+  sg = sg < seg_min ? seg_min : sg;
+  return sg > seg_max ? seg_max : sg;
+}
 template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(const g1_affine_t *__restrict__ bases, const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
-                                                        uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg,
+                                                        uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg_max,
                                                         uint32_t nshift, uint64_t row_stride, uint32_t gather_mask) {
   const uint32_t total = offsets[nbuckets];
+  const uint32_t seg = msm_seg_eff(total, gridDim.x * blockDim.x, seg_max & 0xffffu, seg_max >> 16);   // seg_max: worst-case segment | minimum << 16
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t start64 = (uint64_t)t * seg;
   if (start64 >= total) { part_id[2 * t] = -1; part_id[2 * t + 1] = -1; return; }
@@ -390,7 +404,7 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
 // ---- 5. fix-up of buckets that straddle thread boundaries.  Small spans are summed by one lane; a bucket that spans more than
 //         FIXUP_SERIAL_MAX accumulate-threads (skewed scalars: zeros/ones/small values, or the short top window) is queued and
 //         reduced by a whole workgroup (wavefront-shuffle tree + LDS) in k_msm_fixup_big.
-constexpr uint32_t FIXUP_SERIAL_MAX = 32, FIXUP_HUGE_MIN = 2048, FIXUP_SLICES = 16;
+constexpr uint32_t FIXUP_SERIAL_MAX = 32, FIXUP_HUGE_MIN = 2048, FIXUP_SLICES = 64;   // SLICES <= 64: one wavefront folds the slice sums
 // The fix-up and the whole reduction tail stay in the 29-bit field (g1_xyzz29_add / _dbl): no conversion of the 144-byte records to the
 // saturated form (4 multiplications each) and the faster multiplier; records always hold valid accumulators (g1_29.cuh invariants).
 __device__ __forceinline__ void fixup_take29(g1_xyzz29_t &acc, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t t, uint32_t b) {
@@ -415,10 +429,11 @@ __device__ __forceinline__ g1_xyzz29_t shfl_xor_xyzz29(const g1_xyzz29_t &v, uin
 // (0.60 -> 0.45 ms of tail at 2^14 pairs, 0.73 -> 0.67 ms at 2^20).
 // FIXUP_LANES = 1 (big bucket sets: 2^21 buckets of which few straddle more than two threads) is the plain one-lane-per-bucket kernel.
 template <uint32_t FIXUP_LANES> __global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
-                                                   const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg,
+                                                   const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg_max, uint32_t acc_threads,
                                                    uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
-                                                   uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, uint32_t huge_cap) {
+                                                   uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, uint32_t huge_cap, uint32_t serial_max, uint32_t huge_min) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid / FIXUP_LANES, sub = gid % FIXUP_LANES;
+  const uint32_t seg = msm_seg_eff(offsets[nbuckets], acc_threads, seg_max & 0xffffu, seg_max >> 16);   // the segment length k_msm_accumulate used
   g1_xyzz29_t acc = g1_xyzz29_identity();
   bool mine = false;   // this group sums a straddling bucket of moderate span
   if (b < nbuckets) {
@@ -426,9 +441,9 @@ template <uint32_t FIXUP_LANES> __global__ void __launch_bounds__(256) k_msm_fix
     if (e != s) {
       const uint32_t t0 = s / seg, t1 = (e - 1) / seg;
       if (t0 != t1) {   // t0 == t1: the sole owner wrote it
-        if (t1 - t0 > FIXUP_SERIAL_MAX) {
+        if (t1 - t0 > serial_max) {
           if (sub == 0) {
-            if (huge_cap && t1 - t0 >= FIXUP_HUGE_MIN) {   // thousands of partials: several workgroups (k_msm_fixup_huge)
+            if (huge_cap && t1 - t0 >= huge_min) {   // thousands of partials: several workgroups (k_msm_fixup_huge)
               const uint32_t idx = atomicAdd(huge_count, 1u);
               if (idx < huge_cap) { huge_list[3 * idx] = b; huge_list[3 * idx + 1] = t0; huge_list[3 * idx + 2] = t1; }
             } else {
@@ -463,13 +478,24 @@ __global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyzz29_t *__restrict__
 // A giant bucket (an all-ones selector column puts every point into ONE bucket) spans up to a million accumulate threads: its partials
 // are summed by FIXUP_SLICES workgroups (one slice of the span each) into huge_part and folded by one wavefront.
 // grid = huge_cap * FIXUP_SLICES resp. huge_cap; at most (accumulate threads) / FIXUP_HUGE_MIN buckets can qualify.
+// slices of one giant bucket: a workgroup per ~2048 partial sums (8 per thread), at most FIXUP_SLICES -- a tree per slice costs ~10 additions
+// whatever it sums, so a bucket of a few thousand partials gets 2-3 workgroups and the all-ones column (2^18 .. 2^20 partials) all 64
+__device__ __forceinline__ uint32_t fixup_huge_slices(uint32_t span) { const uint32_t s = span >> 11; return s < 1u ? 1u : (s > FIXUP_SLICES ? FIXUP_SLICES : s); }
 __global__ void __launch_bounds__(256) k_msm_fixup_huge(const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, const uint32_t *__restrict__ huge_list,
-                                                        const uint32_t *__restrict__ huge_count, g1_xyzz29_t *__restrict__ huge_part) {
+                                                        const uint32_t *__restrict__ huge_count, g1_xyzz29_t *__restrict__ huge_part, uint32_t huge_cap) {
   __shared__ g1_xyzz29_t lds29[4];
-  const uint32_t idx = blockIdx.x / FIXUP_SLICES, sl = blockIdx.x - idx * FIXUP_SLICES;
-  if (idx >= *huge_count) return;
+  // block = slice * count + bucket (count = number of giant buckets, known on the device only): the blocks that have work are CONSECUTIVE
+  // whether the column has one giant bucket or hundreds.  With bucket-major order over the allocated capacity the working blocks of a
+  // column with ~200 giant buckets of 2-3 slices each sat at block indices 64 k + {0, 1, 2}, which the dispatcher maps to a handful of
+  // CUs: 2.7 ms for work the one-workgroup-per-bucket kernel does in 0.15 ms (profiles/r02b_giant_bucket_fixup.md)
+  const uint32_t count = min(*huge_count, huge_cap);
+  if (count == 0) return;
+  const uint32_t sl = blockIdx.x / count, idx = blockIdx.x - sl * count;
+  if (sl >= FIXUP_SLICES) return;
   const uint32_t b = huge_list[3 * idx], t0 = huge_list[3 * idx + 1], t1 = huge_list[3 * idx + 2], span = t1 - t0 + 1;
-  const uint32_t lo = t0 + (uint32_t)((uint64_t)span * sl / FIXUP_SLICES), hi = t0 + (uint32_t)((uint64_t)span * (sl + 1) / FIXUP_SLICES);   // [lo, hi)
+  const uint32_t nsl = fixup_huge_slices(span);
+  if (sl >= nsl) return;
+  const uint32_t lo = t0 + (uint32_t)((uint64_t)span * sl / nsl), hi = t0 + (uint32_t)((uint64_t)span * (sl + 1) / nsl);   // [lo, hi)
   g1_xyzz29_t acc = g1_xyzz29_identity();
   for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) fixup_take29(acc, part, part_id, t, b);
   for (uint32_t o = 32; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
@@ -481,7 +507,8 @@ __global__ void __launch_bounds__(64) k_msm_fixup_huge_fold(g1_xyzz29_t *__restr
                                                             const g1_xyzz29_t *__restrict__ huge_part) {
   const uint32_t idx = blockIdx.x;
   if (idx >= *huge_count) return;
-  g1_xyzz29_t acc = threadIdx.x < FIXUP_SLICES ? load_xyzz29(&huge_part[(uint64_t)idx * FIXUP_SLICES + threadIdx.x]) : g1_xyzz29_identity();
+  const uint32_t nsl = fixup_huge_slices(huge_list[3 * idx + 2] - huge_list[3 * idx + 1] + 1);
+  g1_xyzz29_t acc = threadIdx.x < nsl ? load_xyzz29(&huge_part[(uint64_t)idx * FIXUP_SLICES + threadIdx.x]) : g1_xyzz29_identity();
   for (uint32_t o = FIXUP_SLICES / 2; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
   if (threadIdx.x == 0) store_xyzz29(&bucket_sums[huge_list[3 * idx]], acc);
 }
