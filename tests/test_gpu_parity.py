@@ -286,6 +286,30 @@ def test_giant_buckets_take_the_parallel_fixup(zk):
     _ = torch
 
 
+@pytest.mark.parametrize("distinct,zero_frac", [(4, 0.0), (24, 0.0), (3, 0.9), (200, 0.5)])
+def test_many_giant_buckets_and_sparse_columns(zk, distinct, zero_frac):
+    """columns of a few distinct values (every (value, window) pair is ONE bucket of n / distinct entries: dozens to hundreds of giant buckets
+    whose partial sums are cut into 1 .. 64 slices, indexed slice * count + bucket on the device) and mostly-zero columns (the accumulate
+    segment is derived from the actual entry count): commit(p) = p(tau) G in the field, window tables on and off."""
+    import torch
+    h2 = zk.halo2
+    k, tau = 18, 0x5EED5EED
+    n = 1 << k
+    params = h2.ParamsKZG.setup(k, tau)
+    rng = np.random.default_rng(distinct * 1000 + int(zero_frac * 10))
+    vals = np.stack([h2.fr(int.from_bytes(rng.bytes(31), "little") % R) for _ in range(distinct)] + [h2.fr(0)])
+    pick = rng.integers(0, distinct, size=n)
+    pick[rng.random(n) < zero_frac] = distinct
+    sc = np.ascontiguousarray(vals[pick])
+    want = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(sc, h2.fr(tau))))
+    for tables in (False, True):
+        if tables:
+            params.precompute()
+        assert (affine_of(params.commit(sc)) == want).all(), (distinct, zero_frac, tables)
+        assert (affine_of(params.commit(torch.from_numpy(sc.view(np.int64)).cuda())) == want).all()
+    params.release()
+
+
 @pytest.mark.parametrize("c", [0, 5, 13])
 def test_precomputed_window_tables_and_shared_bucket_msm(zk, points, c):
     """mi355_srs_precompute: rows T[w][i] = 2^(c w) P_i against the oracle, then MSMs (whole basis, slices, edge scalars)
