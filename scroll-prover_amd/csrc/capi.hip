@@ -105,6 +105,7 @@ struct Ctx {
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
   uint32_t seg_min = 16;             // MI355_SEG_MIN: shortest accumulate segment (entries per thread) when few digits are non-zero
+  uint32_t fixup_mode = 0;           // MI355_FIXUP_MODE: 0 = per-bucket kernels (four lanes / workgroup / several workgroups per bucket), 1 = one segmented reduction over the partial sums (k_msm_segfix: measured better for two-partial buckets, worse for spans of 15-30, profiles/r02b_segfix_ab.log)
   uint32_t fixup_huge_min = 2048;    // MI355_FIXUP_HUGE_MIN (>= 2048): bucket spans from this many accumulate threads on are summed by several workgroups
   uint32_t fixup_serial_max = 32;    // MI355_FIXUP_SERIAL_MAX: bucket spans (in accumulate threads) above this go to the workgroup-per-bucket fix-up
   uint32_t fixup_lanes_max_log = 17;  // MI355_FIXUP_LANES_MAX_LOG: bucket sets up to 2^this records take the four-lanes-per-bucket fix-up
@@ -428,11 +429,26 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
     HIPCHK(hipMemsetAsync(huge_count, 0, 4, s));
     // four lanes per bucket where buckets straddle many short segments (small and mid-size MSMs); with 2^19 buckets and more the extra
     // threads cost more than the shorter chains save (measured: +0.15 ms at 2^18, +0.5 ms at 2^21 buckets)
+    if (g.fixup_mode == 1) {
+      // one segmented reduction over the 2 * tn partial slots, level by level (64 slots -> 2 per level) until one wavefront holds the rest
+      uint32_t N = 2 * tn; const uint32_t waves1 = ceil_div(N, 64);
+      int32_t *lv_ids; g1_xyzz29_t *lv_recs;
+      { const std::string r1 = role("msm.segfix_ids"), r2 = role("msm.segfix_recs"); const size_t cap = (size_t)2 * waves1 + (size_t)waves1 / 8 + 512;
+        CHK(ws_get(r1.c_str(), cap * 4, (void **)&lv_ids)); CHK(ws_get(r2.c_str(), cap * sizeof(g1_xyzz29_t), (void **)&lv_recs)); }
+      const int32_t *cur_ids = part_id; const g1_xyzz29_t *cur_recs = part; size_t used = 0;
+      while (N > 64) {
+        const uint32_t waves = ceil_div(N, 64);
+        hipLaunchKernelGGL(k_msm_segfix, dim3(ceil_div(N, 256)), dim3(256), 0, s, cur_ids, cur_recs, N, buckets, lv_ids + used, lv_recs + used, 0);
+        cur_ids = lv_ids + used; cur_recs = lv_recs + used; used += (size_t)2 * waves; N = 2 * waves;
+      }
+      hipLaunchKernelGGL(k_msm_segfix, dim3(1), dim3(64), 0, s, cur_ids, cur_recs, N, buckets, (int32_t *)nullptr, (g1_xyzz29_t *)nullptr, 1);
+    } else {
     if (nbuckets <= (1u << g.fixup_lanes_max_log)) hipLaunchKernelGGL(k_msm_fixup<4>, dim3(ceil_div((uint64_t)nbuckets * 4, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, seg_arg, tn, big_list, big_count, big_cap, huge_list, huge_count, huge_cap, g.fixup_serial_max, g.fixup_huge_min);
     else hipLaunchKernelGGL(k_msm_fixup<1>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, seg_arg, tn, big_list, big_count, big_cap, huge_list, huge_count, huge_cap, g.fixup_serial_max, g.fixup_huge_min);
     hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
     hipLaunchKernelGGL(k_msm_fixup_huge, dim3(huge_cap * FIXUP_SLICES), dim3(256), 0, s, part, part_id, huge_list, huge_count, huge_part, huge_cap);
     hipLaunchKernelGGL(k_msm_fixup_huge_fold, dim3(huge_cap), dim3(64), 0, s, buckets, huge_list, huge_count, (const g1_xyzz29_t *)huge_part);
+    }
     if (!skip_tail) CHK(msm_reduce_tail(sh, M, buckets, out_dev, normalise, s, sfx));
   }
   if (piped) HIPCHK(hipEventRecord(slot.red_done, st.c));
@@ -873,6 +889,7 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 7; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
   { const char *e = getenv("MI355_SEG_MIN"); if (e) { int v = atoi(e); if (v >= 1 && v <= 4096) g.seg_min = (uint32_t)v; } }
+  { const char *e = getenv("MI355_FIXUP_MODE"); if (e) g.fixup_mode = e[0] == '1' ? 1u : 0u; }
   { const char *e = getenv("MI355_FIXUP_HUGE_MIN"); if (e) { long v = atol(e); if (v >= 2048 && v <= 0x7fffffffL) g.fixup_huge_min = (uint32_t)v; } }
   { const char *e = getenv("MI355_FIXUP_SERIAL_MAX"); if (e) { int v = atoi(e); if (v >= 1 && v <= 1024) g.fixup_serial_max = (uint32_t)v; } }
   { const char *e = getenv("MI355_FIXUP_LANES_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 0 && v <= 31) g.fixup_lanes_max_log = (uint32_t)v; } }

@@ -459,8 +459,9 @@ template <uint32_t FIXUP_LANES> __global__ void __launch_bounds__(256) k_msm_fix
     }
   }
   // every lane of the wavefront reaches the shuffles; groups with nothing to do carry identities (the addition returns at once)
-#pragma unroll
-  for (uint32_t o = 1; o < FIXUP_LANES; o <<= 1) { const g1_xyzz29_t other = shfl_xor_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
+  if (FIXUP_LANES > 1) { const g1_xyzz29_t other = shfl_xor_xyzz29(acc, 1); g1_xyzz29_add(acc, other); }
+  if (FIXUP_LANES > 2) { const g1_xyzz29_t other = shfl_xor_xyzz29(acc, 2); g1_xyzz29_add(acc, other); }
+  static_assert(FIXUP_LANES == 1 || FIXUP_LANES == 2 || FIXUP_LANES == 4, "two shuffle steps");
   if (mine && sub == 0) store_xyzz29(&bucket_sums[b], acc);
 }
 __global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyzz29_t *__restrict__ bucket_sums, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id,
@@ -511,6 +512,45 @@ __global__ void __launch_bounds__(64) k_msm_fixup_huge_fold(g1_xyzz29_t *__restr
   g1_xyzz29_t acc = threadIdx.x < nsl ? load_xyzz29(&huge_part[(uint64_t)idx * FIXUP_SLICES + threadIdx.x]) : g1_xyzz29_identity();
   for (uint32_t o = FIXUP_SLICES / 2; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
   if (threadIdx.x == 0) store_xyzz29(&bucket_sums[huge_list[3 * idx]], acc);
+}
+
+// ---- 5b. the same fix-up as ONE segmented reduction over the partial sums (MI355_FIXUP_MODE=1).
+// The partial records of the accumulate threads, read in thread order (slot 2t: the bucket that began in an earlier thread, slot 2t + 1: the
+// bucket that continues in the next one, -1: none), are sorted by bucket, so the sums of straddling buckets are a reduction by key over a
+// sorted sequence: every wavefront takes 64 consecutive slots, propagates keys over the empty slots (fill-forward), forms the suffix sums of
+// equal keys by doubling (an addition is only issued for a step in which some lane has a partner of its own key: one step for the common
+// two-partial bucket, six for a run that fills the wavefront) and stores the runs that lie strictly inside it; its first and last run may
+// continue in the neighbouring wavefronts and go, two slots per wavefront, to the next level (1/32 of the size), which is the same kernel.
+// Work and depth no longer depend on how the scalars are distributed: O(partials) additions, log-many levels, no lists, no thresholds.
+__global__ void __launch_bounds__(256) k_msm_segfix(const int32_t *__restrict__ ids, const g1_xyzz29_t *__restrict__ recs, uint32_t n, g1_xyzz29_t *__restrict__ bucket_sums,
+                                                    int32_t *__restrict__ ids_out, g1_xyzz29_t *__restrict__ recs_out, int last_level) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = j >> 6;
+  if (wave >= ((n + 63) >> 6)) return;   // whole wavefronts past the end (the grid is rounded up to workgroups of four)
+  const int32_t key0 = j < n ? ids[j] : -1;
+  g1_xyzz29_t val = key0 >= 0 ? load_xyzz29(&recs[j]) : g1_xyzz29_identity();
+  int32_t key = key0;
+  for (uint32_t o = 1; o < 64; o <<= 1) { const int32_t kk = __shfl_up(key, o); if (lane >= o && key < 0) key = kk; }   // fill-forward over empty slots (they hold identities)
+  for (uint32_t o = 1; o < 64; o <<= 1) {
+    const int32_t k2 = __shfl_down(key, o);
+    const bool take = lane + o < 64 && key >= 0 && k2 == key;
+    if (__ballot(take) == 0) continue;                 // wave-uniform: no run is longer than o here
+    const g1_xyzz29_t other = shfl_down_xyzz29(val, o);
+    if (take) g1_xyzz29_add(val, other);
+  }
+  const int32_t kprev = __shfl_up(key, 1);
+  const bool head = key >= 0 && (lane == 0 || kprev != key);
+  const uint64_t valid = __ballot(key >= 0);
+  const uint32_t first_lane = valid ? (uint32_t)__ffsll((unsigned long long)valid) - 1 : 64u;   // after the fill every lane from first_lane on is valid
+  const int32_t key_last = __shfl(key, 63), key_first = __shfl(key, first_lane < 64u ? (int)first_lane : 0);
+  const bool is_first = head && lane == first_lane, is_last = head && key == key_last;
+  if (last_level) { if (head) store_xyzz29(&bucket_sums[key], val); return; }
+  if (head && !is_first && !is_last) store_xyzz29(&bucket_sums[key], val);
+  if (is_first) { ids_out[2 * wave] = key; store_xyzz29(&recs_out[2 * (uint64_t)wave], val); }
+  if (is_last && !is_first) { ids_out[2 * wave + 1] = key; store_xyzz29(&recs_out[2 * (uint64_t)wave + 1], val); }
+  if (lane == 0) {   // unused output slots are marked empty (the slot writers above and these never touch the same slot)
+    if (first_lane == 64u) { ids_out[2 * wave] = -1; ids_out[2 * wave + 1] = -1; }
+    else if (key_first == key_last) ids_out[2 * wave + 1] = -1;
+  }
 }
 
 // host-chunked MSM: every slice of the point range fills its own bucket set (same layout); buckets[b] += sum_k buckets[k * nbuckets + b]
