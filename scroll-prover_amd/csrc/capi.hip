@@ -105,7 +105,7 @@ struct Ctx {
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
   uint32_t seg_min = 16;             // MI355_SEG_MIN: shortest accumulate segment (entries per thread) when few digits are non-zero
-  uint32_t fixup_mode = 0;           // MI355_FIXUP_MODE: 0 = per-bucket kernels (four lanes / workgroup / several workgroups per bucket), 1 = one segmented reduction over the partial sums (k_msm_segfix: measured better for two-partial buckets, worse for spans of 15-30, profiles/r02b_segfix_ab.log)
+  uint32_t fixup_mode = 2;           // MI355_FIXUP_MODE: 2 = by shape (see msm_enqueue), 0 = per-bucket kernels (four lanes / workgroup / several workgroups per bucket), 1 = one segmented reduction over the partial sums (k_msm_segfix: measured better for two-partial buckets, worse for spans of 15-30, profiles/r02b_segfix_ab.log)
   uint32_t fixup_huge_min = 2048;    // MI355_FIXUP_HUGE_MIN (>= 2048): bucket spans from this many accumulate threads on are summed by several workgroups
   uint32_t fixup_serial_max = 32;    // MI355_FIXUP_SERIAL_MAX: bucket spans (in accumulate threads) above this go to the workgroup-per-bucket fix-up
   uint32_t fixup_lanes_max_log = 17;  // MI355_FIXUP_LANES_MAX_LOG: bucket sets up to 2^this records take the four-lanes-per-bucket fix-up
@@ -429,7 +429,10 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
     HIPCHK(hipMemsetAsync(huge_count, 0, 4, s));
     // four lanes per bucket where buckets straddle many short segments (small and mid-size MSMs); with 2^19 buckets and more the extra
     // threads cost more than the shorter chains save (measured: +0.15 ms at 2^18, +0.5 ms at 2^21 buckets)
-    if (g.fixup_mode == 1) {
+    // auto (2): big bucket sets whose buckets are no longer than a segment straddle two accumulate threads as a rule -- the case the
+    // segmented reduction is measured faster in (2^24 .. 2^26 with c = 22); everything else takes the per-bucket kernels
+    const bool segfix = g.fixup_mode == 1 || (g.fixup_mode == 2 && nbuckets >= (1u << 19) && (uint64_t)P.seg * nbuckets >= emax);
+    if (segfix) {
       // one segmented reduction over the 2 * tn partial slots, level by level (64 slots -> 2 per level) until one wavefront holds the rest
       uint32_t N = 2 * tn; const uint32_t waves1 = ceil_div(N, 64);
       int32_t *lv_ids; g1_xyzz29_t *lv_recs;
@@ -889,7 +892,7 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 7; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
   { const char *e = getenv("MI355_SEG_MIN"); if (e) { int v = atoi(e); if (v >= 1 && v <= 4096) g.seg_min = (uint32_t)v; } }
-  { const char *e = getenv("MI355_FIXUP_MODE"); if (e) g.fixup_mode = e[0] == '1' ? 1u : 0u; }
+  { const char *e = getenv("MI355_FIXUP_MODE"); if (e && e[0] >= '0' && e[0] <= '2') g.fixup_mode = (uint32_t)(e[0] - '0'); }
   { const char *e = getenv("MI355_FIXUP_HUGE_MIN"); if (e) { long v = atol(e); if (v >= 2048 && v <= 0x7fffffffL) g.fixup_huge_min = (uint32_t)v; } }
   { const char *e = getenv("MI355_FIXUP_SERIAL_MAX"); if (e) { int v = atoi(e); if (v >= 1 && v <= 1024) g.fixup_serial_max = (uint32_t)v; } }
   { const char *e = getenv("MI355_FIXUP_LANES_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 0 && v <= 31) g.fixup_lanes_max_log = (uint32_t)v; } }
