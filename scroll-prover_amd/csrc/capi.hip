@@ -104,6 +104,7 @@ struct Ctx {
   uint32_t seg_factor = 16;
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
+  uint32_t seg_fill = 40, seg_fill_segfix = 40;   // MI355_SEG_FILL / MI355_SEG_FILL_SEGFIX (even, 2..126 %): share of the launched accumulate threads the actual entries are spread over
   uint32_t seg_min = 16;             // MI355_SEG_MIN: shortest accumulate segment (entries per thread) when few digits are non-zero
   uint32_t fixup_mode = 2;           // MI355_FIXUP_MODE: 2 = by shape (see msm_enqueue), 0 = per-bucket kernels (four lanes / workgroup / several workgroups per bucket), 1 = one segmented reduction over the partial sums (k_msm_segfix: measured better for two-partial buckets, worse for spans of 15-30, profiles/r02b_segfix_ab.log)
   uint32_t fixup_huge_min = 2048;    // MI355_FIXUP_HUGE_MIN (>= 2048): bucket spans from this many accumulate threads on are summed by several workgroups
@@ -325,7 +326,10 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   const uint64_t want_threads = (uint64_t)g.prop.multiProcessorCount * 256 * g.seg_factor;   // segments per lane slot (MI355_SEG_FACTOR)
   uint64_t seg = (emax + want_threads - 1) / want_threads; if (seg < 16) seg = 16; if (seg > 4096) seg = 4096;
   P.seg = (uint32_t)seg;
-  const uint32_t seg_arg = P.seg | (std::min(g.seg_min, P.seg) << 16);   // worst-case segment (<= 4096) | minimum: the kernels derive the segment from the actual entry count
+  // worst-case segment (<= 4096) | minimum << 13 | (fill percentage / 2) << 26: the kernels derive the segment from the actual entry count.  With the
+  // segmented fix-up (two-partial buckets are cheap) the entries may spread over more threads than with the per-bucket kernels
+  const bool segfix = g.fixup_mode == 1 || (g.fixup_mode == 2 && (uint32_t)sh.nbuckets >= (1u << 19) && (uint64_t)P.seg * sh.nbuckets >= emax);
+  const uint32_t seg_arg = P.seg | (std::min(g.seg_min, P.seg) << 13) | (((segfix ? g.seg_fill_segfix : g.seg_fill) / 2) << 26);
   const uint32_t red_wpp = shared ? 1 : P.windows;        // bucket sets per polynomial
   const uint32_t red_windows = M * red_wpp;               // bucket sets to reduce
   const uint32_t nbuckets = (uint32_t)sh.nbuckets;
@@ -431,7 +435,6 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
     // threads cost more than the shorter chains save (measured: +0.15 ms at 2^18, +0.5 ms at 2^21 buckets)
     // auto (2): big bucket sets whose buckets are no longer than a segment straddle two accumulate threads as a rule -- the case the
     // segmented reduction is measured faster in (2^24 .. 2^26 with c = 22); everything else takes the per-bucket kernels
-    const bool segfix = g.fixup_mode == 1 || (g.fixup_mode == 2 && nbuckets >= (1u << 19) && (uint64_t)P.seg * nbuckets >= emax);
     if (segfix) {
       // one segmented reduction over the 2 * tn partial slots, level by level (64 slots -> 2 per level) until one wavefront holds the rest
       uint32_t N = 2 * tn; const uint32_t waves1 = ceil_div(N, 64);
@@ -891,6 +894,8 @@ static int init_ctx(int slot, int device_id) {
 #endif
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 7; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
+  { const char *e = getenv("MI355_SEG_FILL"); if (e) { int v = atoi(e); if (v >= 2 && v <= 126) g.seg_fill = (uint32_t)v; } }
+  { const char *e = getenv("MI355_SEG_FILL_SEGFIX"); if (e) { int v = atoi(e); if (v >= 2 && v <= 126) g.seg_fill_segfix = (uint32_t)v; } }
   { const char *e = getenv("MI355_SEG_MIN"); if (e) { int v = atoi(e); if (v >= 1 && v <= 4096) g.seg_min = (uint32_t)v; } }
   { const char *e = getenv("MI355_FIXUP_MODE"); if (e && e[0] >= '0' && e[0] <= '2') g.fixup_mode = (uint32_t)(e[0] - '0'); }
   { const char *e = getenv("MI355_FIXUP_HUGE_MIN"); if (e) { long v = atol(e); if (v >= 2048 && v <= 0x7fffffffL) g.fixup_huge_min = (uint32_t)v; } }

@@ -328,8 +328,8 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
 // The segment is chosen so that the entries fill ~40 % of the launched threads (about two rounds of resident wavefronts: enough to keep
 // every SIMD at its three waves, while every further thread only adds partial sums for the fix-up to merge -- calibrated on witness-like,
 // byte-valued and all-ones columns at 2^26, profiles/r02b_segment_calibration.log).
-__device__ __forceinline__ uint32_t msm_seg_eff(uint32_t total, uint32_t threads, uint32_t seg_max, uint32_t seg_min) {
-  const uint64_t target = ((uint64_t)threads * 2 + 4) / 5;
+__device__ __forceinline__ uint32_t msm_seg_eff(uint32_t total, uint32_t threads, uint32_t seg_max, uint32_t seg_min, uint32_t fill_pct) {
+  const uint64_t target = ((uint64_t)threads * fill_pct + 99) / 100;
   uint32_t sg = (uint32_t)(((uint64_t)total + target - 1) / (target ? target : 1));
   sg = sg < seg_min ? seg_min : sg;
   return sg > seg_max ? seg_max : sg;
@@ -338,7 +338,7 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
                                                         uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ part, int32_t *__restrict__ part_id, uint32_t seg_max,
                                                         uint32_t nshift, uint64_t row_stride, uint32_t gather_mask) {
   const uint32_t total = offsets[nbuckets];
-  const uint32_t seg = msm_seg_eff(total, gridDim.x * blockDim.x, seg_max & 0xffffu, seg_max >> 16);   // seg_max: worst-case segment | minimum << 16
+  const uint32_t seg = msm_seg_eff(total, gridDim.x * blockDim.x, seg_max & 0x1fffu, (seg_max >> 13) & 0x1fffu, (seg_max >> 26) * 2);   // worst-case segment | minimum << 13 | (fill % / 2) << 26
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t start64 = (uint64_t)t * seg;
   if (start64 >= total) { part_id[2 * t] = -1; part_id[2 * t + 1] = -1; return; }
@@ -433,7 +433,7 @@ template <uint32_t FIXUP_LANES> __global__ void __launch_bounds__(256) k_msm_fix
                                                    uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
                                                    uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, uint32_t huge_cap, uint32_t serial_max, uint32_t huge_min) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid / FIXUP_LANES, sub = gid % FIXUP_LANES;
-  const uint32_t seg = msm_seg_eff(offsets[nbuckets], acc_threads, seg_max & 0xffffu, seg_max >> 16);   // the segment length k_msm_accumulate used
+  const uint32_t seg = msm_seg_eff(offsets[nbuckets], acc_threads, seg_max & 0x1fffu, (seg_max >> 13) & 0x1fffu, (seg_max >> 26) * 2);   // the segment length k_msm_accumulate used
   g1_xyzz29_t acc = g1_xyzz29_identity();
   bool mine = false;   // this group sums a straddling bucket of moderate span
   if (b < nbuckets) {
