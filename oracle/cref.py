@@ -18,6 +18,32 @@ _SO = os.path.join(_HERE, "liboracle_bn254.so")
 FQ, FR = 0, 1
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (a container on a 256-thread host is
+    typically limited to a few CPUs' worth of time: 256 threads then only contend with each other)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse:
+                quota, period = parse(txt)
+                if quota != "max":
+                    n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+            else:
+                quota = int(txt); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "bn254_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
@@ -111,7 +137,7 @@ def g1_mul(p, s_mont):
 
 def g1_mul_generator_vec(scalars, threads: int | None = None):
     """[n,8] affine points scalars[i] * G (threaded test-input generator)."""
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cpus()
     s = np.ascontiguousarray(scalars); o = np.zeros((s.shape[0], 8), dtype=np.uint64)
     lib().orc_g1_mul_generator_vec(_p(o), _p(s), C.c_uint64(s.shape[0]), C.c_int(threads)); return o
 
@@ -180,7 +206,7 @@ def multiexp_serial(scalars, bases):
 
 
 def best_multiexp(scalars, bases, threads: int | None = None):
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cpus()
     o = np.zeros(12, dtype=np.uint64); s = np.ascontiguousarray(scalars); b = np.ascontiguousarray(bases)
     assert s.shape[0] == b.shape[0]
     lib().orc_best_multiexp(_p(o), _p(s), _p(b), C.c_uint64(s.shape[0]), C.c_int(threads)); return o
@@ -193,7 +219,7 @@ def dft_naive(a, omega):
 
 def best_fft(a, omega, log_n: int, threads: int | None = None):
     """in place on a copy; returns the transformed array."""
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cpus()
     a = np.array(a, dtype=np.uint64, copy=True, order="C"); assert a.shape[0] == 1 << log_n
     lib().orc_best_fft(_p(a), _p(np.ascontiguousarray(omega)), C.c_uint32(log_n), C.c_int(threads)); return a
 
@@ -227,13 +253,13 @@ def prefix_product(v):
 
 
 def ifft(a, omega_inv, log_n: int, divisor, threads: int | None = None):
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cpus()
     a = np.array(a, dtype=np.uint64, copy=True, order="C")
     lib().orc_ifft(_p(a), _p(np.ascontiguousarray(omega_inv)), C.c_uint32(log_n), _p(np.ascontiguousarray(divisor)), C.c_int(threads)); return a
 
 
 def coeff_to_extended(coeffs, k, ext_k, g_coset, g_coset_inv, ext_omega, threads: int | None = None):
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cpus()
     coeffs = np.ascontiguousarray(coeffs); dst = np.zeros((1 << ext_k, 4), dtype=np.uint64)
     lib().orc_coeff_to_extended(_p(dst), _p(coeffs), C.c_uint32(k), C.c_uint32(ext_k), _p(np.ascontiguousarray(g_coset)),
                                 _p(np.ascontiguousarray(g_coset_inv)), _p(np.ascontiguousarray(ext_omega)), C.c_int(threads))
@@ -241,7 +267,7 @@ def coeff_to_extended(coeffs, k, ext_k, g_coset, g_coset_inv, ext_omega, threads
 
 
 def extended_to_coeff(a, ext_k, g_coset, g_coset_inv, ext_omega_inv, ext_divisor, threads: int | None = None):
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cpus()
     a = np.array(a, dtype=np.uint64, copy=True, order="C")
     lib().orc_extended_to_coeff(_p(a), C.c_uint32(ext_k), _p(np.ascontiguousarray(g_coset)), _p(np.ascontiguousarray(g_coset_inv)),
                                 _p(np.ascontiguousarray(ext_omega_inv)), _p(np.ascontiguousarray(ext_divisor)), C.c_int(threads))

@@ -29,7 +29,7 @@ from tests.test_gpu_properties import dev_scalars, field_commit
 pytestmark = pytest.mark.gpu
 R = pyref.R_MOD
 TAU = 0x5343524F4C4C0001
-NPROC = os.cpu_count() or 1
+NPROC = cref.usable_cpus()   # the cgroup quota, not the host's 256 hardware threads
 
 
 @pytest.fixture(scope="module")
