@@ -1727,11 +1727,11 @@ int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *
 }
 
 // ---- distribute_powers / coset NTT
-static int distribute_powers_locked(void *data_dev, uint64_t n, const void *factor) {
+static int distribute_powers_locked(void *data_dev, uint64_t n, const void *factor, const void *src_dev = nullptr) {
   if (!factor || (n && !data_dev)) return fail(MI355_EBADARG, "distribute_powers: null pointer");
   if (n == 0) return MI355_OK;
   fe_t f; memcpy(&f, factor, 32);
-  hipLaunchKernelGGL(k_distribute_powers, dim3(ceil_div(n, (uint64_t)EVAL_RUN * 256)), dim3(256), 0, g.stream, (fe_t *)data_dev, n, f);
+  hipLaunchKernelGGL(k_distribute_powers, dim3(ceil_div(n, (uint64_t)EVAL_RUN * 256)), dim3(256), 0, g.stream, (const fe_t *)(src_dev ? src_dev : data_dev), (fe_t *)data_dev, n, f);
   HIPCHK(hipGetLastError());
   return MI355_OK;
 }
@@ -1747,8 +1747,7 @@ int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n
   std::lock_guard<std::mutex> lk(g_mu);   // one critical section: copy, coset scaling and transform are queued back to back
   CHK(need_init()); CHK(check_ntt_args(dst_dev, log_n, omega));
   if (!coeffs_dev || !coset_factor) return fail(MI355_EBADARG, "coset_ntt: null pointer");
-  if (dst_dev != coeffs_dev) HIPCHK(hipMemcpyAsync(dst_dev, coeffs_dev, sizeof(fe_t) << log_n, hipMemcpyDeviceToDevice, g.stream));
-  CHK(distribute_powers_locked(dst_dev, 1ull << log_n, coset_factor));
+  CHK(distribute_powers_locked(dst_dev, 1ull << log_n, coset_factor, coeffs_dev));   // dst = coeffs[i] * factor^i (one pass, no copy first)
   CHK(ntt_dev_impl((const fe_t *)dst_dev, 1ull << log_n, (fe_t *)dst_dev, log_n, omega, nullptr, nullptr));
   return finish_async();
   });

@@ -227,7 +227,8 @@ __global__ void __launch_bounds__(256) k_eval_poly_partial(const fe_t *__restric
 }
 // a[i] *= f^i  (halo2_proofs distribute_powers: the coset shift of coeff_to_extended_part / general coset FFTs).
 // Same tiling as k_eval_poly_partial: thread t walks i = base + t + 256 k with a running power stepped by f^256.
-__global__ void __launch_bounds__(256) k_distribute_powers(fe_t *__restrict__ a, uint64_t n, fe_t f_sat) {
+// src == a: in place; otherwise a = src scaled (the coset transforms write the scaled copy straight into their destination: no separate copy)
+__global__ void __launch_bounds__(256) k_distribute_powers(const fe_t *src, fe_t *a, uint64_t n, fe_t f_sat) {
   __shared__ uint32_t lds[9];
   const uint64_t base = (uint64_t)blockIdx.x * 256 * EVAL_RUN;
   const fe29_t f = Fr29::reduce_small(Fr29::from_sat(f_sat));
@@ -241,7 +242,7 @@ __global__ void __launch_bounds__(256) k_distribute_powers(fe_t *__restrict__ a,
   for (uint32_t k = 0; k < EVAL_RUN; k++) {
     const uint64_t i = base + threadIdx.x + 256ull * k;
     if (i >= n) break;
-    g_store(&a[i], fr29_finish(Fr29::mul(Fr29::from_sat_plain(g_load(&a[i])), pw)));
+    g_store(&a[i], fr29_finish(Fr29::mul(Fr29::from_sat_plain(g_load(&src[i])), pw)));
     pw = Fr29::mul(pw, y);
   }
 }
