@@ -164,6 +164,7 @@ def main() -> None:
     ap.add_argument("--single-process", action="store_true", help="N GPUs behind ONE process (mi355_init_multi: shards, worker threads, ncclAllGather inside the library) instead of one rank per GPU")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer leg (mi355_msm_g1_host: scalars cross PCIe inside the call; reported next to, never as, the headline value)")
     ap.add_argument("--no-table-free", action="store_true", help="skip the leg without window tables")
+    ap.add_argument("--no-witness-like", action="store_true", help="skip the witness-like column (with every other leg off the run then launches only the timed uniform MSMs: the profile whose per-kernel averages are comparable with roofline.avg_launch_ms)")
     ap.add_argument("--no-sizes", action="store_true", help="skip the k = 20 / 24 legs (MSM on prefix views of the basis + NTT)")
     ap.add_argument("--host-api", action="store_true", help=argparse.SUPPRESS)   # accepted for older command lines: the leg is on by default now
     args = ap.parse_args()
@@ -394,7 +395,7 @@ def main() -> None:
         #   fork's coeff_to_extended_part) with the pointwise accumulation between them | extended_to_coeff on 2^(k+2) | 4 quotient-piece commits
         #   | 2 batch inversions + 2 grand products (permutation / lookup z) | 27 evaluations | multi-open: 8 axpy + 2 kate_division + 2 commits
         extra["proof_mix"] = proof_mix(zk, lib, check, ptr, h2, dev, k, g, handle, tau, args, rand_scalars)
-    if world == 1 and k <= 26:
+    if world == 1 and k <= 26 and not args.no_witness_like:
         # the second scalar distribution the survey asks for: mostly zeros / tiny values (giant buckets, few entries)
         wl = witness_like_scalars(n, 0x5343524F4C4C0004, dev, h2)
         check(lib.mi355_msm_g1_dev(handle.value, 0, ptr(wl), n, ptr(out)))
