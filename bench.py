@@ -93,6 +93,10 @@ def proof_mix(zk, lib, check, ptr, h2, dev, k, g, g_handle, tau, args, rand_scal
     part = torch.empty((n, 4), dtype=torch.int64, device=dev)
     acc = torch.zeros((Q * n, 4), dtype=torch.int64, device=dev)          # the quotient on the extended domain, part by part
     pt = h2.fr(0x1234567890ABCDEF)
+    # steady state of a prover that runs proof after proof: the library's grow-only workspace arena already has its final size (the 2^(k+2)
+    # transform alone allocates an 8 GiB scratch buffer on its first call, 0.1-0.3 s of hipMalloc that the first run of a process pays once)
+    dom.extended_to_coeff(acc); acc.zero_()
+    h2.batch_invert(part); h2.prefix_product(part, dst=part); h2.kate_division(part, pt, dst=acc[: n - 1]); acc.zero_(); part.zero_()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for p_ in polys:                                                        # witness commitments (Lagrange basis)
         check(lib.mi355_msm_g1_dev(hl.value, 0, ptr(p_), n, ptr(out)))
