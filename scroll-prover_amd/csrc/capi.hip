@@ -64,6 +64,7 @@ struct NttPlan {
   fe_t *tw_m[3] = {nullptr, nullptr, nullptr};
   fe_t *tw_s_lo[2] = {nullptr, nullptr}, *tw_s_hi[2] = {nullptr, nullptr};
   uint32_t split[2] = {0, 0};
+  uint32_t direct2[2] = {0, 0};   // tw29_s_lo[l] is the 2^log_s-entry table [k][column] of a big level (ntt29.cuh)
   // the same tables as w * 2^261 mod r in 29-bit limbs (SoA) for the unsaturated kernels (ntt29.cuh)
   Tw29 tw29_m[3] = {}, tw29_s_lo[2] = {}, tw29_s_hi[2] = {};
   std::vector<void *> owned;
@@ -112,6 +113,7 @@ struct Ctx {
   uint32_t fixup_lanes_max_log = 17;  // MI355_FIXUP_LANES_MAX_LOG: bucket sets up to 2^this records take the four-lanes-per-bucket fix-up
   uint32_t reduce_min_chunk = 4;     // MI355_REDUCE_MIN_CHUNK: shortest running-sum chain (buckets per reduce thread) small bucket sets are cut into
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
+  uint32_t ntt_direct2_max_log = 25;   // MI355_NTT_DIRECT2_MAX_LOG: levels up to 2^this elements read their inter-level twiddles from a full table (36 B per element of the level: 2^24 transform 2.41 -> 2.28 ms for 0.6 GB; at 2^26 the 2.4 GB table only buys 1.7 %, so the default stops at 2^25); 0 disables
   uint32_t ntt_radix_log = 2;   // MI355_NTT_RADIX_LOG
   uint32_t ntt_tile_log = 11;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
   bool ntt29 = true;   // unsaturated 29-bit NTT kernels (MI355_NTT_SAT=1 selects the saturated 8x32 ones for A/B runs)
@@ -668,8 +670,20 @@ int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
       p.split[l] = log_s <= NTT_DIRECT_TW_MAX_LOG ? log_s : (log_s + 1) / 2;
       CHK(pow_table(&p.tw_s_lo[l], w, N >> log_s, 1u << p.split[l]));
       CHK(pow_table(&p.tw_s_hi[l], w, (N >> log_s) << p.split[l], 1u << (log_s - p.split[l])));
+      if (g.ntt29 && log_s > NTT_DIRECT_TW_MAX_LOG && log_s <= g.ntt_direct2_max_log) {
+        // big level: every twiddle w_S^(column k) once, in the order the pass reads them (36 B x 2^log_s: 2.4 GB at 2^26, read coalesced
+        // next to the data by a pass that is ALU-bound); saves the lo x hi product per element
+        const uint64_t cnt = 1ull << log_s; uint4 *lo, *hi; uint32_t *top;
+        HIPCHK(hipMalloc((void **)&lo, cnt * 16)); p.owned.push_back(lo);
+        HIPCHK(hipMalloc((void **)&hi, cnt * 16)); p.owned.push_back(hi);
+        HIPCHK(hipMalloc((void **)&top, cnt * 4)); p.owned.push_back(top);
+        hipLaunchKernelGGL(k_pow_table29_2d, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, g.stream, lo, hi, top, Fr::pow_u64(w, N >> log_s), log_s - lm, cnt);
+        HIPCHK(hipGetLastError());
+        p.tw29_s_lo[l].lo = lo; p.tw29_s_lo[l].hi = hi; p.tw29_s_lo[l].top = top; p.tw29_s_hi[l] = p.tw29_s_lo[l]; p.direct2[l] = 1;
+      } else {
       CHK(pow_table29(p, &p.tw29_s_lo[l], w, N >> log_s, 1u << p.split[l]));
       CHK(pow_table29(p, &p.tw29_s_hi[l], w, (N >> log_s) << p.split[l], 1u << (log_s - p.split[l])));
+      }
     }
     log_s -= lm;
   }
@@ -726,7 +740,7 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
       const uint64_t blocks = (N >> log_s) << (L.log_t - lc);
       Scope sc("ntt_pass");
       if (g.ntt29) {
-        Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l]; L9.direct = (p->split[l] == log_s) ? 1u : 0u;
+        Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l]; L9.direct = p->direct2[l] ? 2u : (p->split[l] == log_s) ? 1u : 0u;
         NTT29_LAUNCH(k_ntt29_strided, (uint32_t)blocks, tile, (size_t)36 * tile, cur, scratch, L9, lc, cur_len, cur_pre);
       } else
       hipLaunchKernelGGL(k_ntt_strided, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, scratch, L, lc, cur_len, cur_pre);
@@ -906,6 +920,7 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
+  { const char *e = getenv("MI355_NTT_DIRECT2_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 0 && v <= 28) g.ntt_direct2_max_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_HOST_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64) g.host_chunks = (uint32_t)v; } }

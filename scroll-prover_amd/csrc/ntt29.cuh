@@ -22,7 +22,7 @@ namespace zk {
 #define ZK_NTT_CHAIN false   // limb products of the NTT butterflies as explicitly chained v_mad (fp29.cuh mac_*)
 #endif
 struct Tw29 { const uint4 *lo; const uint4 *hi; const uint32_t *top; };   // entry i: limbs 0-3, 4-7, 8 of w^i * 2^261 mod r
-struct Ntt29Level { uint32_t log_m, log_t, split; Tw29 tw_m, tw_s_lo, tw_s_hi; uint32_t direct; };   // direct: tw_s_lo holds every inter-level twiddle w_S^e (small levels), no lo x hi product
+struct Ntt29Level { uint32_t log_m, log_t, split; Tw29 tw_m, tw_s_lo, tw_s_hi; uint32_t direct; };   // direct 1: tw_s_lo holds every inter-level twiddle w_S^e (small levels), no lo x hi product; direct 2: tw_s_lo is the table [k][column] = w_S^(column k) of a big level, read like the data (8 adjacent columns per row)
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ fe29_t tw29_load(const Tw29 &T, uint32_t i) {
@@ -140,7 +140,10 @@ template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_
     const uint32_t c = e & (C - 1), k = e >> log_c;
     const fe29_t v = lds29_get(S, (bitrev32(k, L.log_m) << log_c) + c);
     const uint32_t ex = ((cb << log_c) + c) * k;     // inter-level twiddle w_S^(col * k); entry 0 of both tables is the unit
-    const fe29_t w = L.direct ? tw29_load(L.tw_s_lo, ex) : Fr29::mul_t<ZK_NTT_CHAIN>(tw29_load(L.tw_s_lo, ex & smask), tw29_load(L.tw_s_hi, ex >> L.split));
+    // the passes are ALU-bound and leave most of the HBM bandwidth idle: a big level reads its twiddles from a 2^log_s-entry table laid out
+    // like the data (coalesced) instead of multiplying two half-size table entries -- one multiplication per element less in the first pass
+    const fe29_t w = L.direct == 2 ? tw29_load(L.tw_s_lo, ((uint32_t)k << L.log_t) + (cb << log_c) + c)
+                   : L.direct ? tw29_load(L.tw_s_lo, ex) : Fr29::mul_t<ZK_NTT_CHAIN>(tw29_load(L.tw_s_lo, ex & smask), tw29_load(L.tw_s_hi, ex >> L.split));
     g_store(&dst[base + ((uint64_t)k << L.log_t) + c], fr29_finish(Fr29::mul_t<ZK_NTT_CHAIN>(v, w)));
   }
 }
@@ -284,6 +287,15 @@ __global__ void __launch_bounds__(256) k_fr_sum(const fe_t *__restrict__ in, uin
   if (threadIdx.x == 0) { for (uint32_t w = 1; w < 4; w++) acc = Fr::add(acc, lds[w]); g_store(out, acc); }
 }
 
+// table [k][col] (col < 2^log_t) of base^(col k) * 2^261 mod r: the inter-level twiddles of a big level in the order the pass reads them
+__global__ void k_pow_table29_2d(uint4 *lo, uint4 *hi, uint32_t *top, fe_t base, uint32_t log_t, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t k = i >> log_t, col = i & ((1ull << log_t) - 1);
+  fe_t m32; { constexpr uint32_t c[8] = {0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u, 0x819caa80u, 0x5301fa84u, 0x563d4475u, 0xdc83629u}; for (int q = 0; q < 8; q++) m32.l[q] = c[q]; }   // 32 in Montgomery form
+  const fe29_t w = Fr29::from_sat_plain(fr_mul_ps(Fr::pow_u64(base, k * col), m32));
+  lo[i] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]); hi[i] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]); top[i] = w.l[8];
+}
 // SoA twiddle table: entry i = (base^step)^i * 2^261 mod r, canonical 29-bit limbs
 __global__ void k_pow_table29(uint4 *lo, uint4 *hi, uint32_t *top, fe_t base, uint64_t step, uint32_t count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
