@@ -86,8 +86,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(PolyPtrs inl, const fe_t *co
   const fe_t *__restrict__ poly = polys ? polys[m] : inl.p[m];
   const uint32_t half = 1u << (P.c - 1), mask = (1u << P.c) - 1;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) {
-    fe_t one_c = Fr::zero(); one_c.l[0] = 1;
-    const fe_t k = fr_mul_ps(g_load(&poly[i]), one_c);   // Montgomery -> canonical (= to_repr())
+    const fe_t k = Fr::redc(g_load(&poly[i]));   // Montgomery -> canonical (= to_repr()): the reduction alone, 64 multiply-adds instead of a product by one
     // the scalar is consumed c bits at a time by shifting the whole 256-bit value right (8 funnel shifts per window, static
     // register indices); indexing k.l[bit >> 5] with a runtime window position would put the limbs in scratch memory
     // k and r - k name the same term up to the sign of the point: take the smaller one.  Uniform scalars gain nothing, but the small

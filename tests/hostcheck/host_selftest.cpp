@@ -23,6 +23,7 @@ template <class F, class P> static void binop(int op, fe_t *o, const fe_t *a, co
     case 8: *o = mont_sqr_ps<P>(*a); break;
     case 9: *o = F::inv_bgcd(*a); break;
     case 10: *o = F::inv_sgcd(*a); break;
+    case 11: *o = F::redc(*a); break;
   }
 }
 extern "C" void hs_f_op(int which, int op, void *o, const void *a, const void *b) {

@@ -52,6 +52,8 @@ def test_field_ops_bit_exact(hs):
             assert (op(hs, w, 1, a, b) == cref.f_sub(w, a, b)).all()
             assert (op(hs, w, 5, np.array(pyref.to_limbs(vals[i]), dtype=np.uint64)) == a).all()
             assert (op(hs, w, 6, a) == np.array(pyref.to_limbs(vals[i]), dtype=np.uint64)).all()
+            assert (op(hs, w, 11, a) == np.array(pyref.to_limbs(vals[i]), dtype=np.uint64)).all()      # reduction-only conversion (k_msm_digits)
+            assert pyref.from_limbs(op(hs, w, 11, np.array(pyref.to_limbs(vals[i]), dtype=np.uint64))) == vals[i] * pow(1 << 256, -1, m) % m
         for i in range(0, 40):
             assert (op(hs, w, 3, mont[i]) == cref.f_inv(w, mont[i])).all()
         for i in range(len(vals)):                                        # binary-Euclid inverse used by the one-lane normalisations
