@@ -414,7 +414,7 @@ def main() -> None:
         cw, ww, ew = C.c_int(), C.c_int(), C.c_uint64()
         check(lib.mi355_msm_last_plan(C.byref(cw), C.byref(ww), C.byref(ew)))
         ok_w = None
-        if k <= 24:
+        if k <= 26:   # ~3 s of host time at 2^26 (one Horner pass), outside every timed region
             from oracle import cref
             ok_w = bool((np.asarray(out)[:8] == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(wl.cpu().numpy().view(np.uint64), tau_m)))).all())
         extra["witness_like"] = {"ms_per_commit": dt_w * 1e3, "pairs_per_s": n / dt_w, "verified_against_field_check": ok_w, "msm_phase_ms": ph_w,
