@@ -79,6 +79,14 @@ template <int R, bool LAST> __device__ __forceinline__ void lds_dif29_round(cons
       }
     }
     fe29_t x[Q];
+    // A sum of two CARRIED values needs no carry pass of its own: its limbs stay below 2^30 + 16, which the next stage's sum (32-bit limbs),
+    // difference (fr29_sub64: u < 2^30.1, v <= 2^30 + 64) and the pass-closing multiplication all accept.  Only sums with an un-carried operand
+    // are carried -- half the carry passes of a round.  Whether the operands of a butterfly are un-carried is a function of the stage and of
+    // the index bits already processed in this round (values read from LDS count as un-carried: the previous round stores its last sums as
+    // they are; a difference is a multiplication output): loose_t = (bit processed at stage t - 1 is 0) and not loose_(t-1), loose_0 = true.
+    // Codegen note: the choice is written as a limb-wise select between the two variants below.  As `if (in_loose) sum = carry(sum)` on the
+    // 36-byte value the compiler kept the butterfly operands in scratch memory (ScratchSize 240, 90 registers) and the transform took 29 ms
+    // instead of 10; check `hipcc -S` (ScratchSize 0, 122 registers) after touching this loop.
 #pragma unroll
     for (uint32_t q = 0; q < Q; q++) x[q] = lds29_get(L, (base | (q << b_lo)) * sm + c * sc);
 #pragma unroll
@@ -91,8 +99,14 @@ template <int R, bool LAST> __device__ __forceinline__ void lds_dif29_round(cons
         if (q0 & (1u << bit)) continue;
         const uint32_t q1 = q0 | (1u << bit);
         const fe29_t u = x[q0], v = x[q1];
-        fe29_t sum = Fr29::carry(Fr29::add(u, v));
-        if (reduce_now) sum = Fr29::reduce_small(Fr29::normalise(sum));
+        // both operands share the processed bits, hence one flag; R <= 3: stage 0 carries, stage 1 does not, stage 2 carries the sums of stage-1 sums
+        static_assert(R <= 3, "closed form of the recurrence for three stages");
+        const bool in_loose = t == 0 ? true : t == 1 ? false : !((q0 >> (R - 2)) & 1u);
+        const fe29_t s_raw = Fr29::add(u, v), s_car = Fr29::carry(s_raw);
+        fe29_t sum;
+#pragma unroll
+        for (int i = 0; i < 9; i++) sum.l[i] = in_loose ? s_car.l[i] : s_raw.l[i];   // a compile-time choice per butterfly: the unused variant is dead code
+        if (reduce_now) sum = Fr29::reduce_small(Fr29::normalise(s_raw));            // normalise is the full carry propagation
         // u - v + 64 r < 103 r: reduce_small is exact up to 2^261 = 168 r (host-checked), result tight < 2 r
         if (LAST && (q0 & ((1u << bit) - 1)) == 0) { x[q1] = Fr29::reduce_small(Fr29::normalise(fr29_sub64(u, v))); n++; }
         else x[q1] = Fr29::mul_t<ZK_NTT_CHAIN>(fr29_sub64(u, v), tw[t][n++]);
