@@ -498,7 +498,7 @@ def main() -> None:
         pairs_per_launch = n / chunks / (args.gpus if single else 1)   # one accumulate launch processes one chunk of this device's point range, all windows
         achieved = 96.0 * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else None
         # HBM bytes of one k_msm_accumulate launch from the PMC counters: RECORDED from a separate rocprofv3 --pmc pass over this same
-        # command (profiles/r02_pmc_msm_k26.md), not measured inside this run (counter collection cannot share a run with the timing)
+        # command (profiles/r02b_pmc_msm_k26.md), not measured inside this run (counter collection cannot share a run with the timing)
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and not single and world == 1:
@@ -523,7 +523,7 @@ def main() -> None:
                          "pairs_per_launch": pairs_per_launch,
                          "alu": {"achieved": (pairs_per_launch * W / (acc_avg_ms * 1e-3)) if acc_avg_ms > 0 else None, "peak": MADD_CHAIN_PEAK, "unit": "G1 mixed additions/s",
                                  "frac": (pairs_per_launch * W / (acc_avg_ms * 1e-3) / MADD_CHAIN_PEAK) if acc_avg_ms > 0 else None,
-                                 "source": "profiles/r02_microbench.log (xyzz29 madd chain, 3 waves/SIMD, boost clock); SQ counters: VALU 98.6 % busy at the sustained 1.96 GHz, 2 371 VALU instructions per addition, profiles/r02_sq_counters.md"},
+                                 "source": "profiles/r02_microbench.log (xyzz29 madd chain, 3 waves/SIMD, boost clock); SQ counters: VALU 98 % busy at the sustained 1.96 GHz, 2 193 VALU instructions per addition, profiles/r02b_sq_counters.md"},
                          "note": "algorithmic bytes = 96 B per (scalar, point) pair x pairs per launch (SURVEY 8d); the kernel is VALU-integer bound, see DESIGN.md"},
             "cpu_baseline": cpu, "ntt": ntt,
         }
