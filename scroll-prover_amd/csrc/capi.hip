@@ -64,7 +64,8 @@ struct NttPlan {
   fe_t *tw_m[3] = {nullptr, nullptr, nullptr};
   fe_t *tw_s_lo[2] = {nullptr, nullptr}, *tw_s_hi[2] = {nullptr, nullptr};
   uint32_t split[2] = {0, 0};
-  uint32_t direct2[2] = {0, 0};   // tw29_s_lo[l] is the 2^log_s-entry table [k][column] of a big level (ntt29.cuh)
+  uint32_t direct2[2] = {0, 0};
+  std::map<std::string, Tw29> scaled;   // the last strided level's direct twiddle table times a constant (key: the 32 bytes of the constant)   // tw29_s_lo[l] is the 2^log_s-entry table [k][column] of a big level (ntt29.cuh)
   // the same tables as w * 2^261 mod r in 29-bit limbs (SoA) for the unsaturated kernels (ntt29.cuh)
   Tw29 tw29_m[3] = {}, tw29_s_lo[2] = {}, tw29_s_hi[2] = {};
   std::vector<void *> owned;
@@ -114,6 +115,7 @@ struct Ctx {
   uint32_t reduce_min_chunk = 4;     // MI355_REDUCE_MIN_CHUNK: shortest running-sum chain (buckets per reduce thread) small bucket sets are cut into
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
   uint32_t ntt_direct2_max_log = 25;   // MI355_NTT_DIRECT2_MAX_LOG: levels up to 2^this elements read their inter-level twiddles from a full table (36 B per element of the level: 2^24 transform 2.41 -> 2.28 ms for 0.6 GB; at 2^26 the 2.4 GB table only buys 1.7 %, so the default stops at 2^25); 0 disables
+  uint32_t ntt_fold_scale = 1;  // MI355_NTT_FOLD_SCALE=0: the inverse transform's divisor stays a multiplication in the closing pass
   uint32_t ntt_radix_log = 2;   // MI355_NTT_RADIX_LOG
   uint32_t ntt_tile_log = 11;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
   bool ntt29 = true;   // unsaturated 29-bit NTT kernels (MI355_NTT_SAT=1 selects the saturated 8x32 ones for A/B runs)
@@ -719,6 +721,28 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     }
   }
   NttPlan *p; CHK(get_plan(log_n, omega, &p));
+  // an inverse transform's divisor (the three post-scaling constants equal) is folded into the inter-level twiddles of the last strided
+  // pass: one table of 2^log_s entries per (plan, divisor), and the closing pass ends with reduce_small instead of a multiplication
+  const Tw29 *fold_tw = nullptr;
+  if (post3_host && !pre3_host && g.ntt29 && g.ntt_fold_scale && p->levels >= 2 && memcmp(&post3_host[0], &post3_host[1], 32) == 0 && memcmp(&post3_host[0], &post3_host[2], 32) == 0) {
+    const uint32_t l = p->levels - 2;
+    uint32_t log_sl = log_n; for (uint32_t q = 0; q < l; q++) log_sl -= p->log_m[q];
+    if (p->split[l] == log_sl && !p->direct2[l]) {   // that level reads ONE direct table
+      const std::string key((const char *)&post3_host[0], 32);
+      auto it = p->scaled.find(key);
+      if (it == p->scaled.end()) {
+        const uint32_t cnt = 1u << log_sl; uint4 *lo, *hi; uint32_t *top;
+        HIPCHK(hipMalloc((void **)&lo, (size_t)cnt * 16)); p->owned.push_back(lo);
+        HIPCHK(hipMalloc((void **)&hi, (size_t)cnt * 16)); p->owned.push_back(hi);
+        HIPCHK(hipMalloc((void **)&top, (size_t)cnt * 4)); p->owned.push_back(top);
+        hipLaunchKernelGGL(k_scale_table29, dim3(ceil_div(cnt, 256)), dim3(256), 0, s, p->tw29_s_lo[l].lo, p->tw29_s_lo[l].hi, p->tw29_s_lo[l].top, lo, hi, top, post3_host[0], cnt);
+        HIPCHK(hipGetLastError());
+        Tw29 t; t.lo = lo; t.hi = hi; t.top = top;
+        it = p->scaled.emplace(key, t).first;
+      }
+      fold_tw = &it->second; post3 = nullptr;
+    }
+  }
   CallTrace tr("ntt_fr", N, 64.0);
   Scope total("ntt_total");
   if (p->levels == 1) {
@@ -741,6 +765,7 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
       Scope sc("ntt_pass");
       if (g.ntt29) {
         Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l]; L9.direct = p->direct2[l] ? 2u : (p->split[l] == log_s) ? 1u : 0u;
+        if (fold_tw && l + 2 == p->levels) L9.tw_s_lo = *fold_tw;
         NTT29_LAUNCH(k_ntt29_strided, (uint32_t)blocks, tile, (size_t)36 * tile, cur, scratch, L9, lc, cur_len, cur_pre);
       } else
       hipLaunchKernelGGL(k_ntt_strided, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, scratch, L, lc, cur_len, cur_pre);
@@ -921,6 +946,7 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
   { const char *e = getenv("MI355_NTT_DIRECT2_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 0 && v <= 28) g.ntt_direct2_max_log = (uint32_t)v; } }
+  { const char *e = getenv("MI355_NTT_FOLD_SCALE"); if (e) g.ntt_fold_scale = e[0] == '0' ? 0u : 1u; }
   { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_HOST_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64) g.host_chunks = (uint32_t)v; } }

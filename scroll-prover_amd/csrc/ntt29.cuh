@@ -101,7 +101,7 @@ template <int R, bool LAST> __device__ __forceinline__ void lds_dif29_round(cons
         const fe29_t u = x[q0], v = x[q1];
         // both operands share the processed bits, hence one flag; R <= 3: stage 0 carries, stage 1 does not, stage 2 carries the sums of stage-1 sums
         static_assert(R <= 3, "closed form of the recurrence for three stages");
-        const bool in_loose = t == 0 ? true : t == 1 ? false : !((q0 >> (R - 2)) & 1u);
+        const bool in_loose = t == 0 ? true : t == 1 ? false : !((q0 >> (R >= 2 ? R - 2 : 0)) & 1u);
         const fe29_t s_raw = Fr29::add(u, v), s_car = Fr29::carry(s_raw);
         fe29_t sum;
 #pragma unroll
@@ -308,6 +308,15 @@ __global__ void k_pow_table29_2d(uint4 *lo, uint4 *hi, uint32_t *top, fe_t base,
   const uint64_t k = i >> log_t, col = i & ((1ull << log_t) - 1);
   fe_t m32; { constexpr uint32_t c[8] = {0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u, 0x819caa80u, 0x5301fa84u, 0x563d4475u, 0xdc83629u}; for (int q = 0; q < 8; q++) m32.l[q] = c[q]; }   // 32 in Montgomery form
   const fe29_t w = Fr29::from_sat_plain(fr_mul_ps(Fr::pow_u64(base, k * col), m32));
+  lo[i] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]); hi[i] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]); top[i] = w.l[8];
+}
+// dst[i] = src[i] * d (d: Montgomery form of the ABI): a twiddle table with a constant folded in -- the inverse transform's divisor rides on
+// the inter-level twiddles of its last strided pass instead of costing the closing pass one more multiplication per element
+__global__ void k_scale_table29(const uint4 *slo, const uint4 *shi, const uint32_t *stop, uint4 *lo, uint4 *hi, uint32_t *top, fe_t d, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  Tw29 S; S.lo = slo; S.hi = shi; S.top = stop;
+  const fe29_t w = Fr29::cond_sub_p(Fr29::normalise(Fr29::mul(tw29_load(S, i), Fr29::from_sat(d))));   // (w 2^261)(d 2^261) / 2^261, canonical
   lo[i] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]); hi[i] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]); top[i] = w.l[8];
 }
 // SoA twiddle table: entry i = (base^step)^i * 2^261 mod r, canonical 29-bit limbs
