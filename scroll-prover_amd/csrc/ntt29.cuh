@@ -6,10 +6,12 @@
 //     w * 2^261 mod r (canonical, SoA tables), so Montgomery products with R' = 2^261 land back in the x * 2^256 domain
 //   * butterfly (DIF): sum = carry(u + v), dif = (u - v + 64 r) * w  -- no branch for w = 1 (table entry 0 is the unit)
 //   * value growth: a sum doubles the bound; after stages 5 and 10 of a tile the sums are brought back below 2r with
-//     reduce_small (no multiplication); differences come out of a multiplication (< 1.6 r).  Bounds: start < 1.2 r,
+//     reduce_small (no multiplication); differences come out of a multiplication (< 1.6 r).  Bounds: start < 1.4 r (a pass reads canonical
+//     input or the previous pass's multiplication output),
 //     <= 38.4 r before a reduction, 64 r is the limit of sub64 / reduce_small.
 //   * elements leave a pass through a multiplication (inter-level twiddle, or the ifft / coset factor) or reduce_small,
-//     then one conditional subtraction: everything written to HBM is canonical, so results stay bit-exact.
+//     then (closing pass) one conditional subtraction: everything the caller sees is canonical, so results stay bit-exact; the strided passes
+//     leave the tight multiplication output (< 1.4 r) in the scratch buffer as it is.
 // LDS: 36 B per element as two 16-byte planes + one 4-byte plane (4096-element tile = 144 KiB of the 160 KiB).
 #pragma once
 #include "fp29.cuh"
@@ -158,7 +160,10 @@ template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_
     // like the data (coalesced) instead of multiplying two half-size table entries -- one multiplication per element less in the first pass
     const fe29_t w = L.direct == 2 ? tw29_load(L.tw_s_lo, ((uint32_t)k << L.log_t) + (cb << log_c) + c)
                    : L.direct ? tw29_load(L.tw_s_lo, ex) : Fr29::mul_t<ZK_NTT_CHAIN>(tw29_load(L.tw_s_lo, ex & smask), tw29_load(L.tw_s_hi, ex >> L.split));
-    g_store(&dst[base + ((uint64_t)k << L.log_t) + c], fr29_finish(Fr29::mul_t<ZK_NTT_CHAIN>(v, w)));
+    // the strided passes only ever write the library's scratch buffer: their outputs stay the multiplication's tight value (< 1.4 r < 2^256, exact
+    // limbs) re-sliced to 8 x 32 bits -- no conditional subtraction; the next pass starts from < 1.4 r (five doublings: < 45 r < the 64 r limit) and
+    // only the closing pass, whose output the caller sees, makes everything canonical
+    g_store(&dst[base + ((uint64_t)k << L.log_t) + c], Fr29::to_sat_plain(Fr29::mul_t<ZK_NTT_CHAIN>(v, w)));
   }
 }
 
