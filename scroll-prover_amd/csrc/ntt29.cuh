@@ -8,7 +8,7 @@
 //   * value growth: a sum doubles the bound; after stages 5 and 10 of a tile the sums are brought back below 2r with
 //     reduce_small (no multiplication); differences come out of a multiplication (< 1.6 r).  Bounds: start < 1.4 r (a pass reads canonical
 //     input or the previous pass's multiplication output),
-//     <= 38.4 r before a reduction, 64 r is the limit of sub64 / reduce_small.
+//     <= 44.8 r before a reduction, 64 r is the limit of sub64 / reduce_small.
 //   * elements leave a pass through a multiplication (inter-level twiddle, or the ifft / coset factor) or reduce_small,
 //     then (closing pass) one conditional subtraction: everything the caller sees is canonical, so results stay bit-exact; the strided passes
 //     leave the tight multiplication output (< 1.4 r) in the scratch buffer as it is.
