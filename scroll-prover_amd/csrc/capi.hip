@@ -106,7 +106,7 @@ struct Ctx {
   uint32_t seg_factor = 16;
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
-  uint32_t seg_fill = 40, seg_fill_segfix = 40;   // MI355_SEG_FILL / MI355_SEG_FILL_SEGFIX (even, 2..126 %): share of the launched accumulate threads the actual entries are spread over
+  uint32_t seg_fill = 40, seg_fill_segfix = 40;   // MI355_SEG_FILL / MI355_SEG_FILL_SEGFIX (even, 2..100 %: above 100 the segments would no longer cover the entries): share of the launched accumulate threads the actual entries are spread over
   uint32_t seg_min = 16;             // MI355_SEG_MIN: shortest accumulate segment (entries per thread) when few digits are non-zero
   uint32_t fixup_mode = 2;           // MI355_FIXUP_MODE: 2 = by shape (see msm_enqueue), 0 = per-bucket kernels (four lanes / workgroup / several workgroups per bucket), 1 = one segmented reduction over the partial sums (k_msm_segfix: measured better for two-partial buckets, worse for spans of 15-30, profiles/r02b_segfix_ab.log)
   uint32_t fixup_huge_min = 2048;    // MI355_FIXUP_HUGE_MIN (>= 2048): bucket spans from this many accumulate threads on are summed by several workgroups
@@ -933,8 +933,8 @@ static int init_ctx(int slot, int device_id) {
 #endif
   { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 7; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
-  { const char *e = getenv("MI355_SEG_FILL"); if (e) { int v = atoi(e); if (v >= 2 && v <= 126) g.seg_fill = (uint32_t)v; } }
-  { const char *e = getenv("MI355_SEG_FILL_SEGFIX"); if (e) { int v = atoi(e); if (v >= 2 && v <= 126) g.seg_fill_segfix = (uint32_t)v; } }
+  { const char *e = getenv("MI355_SEG_FILL"); if (e) { int v = atoi(e); if (v >= 2 && v <= 100) g.seg_fill = (uint32_t)v; } }
+  { const char *e = getenv("MI355_SEG_FILL_SEGFIX"); if (e) { int v = atoi(e); if (v >= 2 && v <= 100) g.seg_fill_segfix = (uint32_t)v; } }
   { const char *e = getenv("MI355_SEG_MIN"); if (e) { int v = atoi(e); if (v >= 1 && v <= 4096) g.seg_min = (uint32_t)v; } }
   { const char *e = getenv("MI355_FIXUP_MODE"); if (e && e[0] >= '0' && e[0] <= '2') g.fixup_mode = (uint32_t)(e[0] - '0'); }
   { const char *e = getenv("MI355_FIXUP_HUGE_MIN"); if (e) { long v = atol(e); if (v >= 2048 && v <= 0x7fffffffL) g.fixup_huge_min = (uint32_t)v; } }

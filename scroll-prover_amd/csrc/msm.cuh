@@ -328,7 +328,7 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
 // every SIMD at its three waves, while every further thread only adds partial sums for the fix-up to merge -- calibrated on witness-like,
 // byte-valued and all-ones columns at 2^26, profiles/r02b_segment_calibration.log).
 __device__ __forceinline__ uint32_t msm_seg_eff(uint32_t total, uint32_t threads, uint32_t seg_max, uint32_t seg_min, uint32_t fill_pct) {
-  const uint64_t target = ((uint64_t)threads * fill_pct + 99) / 100;
+  const uint64_t target = ((uint64_t)threads * (fill_pct > 100u ? 100u : fill_pct) + 99) / 100;   // never more than the launched threads: threads * segment must cover the entries
   uint32_t sg = (uint32_t)(((uint64_t)total + target - 1) / (target ? target : 1));
   sg = sg < seg_min ? seg_min : sg;
   return sg > seg_max ? seg_max : sg;

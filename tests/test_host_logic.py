@@ -122,3 +122,30 @@ def test_signed_digit_recoding_algorithm():
         if c >= 8:
             digits, _ = recode(R - 100, c)
             assert digits[0] == -100 and all(d == 0 for d in digits[1:])
+
+
+def test_accumulate_segment_rule_covers_every_entry():
+    """msm_seg_eff (msm.cuh), restated in integers: the accumulate launch is sized for the worst case (threads = ceil(emax / seg_max) rounded to
+    workgroups), and every kernel derives the segment from the actual entry count as clamp(ceil(total / (fill % of the threads)), seg_min,
+    seg_max).  Whatever the count, threads * segment must cover it, and a full column must get the worst-case segment back."""
+    import random
+
+    def seg_eff(total, threads, seg_max, seg_min, fill_pct):
+        target = (threads * min(fill_pct, 100) + 99) // 100          # the kernel clamps the percentage: more than the launched threads cannot take entries
+        sg = (total + target - 1) // max(target, 1)
+        return min(max(sg, seg_min), seg_max)
+
+    rng = random.Random(7)
+    for _ in range(20000):
+        emax = rng.choice([rng.randrange(1, 1 << 12), rng.randrange(1, 1 << 24), rng.randrange(1, (1 << 32) - 1)])
+        want_threads = 256 * 256 * 16
+        seg_max = min(max((emax + want_threads - 1) // want_threads, 16), 4096)
+        threads = -(-(-(-emax // seg_max)) // 256) * 256
+        seg_min = min(rng.choice([1, 16, 64, 256, 4096]), seg_max)
+        fill = rng.choice([2, 20, 40, 60, 100, 126])
+        total = rng.choice([0, 1, emax, emax // 7, rng.randrange(0, emax + 1)])
+        sg = seg_eff(total, threads, seg_max, seg_min, fill)
+        assert seg_min <= sg <= seg_max
+        assert threads * sg >= total, (emax, total, threads, sg)
+        if total == emax and fill <= 100:
+            assert sg == seg_max or sg * threads >= emax      # nothing is lost for a column in which every digit is non-zero
