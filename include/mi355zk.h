@@ -19,21 +19,26 @@
  *
  * Pointer flavours: `*_host` arguments are ordinary process memory owned by the caller (Rust Vec<..>): the
  * library copies to HBM, computes and copies back before returning.  `*_dev` arguments are HIP device
- * pointers on the bound device (used by the bench and by callers that keep polynomials resident).
+ * pointers on a bound device: blocks from mi355_buf_alloc (what the Rust shim's DevicePoly holds) or any other device
+ * allocation (torch tensors in the bench) -- for callers that keep polynomials resident, SURVEY §8f-1.
  *
  * Errors: every function returns 0 on success or one of MI355_E*; nothing throws, aborts or unwinds across
  * the boundary.  mi355_last_error() gives a thread-local message.  There is NO CPU fallback inside the
  * library: without a usable gfx950 device every compute entry point fails with MI355_ENODEVICE and the
  * caller (the Rust shim) decides what to do.
  *
- * Threading: entry points are serialised by an internal mutex and may be called from any thread (rayon workers): the bound device
- * is re-selected on the calling thread.  The MSM options (mi355_msm_set_normalise / _set_window_bits) are per calling THREAD.
+ * Threading: entry points may be called from any thread (rayon workers); the bound device is re-selected on the calling thread.  Locks are PER
+ * DEVICE: a call that works on one device (every transform, scan, evaluation, element-wise operation, buffer copy) holds that device's lock
+ * only, so callers on different devices run concurrently; MSM entry points hold every bound device (the point range is sharded over all of
+ * them); lifecycle and SRS management hold everything.  The MSM options (mi355_msm_set_normalise / _set_window_bits) are per calling
+ * THREAD: a setting made on one thread does not affect MSMs issued from another.  mi355_profile_enable may be called before mi355_init.
  *
  * Devices: mi355_init(id) binds one device (one process per GPU).  mi355_init_multi(ids, n) binds n devices to ONE process -- the shape
  * of the reference, where one prover process holds one params_map [REF integration/src/prove.rs:11-21]: registered bases are then
  * sharded by point range over the devices, every MSM entry point fans out behind the same signature, the per-device partial sums are
- * exchanged with one ncclAllGather (RCCL over xGMI) and folded on the first device.  NTTs and all other entry points run on
- * the first device (replicas only at k <= 26).
+ * exchanged with one ncclAllGather (RCCL over xGMI) and folded on the first device.  The NTT does not shard at k <= 26
+ * ("replicas only"): a `*_dev` call runs on the device that owns its operands (mi355_buf_alloc(.., slot)), a `*_host` call on whichever
+ * bound device is free (round-robin), and the `*_batch_*` transforms deal independent polynomials over all bound devices.
  */
 #ifndef MI355ZK_H
 #define MI355ZK_H
@@ -69,6 +74,23 @@ int mi355_set_stream(void *hip_stream);
 int mi355_reset_stream(void);
 /* Block until everything queued by the library has finished.                                                  */
 int mi355_synchronize(void);
+
+/* ---- resident buffers: where a proof's polynomials live between the calls of create_proof (the reference's caller is one long
+ *      create_proof per layer [REF integration/src/prove.rs:36-43,67,96]).  A Rust `DevicePoly` (rust_shim/mi355zk.rs) owns one block and frees
+ *      it on Drop; every `*_dev` entry point accepts pointers into these blocks (at any offset) -- and any other HIP device pointer of a bound
+ *      device -- and runs on the device that owns them.  device_slot indexes the list given to mi355_init_multi (0 = the primary / only device).
+ *      mi355_buf_free returns the block to a pool (no hipFree, which would synchronise the device); work already queued on it stays valid.   */
+int mi355_buf_alloc(uint64_t bytes, int device_slot, void **dev_ptr_out);
+int mi355_buf_free(void *dev_ptr);
+int mi355_buf_trim(void);                                   /* give every pooled (free) block back to HIP                                  */
+int mi355_buf_slot(const void *dev_ptr, int *slot_out);     /* which device slot owns this pointer                                         */
+/* host -> device on the owner's COPY stream: overlaps the compute already queued; an upload into a block no call has used since
+ * mi355_buf_alloc waits only for the work queued on it before its last mi355_buf_free.  Later calls see the data; on return the host buffer
+ * may be reused.                                                                                                                          */
+int mi355_buf_upload(void *dst_dev, const void *src_host, uint64_t bytes);
+int mi355_buf_download(void *dst_host, const void *src_dev, uint64_t bytes);   /* ordered after everything queued on the owner; synchronous */
+int mi355_buf_copy(void *dst_dev, const void *src_dev, uint64_t bytes);        /* within a device or between two bound devices (xGMI)       */
+int mi355_buf_zero(void *dst_dev, uint64_t bytes);
 
 /* ---- SRS ownership: ParamsKZG { g, g_lagrange } [halo2_proofs poly/kzg/commitment.rs], held for the process
  *      lifetime by the caller's params_map [REF bin/src/trace_prover.rs:35-43], [REF integration/src/prove.rs:12,26,58].
@@ -159,6 +181,14 @@ int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_
  * what `coeff_to_extended_part(poly, g_coset * extended_omega^j)` of the scroll fork does per quotient part [EXT-recalled domain.rs]. */
 int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *factor);
 int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, const void *coset_factor, const void *omega);
+/* `batch` independent transforms in one call -- the loops of create_proof over columns (the iNTT of every advice column, the
+ * coset NTTs of every polynomial that enters evaluate_h; 8 + 32 for a layer-4 proof [REF integration/configs/layer4.config:3-10]).
+ * divisor == NULL: best_fft; divisor = n^-1: EvaluationDomain::ifft.  Host pointers are dealt round-robin over the bound devices (one
+ * worker thread, staging buffer and PCIe link per device); device pointers run on the device that owns them, concurrently across
+ * devices.  Results equal the serial loop's.                                                                                        */
+int mi355_ntt_fr_batch_host(void *const *data_host, uint32_t batch, uint32_t log_n, const void *omega, const void *divisor);
+int mi355_ntt_fr_batch_dev(void *const *data_dev, uint32_t batch, uint32_t log_n, const void *omega, const void *divisor);
+int mi355_coset_ntt_fr_batch_dev(void *const *dst_dev, const void *const *coeffs_dev, uint32_t batch, uint32_t log_n, const void *coset_factor, const void *omega);
 
 /* element-wise operations on device-resident vectors of Fr (op 0: a + b, 1: a - b, 2: a * b; dst may alias a or b) and
  * data[i] *= table[i mod period] (period a power of two <= 4096; EvaluationDomain::divide_by_vanishing_poly multiplies the extended

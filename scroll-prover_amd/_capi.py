@@ -22,6 +22,14 @@ SIGNATURES = {
     "mi355_set_stream": (_int, [_vp]),
     "mi355_reset_stream": (_int, []),
     "mi355_synchronize": (_int, []),
+    "mi355_buf_alloc": (_int, [_u64, _int, C.POINTER(_vp)]),
+    "mi355_buf_free": (_int, [_vp]),
+    "mi355_buf_trim": (_int, []),
+    "mi355_buf_slot": (_int, [_vp, C.POINTER(_int)]),
+    "mi355_buf_upload": (_int, [_vp, _vp, _u64]),
+    "mi355_buf_download": (_int, [_vp, _vp, _u64]),
+    "mi355_buf_copy": (_int, [_vp, _vp, _u64]),
+    "mi355_buf_zero": (_int, [_vp, _u64]),
     "mi355_srs_register_host": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "mi355_srs_register_dev": (_int, [_vp, _u64, _int, C.POINTER(_u64)]),
     "mi355_srs_register_prefix": (_int, [_u64, _u64, C.POINTER(_u64)]),
@@ -53,6 +61,9 @@ SIGNATURES = {
     "mi355_extended_to_coeff_dev": (_int, [_vp, _u32, _vp, _vp, _vp, _vp]),
     "mi355_distribute_powers_fr_dev": (_int, [_vp, _u64, _vp]),
     "mi355_coset_ntt_fr_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
+    "mi355_ntt_fr_batch_host": (_int, [C.POINTER(_vp), _u32, _u32, _vp, _vp]),
+    "mi355_ntt_fr_batch_dev": (_int, [C.POINTER(_vp), _u32, _u32, _vp, _vp]),
+    "mi355_coset_ntt_fr_batch_dev": (_int, [C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp]),
     "mi355_fr_vec_axpy_dev": (_int, [_vp, _vp, _vp, _vp, _u64]),
     "mi355_fr_vec_op_dev": (_int, [_int, _vp, _vp, _vp, _u64]),
     "mi355_fr_vec_mul_periodic_dev": (_int, [_vp, _u64, _vp, _u32]),

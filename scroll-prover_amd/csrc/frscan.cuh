@@ -131,6 +131,7 @@ template <int PHASE> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_pref
   }
 }
 
+#ifndef ZK_FRSCAN_DEVICE_ONLY   // the non-template kernels are emitted by ONE translation unit (lib_aux.hip); lib_msm.hip only uses the block scans
 // exclusive scan of the m tile products by one workgroup (thread t owns a contiguous run); total_out = product of everything
 __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_scan_tile_products(const fe_t *__restrict__ tile_prod, fe_t *__restrict__ tile_prefix, uint32_t m, fe_t *__restrict__ total_out) {
   __shared__ uint32_t buf[2 * FRSCAN_THREADS * 9];
@@ -142,6 +143,8 @@ __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_scan_tile_products(const 
   for (uint32_t i = lo; i < hi; i++) { g_store(&tile_prefix[i], ex); ex = fr_mul_ps(ex, g_load(&tile_prod[i])); }
   if (threadIdx.x == 0) g_store(total_out, total);
 }
+
+#endif  // ZK_FRSCAN_DEVICE_ONLY
 
 // ---- first-order linear recurrence with a constant multiplier: P_j = b_j + m * P_(j-1), P_(-1) = 0, j < n.
 // halo2's kate_division(a, z) = (a(X) - a(z)) / (X - z) [EXT-recalled halo2_proofs src/arithmetic.rs; the quotient polynomials of the
@@ -198,6 +201,7 @@ template <int FINAL> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_linr
   }
 }
 
+#ifndef ZK_FRSCAN_DEVICE_ONLY
 // ---- group::Curve::batch_normalize(&[G1], &mut [G1Affine]) [EXT-recalled halo2curves / group crate; create_proof turns each vector of
 // projective commitments into affine points with it before they enter the transcript, SURVEY 8f-3]: out[i] = (X / Z^2, Y / Z^3), the
 // identity (Z = 0) becomes (0, 0).  Montgomery's trick per 256-point tile: the Z coordinates are scanned from both ends through LDS
@@ -222,6 +226,7 @@ __global__ void __launch_bounds__(FRSCAN_THREADS) k_g1_batch_normalize(const g1_
   }
   g_store(&out[i].x, r.x); g_store(&out[i].y, r.y);
 }
+#endif  // ZK_FRSCAN_DEVICE_ONLY
 
 #endif  // __HIPCC__
 }  // namespace zk

@@ -1,0 +1,505 @@
+// lib_ntt.hip -- libmi355zk.so, the Fr translation unit: launch orchestration of ntt.cuh / ntt29.cuh (plan cache, <= 3 global passes), the
+// EvaluationDomain wrappers (ifft, coset extension and its inverse), distribute_powers, the element-wise vector operations, the gate-shaped
+// fused evaluation (mi355_fr_gate_eval_dev), eval_polynomial, and the batched / replicated entry points that spread independent transforms
+// over the bound devices.  Host logic only; all arithmetic runs in the kernels.
+// kernel headers first: lib_common.hpp defines the macro `g` (the calling thread's device context), a name the kernels use for locals
+#include "ntt.cuh"
+#include "ntt29.cuh"
+#include "lib_common.hpp"
+
+namespace mi355 {
+
+int ntt_tu_init_device() {
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ NTT
+constexpr uint32_t NTT_DIRECT_TW_MAX_LOG = 20;   // 2^20 x 36 B = 38 MB per table at most
+std::string plan_key(uint32_t log_n, const void *omega) { std::string k((const char *)omega, 32); k.push_back((char)log_n); return k; }
+
+int pow_table(fe_t **out, const fe_t &base, uint64_t step, uint32_t count) {
+  HIPCHK(hipMalloc((void **)out, (size_t)count * sizeof(fe_t)));
+  hipLaunchKernelGGL(k_pow_table, dim3(ceil_div(count, 256)), dim3(256), 0, g.stream, *out, base, step, count);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+
+int pow_table29(NttPlan &p, Tw29 *out, const fe_t &base, uint64_t step, uint32_t count) {
+  uint4 *lo, *hi; uint32_t *top;
+  HIPCHK(hipMalloc((void **)&lo, (size_t)count * 16)); p.owned.push_back(lo);
+  HIPCHK(hipMalloc((void **)&hi, (size_t)count * 16)); p.owned.push_back(hi);
+  HIPCHK(hipMalloc((void **)&top, (size_t)count * 4)); p.owned.push_back(top);
+  hipLaunchKernelGGL(k_pow_table29, dim3(ceil_div(count, 256)), dim3(256), 0, g.stream, lo, hi, top, base, step, count);
+  HIPCHK(hipGetLastError());
+  out->lo = lo; out->hi = hi; out->top = top;
+  return MI355_OK;
+}
+
+int launch_pow_table(fe_t *out, const fe_t &base, uint64_t step, uint32_t count) {
+  hipLaunchKernelGGL(k_pow_table, dim3(ceil_div(count, 256)), dim3(256), 0, g.stream, out, base, step, count);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+
+static void free_plan_tables(NttPlan &p) {
+  for (void *q : p.owned) (void)hipFree(q);
+  p.owned.clear();
+  for (int i = 0; i < 3; i++) if (p.tw_m[i]) { (void)hipFree(p.tw_m[i]); p.tw_m[i] = nullptr; }
+  for (int i = 0; i < 2; i++) { if (p.tw_s_lo[i]) { (void)hipFree(p.tw_s_lo[i]); p.tw_s_lo[i] = nullptr; } if (p.tw_s_hi[i]) { (void)hipFree(p.tw_s_hi[i]); p.tw_s_hi[i] = nullptr; } }
+}
+// three device arrays of one 29-bit table (SoA), all or nothing
+static bool alloc_tw29(uint64_t cnt, uint4 **lo, uint4 **hi, uint32_t **top) {
+  *lo = *hi = nullptr; *top = nullptr;
+  if (hipMalloc((void **)lo, cnt * 16) == hipSuccess && hipMalloc((void **)hi, cnt * 16) == hipSuccess && hipMalloc((void **)top, cnt * 4) == hipSuccess) return true;
+  (void)hipGetLastError();
+  if (*lo) (void)hipFree(*lo); if (*hi) (void)hipFree(*hi); if (*top) (void)hipFree(*top);
+  return false;
+}
+static int build_plan(NttPlan &p, uint32_t log_n, const void *omega) {
+  if (log_n <= 8) { p.levels = 1; p.log_m[0] = log_n; }
+  else if (log_n <= 18) { p.levels = 2; p.log_m[0] = (log_n + 1) / 2; p.log_m[1] = log_n / 2; }
+  else { p.levels = 3; p.log_m[0] = (log_n + 2) / 3; p.log_m[1] = (log_n + 1) / 3; p.log_m[2] = log_n / 3; }
+  fe_t w; memcpy(&w, omega, 32);
+  const uint64_t N = 1ull << log_n;
+  uint32_t log_s = log_n;
+  for (uint32_t l = 0; l < p.levels; l++) {
+    const uint32_t lm = p.log_m[l];
+    if (lm >= 1) CHK(pow_table(&p.tw_m[l], w, N >> lm, std::max(1u, 1u << (lm - 1))));
+    CHK(pow_table29(p, &p.tw29_m[l], w, N >> lm, std::max(1u, (1u << lm) >> 1)));
+    if (l + 1 < p.levels) {
+      // inter-level twiddles w_S^e, e < 2^log_s: ONE table when it is small enough to live in L2 (no lo x hi product per element),
+      // otherwise the usual two half-size tables
+      p.split[l] = log_s <= NTT_DIRECT_TW_MAX_LOG ? log_s : (log_s + 1) / 2;
+      CHK(pow_table(&p.tw_s_lo[l], w, N >> log_s, 1u << p.split[l]));
+      CHK(pow_table(&p.tw_s_hi[l], w, (N >> log_s) << p.split[l], 1u << (log_s - p.split[l])));
+      bool direct = false;
+      if (g.ntt29 && log_s > NTT_DIRECT_TW_MAX_LOG && log_s <= g.ntt_direct2_max_log) {
+        // big level: every twiddle w_S^(column k) once, in the order the pass reads them (36 B x 2^log_s: 2.4 GB at 2^26, read coalesced
+        // next to the data by a pass that is ALU-bound); saves the lo x hi product per element.  HBM may be full of window tables: when the
+        // allocation fails the level falls back to the lo x hi pair, which is functionally equivalent.
+        const uint64_t cnt = 1ull << log_s; uint4 *lo, *hi; uint32_t *top;
+        if (alloc_tw29(cnt, &lo, &hi, &top)) {
+          p.owned.push_back(lo); p.owned.push_back(hi); p.owned.push_back(top);
+          hipLaunchKernelGGL(k_pow_table29_2d, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, g.stream, lo, hi, top, Fr::pow_u64(w, N >> log_s), log_s - lm, cnt);
+          HIPCHK(hipGetLastError());
+          p.tw29_s_lo[l].lo = lo; p.tw29_s_lo[l].hi = hi; p.tw29_s_lo[l].top = top; p.tw29_s_hi[l] = p.tw29_s_lo[l]; p.direct2[l] = 1;
+          direct = true;
+        }
+      }
+      if (!direct) {
+        CHK(pow_table29(p, &p.tw29_s_lo[l], w, N >> log_s, 1u << p.split[l]));
+        CHK(pow_table29(p, &p.tw29_s_hi[l], w, (N >> log_s) << p.split[l], 1u << (log_s - p.split[l])));
+      }
+    }
+    log_s -= lm;
+  }
+  return MI355_OK;
+}
+int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
+  const std::string key = plan_key(log_n, omega);
+  auto it = g.ntt_plans.find(key);
+  if (it != g.ntt_plans.end()) { *out = &it->second; return MI355_OK; }
+  NttPlan p; p.log_n = log_n;
+  const int rc = build_plan(p, log_n, omega);
+  if (rc != MI355_OK) { (void)hipStreamSynchronize(g.stream); free_plan_tables(p); return rc; }   // nothing of a half-built plan is kept
+  g.ntt_plans[key] = p; *out = &g.ntt_plans[key];
+  return MI355_OK;
+}
+
+// radix-2^R register rounds: R = g.ntt_radix_log (1..3); one work item per 2^R elements
+#define NTT29_LAUNCH(KERN, BLOCKS, TILE, LDS, ...)                                                                                          \
+  do {                                                                                                                                     \
+    if (g.ntt_radix_log == 3) hipLaunchKernelGGL(KERN<3>, dim3(BLOCKS), dim3(std::max(64u, std::min(512u, (TILE) / 8))), LDS, s, __VA_ARGS__);       \
+    else if (g.ntt_radix_log == 2) hipLaunchKernelGGL(KERN<2>, dim3(BLOCKS), dim3(std::max(64u, std::min(512u, (TILE) / 4))), LDS, s, __VA_ARGS__);  \
+    else hipLaunchKernelGGL(KERN<1>, dim3(BLOCKS), dim3(std::max(64u, std::min(1024u, (TILE) / 2))), LDS, s, __VA_ARGS__);                            \
+  } while (0)
+
+uint32_t cols_for(uint32_t log_m) { uint32_t lc = 3; while (lc > 0 && log_m + lc > g.ntt_tile_log) lc--; return lc; }
+
+// dst[2^log_n] = NTT_omega( pre3-scaled, zero-padded src[src_len] ), then optional post3 scaling.  src may equal dst.
+int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, const void *omega, const fe_t *pre3_host, const fe_t *post3_host) {
+  if (log_n > 28) return fail(MI355_EBADARG, "ntt: log_n > 28 (BN254 Fr two-adicity)");
+  const uint64_t N = 1ull << log_n;
+  hipStream_t s = g.stream;
+  fe_t *pre3 = nullptr, *post3 = nullptr;
+  if (pre3_host || post3_host) {
+    fe_t *c; CHK(ws_get("ntt.consts", 6 * sizeof(fe_t), (void **)&c));
+    if (pre3_host) { HIPCHK(hipMemcpyAsync(c, pre3_host, 3 * sizeof(fe_t), hipMemcpyHostToDevice, s)); pre3 = c; }
+    if (post3_host) { HIPCHK(hipMemcpyAsync(c + 3, post3_host, 3 * sizeof(fe_t), hipMemcpyHostToDevice, s)); post3 = c + 3; }
+    HIPCHK(hipStreamSynchronize(s));  // the host copies may be stack temporaries of the caller
+  }
+  if (log_n == 0) {
+    if (src != dst || pre3 || post3 || src_len < 1) {
+      // size-1 transform = identity (apart from scalings); handle through the generic final kernel
+    }
+  }
+  NttPlan *p; CHK(get_plan(log_n, omega, &p));
+  // an inverse transform's divisor (the three post-scaling constants equal) is folded into the inter-level twiddles of the last strided
+  // pass: one table of 2^log_s entries per (plan, divisor), and the closing pass ends with reduce_small instead of a multiplication
+  const Tw29 *fold_tw = nullptr;
+  if (post3_host && !pre3_host && g.ntt29 && g.ntt_fold_scale && p->levels >= 2 && memcmp(&post3_host[0], &post3_host[1], 32) == 0 && memcmp(&post3_host[0], &post3_host[2], 32) == 0) {
+    const uint32_t l = p->levels - 2;
+    uint32_t log_sl = log_n; for (uint32_t q = 0; q < l; q++) log_sl -= p->log_m[q];
+    if (p->split[l] == log_sl && !p->direct2[l]) {   // that level reads ONE direct table
+      const std::string key((const char *)&post3_host[0], 32);
+      auto it = p->scaled.find(key);
+      if (it == p->scaled.end()) {
+        const uint32_t cnt = 1u << log_sl; uint4 *lo, *hi; uint32_t *top;
+        if (alloc_tw29(cnt, &lo, &hi, &top)) {
+          p->owned.push_back(lo); p->owned.push_back(hi); p->owned.push_back(top);
+          hipLaunchKernelGGL(k_scale_table29, dim3(ceil_div(cnt, 256)), dim3(256), 0, s, p->tw29_s_lo[l].lo, p->tw29_s_lo[l].hi, p->tw29_s_lo[l].top, lo, hi, top, post3_host[0], cnt);
+          HIPCHK(hipGetLastError());
+          Tw29 t; t.lo = lo; t.hi = hi; t.top = top;
+          it = p->scaled.emplace(key, t).first;
+        }
+      }
+      if (it != p->scaled.end()) { fold_tw = &it->second; post3 = nullptr; }   // allocation failed: the divisor stays a multiplication in the closing pass
+    }
+  }
+  CallTrace tr("ntt_fr", N, 64.0);
+  Scope total("ntt_total");
+  if (p->levels == 1) {
+    const uint32_t lm = p->log_m[0], tile = 1u << lm;
+    const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
+    const size_t lds = (size_t)2 * 16 * (tile + 1);
+    Scope sc("ntt_pass");
+    if (g.ntt29) NTT29_LAUNCH(k_ntt29_final, 1u, tile, (size_t)36 * (tile + 1), src, dst, lm, 0u, 0u, 0u, p->tw29_m[0], src_len, pre3, post3);
+    else hipLaunchKernelGGL(k_ntt_final, dim3(1), dim3(threads), lds, s, src, dst, lm, 0u, 0u, 0u, p->tw_m[0], src_len, pre3, post3);
+  } else {
+    fe_t *scratch; CHK(ws_get("ntt.scratch", N * sizeof(fe_t), (void **)&scratch));
+    uint32_t log_s = log_n;
+    const fe_t *cur = src; uint64_t cur_len = src_len; const fe_t *cur_pre = pre3;
+    for (uint32_t l = 0; l + 1 < p->levels; l++) {
+      NttLevel L; L.log_m = p->log_m[l]; L.log_t = log_s - L.log_m; L.tw_m = p->tw_m[l]; L.tw_s_lo = p->tw_s_lo[l]; L.tw_s_hi = p->tw_s_hi[l]; L.split = p->split[l];
+      const uint32_t lc = std::min(cols_for(L.log_m), L.log_t), tile = 1u << (L.log_m + lc);
+      const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
+      const size_t lds = (size_t)2 * 16 * tile;
+      const uint64_t blocks = (N >> log_s) << (L.log_t - lc);
+      Scope sc("ntt_pass");
+      if (g.ntt29) {
+        Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l]; L9.direct = p->direct2[l] ? 2u : (p->split[l] == log_s) ? 1u : 0u;
+        if (fold_tw && l + 2 == p->levels) L9.tw_s_lo = *fold_tw;
+        NTT29_LAUNCH(k_ntt29_strided, (uint32_t)blocks, tile, (size_t)36 * tile, cur, scratch, L9, lc, cur_len, cur_pre);
+      } else
+      hipLaunchKernelGGL(k_ntt_strided, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, scratch, L, lc, cur_len, cur_pre);
+      cur = scratch; cur_len = N; cur_pre = nullptr; log_s -= L.log_m;
+    }
+    const uint32_t lm = p->log_m[p->levels - 1], log_a = p->log_m[0], log_b = p->levels == 3 ? p->log_m[1] : 0;
+    const uint32_t lc = std::min(cols_for(lm), log_a), tile = 1u << (lm + lc);
+    const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
+    const size_t lds = (size_t)2 * 16 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc);
+    const uint64_t blocks = ((uint64_t)1 << log_b) << (log_a - lc);
+    Scope sc("ntt_pass");
+    if (g.ntt29) NTT29_LAUNCH(k_ntt29_final, (uint32_t)blocks, tile, (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
+    else hipLaunchKernelGGL(k_ntt_final, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, dst, lm, log_a, log_b, lc, p->tw_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
+  }
+  HIPCHK(hipGetLastError());
+  total.close();
+  tr.done();
+  return MI355_OK;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+namespace {
+struct BatchItem { uint32_t index; int slot; };
+// run(slot, index) for every item, one thread per device that has items; the first error wins
+template <class F> int run_per_device(const std::vector<BatchItem> &items, F run) {
+  std::vector<std::vector<uint32_t>> by_slot(MAX_DEV);
+  for (const auto &it : items) by_slot[it.slot].push_back(it.index);
+  std::vector<int> slots; for (int s = 0; s < MAX_DEV; s++) if (!by_slot[s].empty()) slots.push_back(s);
+  std::vector<int> rcs(slots.size(), MI355_OK); std::vector<std::string> errs(slots.size());
+  auto work = [&](size_t k) {
+    const int slot = slots[k];
+    rcs[k] = guarded([&]() -> int {
+      DevGuard lk(slot);
+      CHK(need_init(slot));
+      for (uint32_t idx : by_slot[slot]) CHK(run(slot, idx));
+      HIPCHK(hipStreamSynchronize(g.stream));
+      resolve_spans();
+      return MI355_OK;
+    });
+    if (rcs[k] != MI355_OK) errs[k] = g_err;
+  };
+  {
+    struct Joiner { std::vector<std::thread> th; ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); } } workers;
+    for (size_t k = 1; k < slots.size(); k++) workers.th.emplace_back(work, k);
+    if (!slots.empty()) work(0);
+  }
+  for (size_t k = 0; k < slots.size(); k++) if (rcs[k] != MI355_OK) return fail(rcs[k], "device slot " + std::to_string(slots[k]) + ": " + errs[k]);
+  return MI355_OK;
+}
+int transform_in_place(fe_t *data, uint32_t log_n, const void *omega, const void *divisor) {
+  if (!divisor) return ntt_dev_impl(data, 1ull << log_n, data, log_n, omega, nullptr, nullptr);
+  fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], divisor, 32);
+  return ntt_dev_impl(data, 1ull << log_n, data, log_n, omega, nullptr, post);
+}
+}  // namespace
+
+extern "C" {
+
+// ---- NTT
+int mi355_ntt_fr_dev(void *data_dev, uint32_t log_n, const void *omega) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({data_dev}, &slot, "ntt")); DevGuard lk(slot);
+  CHK(need_init(slot)); CHK(check_ntt_args(data_dev, log_n, omega));
+  CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_n, (fe_t *)data_dev, log_n, omega, nullptr, nullptr));
+  return finish_async();
+  });
+}
+int mi355_intt_fr_dev(void *data_dev, uint32_t log_n, const void *omega_inv, const void *divisor) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({data_dev}, &slot, "intt")); DevGuard lk(slot);
+  CHK(need_init(slot)); CHK(check_ntt_args(data_dev, log_n, omega_inv));
+  if (!divisor) return fail(MI355_EBADARG, "intt: null divisor");
+  fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], divisor, 32);
+  CHK(ntt_dev_impl((const fe_t *)data_dev, 1ull << log_n, (fe_t *)data_dev, log_n, omega_inv, nullptr, post));
+  return finish_async();
+  });
+}
+int mi355_coeff_to_extended_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({dst_dev, coeffs_dev}, &slot, "coeff_to_extended")); DevGuard lk(slot);
+  CHK(need_init(slot)); CHK(check_ntt_args(dst_dev, log_ext, extended_omega));
+  if (!coeffs_dev || !g_coset || !g_coset_inv || log_n > log_ext) return fail(MI355_EBADARG, "coeff_to_extended: bad argument");
+  fe_t pre[3]; pre[0] = Fr::one(); memcpy(&pre[1], g_coset, 32); memcpy(&pre[2], g_coset_inv, 32);
+  CHK(ntt_dev_impl((const fe_t *)coeffs_dev, 1ull << log_n, (fe_t *)dst_dev, log_ext, extended_omega, pre, nullptr));
+  return finish_async();
+  });
+}
+static int extended_to_coeff_locked(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor);
+int mi355_extended_to_coeff_dev(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({data_dev}, &slot, "extended_to_coeff")); DevGuard lk(slot);
+  CHK(need_init(slot));
+  CHK(extended_to_coeff_locked(data_dev, log_ext, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor));
+  return finish_async();
+  });
+}
+
+int mi355_ntt_fr_host(void *data_host, uint32_t log_n, const void *omega) {
+  return guarded([&]() -> int {
+  const int slot = pick_replica_slot(); DevGuard lk(slot);   // host-pointer calls may run on any bound device (replicas): callers on different threads land on different devices
+  CHK(need_init(slot)); CHK(check_ntt_args(data_host, log_n, omega));
+  NttHostArgs a{log_n, omega, nullptr};
+  const size_t bytes = sizeof(fe_t) << log_n;
+  return with_host_io(data_host, bytes, bytes, bytes, "io.ntt", [](void *dev, void *ud) { auto *a = (NttHostArgs *)ud; return ntt_dev_impl((const fe_t *)dev, 1ull << a->log_n, (fe_t *)dev, a->log_n, a->omega, nullptr, nullptr); }, &a);
+  });
+}
+int mi355_intt_fr_host(void *data_host, uint32_t log_n, const void *omega_inv, const void *divisor) {
+  return guarded([&]() -> int {
+  const int slot = pick_replica_slot(); DevGuard lk(slot);   // host-pointer calls may run on any bound device (replicas): callers on different threads land on different devices
+  CHK(need_init(slot)); CHK(check_ntt_args(data_host, log_n, omega_inv));
+  if (!divisor) return fail(MI355_EBADARG, "intt: null divisor");
+  NttHostArgs a{log_n, omega_inv, divisor};
+  const size_t bytes = sizeof(fe_t) << log_n;
+  return with_host_io(data_host, bytes, bytes, bytes, "io.ntt", [](void *dev, void *ud) {
+    auto *a = (NttHostArgs *)ud; fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], a->divisor, 32);
+    return ntt_dev_impl((const fe_t *)dev, 1ull << a->log_n, (fe_t *)dev, a->log_n, a->omega, nullptr, post); }, &a);
+  });
+}
+int mi355_coeff_to_extended_host(void *dst_host, const void *coeffs_host, uint32_t log_n, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega) {
+  return guarded([&]() -> int {
+  {
+    const int slot = pick_replica_slot(); DevGuard lk(slot);   // host-pointer calls may run on any bound device (replicas): callers on different threads land on different devices
+    CHK(need_init(slot)); CHK(check_ntt_args(dst_host, log_ext, extended_omega));
+    if (!coeffs_host || !g_coset || !g_coset_inv || log_n > log_ext) return fail(MI355_EBADARG, "coeff_to_extended: bad argument");
+    void *src, *dst; CHK(ws_get("io.ntt_src", sizeof(fe_t) << log_n, &src)); CHK(ws_get("io.ntt", sizeof(fe_t) << log_ext, &dst));
+    HIPCHK(hipMemcpyAsync(src, coeffs_host, sizeof(fe_t) << log_n, hipMemcpyHostToDevice, g.stream));
+    fe_t pre[3]; pre[0] = Fr::one(); memcpy(&pre[1], g_coset, 32); memcpy(&pre[2], g_coset_inv, 32);
+    CHK(ntt_dev_impl((const fe_t *)src, 1ull << log_n, (fe_t *)dst, log_ext, extended_omega, pre, nullptr));
+    HIPCHK(hipMemcpyAsync(dst_host, dst, sizeof(fe_t) << log_ext, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans();
+  }
+  return MI355_OK;
+  });
+}
+// body of mi355_extended_to_coeff_dev, to be called with the device lock held
+static int extended_to_coeff_locked(void *data_dev, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
+  CHK(check_ntt_args(data_dev, log_ext, extended_omega_inv));
+  if (!g_coset || !g_coset_inv || !extended_ifft_divisor) return fail(MI355_EBADARG, "extended_to_coeff: null pointer");
+  // post-scale table {d, d * g_coset_inv, d * g_coset}: three constant products formed on the host (setup, not data path)
+  fe_t d, gc, gci, post[3]; memcpy(&d, extended_ifft_divisor, 32); memcpy(&gc, g_coset, 32); memcpy(&gci, g_coset_inv, 32);
+  post[0] = d; post[1] = Fr::mul(d, gci); post[2] = Fr::mul(d, gc);
+  return ntt_dev_impl((const fe_t *)data_dev, 1ull << log_ext, (fe_t *)data_dev, log_ext, extended_omega_inv, nullptr, post);
+}
+int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *g_coset, const void *g_coset_inv, const void *extended_omega_inv, const void *extended_ifft_divisor) {
+  return guarded([&]() -> int {
+  const int slot = pick_replica_slot(); DevGuard lk(slot);   // host-pointer calls may run on any bound device (replicas): callers on different threads land on different devices
+  CHK(need_init(slot)); CHK(check_ntt_args(data_host, log_ext, extended_omega_inv));
+  void *dev; CHK(ws_get("io.ntt", sizeof(fe_t) << log_ext, &dev));
+  HIPCHK(hipMemcpyAsync(dev, data_host, sizeof(fe_t) << log_ext, hipMemcpyHostToDevice, g.stream));
+  CHK(extended_to_coeff_locked(dev, log_ext, g_coset, g_coset_inv, extended_omega_inv, extended_ifft_divisor));
+  HIPCHK(hipMemcpyAsync(data_host, dev, sizeof(fe_t) << log_ext, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream)); resolve_spans();
+  return MI355_OK;
+  });
+}
+
+// ---- distribute_powers / coset NTT
+static int distribute_powers_locked(void *data_dev, uint64_t n, const void *factor, const void *src_dev = nullptr) {
+  if (!factor || (n && !data_dev)) return fail(MI355_EBADARG, "distribute_powers: null pointer");
+  if (n == 0) return MI355_OK;
+  fe_t f; memcpy(&f, factor, 32);
+  hipLaunchKernelGGL(k_distribute_powers, dim3(ceil_div(n, (uint64_t)EVAL_RUN * 256)), dim3(256), 0, g.stream, (const fe_t *)(src_dev ? src_dev : data_dev), (fe_t *)data_dev, n, f);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *factor) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({data_dev}, &slot, "distribute_powers")); DevGuard lk(slot);
+  CHK(need_init(slot));
+  return distribute_powers_locked(data_dev, n, factor);
+  });
+}
+int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n, const void *coset_factor, const void *omega) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({dst_dev, coeffs_dev}, &slot, "coset_ntt")); DevGuard lk(slot);
+  CHK(need_init(slot)); CHK(check_ntt_args(dst_dev, log_n, omega));
+  if (!coeffs_dev || !coset_factor) return fail(MI355_EBADARG, "coset_ntt: null pointer");
+  CHK(distribute_powers_locked(dst_dev, 1ull << log_n, coset_factor, coeffs_dev));   // dst = coeffs[i] * factor^i (one pass, no copy first)
+  CHK(ntt_dev_impl((const fe_t *)dst_dev, 1ull << log_n, (fe_t *)dst_dev, log_n, omega, nullptr, nullptr));
+  return finish_async();
+  });
+}
+
+// ---- batches of independent transforms, spread over the bound devices (the NTT does not shard at k <= 26 -- "replicas only" --
+// but the 8 iNTTs and 32 coset NTTs of one layer-4 proof are independent of each other).  Host pointers are dealt round-robin, one worker
+// thread, one staging buffer and one PCIe link per device; device pointers run on the device that owns them (mi355_buf_alloc(.., slot)),
+// concurrently across devices.  Each worker holds only its own device's lock.  Results are those of the serial loop.
+
+// `batch` x best_fft (divisor == NULL) or EvaluationDomain::ifft (divisor = n^-1), in place, host memory
+int mi355_ntt_fr_batch_host(void *const *data_host, uint32_t batch, uint32_t log_n, const void *omega, const void *divisor) {
+  return guarded([&]() -> int {
+  if (batch == 0) return MI355_OK;
+  if (!data_host || !omega || log_n > 28) return fail(MI355_EBADARG, "ntt_batch: bad argument");
+  for (uint32_t i = 0; i < batch; i++) if (!data_host[i]) return fail(MI355_EBADARG, "ntt_batch: null polynomial pointer");
+  const int D = std::max(1, g_ndev);
+  std::vector<BatchItem> items(batch);
+  for (uint32_t i = 0; i < batch; i++) items[i] = {i, (int)(i % (uint32_t)D)};
+  const size_t bytes = sizeof(fe_t) << log_n;
+  return run_per_device(items, [&](int, uint32_t i) -> int {
+    void *dev; CHK(ws_get("io.ntt", bytes, &dev));
+    HIPCHK(hipMemcpyAsync(dev, data_host[i], bytes, hipMemcpyHostToDevice, g.stream));
+    CHK(transform_in_place((fe_t *)dev, log_n, omega, divisor));
+    HIPCHK(hipMemcpyAsync(data_host[i], dev, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));   // the staging buffer is reused by the next item
+    return MI355_OK;
+  });
+  });
+}
+// the same on resident polynomials: each transform runs on the device that owns its buffer, asynchronously within a device
+int mi355_ntt_fr_batch_dev(void *const *data_dev, uint32_t batch, uint32_t log_n, const void *omega, const void *divisor) {
+  return guarded([&]() -> int {
+  if (batch == 0) return MI355_OK;
+  if (!data_dev || !omega || log_n > 28) return fail(MI355_EBADARG, "ntt_batch: bad argument");
+  std::vector<BatchItem> items(batch);
+  for (uint32_t i = 0; i < batch; i++) { if (!data_dev[i]) return fail(MI355_EBADARG, "ntt_batch: null polynomial pointer"); items[i] = {i, slot_of(data_dev[i])}; }
+  return run_per_device(items, [&](int, uint32_t i) -> int { return transform_in_place((fe_t *)data_dev[i], log_n, omega, divisor); });
+  });
+}
+// `batch` x coeff_to_extended_part: dst[i] = best_fft(coeffs[i][j] * coset_factor^j, omega); dst[i] and coeffs[i] must live on one device
+int mi355_coset_ntt_fr_batch_dev(void *const *dst_dev, const void *const *coeffs_dev, uint32_t batch, uint32_t log_n, const void *coset_factor, const void *omega) {
+  return guarded([&]() -> int {
+  if (batch == 0) return MI355_OK;
+  if (!dst_dev || !coeffs_dev || !coset_factor || !omega || log_n > 28) return fail(MI355_EBADARG, "coset_ntt_batch: bad argument");
+  std::vector<BatchItem> items(batch);
+  for (uint32_t i = 0; i < batch; i++) {
+    if (!dst_dev[i] || !coeffs_dev[i]) return fail(MI355_EBADARG, "coset_ntt_batch: null polynomial pointer");
+    int slot; CHK(common_slot({dst_dev[i], coeffs_dev[i]}, &slot, "coset_ntt_batch")); items[i] = {i, slot};
+  }
+  return run_per_device(items, [&](int, uint32_t i) -> int {
+    CHK(distribute_powers_locked(dst_dev[i], 1ull << log_n, coset_factor, coeffs_dev[i]));
+    return ntt_dev_impl((const fe_t *)dst_dev[i], 1ull << log_n, (fe_t *)dst_dev[i], log_n, omega, nullptr, nullptr);
+  });
+  });
+}
+
+// ---- element-wise vector operations on resident polynomials
+int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_dev, uint64_t n) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({dst_dev, a_dev, b_dev}, &slot, "fr_vec_op")); DevGuard lk(slot);
+  CHK(need_init(slot));
+  if (op < 0 || op > 2 || (n && (!dst_dev || !a_dev || !b_dev))) return fail(MI355_EBADARG, "fr_vec_op: bad argument");
+  if (n == 0) return MI355_OK;
+  hipLaunchKernelGGL(k_fr_vec_op, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, op, (fe_t *)dst_dev, (const fe_t *)a_dev, (const fe_t *)b_dev, n);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+  });
+}
+int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, const void *scalar, uint64_t n) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({dst_dev, a_dev, b_dev}, &slot, "fr_vec_axpy")); DevGuard lk(slot);
+  CHK(need_init(slot));
+  if (!scalar || (n && (!dst_dev || !b_dev))) return fail(MI355_EBADARG, "fr_vec_axpy: null pointer");
+  if (n == 0) return MI355_OK;
+  fe_t s; memcpy(&s, scalar, 32);
+  hipLaunchKernelGGL(k_fr_vec_axpy, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, (fe_t *)dst_dev, (const fe_t *)a_dev, (const fe_t *)b_dev, s, n);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+  });
+}
+int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_host, uint32_t period) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({data_dev}, &slot, "fr_vec_mul_periodic")); DevGuard lk(slot);
+  CHK(need_init(slot));
+  if (!table_host || period == 0 || (period & (period - 1)) || period > 4096 || (n && !data_dev)) return fail(MI355_EBADARG, "fr_vec_mul_periodic: period must be a power of two <= 4096");
+  if (n == 0) return MI355_OK;
+  fe_t *tab; CHK(ws_get("vec.table", (size_t)period * sizeof(fe_t), (void **)&tab));
+  HIPCHK(hipMemcpyAsync(tab, table_host, (size_t)period * sizeof(fe_t), hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  hipLaunchKernelGGL(k_fr_vec_mul_periodic, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, (fe_t *)data_dev, n, tab, period - 1);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+  });
+}
+
+// ---- eval_polynomial
+static int eval_polynomial_locked(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host) {
+  if (!out_fr_host || !point || (n && !poly_dev)) return fail(MI355_EBADARG, "eval_polynomial: null pointer");
+  fe_t res = Fr::zero();
+  if (n == 0) { memcpy(out_fr_host, &res, 32); return MI355_OK; }
+  fe_t x; memcpy(&x, point, 32);
+  const uint32_t blocks = ceil_div(n, (uint64_t)EVAL_RUN * 256);
+  fe_t *partial; CHK(ws_get("eval.partial", ((size_t)blocks + 1) * sizeof(fe_t), (void **)&partial));
+  {
+    Scope sc("eval_poly");
+    hipLaunchKernelGGL(k_eval_poly_partial, dim3(blocks), dim3(256), 0, g.stream, (const fe_t *)poly_dev, n, x, partial);
+    hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, g.stream, partial, (uint64_t)blocks, partial + blocks);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&res, partial + blocks, sizeof res, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  resolve_spans();
+  memcpy(out_fr_host, &res, 32);
+  return MI355_OK;
+}
+int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({poly_dev}, &slot, "eval_polynomial")); DevGuard lk(slot);
+  CHK(need_init(slot));
+  return eval_polynomial_locked(poly_dev, n, point, out_fr_host);
+  });
+}
+int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *point, void *out_fr_host) {
+  return guarded([&]() -> int {
+  const int slot = pick_replica_slot(); DevGuard lk(slot);   // host-pointer calls may run on any bound device (replicas): callers on different threads land on different devices
+  CHK(need_init(slot));
+  if (n && !poly_host) return fail(MI355_EBADARG, "eval_polynomial: null pointer");
+  void *dev = nullptr;
+  if (n) { CHK(ws_get("io.ntt", n * sizeof(fe_t), &dev)); HIPCHK(hipMemcpyAsync(dev, poly_host, n * sizeof(fe_t), hipMemcpyHostToDevice, g.stream)); }
+  return eval_polynomial_locked(dev, n, point, out_fr_host);
+  });
+}
+
+}  // extern "C"

@@ -17,13 +17,13 @@
 #include "fp29.cuh"
 #include "fp_asm.cuh"
 #include "ntt.cuh"
+#include "ntt_types.cuh"
 
 namespace zk {
 
 #ifndef ZK_NTT_CHAIN
 #define ZK_NTT_CHAIN false   // limb products of the NTT butterflies as explicitly chained v_mad (fp29.cuh mac_*)
 #endif
-struct Tw29 { const uint4 *lo; const uint4 *hi; const uint32_t *top; };   // entry i: limbs 0-3, 4-7, 8 of w^i * 2^261 mod r
 struct Ntt29Level { uint32_t log_m, log_t, split; Tw29 tw_m, tw_s_lo, tw_s_hi; uint32_t direct; };   // direct 1: tw_s_lo holds every inter-level twiddle w_S^e (small levels), no lo x hi product; direct 2: tw_s_lo is the table [k][column] = w_S^(column k) of a big level, read like the data (8 adjacent columns per row)
 
 #if defined(__HIPCC__)
