@@ -668,21 +668,26 @@ __global__ void __launch_bounds__(FRSCAN_THREADS) k_srs_precompute(const g1_affi
   g1_affine_t P; P.x = Fq::zero(); P.y = Fq::zero();
   if (live) { P = load_affine(&base[i]); g_store(&table[i].x, P.x); g_store(&table[i].y, P.y); }
   const bool ident = !live || g1_affine_is_identity(P);   // the identity stays the identity in every row
+  bool dead = false;                                       // a degenerate input whose multiple hit Z = 0 (see below)
   for (uint32_t w = 1; w < W; w++) {
     g1_xyzz_t acc = g1_xyzz_identity();
     fe_t z = Fq::one();
-    if (!ident) {
+    if (!ident && !dead) {
       acc = g1_xyzz_dbl_affine_ps(P);
       for (uint32_t k = 1; k < c; k++) acc = g1_xyzz_dbl_ps(acc);
-      // BN254 G1 has prime order and no 2-torsion: doubling a non-identity point never gives the identity, so ZZ ZZZ != 0
+      // BN254 G1 has prime order and no 2-torsion: doubling a non-identity CURVE point never gives the identity, so ZZ ZZZ != 0.  Bases are
+      // not validated at registration (mi355_srs_register_host / _dev), and an input with y = 0 or off the curve can reach ZZ ZZZ = 0: such a
+      // point becomes the identity in this row and every later one, and must not zero the shared product of its 255 neighbours
       z = fq_mul_ps(acc.zz, acc.zzz);
+      if (Fq::is_zero(z)) { dead = true; z = Fq::one(); }
     }
     fe_t total, total_r;
     const fe_t left = block_exclusive_mul_scan<false, true>(z, buf, total);
     const fe_t right = block_exclusive_mul_scan<true, true>(z, buf, total_r);
     if (threadIdx.x == 0) lds_put(inv_total, Fq::inv_sgcd(total));
     __syncthreads();
-    if (!ident) {
+    if (dead) { P.x = Fq::zero(); P.y = Fq::zero(); }
+    else if (!ident) {
       const fe_t inv = fq_mul_ps(fq_mul_ps(lds_get(inv_total), left), right);   // 1 / (ZZ ZZZ) of this thread's point
       P.x = fq_mul_ps(acc.x, fq_mul_ps(inv, acc.zzz)); P.y = fq_mul_ps(acc.y, fq_mul_ps(inv, acc.zz));
     }

@@ -78,6 +78,71 @@ def best_fft(a, omega: np.ndarray, log_n: int) -> None:
         check(lib().mi355_ntt_fr_host(ptr(a), log_n, ptr(omega)))
 
 
+def best_fft_many(polys, omega: np.ndarray, log_n: int, divisor=None) -> None:
+    """`for a in polys: best_fft(a, omega, log_n)` (divisor: ... followed by a *= divisor, i.e. EvaluationDomain::ifft) as ONE call:
+    mi355_ntt_fr_batch_host / _dev deal the independent transforms over the bound devices (host arrays round-robin; device buffers on the
+    device that owns them).  In place; all host arrays or all device buffers."""
+    if len(polys) == 0:
+        return
+    dev = _is_device(polys[0])
+    assert all(_is_device(q) == dev for q in polys), "best_fft_many: mix of host and device polynomials"
+    if dev:
+        arr = (C.c_void_p * len(polys))(*[q.data_ptr() for q in polys])
+        check(lib().mi355_ntt_fr_batch_dev(arr, len(polys), log_n, ptr(omega), ptr(divisor)))
+    else:
+        for q in polys:
+            assert q.shape == (1 << log_n, 4) and q.dtype == np.uint64 and q.flags["C_CONTIGUOUS"]
+        arr = (C.c_void_p * len(polys))(*[q.ctypes.data for q in polys])
+        check(lib().mi355_ntt_fr_batch_host(arr, len(polys), log_n, ptr(omega), ptr(divisor)))
+
+
+class DeviceBuffer:
+    """One mi355_buf_alloc block: the Python twin of the Rust shim's DevicePoly (rust_shim/mi355zk.rs).  Quacks like a device tensor for
+    the wrappers of this module (data_ptr / numel / element_size); `slot` picks the device of an mi355_init_multi process."""
+
+    def __init__(self, nbytes: int, slot: int = 0):
+        p = C.c_void_p()
+        check(lib().mi355_buf_alloc(nbytes, slot, C.byref(p)))
+        self._ptr, self.nbytes, self.slot = p.value, nbytes, slot
+
+    @classmethod
+    def from_host(cls, arr: np.ndarray, slot: int = 0) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes, slot)
+        b.upload(arr)
+        return b
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def numel(self) -> int:
+        return self.nbytes
+
+    def element_size(self) -> int:
+        return 1
+
+    is_cuda = True
+
+    def upload(self, arr: np.ndarray, offset: int = 0) -> None:
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        check(lib().mi355_buf_upload(C.c_void_p(self._ptr + offset), ptr(arr), arr.nbytes))
+
+    def download(self, nbytes: int | None = None, offset: int = 0) -> np.ndarray:
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(nbytes // 8, dtype=np.uint64)
+        check(lib().mi355_buf_download(ptr(out), C.c_void_p(self._ptr + offset), nbytes))
+        return out
+
+    def fr(self) -> np.ndarray:
+        return self.download().reshape(-1, 4)
+
+    def free(self) -> None:
+        if self._ptr:
+            check(lib().mi355_buf_free(C.c_void_p(self._ptr)))
+            self._ptr = 0
+
+
 def g_to_lagrange(g_dev, k: int):
     """g_to_lagrange(g_projective, k) [EXT-recalled halo2_proofs src/arithmetic.rs]: g_lagrange = n^-1 * best_fft(g, omega^-1, k), as a new
     device tensor of 2^k affine points; g_dev: device tensor (or raw device address) holding at least 2^k affine points."""

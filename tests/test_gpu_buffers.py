@@ -1,0 +1,222 @@
+"""
+-m gpu: the resident-buffer half of the C-ABI (mi355_buf_*: what rust_shim/mi355zk.rs wraps as `DevicePoly`), the batched transforms and
+the per-device locks (VERDICT r2 missing #1 / #2, weak #10).
+
+  * a polynomial uploaded once goes through iNTT -> coset NTT -> element-wise work -> commitment -> evaluation without touching host memory,
+    every step equal to the oracle's;
+  * pool semantics: a freed block is handed out again (no hipMalloc / hipFree between proofs), an upload into a recycled block waits for the
+    work that was queued on it, wrong pointers are refused;
+  * several device slots behind one process (the same physical GPU twice on this box): buffers on slot 1, transforms there, commitments
+    whose scalars live on slot 1 while the basis is sharded over both, peer copies, mi355_ntt_fr_batch_{host,dev} / mi355_coset_ntt_fr_batch_dev
+    against the serial loop, four host threads calling into the library at once.
+"""
+import ctypes as C
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+from oracle import cref, pyref
+from tests.gpu_common import affine_of, rand_fr
+from tests.test_gpu_properties import dev_scalars, field_commit
+from tests.test_gpu_headline import last_run
+
+pytestmark = pytest.mark.gpu
+TAU = 0x5343524F4C4C000B
+R = pyref.R_MOD
+
+
+def _reinit(pkg, ids, env):
+    pkg.shutdown()
+    for k in ("MI355_ALLOW_DUP_DEVICES", "MI355_MULTI_FORCE", "MI355_SHARD_MIN_LOG"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    pkg.init(ids)
+
+
+@pytest.fixture(scope="module")
+def zk():
+    pkg = ge.load_package()
+    pkg.init(0)
+    return pkg
+
+
+def test_resident_polynomial_pipeline_matches_oracle(zk):
+    h2 = zk.halo2
+    k = 12
+    n = 1 << k
+    rng = np.random.default_rng(5)
+    evals = rand_fr(rng, n)
+    dom = h2.EvaluationDomain(3, k)
+    params = h2.ParamsKZG.setup(k, TAU)
+    a = h2.DeviceBuffer.from_host(evals)                      # witness upload: the only bulk host -> device traffic
+    c_l = affine_of(params.commit_lagrange(a))
+    dom.lagrange_to_coeff(a)                                  # iNTT in place, resident
+    coeffs = cref.ifft(evals, dom.omega_inv, k, dom.ifft_divisor, threads=4)
+    assert (a.fr() == coeffs).all()
+    assert (affine_of(params.commit(a)) == c_l).all()         # commit(coeff(a)) == commit_lagrange(a)
+    assert (c_l == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(coeffs, cref.fr_mont(TAU))))).all()
+    ext = h2.DeviceBuffer(32 << dom.extended_k)
+    dom.coeff_to_extended(a, out=ext)
+    want_ext = cref.coeff_to_extended(coeffs, k, dom.extended_k, dom.g_coset, dom.g_coset_inv, dom.extended_omega, threads=4)
+    assert (ext.fr() == want_ext).all()
+    h2.fr_vec_op("mul", ext, ext, ext)                        # element-wise, resident
+    sq = cref.f_mul_vec(cref.FR, want_ext, want_ext)
+    assert (ext.fr() == sq).all()
+    x = h2.fr(0x1234567)
+    assert (h2.eval_polynomial(a, x) == cref.eval_polynomial(coeffs, x)).all()
+    # offsets into a block are device pointers like any other
+    lib, capi = zk._capi.lib(), zk._capi
+    half = C.c_void_p(a.data_ptr() + 32 * (n // 2))
+    out = np.zeros(4, dtype=np.uint64)
+    capi.check(lib.mi355_eval_polynomial_dev(half, n // 2, capi.ptr(x), capi.ptr(out)))
+    assert (out == cref.eval_polynomial(coeffs[n // 2:], x)).all()
+    a.free(); ext.free(); params.release()
+
+
+def test_pool_reuse_and_argument_checks(zk):
+    h2 = zk.halo2
+    lib, capi = zk._capi.lib(), zk._capi
+    k = 14
+    n = 1 << k
+    rng = np.random.default_rng(6)
+    dom = h2.EvaluationDomain(2, k)
+    v1, v2 = rand_fr(rng, n), rand_fr(rng, n)
+    b = h2.DeviceBuffer.from_host(v1)
+    p1 = b.data_ptr()
+    dom.coeff_to_lagrange(b)                                  # queued on the block ...
+    b.free()                                                  # ... returned to the pool while that work may still be running
+    b2 = h2.DeviceBuffer(32 * n)
+    assert b2.data_ptr() == p1                                # recycled, no hipMalloc
+    b2.upload(v2)                                             # must wait for the transform queued on the block before its free
+    assert (b2.fr() == v2).all()
+    dom.coeff_to_lagrange(b2)
+    assert (b2.fr() == cref.best_fft(v2, dom.omega, k, threads=4)).all()
+    slot = C.c_int(-1)
+    capi.check(lib.mi355_buf_slot(C.c_void_p(b2.data_ptr() + 64), C.byref(slot)))
+    assert slot.value == 0
+    assert lib.mi355_buf_free(C.c_void_p(b2.data_ptr() + 32)) == capi.EBADARG      # not a base pointer
+    assert lib.mi355_buf_upload(C.c_void_p(b2.data_ptr() + 32), capi.ptr(v1), 32 * n) == capi.EBADARG   # runs past the end of the block
+    p = C.c_void_p()
+    assert lib.mi355_buf_alloc(0, 0, C.byref(p)) == capi.EBADARG
+    assert lib.mi355_buf_alloc(64, 5, C.byref(p)) == capi.ENODEVICE               # slot 5 is not bound
+    b2.free()
+    assert lib.mi355_buf_free(C.c_void_p(p1)) == capi.EBADARG                     # double free
+    capi.check(lib.mi355_buf_trim())
+    b3 = h2.DeviceBuffer.from_host(v1)                        # after a trim the pool is empty: a fresh allocation
+    assert (b3.fr() == v1).all()
+    b3.free()
+
+
+def test_batched_transforms_equal_the_serial_loop_one_device(zk):
+    h2 = zk.halo2
+    k = 13
+    n = 1 << k
+    rng = np.random.default_rng(7)
+    dom = h2.EvaluationDomain(2, k)
+    polys = [rand_fr(rng, n) for _ in range(5)]
+    want_f = [cref.best_fft(p, dom.omega, k, threads=4) for p in polys]
+    hp = [p.copy() for p in polys]
+    h2.best_fft_many(hp, dom.omega, k)
+    for a, w in zip(hp, want_f):
+        assert (a == w).all()
+    h2.best_fft_many(hp, dom.omega_inv, k, divisor=dom.ifft_divisor)     # EvaluationDomain::ifft x 5
+    for a, p in zip(hp, polys):
+        assert (a == p).all()
+    bufs = [h2.DeviceBuffer.from_host(p) for p in polys]
+    h2.best_fft_many(bufs, dom.omega, k)
+    for b, w in zip(bufs, want_f):
+        assert (b.fr() == w).all()
+    h2.best_fft_many([], dom.omega, k)
+    for b in bufs:
+        b.free()
+
+
+def test_buffers_and_batches_over_two_device_slots():
+    pkg = ge.load_package()
+    pkg.init(0)
+    _reinit(pkg, [0, 0], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "8"})
+    try:
+        h2 = pkg.halo2
+        lib, capi = pkg._capi.lib(), pkg._capi
+        k = 14
+        n = 1 << k
+        rng = np.random.default_rng(8)
+        dom = h2.EvaluationDomain(2, k)
+        params = h2.ParamsKZG.setup(k, TAU + 1)                # sharded over both slots
+        vals = [rand_fr(rng, n) for _ in range(4)]
+        bufs = [h2.DeviceBuffer.from_host(v, slot=i % 2) for i, v in enumerate(vals)]
+        for i, b in enumerate(bufs):
+            s = C.c_int(-1); capi.check(lib.mi355_buf_slot(C.c_void_p(b.data_ptr()), C.byref(s))); assert s.value == i % 2
+        # a commitment whose scalars live on slot 1 while the basis is sharded over both slots
+        got = affine_of(params.commit(bufs[1]))
+        run = last_run(pkg)
+        assert run["devices"] == 2, run
+        assert (got == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(vals[1], cref.fr_mont(TAU + 1))))).all()
+        outs = params.commit_many(bufs)                        # scalars on alternating slots in one batch
+        for o, v in zip(outs, vals):
+            assert (affine_of(o) == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(v, cref.fr_mont(TAU + 1))))).all()
+        # transforms run where the buffers live; the batch spreads over both slots
+        h2.best_fft_many(bufs, dom.omega, k)
+        for b, v in zip(bufs, vals):
+            assert (b.fr() == cref.best_fft(v, dom.omega, k, threads=4)).all()
+        dom.lagrange_to_coeff(bufs[3])                         # single call on slot 1
+        assert (bufs[3].fr() == vals[3]).all()
+        # coset batch (coeff_to_extended_part of the scroll fork) on both slots
+        factor = h2.fr(h2.FR_ZETA)
+        dsts = [h2.DeviceBuffer(32 * n, slot=i % 2) for i in range(4)]
+        srcs = [h2.DeviceBuffer.from_host(v, slot=i % 2) for i, v in enumerate(vals)]
+        capi.check(lib.mi355_coset_ntt_fr_batch_dev((C.c_void_p * 4)(*[d.data_ptr() for d in dsts]), (C.c_void_p * 4)(*[s.data_ptr() for s in srcs]), 4, k, capi.ptr(factor), capi.ptr(dom.omega)))
+        zeta = h2.FR_ZETA
+        for d, v in zip(dsts, vals):
+            scaled = np.stack([cref.f_mul(cref.FR, v[i], cref.fr_mont(pow(zeta, i, R))) for i in range(0, n, 997)])
+            full = v.copy()
+            pw = np.stack([cref.fr_mont(pow(zeta, i, R)) for i in range(n)])
+            want = cref.best_fft(cref.f_mul_vec(cref.FR, full, pw), dom.omega, k, threads=4)
+            assert (d.fr() == want).all()
+            _ = scaled
+        # device-to-device copy between slots, then an element-wise operation on the destination's slot
+        cp = h2.DeviceBuffer(32 * n, slot=0)
+        capi.check(lib.mi355_buf_copy(C.c_void_p(cp.data_ptr()), C.c_void_p(srcs[1].data_ptr()), 32 * n))
+        assert (cp.fr() == vals[1]).all()
+        # host batches are dealt over the slots; four threads call into the library at once (per-device locks)
+        hp = [v.copy() for v in vals * 2]
+        h2.best_fft_many(hp, dom.omega, k)
+        for a, v in zip(hp, vals * 2):
+            assert (a == cref.best_fft(v, dom.omega, k, threads=2)).all()
+        errs = []
+
+        def worker(seed):
+            try:
+                r = np.random.default_rng(seed)
+                for _ in range(6):
+                    v = rand_fr(r, n)
+                    w = v.copy()
+                    dom.coeff_to_lagrange(w)                   # mi355_ntt_fr_host: lands on whichever slot is free
+                    dom.lagrange_to_coeff(w)
+                    if not (w == v).all():
+                        errs.append("round trip")
+                    x = h2.fr(int(r.integers(1, 1 << 60)))
+                    if not (h2.eval_polynomial(v, x) == cref.eval_polynomial(v, x)).all():
+                        errs.append("eval")
+                    if not (affine_of(params.commit(v)) == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(v, cref.fr_mont(TAU + 1))))).all():
+                        errs.append("commit")
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        th = [threading.Thread(target=worker, args=(100 + i,)) for i in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for b in bufs + dsts + srcs + [cp]:
+            b.free()
+        params.release()
+    finally:
+        _reinit(pkg, 0, {})

@@ -28,7 +28,7 @@ TAU = 0x5343524F4C4C0009
 
 def _reinit(pkg, ids, env):
     pkg.shutdown()
-    for k in ("MI355_ALLOW_DUP_DEVICES", "MI355_MULTI_FORCE"):
+    for k in ("MI355_ALLOW_DUP_DEVICES", "MI355_MULTI_FORCE", "MI355_SHARD_MIN_LOG"):
         os.environ.pop(k, None)
     os.environ.update(env)
     pkg.init(ids)
@@ -189,3 +189,44 @@ def test_prefix_view_gets_private_tables_when_much_smaller(zk2):
     check(lib.mi355_srs_pre_dev_ptr(big._g, C.byref(pb), C.byref(cb), None))
     assert pb.value == pa.value and cb.value == ca.value
     view.release(); big.release()
+
+
+def test_distinct_devices_rccl_allgather_over_xgmi():
+    """Arms itself on the first box with >= 2 GPUs (VERDICT r2 next #1 iii): mi355_init_multi over DISTINCT devices, one communicator
+    (ncclCommInitAll), the grouped ncclAllGather of the 96-byte partials over D > 1 ranks, fold on the primary -- the path that duplicate
+    slots cannot execute.  Skips only when the box has a single GPU."""
+    ngpu = torch.cuda.device_count()
+    if ngpu < 2:
+        pytest.skip("one GPU visible: the D > 1 RCCL exchange needs distinct devices (runs unedited on any multi-GPU box)")
+    pkg = ge.load_package()
+    D = min(ngpu, 8)
+    _reinit(pkg, list(range(D)), {})
+    try:
+        h2 = pkg.halo2
+        k = 20
+        n = 1 << k
+        params = h2.ParamsKZG.setup(k, TAU + 5)
+        sc = dev_scalars(n, 1234)
+        want = field_commit(sc, TAU + 5)
+        got = affine_of(params.commit(sc))                       # scalars on the primary, slices cross xGMI to their shard's device
+        run = last_run(pkg)
+        assert run["exchange"] == "rccl_allgather" and run["devices"] == D, run
+        assert (got == want).all()
+        sc_host = sc.cpu().numpy().view(np.uint64).reshape(n, 4)
+        assert (affine_of(params.commit(sc_host)) == want).all()  # one worker thread and PCIe link per device
+        params.precompute(lagrange=False)
+        assert (affine_of(params.commit(sc)) == want).all() and last_run(pkg)["exchange"] == "rccl_allgather"
+        outs = params.commit_many([sc, dev_scalars(n, 1235)])
+        assert (affine_of(outs[0]) == want).all()
+        # replicas: a batch of independent transforms dealt over the D devices equals the serial loop on one
+        dom = h2.EvaluationDomain(2, 16)
+        polys = [dev_scalars(1 << 16, 50 + i).cpu().numpy().view(np.uint64).reshape(1 << 16, 4) for i in range(2 * D + 1)]
+        serial = [p.copy() for p in polys]
+        for p in serial:
+            dom.coeff_to_lagrange(p)
+        h2.best_fft_many(polys, dom.omega, 16)
+        for a, b in zip(polys, serial):
+            assert (a == b).all()
+        params.release()
+    finally:
+        _reinit(pkg, [0, 0], {"MI355_ALLOW_DUP_DEVICES": "1"})
