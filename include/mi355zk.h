@@ -198,6 +198,16 @@ int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_
  * multi-open argument and every other "poly * scalar" of create_proof [EXT-recalled halo2_proofs poly: Polynomial * F, + ].       */
 int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, const void *scalar, uint64_t n);
 int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_host, uint32_t period);
+/* The operand shape of evaluate_h [EXT-recalled halo2_proofs src/plonk/evaluation.rs; SURVEY 3.2 step 7: gates read ROTATED columns,
+ * a[(i + rot * 2^(extended_k - k)) mod n], and evaluate an expression over dozens of extended-domain polynomials]:
+ *     dst[i] (+)= sum_{j < n_terms} coeffs[j] * prod_{k < term_len[j]} polys[factor_poly[.]][(i + factor_rot[.]) mod n]
+ * in ONE launch instead of a chain of mi355_fr_vec_op_dev calls (each a full HBM round trip).  Term j owns term_len[j] consecutive entries
+ * of factor_poly / factor_rot (host arrays); coeffs: n_terms x 32 B Montgomery (host); rotations in ELEMENTS, already scaled by the caller,
+ * negative values allowed; n a power of two (the extended domain, or one 2^k coset part).  Limits per launch: 24 polynomials, 16 terms,
+ * 8 factors per term, 48 factors in all (larger expressions are split, accumulate = 1 adds to dst).  dst may alias a polynomial only
+ * when every rotation of that polynomial is zero.                                                                                   */
+int mi355_fr_gate_eval_dev(void *dst_dev, const void *const *polys_dev, uint32_t n_polys, const void *coeffs_fr_host, const uint32_t *term_len,
+                           uint32_t n_terms, const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate);
 /* the multiplicative scans of the permutation / lookup arguments [EXT-recalled halo2_proofs src/plonk/permutation/prover.rs,
  * src/plonk/lookup/prover.rs]: data[i] = data[i]^-1 with zeros left zero (ff::BatchInvert), and the grand product
  * dst[0] = 1, dst[i] = prod_{j<i} src[j] (dst may alias src; total_out_host, optional, receives prod_{j<n} src[j] and makes the

@@ -519,6 +519,46 @@ void orc_eval_polynomial(fe *out, const fe *poly, uint64_t n, const fe *point) {
   *out = acc;
 }
 
+/* eval_polynomial split over threads (checker for polynomials of 2^26 coefficients): thread t runs Horner over its contiguous chunk,
+ * the chunk values are combined with point^(chunk start).  Same value as orc_eval_polynomial. */
+typedef struct { const fe *poly; uint64_t lo, hi; const fe *point; fe out; } evp_job;
+static void *evp_worker(void *arg) { evp_job *j = (evp_job *)arg; orc_eval_polynomial(&j->out, j->poly + j->lo, j->hi - j->lo, j->point); return NULL; }
+void orc_eval_polynomial_mt(fe *out, const fe *poly, uint64_t n, const fe *point, int num_threads) {
+  if (num_threads < 1) num_threads = 1;
+  if (num_threads > 256) num_threads = 256;
+  if (n < 4096 || num_threads == 1) { orc_eval_polynomial(out, poly, n, point); return; }
+  pthread_t th[256]; evp_job jobs[256]; int T = num_threads;
+  for (int t = 0; t < T; t++) { jobs[t] = (evp_job){poly, n * t / T, n * (t + 1) / T, point, {{0, 0, 0, 0}}}; pthread_create(&th[t], NULL, evp_worker, &jobs[t]); }
+  for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+  fe acc = {{0, 0, 0, 0}};
+  for (int t = T - 1; t >= 0; t--) {   /* acc = acc * point^(len of chunk t) + value of chunk t */
+    uint64_t e[4] = {jobs[t].hi - jobs[t].lo, 0, 0, 0}; fe pw; fe_pow(&pw, point, e, &FR);
+    fe_mul(&acc, &acc, &pw, &FR); fe_add(&acc, &acc, &jobs[t].out, &FR);
+  }
+  *out = acc;
+}
+
+/* The gate-shaped evaluation of evaluate_h [EXT-recalled halo2_proofs src/plonk/evaluation.rs: GraphEvaluator evaluates, per row i of the
+ * extended domain, sums of products of ROTATED column values, a[get_rotation_idx(i, rot, rot_scale, isize)] = a[(i + rot * rot_scale) mod isize]]:
+ *   dst[i] (+)= sum_j coeffs[j] * prod_k polys[factor_poly[.]][(i + factor_rot[.]) mod n],   term j owning term_len[j] consecutive factors.
+ * Plain loops over the definition (checker for mi355_fr_gate_eval_dev). */
+void orc_gate_eval(fe *dst, const fe *const *polys, const fe *coeffs, const uint32_t *term_len, uint32_t n_terms,
+                   const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate) {
+  for (uint64_t i = 0; i < n; i++) {
+    fe acc = {{0, 0, 0, 0}}; uint32_t f = 0;
+    for (uint32_t j = 0; j < n_terms; j++) {
+      fe t = coeffs[j];
+      for (uint32_t q = 0; q < term_len[j]; q++, f++) {
+        int64_t idx = ((int64_t)i + (int64_t)factor_rot[f]) % (int64_t)n; if (idx < 0) idx += (int64_t)n;
+        fe_mul(&t, &t, &polys[factor_poly[f]][idx], &FR);
+      }
+      fe_add(&acc, &acc, &t, &FR);
+    }
+    if (accumulate) fe_add(&acc, &acc, &dst[i], &FR);
+    dst[i] = acc;
+  }
+}
+
 /* ParamsKZG::setup-style synthetic SRS [EXT-recalled src/poly/kzg/commitment.rs setup]:
  * g[i] = tau^i * G,  g_lagrange[i] = L_i(tau) * G with L_i(tau) = omega^i (tau^n - 1) / (n (tau - omega^i)).
  * scalars_out (optional) receives the Fr multipliers so tests can check commitments in the field. */

@@ -279,6 +279,25 @@ def eval_polynomial(poly, point):
     lib().orc_eval_polynomial(_p(o), _p(poly), C.c_uint64(poly.shape[0]), _p(np.ascontiguousarray(point))); return o
 
 
+def eval_polynomial_mt(poly, point, threads: int | None = None):
+    threads = threads or usable_cpus()
+    o = _fe(); poly = np.ascontiguousarray(poly)
+    lib().orc_eval_polynomial_mt(_p(o), _p(poly), C.c_uint64(poly.shape[0]), _p(np.ascontiguousarray(point)), C.c_int(threads)); return o
+
+
+def gate_eval(polys, coeffs, term_len, factor_poly, factor_rot, n: int, dst=None):
+    """dst[i] (+)= sum_j coeffs[j] * prod_k polys[factor_poly[.]][(i + factor_rot[.]) mod n]  (restated evaluate_h operand shape); dst given: accumulate"""
+    polys = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
+    arr = (C.c_void_p * max(1, len(polys)))(*[p.ctypes.data for p in polys])
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    tl = np.ascontiguousarray(term_len, dtype=np.uint32); fp = np.ascontiguousarray(factor_poly, dtype=np.uint32); fr_ = np.ascontiguousarray(factor_rot, dtype=np.int32)
+    acc = dst is not None
+    out = np.array(dst, dtype=np.uint64, copy=True, order="C") if acc else np.zeros((n, 4), dtype=np.uint64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().orc_gate_eval(_p(out), arr, _p(coeffs), vp(tl), C.c_uint32(len(tl)), vp(fp), vp(fr_), C.c_uint64(n), C.c_int(1 if acc else 0))
+    return out
+
+
 def srs_setup(k: int, tau_mont, omega_mont):
     n = 1 << k
     g = np.zeros((n, 8), dtype=np.uint64); gl = np.zeros((n, 8), dtype=np.uint64)

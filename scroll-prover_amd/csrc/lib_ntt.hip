@@ -437,6 +437,40 @@ int mi355_fr_vec_op_dev(int op, void *dst_dev, const void *a_dev, const void *b_
   return MI355_OK;
   });
 }
+// dst[i] (+)= sum_j coeffs[j] * prod_k polys[factor_poly[..]][(i + factor_rot[..]) mod n]: the gate / permutation / lookup expressions of
+// evaluate_h as ONE launch (k_fr_gate_eval).  Term j owns term_len[j] consecutive entries of factor_poly / factor_rot.
+int mi355_fr_gate_eval_dev(void *dst_dev, const void *const *polys_dev, uint32_t n_polys, const void *coeffs, const uint32_t *term_len, uint32_t n_terms,
+                           const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate) {
+  return guarded([&]() -> int {
+  if (!dst_dev || (n_polys && !polys_dev) || (n_terms && (!coeffs || !term_len))) return fail(MI355_EBADARG, "fr_gate_eval: null pointer");
+  if (n == 0 || (n & (n - 1))) return fail(MI355_EBADARG, "fr_gate_eval: n must be a power of two (rotations wrap modulo the domain size)");
+  if (n_polys > GATE_MAX_POLYS || n_terms > GATE_MAX_TERMS) return fail(MI355_EBADARG, "fr_gate_eval: at most 24 polynomials and 16 terms per launch (split the expression)");
+  GatePlan G; memset(&G, 0, sizeof G);
+  G.n_terms = n_terms; G.accumulate = accumulate ? 1u : 0u;
+  uint32_t nf = 0;
+  for (uint32_t j = 0; j < n_terms; j++) {
+    if (term_len[j] > 8 || nf + term_len[j] > GATE_MAX_FACTORS) return fail(MI355_EBADARG, "fr_gate_eval: at most 8 factors per term and 48 per launch");
+    G.term_len[j] = (uint8_t)term_len[j]; nf += term_len[j];
+    memcpy(&G.coeff[j], (const char *)coeffs + 32 * (size_t)j, 32);
+  }
+  if (nf && (!factor_poly || !factor_rot)) return fail(MI355_EBADARG, "fr_gate_eval: null factor list");
+  for (uint32_t q = 0; q < nf; q++) {
+    if (factor_poly[q] >= n_polys) return fail(MI355_EBADARG, "fr_gate_eval: factor refers to a polynomial outside the list");
+    G.factor_poly[q] = (uint8_t)factor_poly[q]; G.factor_rot[q] = factor_rot[q];
+  }
+  int slot = slot_of(dst_dev);
+  for (uint32_t p = 0; p < n_polys; p++) {
+    if (!polys_dev[p]) return fail(MI355_EBADARG, "fr_gate_eval: null polynomial pointer");
+    int s; CHK(common_slot({dst_dev, polys_dev[p]}, &s, "fr_gate_eval"));
+    G.poly[p] = (const fe_t *)polys_dev[p];
+  }
+  DevGuard lk(slot);
+  CHK(need_init(slot));
+  hipLaunchKernelGGL(k_fr_gate_eval, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, (fe_t *)dst_dev, G, n);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+  });
+}
 int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, const void *scalar, uint64_t n) {
   return guarded([&]() -> int {
   int slot; CHK(common_slot({dst_dev, a_dev, b_dev}, &slot, "fr_vec_axpy")); DevGuard lk(slot);

@@ -295,6 +295,46 @@ __global__ void __launch_bounds__(256) k_fr_vec_mul_periodic(fe_t *__restrict__ 
     g_store(&data[i], fr29_finish(Fr29::mul(Fr29::from_sat_plain(g_load(&data[i])), Fr29::from_sat(g_load(&table[i & period_mask])))));
 }
 
+// ---- gate-shaped fused evaluation (the operand shape of halo2's evaluate_h [EXT-recalled halo2_proofs src/plonk/evaluation.rs: GraphEvaluator /
+// get_rotation_idx]): dst[i] (+)= sum_j c_j * prod_k p_{jk}[(i + r_jk) mod n] for a small term list, rotations included, in
+// ONE pass -- every operand is read once per use and nothing but dst is written, instead of one full HBM round trip per add / mul of a chain of
+// k_fr_vec_op launches.  The term list travels as a kernel argument (scalar loads, uniform across the wavefront).  n is a power of two (the
+// extended domain, or one 2^k coset part of the scroll fork); rotations arrive already scaled (rot * 2^(extended_k - k) on the extended domain).
+// Arithmetic: the first factor is re-sliced in the ABI domain (x 2^256), the coefficient and every further factor enter as y 2^261, so each
+// Montgomery product (R' = 2^261) lands back in the ABI domain; term values (< 2 r) are summed lazily, carried every fourth term, and reduced
+// once (<= 16 terms + dst: < 34 r, below reduce_small's 64 r).
+constexpr uint32_t GATE_MAX_TERMS = 16, GATE_MAX_FACTORS = 48, GATE_MAX_POLYS = 24;
+struct GatePlan {
+  const fe_t *poly[GATE_MAX_POLYS];
+  fe_t coeff[GATE_MAX_TERMS];            // Montgomery (ABI) form
+  int32_t factor_rot[GATE_MAX_FACTORS];
+  uint8_t factor_poly[GATE_MAX_FACTORS];
+  uint8_t term_len[GATE_MAX_TERMS];      // factors per term (0: the constant c_j)
+  uint32_t n_terms, accumulate;
+};
+__global__ void __launch_bounds__(256) k_fr_gate_eval(fe_t *__restrict__ dst, GatePlan G, uint64_t n) {
+  const uint64_t mask = n - 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    fe29_t acc = Fr29::zero();
+    uint32_t f = 0;
+    for (uint32_t j = 0; j < G.n_terms; j++) {
+      const uint32_t len = G.term_len[j];
+      fe29_t t;
+      if (len == 0) t = Fr29::from_sat_plain(G.coeff[j]);
+      else {
+        t = Fr29::mul(Fr29::from_sat_plain(g_load(&G.poly[G.factor_poly[f]][(i + (uint64_t)(int64_t)G.factor_rot[f]) & mask])), Fr29::from_sat(G.coeff[j]));
+        for (uint32_t q = 1; q < len; q++)
+          t = Fr29::mul(t, Fr29::from_sat(g_load(&G.poly[G.factor_poly[f + q]][(i + (uint64_t)(int64_t)G.factor_rot[f + q]) & mask])));
+      }
+      f += len;
+      acc = Fr29::add(acc, t);
+      if ((j & 3) == 3) acc = Fr29::carry(acc);
+    }
+    if (G.accumulate) acc = Fr29::add(acc, Fr29::from_sat_plain(g_load(&dst[i])));
+    g_store(&dst[i], fr29_finish(Fr29::reduce_small(Fr29::normalise(acc))));
+  }
+}
+
 // sum of m canonical field elements (the per-block partials) by one workgroup
 __global__ void __launch_bounds__(256) k_fr_sum(const fe_t *__restrict__ in, uint64_t m, fe_t *__restrict__ out) {
   __shared__ fe_t lds[4];

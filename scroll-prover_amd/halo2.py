@@ -181,6 +181,19 @@ def fr_vec_axpy(dst, a, b, scalar: np.ndarray):
     return dst
 
 
+def gate_eval(dst, polys, terms, n: int, accumulate: bool = False):
+    """dst[i] (+)= sum_j c_j * prod_k polys[p][(i + rot) mod n] in ONE launch (mi355_fr_gate_eval_dev): the operand shape of halo2's
+    evaluate_h (rotated columns, sums of products).  terms: list of (c_j: [4] u64 Montgomery, [(poly index, rotation in elements), ...])."""
+    coeffs = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64) for c, _ in terms])) if terms else np.zeros((0, 4), dtype=np.uint64)
+    term_len = (C.c_uint32 * max(1, len(terms)))(*[len(f) for _, f in terms])
+    flat = [pr for _, f in terms for pr in f]
+    fp = (C.c_uint32 * max(1, len(flat)))(*[p for p, _ in flat])
+    fr_ = (C.c_int32 * max(1, len(flat)))(*[r for _, r in flat])
+    arr = (C.c_void_p * max(1, len(polys)))(*[q.data_ptr() for q in polys])
+    check(lib().mi355_fr_gate_eval_dev(ptr(dst), arr, len(polys), ptr(coeffs), term_len, len(terms), fp, fr_, n, 1 if accumulate else 0))
+    return dst
+
+
 def kate_division(poly, z: np.ndarray, dst=None):
     """halo2_proofs::arithmetic::kate_division: (poly(X) - poly(z)) / (X - z) on a device-resident coefficient vector -> n - 1 coefficients."""
     import torch

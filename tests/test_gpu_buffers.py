@@ -220,3 +220,54 @@ def test_buffers_and_batches_over_two_device_slots():
         params.release()
     finally:
         _reinit(pkg, 0, {})
+
+
+def test_gate_eval_matches_oracle_on_random_term_lists(zk):
+    """mi355_fr_gate_eval_dev (one launch: rotated operands, sums of products) against the oracle's restatement of the evaluate_h operand
+    shape: random term lists, negative and wrapping rotations, a constant term, accumulation, the per-launch limits."""
+    h2 = zk.halo2
+    lib, capi = zk._capi.lib(), zk._capi
+    rng = np.random.default_rng(91)
+    for k in (6, 11, 14):
+        n = 1 << k
+        polys_h = [rand_fr(rng, n) for _ in range(6)]
+        polys_d = [h2.DeviceBuffer.from_host(p) for p in polys_h]
+        dst = h2.DeviceBuffer(32 * n)
+        for trial in range(4):
+            nt = [1, 5, 16, 9][trial]
+            terms = []
+            for j in range(nt):
+                ln = 0 if (trial == 1 and j == 2) else int(rng.integers(1, 4 if nt > 9 else 6))
+                terms.append((rand_fr(rng, 1, full=False)[0], [(int(rng.integers(0, 6)), int(rng.integers(-3 * n, 3 * n)) if j % 3 else int(rng.integers(-2, 3))) for _ in range(ln)]))
+            coeffs = np.stack([c for c, _ in terms])
+            tl = [len(f) for _, f in terms]; fp = [p for _, f in terms for p, _ in f]; fr_ = [r for _, f in terms for _, r in f]
+            want = cref.gate_eval(polys_h, coeffs, tl, fp, fr_, n)
+            h2.gate_eval(dst, polys_d, terms, n)
+            got = dst.fr()
+            assert (got == want).all(), (k, trial)
+            want2 = cref.gate_eval(polys_h, coeffs, tl, fp, fr_, n, dst=want)
+            h2.gate_eval(dst, polys_d, terms, n, accumulate=True)
+            assert (dst.fr() == want2).all()
+        # a permutation-argument-shaped expression: z(wX) * prod(a_i + beta s_i + gamma) - z(X) * prod(a_i + beta d^i X + gamma) has degree-3
+        # products of rotated columns; here: z[i+1] * a[i] * b[i] - z[i] * c[i] * d[i]   (rotation scaled as on a coset part: rot_scale = 1)
+        one, minus_one = cref.fr_mont(1), cref.fr_mont(R - 1)
+        terms = [(one, [(0, 1), (1, 0), (2, 0)]), (minus_one, [(0, 0), (3, 0), (4, 0)])]
+        h2.gate_eval(dst, polys_d, terms, n)
+        z, a, b, c, d = polys_h[:5]
+        lhs = cref.f_mul_vec(cref.FR, cref.f_mul_vec(cref.FR, np.roll(z, -1, axis=0), a), b)
+        rhs = cref.f_mul_vec(cref.FR, cref.f_mul_vec(cref.FR, z, c), d)
+        want = np.stack([cref.f_sub(cref.FR, lhs[i], rhs[i]) for i in range(n)]) if n <= 2048 else None
+        if want is not None:
+            assert (dst.fr() == want).all()
+        for b_ in polys_d + [dst]:
+            b_.free()
+    # limits and argument checks
+    d0 = h2.DeviceBuffer(32 * 8)
+    arr = (C.c_void_p * 1)(d0.data_ptr())
+    one = np.ascontiguousarray(np.stack([cref.fr_mont(1)] * 17))
+    tl17 = (C.c_uint32 * 17)(*([0] * 17)); fp1 = (C.c_uint32 * 1)(0); fr1 = (C.c_int32 * 1)(0)
+    assert lib.mi355_fr_gate_eval_dev(C.c_void_p(d0.data_ptr()), arr, 1, capi.ptr(one), tl17, 17, fp1, fr1, 8, 0) == capi.EBADARG    # 17 terms
+    assert lib.mi355_fr_gate_eval_dev(C.c_void_p(d0.data_ptr()), arr, 1, capi.ptr(one), tl17, 1, fp1, fr1, 12, 0) == capi.EBADARG    # n not a power of two
+    tl1 = (C.c_uint32 * 1)(1); fp_bad = (C.c_uint32 * 1)(3)
+    assert lib.mi355_fr_gate_eval_dev(C.c_void_p(d0.data_ptr()), arr, 1, capi.ptr(one), tl1, 1, fp_bad, fr1, 8, 0) == capi.EBADARG   # factor outside the list
+    d0.free()

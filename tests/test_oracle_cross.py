@@ -242,3 +242,34 @@ def test_kate_division_oracle():
             back[i + 1] = (back[i + 1] + c) % R; back[i] = (back[i] - z * c) % R
         back[0] = (back[0] + pyref.eval_poly(coeffs, z)) % R
         assert back == coeffs
+
+
+def test_gate_eval_restatement_matches_big_integer_definition():
+    """orc_gate_eval (the checker of mi355_fr_gate_eval_dev) against the definition in Python big integers: random term lists with
+    positive / negative rotations, a constant term, repeated factors, with and without accumulation."""
+    rng = np.random.default_rng(77)
+    n = 64
+    R_ = pyref.R_MOD
+    vals = [[(int(x) * 0x9E3779B97F4A7C15 * int(x) + 12345) % R_ for x in rng.integers(0, 2**63, size=n)] for _ in range(5)]
+    polys = [np.stack([cref.fr_mont(v) for v in col]) for col in vals]
+    for trial in range(6):
+        nt = int(rng.integers(1, 8))
+        terms = []
+        for j in range(nt):
+            ln = 0 if (trial == 0 and j == 0) else int(rng.integers(1, 5))
+            c = int(rng.integers(1, 2**62)) * 3 + 1
+            terms.append((c, [(int(rng.integers(0, 5)), int(rng.integers(-70, 70))) for _ in range(ln)]))
+        coeffs = np.stack([cref.fr_mont(c) for c, _ in terms])
+        tl = [len(f) for _, f in terms]; fp = [p for _, f in terms for p, _ in f]; fr_ = [r for _, f in terms for _, r in f]
+        base = [int(x) % R_ for x in rng.integers(0, 2**63, size=n)]
+        dst0 = np.stack([cref.fr_mont(v) for v in base])
+        for acc in (False, True):
+            got = cref.gate_eval(polys, coeffs, tl, fp, fr_, n, dst=dst0 if acc else None)
+            for i in (0, 1, n // 2, n - 1):
+                want = base[i] if acc else 0
+                for c, f in terms:
+                    t = c
+                    for p, r in f:
+                        t = t * vals[p][(i + r) % n] % R_
+                    want = (want + t) % R_
+                assert cref.limbs_to_int(cref.f_to_canonical_vec(cref.FR, got[i:i + 1])[0]) == want
