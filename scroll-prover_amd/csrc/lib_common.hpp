@@ -78,7 +78,7 @@ struct Ctx {
   // host-pointer MSM: chunked copy on its own stream, overlapped with the digit extraction (msm_host_single); also the stream the
   // resident-buffer uploads run on (mi355_buf_upload)
   hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_up = nullptr;   // last upload on copy_stream (the compute stream waits for it)
+  hipEvent_t ev_up[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint32_t up_next = 0;   // uploads on copy_stream (ring: several threads may upload at once); the compute stream waits for each
   uint32_t host_slice_min_log = 22;   // MI355_HOST_SLICE_MIN_LOG: smallest log2(n) the host-pointer MSM cuts into slices (tests lower it)
   uint32_t host_chunks = 8;     // MI355_HOST_CHUNKS: upper bound on the point-range slices of the host-pointer MSM (1 = one copy, then compute)
   int device = -1;

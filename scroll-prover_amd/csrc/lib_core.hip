@@ -172,7 +172,7 @@ static int init_ctx(int slot, int device_id) {
   HIPCHK(hipEventCreateWithFlags(&g.ev_xchg, hipEventDisableTiming));
   HIPCHK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[i], hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&g.ev_up, hipEventDisableTiming));
+  for (int i = 0; i < 8; i++) HIPCHK(hipEventCreateWithFlags(&g.ev_up[i], hipEventDisableTiming));
   { const char *e = getenv("MI355_MSM_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 16) g.msm_chunks = (uint32_t)v; } }
   // dynamic-LDS limits are per device and per kernel: each translation unit sets the ones of the kernels it launches
   CHK(msm_tu_init_device());
@@ -226,7 +226,7 @@ static void destroy_ctx(int slot) {
   }
   if (g.ev_fork) { (void)hipEventDestroy(g.ev_fork); g.ev_fork = nullptr; }
   if (g.ev_xchg) { (void)hipEventDestroy(g.ev_xchg); g.ev_xchg = nullptr; }
-  if (g.ev_up) { (void)hipEventDestroy(g.ev_up); g.ev_up = nullptr; }
+  for (int i = 0; i < 8; i++) if (g.ev_up[i]) { (void)hipEventDestroy(g.ev_up[i]); g.ev_up[i] = nullptr; }
   for (int i = 0; i < 4; i++) if (g.ev_copy[i]) { (void)hipEventDestroy(g.ev_copy[i]); g.ev_copy[i] = nullptr; }
   if (g.copy_stream) { (void)hipStreamDestroy(g.copy_stream); g.copy_stream = nullptr; }
   g.own_stream = g.stream = nullptr; g.inited = false; g.device = -1;
@@ -560,13 +560,15 @@ int mi355_buf_slot(const void *dev_ptr, int *slot_out) {
 // Host -> device.  The copy runs on the owner device's COPY stream, so it overlaps whatever the compute stream is doing: an upload into a
 // block that no library call has used since mi355_buf_alloc only waits for the work that was queued on the block before its last
 // mi355_buf_free; an upload into a block in use waits for the compute stream.  Later library calls on the device see the data (the compute
-// stream waits for the copy).  On return the host buffer may be reused.
+// stream waits for the copy).  On return the host buffer may be reused.  The device lock is NOT held while the DMA runs (a pageable source
+// blocks the calling thread for the length of the copy): another thread's commitments and transforms proceed on the device meanwhile --
+// the witness of column i + 1 crosses PCIe while column i is being committed.
 int mi355_buf_upload(void *dst_dev, const void *src_host, uint64_t bytes) {
   return guarded([&]() -> int {
   if (bytes == 0) return MI355_OK;
   if (!dst_dev || !src_host) return fail(MI355_EBADARG, "buf_upload: null pointer");
   const int slot = slot_of(dst_dev, false);
-  hipEvent_t done = nullptr;
+  hipStream_t cs = nullptr; hipEvent_t done = nullptr;
   {
     DevGuard lk(slot);
     CHK(need_init(slot));
@@ -574,12 +576,16 @@ int mi355_buf_upload(void *dst_dev, const void *src_host, uint64_t bytes) {
     { std::lock_guard<std::mutex> bl(g_buf_mu); if (BufBlock *b = buf_find_locked(dst_dev)) { if ((uintptr_t)dst_dev + bytes > (uintptr_t)b->p + b->bytes) return fail(MI355_EBADARG, "buf_upload: range exceeds the block"); fresh = !b->used; free_ev = b->free_ev; b->used = true; } }
     if (fresh) { if (free_ev) HIPCHK(hipStreamWaitEvent(g.copy_stream, free_ev, 0)); }
     else { HIPCHK(hipEventRecord(g.ev_fork, g.stream)); HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_fork, 0)); }
-    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, g.copy_stream));   // pageable source: blocks this thread while the DMA runs
-    HIPCHK(hipEventRecord(g.ev_up, g.copy_stream));
-    HIPCHK(hipStreamWaitEvent(g.stream, g.ev_up, 0));
-    done = g.ev_up;
+    cs = g.copy_stream; done = g.ev_up[g.up_next++ & 7];
   }
-  HIPCHK(hipEventSynchronize(done));   // pinned sources return from hipMemcpyAsync at once: wait here, with the device lock released
+  HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, cs));   // this thread stays bound to the device (need_init above)
+  HIPCHK(hipEventRecord(done, cs));
+  {
+    DevGuard lk(slot);
+    CHK(need_init(slot));
+    HIPCHK(hipStreamWaitEvent(g.stream, done, 0));
+  }
+  HIPCHK(hipEventSynchronize(done));   // pinned sources return from hipMemcpyAsync at once
   return MI355_OK;
   });
 }

@@ -55,3 +55,37 @@ def test_shim_replay_on_gpu():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
+
+
+def test_create_proof_replay_compiles_and_fails_loudly_without_a_gpu():
+    """tests/cpp/test_create_proof_replay.cpp = create_proof's step order over resident buffers, compiled: without a GPU it stops at mi355_init."""
+    import torch
+    exe = build_exe("test_create_proof_replay")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the full replay runs under -m gpu")
+    out = subprocess.run([exe, "--k", "8"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "mi355_init" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,env", [
+    (["--layer", "4", "--k", "13"], {}),
+    (["--layer", "2", "--k", "12", "--host-api"], {}),
+    (["--layer", "1", "--k", "10", "--no-tables"], {}),
+    (["--layer", "4", "--k", "12", "--devices", "2"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "8"}),
+    (["--layer", "2", "--k", "11", "--devices", "3"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "6"}),
+])
+def test_create_proof_replay_on_gpu(args, env):
+    """SURVEY 3.2 steps 1-10 for the layer-4 / layer-2 / layer-1 counts at test sizes, polynomials resident, every commitment checked against
+    p(tau) G and every evaluation against Horner (oracle); two and three device slots: columns live round-robin on the devices, coset parts
+    are computed on different devices by different host threads, commitments take scalars from whichever device holds them."""
+    import json
+    exe = build_exe("test_create_proof_replay")
+    e = dict(os.environ); e.update(env)
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed" in out.stdout
+    line = next(l for l in out.stdout.splitlines() if l.startswith("{"))
+    rec = json.loads(line)
+    counts = {4: (14, 27), 2: (11, 17), 1: (28, 60)}[rec["layer"]]
+    assert rec["ok"] and rec["msm"] == counts[0] and rec["evals"] == counts[1] and rec["checked"] == counts[0] + counts[1], rec
