@@ -73,83 +73,22 @@ def witness_like_scalars(n: int, seed: int, device, h2) -> torch.Tensor:
     return a.contiguous()
 
 
-def proof_mix(zk, lib, check, ptr, h2, dev, k, g, g_handle, tau, args, rand_scalars):
-    """one layer-4 proof's call mix (see the call site); returns wall-clock ms device-resident and through the host-pointer API."""
-    n = 1 << k
-    dom = h2.EvaluationDomain(5, k)                   # quotient degree 4 -> extended_k = k + 2, four cosets of size 2^k
-    out = np.zeros(12, dtype=np.uint64)
-    # the Lagrange basis of the same SRS, registered with its window tables like g (registration-time work, outside the timing)
-    gl = torch.empty(n * 64, dtype=torch.uint8, device=dev)
-    scratch = torch.empty(n * 64, dtype=torch.uint8, device=dev)
-    w_k = pow(h2.FR_ROOT_OF_UNITY, 1 << (h2.FR_S - k), h2.R_MOD)
-    check(lib.mi355_srs_setup_dev(ptr(scratch), ptr(gl), k, ptr(h2.fr(tau)), ptr(h2.fr(w_k))))
-    del scratch
-    hl = C.c_uint64(); check(lib.mi355_srs_register_dev(ptr(gl), n, 0, C.byref(hl)))
-    tables = not args.no_precompute and not args.window_bits
-    if tables:
-        check(lib.mi355_srs_precompute(hl.value, 0, 0))
-    NW, Q = 8, 4
-    polys = [rand_scalars(n, 7000 + i, dev) for i in range(NW)]
-    part = torch.empty((n, 4), dtype=torch.int64, device=dev)
-    acc = torch.zeros((Q * n, 4), dtype=torch.int64, device=dev)          # the quotient on the extended domain, part by part
-    pt = h2.fr(0x1234567890ABCDEF)
-    # steady state of a prover that runs proof after proof: the library's grow-only workspace arena already has its final size (the 2^(k+2)
-    # transform alone allocates an 8 GiB scratch buffer on its first call, 0.1-0.3 s of hipMalloc that the first run of a process pays once)
-    dom.extended_to_coeff(acc); acc.zero_()
-    h2.batch_invert(part); h2.prefix_product(part, dst=part); h2.kate_division(part, pt, dst=acc[: n - 1]); acc.zero_(); part.zero_()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for p_ in polys:                                                        # witness commitments (Lagrange basis)
-        check(lib.mi355_msm_g1_dev(hl.value, 0, ptr(p_), n, ptr(out)))
-    for i in (0, 1):                                                        # permutation / lookup products: batch inversion + running product
-        h2.batch_invert(polys[i]); h2.prefix_product(polys[i], dst=part)
-    for p_ in polys:
-        dom.lagrange_to_coeff(p_)
-    for q in range(Q):
-        hq = acc[q * n:(q + 1) * n]
-        for i, p_ in enumerate(polys):
-            dom.coeff_to_extended_part(p_, q, part)
-            h2.fr_vec_op("mul" if i % 2 else "add", hq, hq, part)         # stand-in for the gate / permutation / lookup expressions of evaluate_h
-    dom.divide_by_vanishing_poly(acc)
-    dom.extended_to_coeff(acc)
-    for q in range(Q):                                                      # quotient pieces (coefficient basis)
-        check(lib.mi355_msm_g1_dev(g_handle.value, 0, ptr(acc[q * n:(q + 1) * n]), n, ptr(out)))
-    for i in range(27):
-        h2.eval_polynomial(polys[i % NW], pt)
-    for i in range(NW):                                                     # multi-open: linear combination, two quotients, two commitments
-        h2.fr_vec_axpy(part, part if i else None, polys[i], pt)
-    for _ in range(2):
-        h2.kate_division(part, pt, dst=acc[: n - 1])
-        check(lib.mi355_msm_g1_dev(g_handle.value, 0, ptr(acc[:n]), n, ptr(out)))
-    check(lib.mi355_synchronize()); torch.cuda.synchronize()
-    dev_ms = (time.perf_counter() - t0) * 1e3
-    res = {"layer": "4 (batch compression, k = %d)" % k, "device_resident_ms": dev_ms,
-           "calls": "14 MSM 2^%d (8 Lagrange + 6 coefficient basis), 8 iNTT + 32 coset NTT 2^%d, 1 extended_to_coeff 2^%d, 2 batch_invert + 2 prefix_product, 27 eval_polynomial, 8 axpy, 2 kate_division, 40 pointwise" % (k, k, k + 2),
-           "window_tables": tables, "excludes": "witness synthesis, the gate arithmetic of evaluate_h, transcript hashing (CPU side of create_proof)"}
-    del acc, part
-    if not args.no_host_api:
-        # the same MSM / NTT calls through the host-pointer entry points the Rust shim binds (every operand crosses PCIe both ways;
-        # the pointwise steps and scans stay on the CPU in that integration and are not part of this leg)
-        hp = polys[0].cpu().numpy().view(np.uint64)
-        hext = np.zeros((Q * n, 4), dtype=np.uint64)
-        t1 = time.perf_counter()
-        for _ in range(8):
-            check(lib.mi355_msm_g1_host(hl.value, 0, ptr(hp), n, ptr(out)))
-        for _ in range(6):
-            check(lib.mi355_msm_g1_host(g_handle.value, 0, ptr(hp), n, ptr(out)))
-        for _ in range(8):
-            dom.lagrange_to_coeff(hp)
-        for _ in range(32):
-            h2.best_fft(hp, dom.omega, k)
-        check(lib.mi355_extended_to_coeff_host(ptr(hext), dom.extended_k, ptr(dom.g_coset), ptr(dom.g_coset_inv), ptr(dom.extended_omega_inv), ptr(dom.extended_ifft_divisor)))
-        for _ in range(27):
-            h2.eval_polynomial(hp, pt)
-        res["host_api_ms"] = (time.perf_counter() - t1) * 1e3
-        res["host_api_calls"] = "14 mi355_msm_g1_host, 8 mi355_intt_fr_host, 32 mi355_ntt_fr_host, 1 mi355_extended_to_coeff_host (2^%d), 27 mi355_eval_polynomial_host; pageable numpy buffers" % (k + 2)
-        del hp, hext
-    check(lib.mi355_srs_release(hl.value))
-    del polys, gl
-    torch.cuda.empty_cache()
-    return res
+def replay_create_proof(layer: int, k: int | None = None, host_api: bool = True, timeout: int = 900):
+    """tests/cpp/test_create_proof_replay: SURVEY 3.2 steps 1-10 for one layer's counts, a COMPILED caller of the C-ABI with the proof's
+    polynomials resident in HBM (mi355_buf_*), witness uploads overlapped, every commitment and evaluation checked afterwards.  Run as its own
+    process BEFORE this process binds the GPU (each needs the window tables of both bases: 96 GiB at k = 26).  Returns the program's JSON record."""
+    import subprocess
+    exe = ge.build_cpp("test_create_proof_replay")
+    cmd = [exe, "--layer", str(layer)] + (["--k", str(k)] if k else []) + (["--host-api"] if host_api else [])
+    t0 = time.perf_counter()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    wall = time.perf_counter() - t0
+    line = next((l for l in out.stdout.splitlines() if l.startswith("{")), None)
+    if out.returncode != 0 or line is None:
+        return {"layer": layer, "ok": False, "error": (out.stdout + out.stderr)[-400:]}
+    rec = json.loads(line)
+    rec["process_wall_s"] = wall
+    return rec
 
 
 def main() -> None:
@@ -161,9 +100,11 @@ def main() -> None:
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--table-bits", type=int, default=0, help="window bits of the registration-time tables (mi355_srs_precompute; 0 = automatic, up to 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log", type=int, default=26, help="log2 of the sample the CPU baselines run on (default: the full workload, ~25 s MSM + ~10 s NTT on 16 CPUs)")
+    ap.add_argument("--no-batch-legs", action="store_true", help="skip the many-column legs (110 x 2^21, 256 x 2^20 through mi355_msm_g1_batch_dev)")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="skip the registration-time window tables (mi355_srs_precompute)")
-    ap.add_argument("--no-proof-mix", action="store_true", help="skip the replay of one layer-4 (k = 26) proof's MSM / NTT call mix (device-resident and through the host API)")
+    ap.add_argument("--no-proof-mix", action="store_true", help="skip the compiled create_proof replays (layer 4, and layers 1 + 2 as the chunk-proof proxy; resident and through the host API)")
     ap.add_argument("--proxy-chunk-proof", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--single-process", action="store_true", help="N GPUs behind ONE process (mi355_init_multi: shards, worker threads, ncclAllGather inside the library) instead of one rank per GPU")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer leg (mi355_msm_g1_host: scalars cross PCIe inside the call; reported next to, never as, the headline value)")
@@ -194,6 +135,23 @@ def main() -> None:
         else:
             dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" == RCCL on ROCm
 
+    # ---- "chunk-proof wall-clock" (third part of the BASELINE metric): not producible here (no Rust / Go / SRS / trace), so the stated stand-in is
+    # the compiled replay of create_proof's GPU-side step order per layer: layer 4 (k = 26, the batch proof: 14 MSM, 8 iNTT,
+    # 32 coset NTT, 2^28 inverse, scans, 27 evaluations, multi-open) and the two compression layers a CHUNK proof runs, layer 1 (k = 24) +
+    # layer 2 (k = 25: 11 MSM, [1,1,3] witness polynomials, Q = 4, 17 evaluations).  Each replay is its own
+    # process and runs before this one binds the GPU; resident = polynomials stay in HBM between calls, host_api = every operand crosses PCIe.
+    proof_mix = None
+    if world == 1 and not single and rank == 0 and not args.no_proof_mix and args.logn == 26:
+        l4 = replay_create_proof(4, host_api=not args.no_host_api)
+        l2 = replay_create_proof(2, host_api=not args.no_host_api)
+        l1 = replay_create_proof(1, host_api=not args.no_host_api)
+        ok_all = all(r.get("ok") for r in (l4, l2, l1))
+        proof_mix = {"c_abi_resident_ms": l4.get("resident_ms"), "host_api_ms": l4.get("host_api_ms"), "layer4": l4,
+                     "chunk_proof_proxy": {"what": "layer 1 (k = 24) + layer 2 (k = 25) compression proofs of one chunk, GPU side of create_proof; layer 0 (the k = 20 inner SuperCircuit proof, O(10^3) commitments) is not replayed",
+                                           "resident_ms": (l1.get("resident_ms", 0) + l2.get("resident_ms", 0)) if ok_all else None,
+                                           "host_api_ms": (l1.get("host_api_ms", 0) + l2.get("host_api_ms", 0)) if ok_all else None, "layer1": l1, "layer2": l2},
+                     "all_commitments_and_evaluations_checked": ok_all,
+                     "excludes": "witness synthesis, transcript hashing (CPU side of create_proof); the gate expression is a stand-in of the right shape (rotated operands, degree-3 products)"}
     zk = ge.load_package()
     lib, check, ptr, h2 = zk._capi.lib(), zk._capi.check, zk._capi.ptr, zk.halo2
     if single:
@@ -348,16 +306,20 @@ def main() -> None:
         ntt["eval_polynomial"] = {"log_n": k, "ms": dt_ev * 1e3, "roofline": {"bound": "hbm", "achieved": 32.0 * (1 << k) / dt_ev / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": 32.0 * (1 << k) / dt_ev / 1e9 / HBM_PEAK_GBS, "note": "algorithmic bytes = 32 B per coefficient, host wall time incl. the 32-byte result copy"}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            # CPU baseline of the transform (rank 0, N = 1): the oracle's restatement of best_fft (bit-reverse + radix-2 layers, thread
-            # split) on a bounded sample: 2^22 coefficients of the same data, all host threads
+            # CPU baseline of the transform (rank 0, N = 1): the oracle's restatement of best_fft (bit-reverse + radix-2 layers, thread split) on
+            # the SAME 2^k coefficients, all usable host threads (~10 s at 2^26); its output doubles as the checker of the device transform
             from oracle import cref
             cores = cref.usable_cpus()   # affinity mask and cgroup quota, not the host's hardware threads
-            ks_ = min(k, 22)
+            ks_ = min(k, args.cpu_sample_log)
             sample = poly[: 1 << ks_].cpu().numpy().view(np.uint64).reshape(1 << ks_, 4).copy()
             dom_s = h2.EvaluationDomain(2, ks_)
-            t8 = time.perf_counter(); cref.best_fft(sample, dom_s.omega, ks_, threads=cores); dt_c = time.perf_counter() - t8
+            t8 = time.perf_counter(); want_f = cref.best_fft(sample, dom_s.omega, ks_, threads=cores); dt_c = time.perf_counter() - t8
             ntt["cpu_baseline"] = {"value": (1 << ks_) // 2 * ks_ / dt_c, "unit": "butterflies/s", "cores": cores, "host_hw_threads": os.cpu_count(), "kind": "port",
-                                   "sample": f"best_fft restatement (oracle/bn254_oracle.c, pthreads) on 2^{ks_} coefficients of the same data, {dt_c:.2f} s wall"}
+                                   "sample": f"best_fft restatement (oracle/bn254_oracle.c, pthreads) on 2^{ks_} coefficients of the same data" + (" (the full workload)" if ks_ == k else "") + f", {dt_c:.2f} s wall"}
+            if ks_ == k:
+                dom.coeff_to_lagrange(poly)
+                ntt["full_vector_equals_cpu_baseline"] = bool((poly.cpu().numpy().view(np.uint64).reshape(1 << k, 4) == want_f).all())
+            del sample, want_f
         del poly
 
     extra = {}
@@ -391,14 +353,8 @@ def main() -> None:
         check(lib.mi355_msm_last_plan(C.byref(c2), C.byref(w2), C.byref(e2)))
         check(lib.mi355_msm_set_window_bits(0))
         extra["without_window_tables"] = {"ms_per_commit": nt_ms, "window_bits": c2.value, "windows": w2.value, "same_result": nt_ok}
-    if world == 1 and not args.no_proof_mix:
-        # ---- proxy for "chunk-proof wall-clock" (BASELINE metric, third part): the MSM / NTT / scan call mix of ONE layer-4 compression
-        # proof (k = 26: the batch proof; fixture counts [3, 1, 4] witness columns, Q = 4, 27 evaluations) replayed on synthetic
-        # data -- the GPU side of create_proof only (witness synthesis, evaluate_h's gate arithmetic and the transcript stay on the CPU).
-        #   8 commit_lagrange (advice 3, lookup 1, permutation / lookup / random 4) | 8 lagrange_to_coeff | 8 x 4 coset NTTs of 2^k (the scroll
-        #   fork's coeff_to_extended_part) with the pointwise accumulation between them | extended_to_coeff on 2^(k+2) | 4 quotient-piece commits
-        #   | 2 batch inversions + 2 grand products (permutation / lookup z) | 27 evaluations | multi-open: 8 axpy + 2 kate_division + 2 commits
-        extra["proof_mix"] = proof_mix(zk, lib, check, ptr, h2, dev, k, g, handle, tau, args, rand_scalars)
+    if proof_mix is not None:
+        extra["proof_mix"] = proof_mix
     if world == 1 and k <= 26 and not args.no_witness_like:
         # the second scalar distribution the survey asks for: mostly zeros / tiny values (giant buckets, few entries)
         wl = witness_like_scalars(n, 0x5343524F4C4C0004, dev, h2)
@@ -471,12 +427,50 @@ def main() -> None:
             sizes["k%d" % ks] = rec
         extra["sizes"] = sizes
 
+    if world == 1 and not args.no_batch_legs and k >= 22:
+        # the k = 20 / 21 regime of the real proof: layer 3 commits ~110 columns of 2^21 [REF integration/configs/layer3.config:3-8], layer 0 O(10^3)
+        # columns of 2^20 [REF integration/src/capacity_checker.rs:90-92].  One mi355_msm_g1_batch_dev call = the per-column commit loop of
+        # create_proof as ONE pass (one reduction tail per batch instead of per column); first and last result checked in the field.
+        from oracle import cref
+        legs = {}
+        for ks, M in ((21, 110), (20, 256)):
+            ns = 1 << ks
+            hp = C.c_uint64()
+            check(lib.mi355_srs_register_prefix(handle.value, ns, C.byref(hp)))
+            if pre_ms is not None:
+                check(lib.mi355_srs_precompute(hp.value, 0, 0))
+            cols = rand_scalars(M * ns, 0x5343524F4C4C0010 + ks, dev)
+            arr = (C.c_void_p * M)(*[cols[m * ns:(m + 1) * ns].data_ptr() for m in range(M)])
+            outs = np.zeros((M, 12), dtype=np.uint64)
+            check(lib.mi355_msm_g1_batch_dev(hp.value, 0, arr, M, ns, ptr(outs)))
+            torch.cuda.synchronize(); tb = time.perf_counter()
+            for _ in range(2):
+                check(lib.mi355_msm_g1_batch_dev(hp.value, 0, arr, M, ns, ptr(outs)))
+            dt_b = (time.perf_counter() - tb) / 2
+            cb, wb, eb = C.c_int(), C.c_int(), C.c_uint64()
+            check(lib.mi355_msm_last_plan(C.byref(cb), C.byref(wb), C.byref(eb)))
+            one = np.zeros(12, dtype=np.uint64)
+            check(lib.mi355_msm_g1_dev(hp.value, 0, ptr(cols[:ns]), ns, ptr(one)))
+            torch.cuda.synchronize(); t1c = time.perf_counter()
+            for _ in range(10):
+                check(lib.mi355_msm_g1_dev(hp.value, 0, ptr(cols[:ns]), ns, ptr(one)))
+            dt_1 = (time.perf_counter() - t1c) / 10
+            ok_b = all(bool((outs[m][:8] == cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(cols[m * ns:(m + 1) * ns].cpu().numpy().view(np.uint64), tau_m)))).all()) for m in (0, M - 1))
+            ok_b = ok_b and bool((outs[0] == one).all())
+            legs[f"{M}x2^{ks}"] = {"columns": M, "log_n": ks, "ms_per_batch": dt_b * 1e3, "ms_per_commit": dt_b * 1e3 / M, "pairs_per_s": M * ns / dt_b,
+                                   "g1_adds_per_s": eb.value / dt_b, "window_bits": cb.value, "windows": wb.value,
+                                   "single_commit_ms": dt_1 * 1e3, "single_commit_pairs_per_s": ns / dt_1, "verified_against_field_check": ok_b}
+            check(lib.mi355_srs_release(hp.value))
+            del cols
+            torch.cuda.empty_cache()
+        extra["batched_commitments"] = legs
+
     # ---- CPU baseline (rank 0, N = 1 only): the restated reference algorithm on a bounded sample of the same workload
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cref
         cores = cref.usable_cpus()   # affinity mask and cgroup quota, not the host's hardware threads
-        ks = min(k, 23)   # ~3 s wall on 16 usable CPUs (~50 CPU-seconds)
+        ks = min(k, args.cpu_sample_log)   # the full 2^26 workload: ~25 s wall on 16 usable CPUs
         ns = 1 << ks
         sc_host = scalars[:ns].cpu().numpy().view(np.uint64)
         g_host = g[: ns * 64].cpu().numpy().view(np.uint64).reshape(ns, 8)

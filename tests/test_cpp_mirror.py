@@ -14,12 +14,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "test_halo2_mirror")
 
 def build_exe(name="test_halo2_mirror"):
     ge.build()
-    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
-    exe = os.path.join(ROOT, "tests", "cpp", name)
-    pkg = os.path.join(ROOT, "scroll-prover_amd"); orc = os.path.join(ROOT, "oracle")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
-                           "-L", pkg, "-lmi355zk", "-L", orc, "-loracle_bn254", f"-Wl,-rpath,{pkg}", f"-Wl,-rpath,{orc}", "-Wl,-rpath,/opt/rocm/lib"])
-    return exe
+    return ge.build_cpp(name)
 
 
 def test_cpp_mirror_host_only():
