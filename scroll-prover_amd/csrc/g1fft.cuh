@@ -98,7 +98,7 @@ __device__ __noinline__ g1_xyzz29_t g1_xyzz29_mul_fr(const g1_xyzz29_t &p, const
 #ifndef ZK_G1FFT_GLV
 #define ZK_G1FFT_GLV true
 #endif
-__device__ __noinline__ g1_xyzz29_t g1_xyzz29_mul_scalar(const g1_xyzz29_t &p, const fe_t &k) { return ZK_G1FFT_GLV ? g1_xyzz29_mul_glv(p, k) : g1_xyzz29_mul_fr(p, k); }
+__device__ __forceinline__ g1_xyzz29_t g1_xyzz29_mul_scalar(const g1_xyzz29_t &p, const fe_t &k) { return ZK_G1FFT_GLV ? g1_xyzz29_mul_glv(p, k) : g1_xyzz29_mul_fr(p, k); }
 
 __device__ __forceinline__ g1_xyzz_t g1fft_load_xyzz(const g1_xyzz_t *p) {
   g1_xyzz_t r; r.x = g_load(&p->x); r.y = g_load(&p->y); r.zz = g_load(&p->zz); r.zzz = g_load(&p->zzz); return r;
@@ -127,17 +127,19 @@ template <int JAC> __global__ void __launch_bounds__(256) k_g1fft_load(const voi
 }
 
 // one decimation-in-time stage; tw[i] = omega^i (Montgomery), i < n / 2
-__global__ void __launch_bounds__(256) k_g1fft_stage(g1_xyzz_t *__restrict__ work, const fe_t *__restrict__ tw, uint32_t log_n, uint32_t s) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_g1fft_stage(g1_xyzz_t *__restrict__ work, const fe_t *__restrict__ tw, uint32_t log_n, uint32_t s) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (1u << log_n) / 2) return;
   const uint32_t m = 1u << s, j = t & (m - 1), ia = ((t >> s) << (s + 1)) + j, ib = ia + m;
-  const g1_xyzz_t a = g1fft_load_xyzz(&work[ia]), b = g1fft_load_xyzz(&work[ib]);
-  g1_xyzz29_t wb = g1_xyzz29_from_sat(b);
+  g1_xyzz29_t wb = g1_xyzz29_from_sat(g1fft_load_xyzz(&work[ib]));
   if (j) {
     fe_t one_c = Fr::zero(); one_c.l[0] = 1;
     const fe_t k = fr_mul_ps(g_load(&tw[(uint64_t)j << (log_n - 1 - s)]), one_c);   // Montgomery -> canonical
     wb = g1_xyzz29_mul_scalar(wb, k);
   }
+  // `a` is loaded AFTER the scalar multiple (inlined: no call, no scratch memory): 32 registers less across the ladder, the kernel stays at
+  // two waves per SIMD without spilling
+  const g1_xyzz_t a = g1fft_load_xyzz(&work[ia]);
   g1_xyzz29_t lo = g1_xyzz29_from_sat(a), hi = lo;
   g1_xyzz29_add(lo, wb);
   if (!g1_xyzz29_is_identity(wb)) wb.y = Fq29::sub8(Fq29::zero(), wb.y);   // -w b: 8p - y (accumulator invariant: y < 6.1 p, limbs <= 2^30 - 2); only ever a multiplication operand below

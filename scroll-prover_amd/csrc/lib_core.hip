@@ -192,6 +192,8 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_FIXUP_HUGE_MIN"); if (e) { long v = atol(e); if (v >= 2048 && v <= 0x7fffffffL) g.fixup_huge_min = (uint32_t)v; } }
   { const char *e = getenv("MI355_FIXUP_SERIAL_MAX"); if (e) { int v = atoi(e); if (v >= 1 && v <= 1024) g.fixup_serial_max = (uint32_t)v; } }
   { const char *e = getenv("MI355_FIXUP_LANES_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 0 && v <= 31) g.fixup_lanes_max_log = (uint32_t)v; } }
+  { const char *e = getenv("MI355_TAIL_COOP_MASK"); if (e) g.tail_coop_mask = (uint32_t)atoi(e) & 15u; }
+  { const char *e = getenv("MI355_TAIL_COOP_MAX"); if (e) { long v = atol(e); if (v >= 0 && v <= (1l << 24)) g.tail_coop_max = (uint32_t)v; } }
   { const char *e = getenv("MI355_REDUCE_MIN_CHUNK"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) g.reduce_min_chunk = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_FB"); if (e) { int v = atoi(e); if (v >= 9 && v <= 12) g.sort_fb = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_FUSED_HIST"); if (e) g.sort_fused = e[0] == '0' ? 0u : 1u; }

@@ -86,23 +86,31 @@ int msm_reduce_tail(const MsmShape &sh, uint32_t M, const g1_xyzz29_t *buckets, 
   const uint32_t chunks_per_window = nb / chunk, nchunks = chunks_per_window * red_windows;
   g1_xyzz29_t *chunk_out, *tree_a, *tree_b, *window_sums;
   CHK(ws_get(role("msm.chunk_out").c_str(), (size_t)nchunks * sizeof(g1_xyzz29_t), (void **)&chunk_out));
-  { const size_t lvl = (size_t)ceil_div(chunks_per_window, 256 * TREE_PER_THREAD) * red_windows + 1;
+  { const size_t lvl = (size_t)ceil_div(chunks_per_window, 64 * TREE_PER_THREAD) * red_windows + 1;   // 64: the quad form's logical threads per block
     CHK(ws_get(role("msm.tree_a").c_str(), lvl * sizeof(g1_xyzz29_t), (void **)&tree_a)); CHK(ws_get(role("msm.tree_b").c_str(), lvl * sizeof(g1_xyzz29_t), (void **)&tree_b)); }
   CHK(ws_get(role("msm.window_sums").c_str(), (size_t)red_windows * sizeof(g1_xyzz29_t), (void **)&window_sums));
   MsmPlan PR; PR.n = 0; PR.c = sh.c; PR.windows = red_windows; PR.nb = nb; PR.seg = 0; PR.batch = M;
-  hipLaunchKernelGGL(k_msm_bucket_reduce, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
+  // latency form (a quad per logical thread, g1_xyzz29_add_q4: ~2.6x shorter dependent chain per addition) where the kernel cannot fill the
+  // GPU anyway; throughput form (one lane per thread) for big bucket sets.  MI355_TAIL_COOP_MAX = largest logical thread count that takes the quads.
+  const bool coop_reduce = nchunks <= g.tail_coop_max && (g.tail_coop_mask & 2u);
+  if (coop_reduce) hipLaunchKernelGGL(k_msm_bucket_reduce<4>, dim3(ceil_div((uint64_t)nchunks * 4, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
+  else hipLaunchKernelGGL(k_msm_bucket_reduce<1>, dim3(ceil_div(nchunks, 128)), dim3(128), 0, s, buckets, chunk_out, PR, chunk);
   {
     // tree-sum the chunk results per window, ping-ponging between two small buffers
     const g1_xyzz29_t *cur = chunk_out; uint32_t cnt = chunks_per_window; g1_xyzz29_t *bufs[2] = {tree_a, tree_b}; int which = 0;
     while (true) {
-      const uint32_t outn = ceil_div(cnt, 256 * TREE_PER_THREAD);
+      const bool coop = (uint64_t)cnt * red_windows <= g.tail_coop_max && (g.tail_coop_mask & 4u);
+      const uint32_t per_block = (coop ? 64u : 256u) * TREE_PER_THREAD;
+      const uint32_t outn = ceil_div(cnt, per_block);
       g1_xyzz29_t *dst = outn == 1 ? window_sums : bufs[which];
-      hipLaunchKernelGGL(k_msm_tree_sum29, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
+      if (coop) hipLaunchKernelGGL(k_msm_tree_sum29<4>, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
+      else hipLaunchKernelGGL(k_msm_tree_sum29<1>, dim3(outn, red_windows), dim3(256), 0, s, cur, cnt, dst, outn);
       if (outn == 1) break;
       cur = dst; cnt = outn; which ^= 1;
     }
   }
-  hipLaunchKernelGGL(k_msm_final29, dim3(M), dim3(64), 0, s, (const g1_xyzz29_t *)window_sums, red_wpp, sh.shared ? 0u : sh.c, out_dev, normalise ? 1 : 0);
+  if (g.tail_coop_max && (g.tail_coop_mask & 8u)) hipLaunchKernelGGL(k_msm_final29<4>, dim3(M), dim3(64), 0, s, (const g1_xyzz29_t *)window_sums, red_wpp, sh.shared ? 0u : sh.c, out_dev, normalise ? 1 : 0);
+  else hipLaunchKernelGGL(k_msm_final29<1>, dim3(M), dim3(64), 0, s, (const g1_xyzz29_t *)window_sums, red_wpp, sh.shared ? 0u : sh.c, out_dev, normalise ? 1 : 0);
   HIPCHK(hipGetLastError());
   return MI355_OK;
 }
@@ -253,8 +261,9 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
       }
       hipLaunchKernelGGL(k_msm_segfix, dim3(1), dim3(64), 0, s, cur_ids, cur_recs, N, buckets, (int32_t *)nullptr, (g1_xyzz29_t *)nullptr, 1);
     } else {
-    if (nbuckets <= (1u << g.fixup_lanes_max_log)) hipLaunchKernelGGL(k_msm_fixup<4>, dim3(ceil_div((uint64_t)nbuckets * 4, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, seg_arg, tn, big_list, big_count, big_cap, huge_list, huge_count, huge_cap, g.fixup_serial_max, g.fixup_huge_min);
-    else hipLaunchKernelGGL(k_msm_fixup<1>, dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, seg_arg, tn, big_list, big_count, big_cap, huge_list, huge_count, huge_cap, g.fixup_serial_max, g.fixup_huge_min);
+    if ((uint64_t)nbuckets * 4 <= g.tail_coop_max && (g.tail_coop_mask & 1u)) hipLaunchKernelGGL((k_msm_fixup<4, 4>), dim3(ceil_div((uint64_t)nbuckets * 16, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, seg_arg, tn, big_list, big_count, big_cap, huge_list, huge_count, huge_cap, g.fixup_serial_max, g.fixup_huge_min);
+    else if (nbuckets <= (1u << g.fixup_lanes_max_log)) hipLaunchKernelGGL((k_msm_fixup<4, 1>), dim3(ceil_div((uint64_t)nbuckets * 4, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, seg_arg, tn, big_list, big_count, big_cap, huge_list, huge_count, huge_cap, g.fixup_serial_max, g.fixup_huge_min);
+    else hipLaunchKernelGGL((k_msm_fixup<1, 1>), dim3(ceil_div(nbuckets, 256)), dim3(256), 0, s, offsets, nbuckets, buckets, part, part_id, seg_arg, tn, big_list, big_count, big_cap, huge_list, huge_count, huge_cap, g.fixup_serial_max, g.fixup_huge_min);
     hipLaunchKernelGGL(k_msm_fixup_big, dim3(big_cap), dim3(256), 0, s, buckets, part, part_id, big_list, big_count);
     hipLaunchKernelGGL(k_msm_fixup_huge, dim3(huge_cap * FIXUP_SLICES), dim3(256), 0, s, part, part_id, huge_list, huge_count, huge_part, huge_cap);
     hipLaunchKernelGGL(k_msm_fixup_huge_fold, dim3(huge_cap), dim3(64), 0, s, buckets, huge_list, huge_count, (const g1_xyzz29_t *)huge_part);

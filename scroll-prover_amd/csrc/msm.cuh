@@ -70,6 +70,82 @@ __device__ __forceinline__ g1_xyzz29_t load_xyzz29(const g1_xyzz29_t *p) {
   return v;
 }
 
+// ---- quad-cooperative point addition / doubling for the latency-bound reduction tail (fix-up of small bucket sets, running sums, trees,
+// the final Horner): ONE addition spread over the 4 lanes of a quad.  All four lanes enter with the same operands and leave with the same
+// result; in each of four rounds every lane multiplies a different pair (selected by its position in the quad) and the four products are
+// broadcast inside the quad with DPP quad_perm moves (full-rate VALU, no LDS).  The dependent chain of an addition drops from 14 field
+// multiplications to 4 (a doubling: 9 -> 3): ~1 250 instructions per wavefront instead of ~2 900, i.e. the latency of every step of the
+// ~60-step serial chain of a small MSM's tail.  It costs 4x the lanes and ~1.7x the total instructions, so the launch code only uses it where
+// the kernels are latency-bound (few logical threads).  Same formulas, bounds and exceptional cases as g1_xyzz29_add / _dbl (g1_29.cuh); the
+// only difference is Y3 = A - B + 4p as two products instead of one fused reduction (value < 5.6 p, inside the accumulator invariant).
+template <int J> __device__ __forceinline__ fe29_t quad_bcast(const fe29_t &v) {
+  fe29_t r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    int x = __builtin_amdgcn_mov_dpp((int)v.l[i], J * 0x55, 0xf, 0xf, true);   // quad_perm(J, J, J, J)
+    // the result is pinned in a register: left to itself the compiler folds the DPP move into the consuming instruction, and for the
+    // pattern (bcast<0>(m) + c) - bcast<1>(m) of Y3 it dropped the lane permutation of the subtrahend (every lane then subtracted its OWN
+    // product; found on the device with a staged comparison against the plain addition, tools/_scratch in round 3)
+    asm volatile("" : "+v"(x));
+    r.l[i] = (uint32_t)x;
+  }   // quad_perm(J, J, J, J)
+  return r;
+}
+// operand of this lane's product: a_q.  Written as limb-wise selects on VALUES passed by value: with references and a nested ternary the
+// compiler selects between the four ADDRESSES instead and keeps the operands in scratch memory (ScratchSize 508, checked with
+// -Rpass-analysis=kernel-resource-usage; this form: 0)
+__device__ __forceinline__ fe29_t quad_sel(uint32_t q, const fe29_t a0, const fe29_t a1, const fe29_t a2, const fe29_t a3) {
+  fe29_t r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { const uint32_t x0 = a0.l[i], x1 = a1.l[i], x2 = a2.l[i], x3 = a3.l[i]; const uint32_t lo = q & 1u ? x1 : x0, hi = q & 1u ? x3 : x2; r.l[i] = q & 2u ? hi : lo; }
+  return r;
+}
+__device__ __forceinline__ g1_xyzz29_t g1_xyzz29_dbl_q4(const g1_xyzz29_t &a) {
+  if (g1_xyzz29_is_identity(a)) return a;
+  const uint32_t q = threadIdx.x & 3u;
+  const fe29_t xt = Fq29::reduce_small(Fq29::normalise(a.x));   // tight, < 2 p
+  const fe29_t yc = Fq29::carry(a.y);                           // limbs <= 2^29 + 2, value < 6.1 p
+  const fe29_t U = Fq29::dbl(yc);                               // limbs <= 2^30 + 4, < 12.2 p
+  fe29_t m = FQ29_MUL(quad_sel(q, U, xt, U, xt), quad_sel(q, U, xt, U, xt));
+  const fe29_t V = quad_bcast<0>(m), xx = quad_bcast<1>(m);
+  const fe29_t M = Fq29::carry(Fq29::add(Fq29::dbl(xx), xx));   // 3 x^2, limbs <= 2^29 + 8, < 3.3 p
+  m = FQ29_MUL(quad_sel(q, U, xt, M, V), quad_sel(q, V, V, M, a.zz));
+  const fe29_t W = quad_bcast<0>(m), S = quad_bcast<1>(m), MM = quad_bcast<2>(m), ZZ3 = quad_bcast<3>(m);
+  g1_xyzz29_t r;
+  r.x = Fq29::sub8(MM, Fq29::dbl(S));                           // < 1.1 p + 8 p
+  const fe29_t t = Fq29::sub16(S, r.x);                          // < 17.1 p
+  m = FQ29_MUL(quad_sel(q, M, W, W, W), quad_sel(q, t, yc, a.zzz, a.zzz));
+  r.y = Fq29::sub4(quad_bcast<0>(m), quad_bcast<1>(m));         // < 1.4 p + 4 p
+  r.zz = ZZ3; r.zzz = quad_bcast<2>(m);
+  return r;
+}
+__device__ __forceinline__ void g1_xyzz29_add_q4(g1_xyzz29_t &acc, const g1_xyzz29_t &o) {
+  if (g1_xyzz29_is_identity(o)) return;
+  if (g1_xyzz29_is_identity(acc)) { acc = o; return; }
+  const uint32_t q = threadIdx.x & 3u;
+  fe29_t m = FQ29_MUL(quad_sel(q, acc.x, acc.y, o.x, o.y), quad_sel(q, o.zz, o.zzz, acc.zz, acc.zzz));
+  const fe29_t U1 = quad_bcast<0>(m), S1 = quad_bcast<1>(m), U2 = quad_bcast<2>(m), S2 = quad_bcast<3>(m);   // tight, < 1.1 p
+  const fe29_t Pd = Fq29::sub4(U2, U1), Rd = Fq29::sub4(S2, S1);                                              // < 5.1 p
+  m = FQ29_MUL(quad_sel(q, Pd, Rd, acc.zz, acc.zzz), quad_sel(q, Pd, Rd, o.zz, o.zzz));
+  const fe29_t PP = quad_bcast<0>(m), RR = quad_bcast<1>(m), ZZ12 = quad_bcast<2>(m), ZZZ12 = quad_bcast<3>(m);
+  const fe29_t one = Fq29::one();
+  m = FQ29_MUL(quad_sel(q, Pd, U1, ZZ12, Rd), quad_sel(q, PP, PP, PP, one));
+  const fe29_t PPP = quad_bcast<0>(m), Q = quad_bcast<1>(m), ZZ3 = quad_bcast<2>(m), Rone = quad_bcast<3>(m);
+  if (Fq29::is_zero_tight(ZZ3)) {   // Pd == 0 (both zz != 0): o == +-acc, doubling or annihilation
+    if (Fq29::is_zero_tight(Rone)) acc = g1_xyzz29_dbl_q4(acc);
+    else acc = g1_xyzz29_identity();
+    return;
+  }
+  const fe29_t X3 = Fq29::sub4_8(RR, PPP, Fq29::dbl(Q));                                                      // 13.2 p, one carry
+  const fe29_t t = Fq29::sub16(Q, X3);
+  m = FQ29_MUL(quad_sel(q, Rd, S1, ZZZ12, ZZZ12), quad_sel(q, t, PPP, PPP, PPP));
+  acc.x = X3; acc.y = Fq29::sub4(quad_bcast<0>(m), quad_bcast<1>(m));                                         // < 1.6 p + 4 p
+  acc.zz = ZZ3; acc.zzz = quad_bcast<2>(m);
+}
+// Q = 1: one lane per logical thread (the throughput form); Q = 4: a quad per logical thread (the latency form)
+template <int Q> __device__ __forceinline__ void g1_vadd(g1_xyzz29_t &acc, const g1_xyzz29_t &o) { if (Q == 4) g1_xyzz29_add_q4(acc, o); else g1_xyzz29_add(acc, o); }
+template <int Q> __device__ __forceinline__ g1_xyzz29_t g1_vdbl(const g1_xyzz29_t &a) { return Q == 4 ? g1_xyzz29_dbl_q4(a) : g1_xyzz29_dbl(a); }
+
 // ---- 1. digits.  Plane layout enc[w * n + i]: 0 for a zero digit, else |d| (1 .. 2^(c-1)) with bit 31 = sign.
 // up to 8 polynomial pointers travel as a kernel argument (copied at launch: no staging copy, nothing for an asynchronous caller to keep
 // alive); larger batches pass a device array
@@ -406,9 +482,9 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
 constexpr uint32_t FIXUP_SERIAL_MAX = 32, FIXUP_HUGE_MIN = 2048, FIXUP_SLICES = 64;   // SLICES <= 64: one wavefront folds the slice sums
 // The fix-up and the whole reduction tail stay in the 29-bit field (g1_xyzz29_add / _dbl): no conversion of the 144-byte records to the
 // saturated form (4 multiplications each) and the faster multiplier; records always hold valid accumulators (g1_29.cuh invariants).
-__device__ __forceinline__ void fixup_take29(g1_xyzz29_t &acc, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t t, uint32_t b) {
-  if (part_id[2 * t] == (int32_t)b) g1_xyzz29_add(acc, load_xyzz29(&part[2 * (uint64_t)t]));
-  else if (part_id[2 * t + 1] == (int32_t)b) g1_xyzz29_add(acc, load_xyzz29(&part[2 * (uint64_t)t + 1]));
+template <int Q = 1> __device__ __forceinline__ void fixup_take29(g1_xyzz29_t &acc, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t t, uint32_t b) {
+  if (part_id[2 * t] == (int32_t)b) g1_vadd<Q>(acc, load_xyzz29(&part[2 * (uint64_t)t]));
+  else if (part_id[2 * t + 1] == (int32_t)b) g1_vadd<Q>(acc, load_xyzz29(&part[2 * (uint64_t)t + 1]));
 }
 __device__ __forceinline__ g1_xyzz29_t shfl_down_xyzz29(const g1_xyzz29_t &v, uint32_t o) {
   g1_xyzz29_t r; const uint32_t *s = reinterpret_cast<const uint32_t *>(&v); uint32_t *d = reinterpret_cast<uint32_t *>(&r);
@@ -427,11 +503,12 @@ __device__ __forceinline__ g1_xyzz29_t shfl_xor_xyzz29(const g1_xyzz29_t &v, uin
 // Each lane of the group sums every FIXUP_LANES-th partial and two shuffle steps combine them; launch = nbuckets * FIXUP_LANES threads
 // (0.60 -> 0.45 ms of tail at 2^14 pairs, 0.73 -> 0.67 ms at 2^20).
 // FIXUP_LANES = 1 (big bucket sets: 2^21 buckets of which few straddle more than two threads) is the plain one-lane-per-bucket kernel.
-template <uint32_t FIXUP_LANES> __global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
+template <uint32_t FIXUP_LANES, int Q = 1> __global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t *__restrict__ offsets, uint32_t nbuckets, g1_xyzz29_t *__restrict__ bucket_sums,
                                                    const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t seg_max, uint32_t acc_threads,
                                                    uint32_t *__restrict__ big_list, uint32_t *__restrict__ big_count, uint32_t big_cap,
                                                    uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, uint32_t huge_cap, uint32_t serial_max, uint32_t huge_min) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid / FIXUP_LANES, sub = gid % FIXUP_LANES;
+  const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) / Q, b = gid / FIXUP_LANES, sub = gid % FIXUP_LANES;   // Q lanes per logical thread
+  const bool lead = (threadIdx.x & (Q - 1)) == 0;
   const uint32_t seg = msm_seg_eff(offsets[nbuckets], acc_threads, seg_max & 0x1fffu, (seg_max >> 13) & 0x1fffu, (seg_max >> 26) * 2);   // the segment length k_msm_accumulate used
   g1_xyzz29_t acc = g1_xyzz29_identity();
   bool mine = false;   // this group sums a straddling bucket of moderate span
@@ -441,7 +518,7 @@ template <uint32_t FIXUP_LANES> __global__ void __launch_bounds__(256) k_msm_fix
       const uint32_t t0 = s / seg, t1 = (e - 1) / seg;
       if (t0 != t1) {   // t0 == t1: the sole owner wrote it
         if (t1 - t0 > serial_max) {
-          if (sub == 0) {
+          if (sub == 0 && lead) {
             if (huge_cap && t1 - t0 >= huge_min) {   // thousands of partials: several workgroups (k_msm_fixup_huge)
               const uint32_t idx = atomicAdd(huge_count, 1u);
               if (idx < huge_cap) { huge_list[3 * idx] = b; huge_list[3 * idx + 1] = t0; huge_list[3 * idx + 2] = t1; }
@@ -452,16 +529,16 @@ template <uint32_t FIXUP_LANES> __global__ void __launch_bounds__(256) k_msm_fix
           }
         } else {
           mine = true;
-          for (uint32_t t = t0 + sub; t <= t1; t += FIXUP_LANES) fixup_take29(acc, part, part_id, t, b);
+          for (uint32_t t = t0 + sub; t <= t1; t += FIXUP_LANES) fixup_take29<Q>(acc, part, part_id, t, b);
         }
       }
     }
   }
   // every lane of the wavefront reaches the shuffles; groups with nothing to do carry identities (the addition returns at once)
-  if (FIXUP_LANES > 1) { const g1_xyzz29_t other = shfl_xor_xyzz29(acc, 1); g1_xyzz29_add(acc, other); }
-  if (FIXUP_LANES > 2) { const g1_xyzz29_t other = shfl_xor_xyzz29(acc, 2); g1_xyzz29_add(acc, other); }
+  if (FIXUP_LANES > 1) { const g1_xyzz29_t other = shfl_xor_xyzz29(acc, 1 * Q); g1_vadd<Q>(acc, other); }
+  if (FIXUP_LANES > 2) { const g1_xyzz29_t other = shfl_xor_xyzz29(acc, 2 * Q); g1_vadd<Q>(acc, other); }
   static_assert(FIXUP_LANES == 1 || FIXUP_LANES == 2 || FIXUP_LANES == 4, "two shuffle steps");
-  if (mine && sub == 0) store_xyzz29(&bucket_sums[b], acc);
+  if (mine && sub == 0 && lead) store_xyzz29(&bucket_sums[b], acc);
 }
 __global__ void __launch_bounds__(256) k_msm_fixup_big(g1_xyzz29_t *__restrict__ bucket_sums, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id,
                                                        const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count) {
@@ -563,35 +640,37 @@ __global__ void __launch_bounds__(256) k_msm_bucket_fold(g1_xyzz29_t *__restrict
 
 // ---- 6a. chunked running sums: thread j of window w covers buckets [j*K, (j+1)*K) and emits
 //          T + (j*K) * S  where S = sum B_i, T = sum (i_local + 1) B_i
-__global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {
+template <int Q> __global__ void __launch_bounds__(128) k_msm_bucket_reduce(const g1_xyzz29_t *__restrict__ bucket_sums, g1_xyzz29_t *__restrict__ chunk_out, MsmPlan P, uint32_t chunk) {
   const uint32_t chunks_per_window = P.nb / chunk;
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) / Q;   // logical thread (Q lanes each)
   if (g >= chunks_per_window * P.windows) return;
   const uint32_t w = g / chunks_per_window, j = g - w * chunks_per_window;
   const g1_xyzz29_t *B = bucket_sums + (uint64_t)w * P.nb + (uint64_t)j * chunk;
   g1_xyzz29_t run = g1_xyzz29_identity(), T = g1_xyzz29_identity();
-  for (uint32_t i = chunk; i-- > 0;) { g1_xyzz29_add(run, load_xyzz29(&B[i])); g1_xyzz29_add(T, run); }
+  for (uint32_t i = chunk; i-- > 0;) { g1_vadd<Q>(run, load_xyzz29(&B[i])); g1_vadd<Q>(T, run); }
   if (j != 0) {
     const uint32_t k = j * chunk;
     g1_xyzz29_t kS = g1_xyzz29_identity();
-    for (int bit = 31 - __clz(k); bit >= 0; bit--) { kS = g1_xyzz29_dbl(kS); if ((k >> bit) & 1) g1_xyzz29_add(kS, run); }
-    g1_xyzz29_add(T, kS);
+    for (int bit = 31 - __clz(k); bit >= 0; bit--) { kS = g1_vdbl<Q>(kS); if ((k >> bit) & 1) g1_vadd<Q>(kS, run); }
+    g1_vadd<Q>(T, kS);
   }
-  store_xyzz29(&chunk_out[g], T);
+  if ((threadIdx.x & (Q - 1)) == 0) store_xyzz29(&chunk_out[g], T);
 }
 // ---- 6b. per window: tree-sum of the chunk results.  grid = (blocks, windows); a block folds up to 256 * TREE_PER_THREAD inputs
 //          (wavefront shuffles, then LDS across the 4 waves) into one output; launched repeatedly until one value per window is left.
 constexpr uint32_t TREE_PER_THREAD = 4;
-__global__ void __launch_bounds__(256) k_msm_tree_sum29(const g1_xyzz29_t *__restrict__ in, uint32_t in_per_window, g1_xyzz29_t *__restrict__ out, uint32_t out_per_window) {
+// a block of 256 lanes = 256 / Q logical threads folds up to (256 / Q) * TREE_PER_THREAD inputs
+template <int Q> __global__ void __launch_bounds__(256) k_msm_tree_sum29(const g1_xyzz29_t *__restrict__ in, uint32_t in_per_window, g1_xyzz29_t *__restrict__ out, uint32_t out_per_window) {
   __shared__ g1_xyzz29_t lds[4];
-  const uint32_t w = blockIdx.y, first = blockIdx.x * 256 * TREE_PER_THREAD;
+  constexpr uint32_t VT = 256 / Q;                               // logical threads per block, 64 / Q per wavefront
+  const uint32_t w = blockIdx.y, first = blockIdx.x * VT * TREE_PER_THREAD, vt = threadIdx.x / Q;
   const g1_xyzz29_t *src = in + (uint64_t)w * in_per_window;
   g1_xyzz29_t acc = g1_xyzz29_identity();
-  for (uint32_t k = 0; k < TREE_PER_THREAD; k++) { const uint32_t i = first + k * 256 + threadIdx.x; if (i < in_per_window) g1_xyzz29_add(acc, load_xyzz29(&src[i])); }
-  for (uint32_t o = 32; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o); g1_xyzz29_add(acc, other); }
+  for (uint32_t k = 0; k < TREE_PER_THREAD; k++) { const uint32_t i = first + k * VT + vt; if (i < in_per_window) g1_vadd<Q>(acc, load_xyzz29(&src[i])); }
+  for (uint32_t o = 32 / Q; o >= 1; o >>= 1) { const g1_xyzz29_t other = shfl_down_xyzz29(acc, o * Q); g1_vadd<Q>(acc, other); }
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) { for (uint32_t k = 1; k < 4; k++) g1_xyzz29_add(acc, lds[k]); store_xyzz29(&out[(uint64_t)w * out_per_window + blockIdx.x], acc); }
+  if (threadIdx.x < Q) { for (uint32_t k = 1; k < 4; k++) g1_vadd<Q>(acc, lds[k]); if (threadIdx.x == 0) store_xyzz29(&out[(uint64_t)w * out_per_window + blockIdx.x], acc); }
 }
 __device__ __forceinline__ void msm_emit_result(const g1_xyzz_t &acc, g1_jac_t *out, int normalise) {
   if (normalise) { *out = g1_xyzz_to_jac_normalised(acc); return; }
@@ -603,15 +682,15 @@ __device__ __forceinline__ void msm_emit_result(const g1_xyzz_t &acc, g1_jac_t *
   *out = r;
 }
 // ---- 7. Horner over windows + normalisation.  One lane; 255 doublings are inherently serial (none with window tables).
-__global__ void k_msm_final29(const g1_xyzz29_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
-  if (threadIdx.x != 0) return;
+template <int Q> __global__ void k_msm_final29(const g1_xyzz29_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
+  if (threadIdx.x >= Q) return;
   window_sums += (uint64_t)blockIdx.x * windows; out += blockIdx.x;
   g1_xyzz29_t acc = g1_xyzz29_identity();
   for (uint32_t w = windows; w-- > 0;) {
-    for (uint32_t k = 0; k < c; k++) acc = g1_xyzz29_dbl(acc);
-    g1_xyzz29_add(acc, load_xyzz29(&window_sums[w]));
+    for (uint32_t k = 0; k < c; k++) acc = g1_vdbl<Q>(acc);
+    g1_vadd<Q>(acc, load_xyzz29(&window_sums[w]));
   }
-  msm_emit_result(g1_xyzz29_to_sat(acc), out, normalise);
+  if (threadIdx.x == 0) msm_emit_result(g1_xyzz29_to_sat(acc), out, normalise);
 }
 // sum of n Jacobian points (fold of per-GPU partial results), normalised
 __global__ void k_g1_sum(const g1_jac_t *__restrict__ pts, uint32_t n, g1_jac_t *__restrict__ out) {

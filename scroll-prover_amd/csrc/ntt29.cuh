@@ -8,7 +8,8 @@
 //   * value growth: a sum doubles the bound; after stages 5 and 10 of a tile the sums are brought back below 2r with
 //     reduce_small (no multiplication); differences come out of a multiplication (< 1.6 r).  Bounds: start < 1.4 r (a pass reads canonical
 //     input or the previous pass's multiplication output),
-//     <= 44.8 r before a reduction, 64 r is the limit of sub64 / reduce_small.
+//     <= 44.8 r before a reduction, 64 r is the limit of sub64 / reduce_small.  (Round 3: the trivial-twiddle differences of a tile's LAST stage
+//     stay un-reduced, < 103 r, when their consumer allows it -- a pass then starts below 1.62 r and reaches 51.6 r before its reduction.)
 //   * elements leave a pass through a multiplication (inter-level twiddle, or the ifft / coset factor) or reduce_small,
 //     then (closing pass) one conditional subtraction: everything the caller sees is canonical, so results stay bit-exact; the strided passes
 //     leave the tight multiplication output (< 1.4 r) in the scratch buffer as it is.
@@ -21,8 +22,11 @@
 
 namespace zk {
 
+#ifndef ZK_NTT_LAZY_LAST
+#define ZK_NTT_LAZY_LAST true   // trivial-twiddle differences of a tile's last stage stay un-reduced (see lds_dif29_round)
+#endif
 #ifndef ZK_NTT_CHAIN
-#define ZK_NTT_CHAIN false   // limb products of the NTT butterflies as explicitly chained v_mad (fp29.cuh mac_*)
+#define ZK_NTT_CHAIN true    // limb products of the NTT butterflies as column blocks of chained v_mad (fp29.cuh mul_c): 8.61 vs 8.86 ms at 2^26 in round 3 (round 2 measured no gain; false restores the C++ multiplier for A/B builds)
 #endif
 struct Ntt29Level { uint32_t log_m, log_t, split; Tw29 tw_m, tw_s_lo, tw_s_hi; uint32_t direct; };   // direct 1: tw_s_lo holds every inter-level twiddle w_S^e (small levels), no lo x hi product; direct 2: tw_s_lo is the table [k][column] = w_S^(column k) of a big level, read like the data (8 adjacent columns per row)
 
@@ -59,7 +63,7 @@ __device__ __forceinline__ fe_t fr29_finish(const fe29_t &t) { return Fr29::to_s
 // difference is brought back below 2r with reduce_small instead (~40 instructions against ~220).  Over a 2^26 transform this removes
 // 2.6 of the 17 multiplications per element.
 template <int R, bool LAST> __device__ __forceinline__ void lds_dif29_round(const Lds29 &L, uint32_t log_m, uint32_t log_c, uint32_t sm, uint32_t sc,
-                                                                const Tw29 &tw_m, bool col_fast, uint32_t s0) {
+                                                                const Tw29 &tw_m, bool col_fast, uint32_t s0, bool lazy_last) {
   constexpr uint32_t Q = 1u << R;
   const uint32_t M = 1u << log_m, C = 1u << log_c, b_lo = log_m - s0 - R, items = (M >> R) << log_c;
   for (uint32_t g = threadIdx.x; g < items; g += blockDim.x) {
@@ -109,8 +113,12 @@ template <int R, bool LAST> __device__ __forceinline__ void lds_dif29_round(cons
 #pragma unroll
         for (int i = 0; i < 9; i++) sum.l[i] = in_loose ? s_car.l[i] : s_raw.l[i];   // a compile-time choice per butterfly: the unused variant is dead code
         if (reduce_now) sum = Fr29::reduce_small(Fr29::normalise(s_raw));            // normalise is the full carry propagation
-        // u - v + 64 r < 103 r: reduce_small is exact up to 2^261 = 168 r (host-checked), result tight < 2 r
-        if (LAST && (q0 & ((1u << bit) - 1)) == 0) { x[q1] = Fr29::reduce_small(Fr29::normalise(fr29_sub64(u, v))); n++; }
+        // u - v + 64 r < 103 r: reduce_small is exact up to 2^261 = 168 r (host-checked), result tight < 2 r.  In the LAST STAGE of the tile
+        // (t == R - 1 of the closing round) the difference is left as it is: nothing adds to it any more, and both consumers accept a loose
+        // value below 103 r with limbs < 2^31.4 -- the strided pass multiplies every output by a canonical twiddle (9 limb products
+        // < 2^60.4 per column plus the reduction terms stay below 2^64; (103 r)(r) / 2^261 + r < 1.7 r), the closing pass ends with
+        // reduce_small(normalise(.)) or a multiplication itself.  One reduction (~70 instructions) per butterfly of that stage saved.
+        if (LAST && (q0 & ((1u << bit) - 1)) == 0) { x[q1] = (ZK_NTT_LAZY_LAST && lazy_last && t == R - 1) ? fr29_sub64(u, v) : Fr29::reduce_small(Fr29::normalise(fr29_sub64(u, v))); n++; }
         else x[q1] = Fr29::mul_t<ZK_NTT_CHAIN>(fr29_sub64(u, v), tw[t][n++]);
         x[q0] = sum;
       }
@@ -120,13 +128,17 @@ template <int R, bool LAST> __device__ __forceinline__ void lds_dif29_round(cons
   }
   __syncthreads();
 }
-template <int RMAX> __device__ __forceinline__ void lds_dif29(const Lds29 &L, uint32_t log_m, uint32_t log_c, uint32_t sm, uint32_t sc, const Tw29 &tw_m, bool col_fast) {
+// lazy_last: the consumer of the tile accepts loose last-stage differences (< 103 r): true for the strided passes (every output is multiplied
+// by an inter-level twiddle that is canonical, or the product of two canonical table entries: (103 r)(1.006 r) / 2^261 + r < 1.62 r) and for a
+// closing pass without post-scaling (it ends with reduce_small(normalise(.)), exact below 168 r); a closing pass that multiplies by a
+// post-scaling constant (tight, < 2 r) needs the reduced value ((103 r)(2 r) / 2^261 + r would exceed the single conditional subtraction).
+template <int RMAX> __device__ __forceinline__ void lds_dif29(const Lds29 &L, uint32_t log_m, uint32_t log_c, uint32_t sm, uint32_t sc, const Tw29 &tw_m, bool col_fast, bool lazy_last) {
   uint32_t s = 0;
   while (s < log_m) {
     const uint32_t left = log_m - s;
-    if (RMAX >= 3 && left >= 3 && left != 4) { if (left == 3) lds_dif29_round<3, true>(L, log_m, log_c, sm, sc, tw_m, col_fast, s); else lds_dif29_round<3, false>(L, log_m, log_c, sm, sc, tw_m, col_fast, s); s += 3; }
-    else if (RMAX >= 2 && left >= 2) { if (left == 2) lds_dif29_round<2, true>(L, log_m, log_c, sm, sc, tw_m, col_fast, s); else lds_dif29_round<2, false>(L, log_m, log_c, sm, sc, tw_m, col_fast, s); s += 2; }
-    else { if (left == 1) lds_dif29_round<1, true>(L, log_m, log_c, sm, sc, tw_m, col_fast, s); else lds_dif29_round<1, false>(L, log_m, log_c, sm, sc, tw_m, col_fast, s); s += 1; }
+    if (RMAX >= 3 && left >= 3 && left != 4) { if (left == 3) lds_dif29_round<3, true>(L, log_m, log_c, sm, sc, tw_m, col_fast, s, lazy_last); else lds_dif29_round<3, false>(L, log_m, log_c, sm, sc, tw_m, col_fast, s, false); s += 3; }
+    else if (RMAX >= 2 && left >= 2) { if (left == 2) lds_dif29_round<2, true>(L, log_m, log_c, sm, sc, tw_m, col_fast, s, lazy_last); else lds_dif29_round<2, false>(L, log_m, log_c, sm, sc, tw_m, col_fast, s, false); s += 2; }
+    else { if (left == 1) lds_dif29_round<1, true>(L, log_m, log_c, sm, sc, tw_m, col_fast, s, lazy_last); else lds_dif29_round<1, false>(L, log_m, log_c, sm, sc, tw_m, col_fast, s, false); s += 1; }
   }
 }
 __device__ __forceinline__ fe29_t load_input29(const fe_t *__restrict__ src, uint64_t gi, uint64_t src_len, const fe_t *__restrict__ pre3) {
@@ -150,7 +162,7 @@ template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_
     lds29_put(S, e, load_input29(src, base + ((uint64_t)m << L.log_t) + c, src_len, pre3));
   }
   __syncthreads();
-  lds_dif29<RMAX>(S, L.log_m, log_c, C, 1, L.tw_m, true);
+  lds_dif29<RMAX>(S, L.log_m, log_c, C, 1, L.tw_m, true, true);
   const uint32_t smask = (1u << L.split) - 1;
   for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
     const uint32_t c = e & (C - 1), k = e >> log_c;
@@ -180,7 +192,7 @@ template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_
     lds29_put(S, c * seg + m, load_input29(src, (q << log_m) + m, src_len, pre3));
   }
   __syncthreads();
-  lds_dif29<RMAX>(S, log_m, log_c, 1, seg, tw_m, false);
+  lds_dif29<RMAX>(S, log_m, log_c, 1, seg, tw_m, false, post3 == nullptr);
   const uint32_t log_stride = log_a + log_b;  // N / M
   fe29_t post0 = Fr29::zero(), post1 = post0, post2 = post0;   // named (not an array): runtime-indexed arrays go to scratch
   if (post3) { post0 = Fr29::reduce_small(Fr29::from_sat(g_load(&post3[0]))); post1 = Fr29::reduce_small(Fr29::from_sat(g_load(&post3[1]))); post2 = Fr29::reduce_small(Fr29::from_sat(g_load(&post3[2]))); }   // c * 2^261, tight
