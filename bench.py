@@ -73,13 +73,13 @@ def witness_like_scalars(n: int, seed: int, device, h2) -> torch.Tensor:
     return a.contiguous()
 
 
-def replay_create_proof(layer: int, k: int | None = None, host_api: bool = True, timeout: int = 900):
+def replay_create_proof(layer: int, k: int | None = None, host_api: bool = True, timeout: int = 900, devices: int = 1):
     """tests/cpp/test_create_proof_replay: SURVEY 3.2 steps 1-10 for one layer's counts, a COMPILED caller of the C-ABI with the proof's
     polynomials resident in HBM (mi355_buf_*), witness uploads overlapped, every commitment and evaluation checked afterwards.  Run as its own
     process BEFORE this process binds the GPU (each needs the window tables of both bases: 96 GiB at k = 26).  Returns the program's JSON record."""
     import subprocess
     exe = ge.build_cpp("test_create_proof_replay")
-    cmd = [exe, "--layer", str(layer)] + (["--k", str(k)] if k else []) + (["--host-api"] if host_api else [])
+    cmd = [exe, "--layer", str(layer)] + (["--k", str(k)] if k else []) + (["--host-api"] if host_api else []) + (["--devices", str(devices)] if devices > 1 else [])
     t0 = time.perf_counter()
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     wall = time.perf_counter() - t0
@@ -152,6 +152,12 @@ def main() -> None:
                                            "host_api_ms": (l1.get("host_api_ms", 0) + l2.get("host_api_ms", 0)) if ok_all else None, "layer1": l1, "layer2": l2},
                      "all_commitments_and_evaluations_checked": ok_all,
                      "excludes": "witness synthesis, transcript hashing (CPU side of create_proof); the gate expression is a stand-in of the right shape (rotated operands, degree-3 products)"}
+    if single and args.gpus > 1 and not args.no_proof_mix and args.logn == 26:
+        # N devices behind ONE prover process: witness columns live round-robin on the devices, commitments take scalars from whichever device
+        # holds them (shards of the basis everywhere), the iNTT batch and the coset parts of the quotient run concurrently on different devices
+        # (per-device locks, one host thread per device) -- the layer-4 mix with the other GPUs given work during the NTT phase
+        l4m = replay_create_proof(4, host_api=False, devices=args.gpus)
+        proof_mix = {"c_abi_resident_ms": l4m.get("resident_ms"), "devices": args.gpus, "layer4": l4m}
     zk = ge.load_package()
     lib, check, ptr, h2 = zk._capi.lib(), zk._capi.check, zk._capi.ptr, zk.halo2
     if single:
@@ -292,10 +298,16 @@ def main() -> None:
         check(lib.mi355_profile_enable(0))
         pass_ms, pass_cnt = prof("ntt_pass")
         bf = (1 << k) // 2 * k
+        ntt_traffic, ntt_traffic_src = None, None   # HBM bytes per transform from the separate --pmc passes (recorded, like the MSM's)
+        try:
+            rec_ = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            ntt_traffic, ntt_traffic_src = rec_.get(f"ntt_k{k}_hbm_bytes_per_transform"), rec_.get("source")
+        except Exception:
+            pass
         ntt = {"log_n": k, "ms_per_transform": dt_ntt * 1e3, "butterflies_per_s": bf / dt_ntt, "roundtrip_ok": rt_ok,
                "passes_per_transform": pass_cnt / (2 * reps),
                "roofline": {"bound": "hbm", "achieved": 64.0 * (1 << k) / dt_ntt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": 64.0 * (1 << k) / dt_ntt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "frac": 64.0 * (1 << k) / dt_ntt / 1e9 / HBM_PEAK_GBS, "traffic": ntt_traffic, "traffic_source": ntt_traffic_src,
                             "note": "algorithmic bytes = 64*N per transform (SURVEY 8d); whole-transform time, all passes"}}
         # eval_polynomial (step 9 of create_proof): streaming, 1 multiplication per 32-byte coefficient -> the HBM-bound kernel of the path
         pt = h2.fr(0x1234567890ABCDEF)
@@ -518,7 +530,7 @@ def main() -> None:
                          "pairs_per_launch": pairs_per_launch,
                          "alu": {"achieved": (pairs_per_launch * W / (acc_avg_ms * 1e-3)) if acc_avg_ms > 0 else None, "peak": MADD_CHAIN_PEAK, "unit": "G1 mixed additions/s",
                                  "frac": (pairs_per_launch * W / (acc_avg_ms * 1e-3) / MADD_CHAIN_PEAK) if acc_avg_ms > 0 else None,
-                                 "source": "profiles/r02_microbench.log (xyzz29 madd chain, 3 waves/SIMD, boost clock); SQ counters: VALU 98 % busy at the sustained 1.96 GHz, 2 193 VALU instructions per addition, profiles/r02b_sq_counters.md"},
+                                 "source": "profiles/r02_microbench.log (xyzz29 madd chain, 3 waves/SIMD, boost clock); SQ counters: VALU 98 % busy at the sustained 1.93 GHz, 2 193 VALU instructions per addition, profiles/r03_sq_counters.md"},
                          "note": "algorithmic bytes = 96 B per (scalar, point) pair x pairs per launch (SURVEY 8d); the kernel is VALU-integer bound, see DESIGN.md"},
             "cpu_baseline": cpu, "ntt": ntt,
         }
