@@ -124,6 +124,28 @@ inline bool g1_from_bytes(const G1Bytes &b, G1Affine &out) {
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------ resident polynomials
+// One vector of Fr resident in HBM: a mi355_buf_alloc block (the C++ twin of the Rust shim's DevicePoly).  Move-only; the destructor hands the
+// block back to the library's pool (no hipFree, no device synchronisation; work already queued on it stays valid).  `slot` picks the device of an
+// mi355_init_multi process.  create_proof uploads each witness column ONCE (from_host: the DMA overlaps whatever the device computes for other
+// threads) and then works on it through the `*_dev` entry points; host memory sees the 96-byte commitments and 32-byte evaluations only.
+struct DevicePoly {
+  void *p = nullptr; uint64_t n = 0; int slot = 0;
+  DevicePoly() = default;
+  DevicePoly(uint64_t n_, int slot_ = 0) : n(n_), slot(slot_) { check(mi355_buf_alloc(n_ * 32, slot_, &p)); }
+  DevicePoly(const DevicePoly &) = delete;
+  DevicePoly &operator=(const DevicePoly &) = delete;
+  DevicePoly(DevicePoly &&o) noexcept : p(o.p), n(o.n), slot(o.slot) { o.p = nullptr; }
+  DevicePoly &operator=(DevicePoly &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; slot = o.slot; o.p = nullptr; } return *this; }
+  ~DevicePoly() { release(); }
+  void release() noexcept { if (p) { (void)mi355_buf_free(p); p = nullptr; } }
+  static DevicePoly from_host(const std::vector<Fr> &v, int slot = 0) { DevicePoly d(v.size(), slot); check(mi355_buf_upload(d.p, v.data(), v.size() * 32)); return d; }
+  std::vector<Fr> to_host() const { std::vector<Fr> v(n); check(mi355_buf_download(v.data(), p, n * 32)); return v; }
+  // element offset into the block: a device pointer like any other
+  void *at(uint64_t i) const { return static_cast<char *>(p) + i * 32; }
+  Fr eval(const Fr &point) const { Fr out; check(mi355_eval_polynomial_dev(p, n, point.data(), out.data())); return out; }
+};
+
 // ------------------------------------------------------------------------------------------------ poly/domain.rs
 class EvaluationDomain {
  public:
@@ -154,6 +176,10 @@ class EvaluationDomain {
   void lagrange_to_coeff(std::vector<Fr> &a) const {
     if (a.size() != n) throw std::invalid_argument("lagrange_to_coeff: wrong length");
     check(mi355_intt_fr_host(a.data(), k, omega_inv.data(), ifft_divisor.data()));
+  }
+  void lagrange_to_coeff(DevicePoly &a) const {
+    if (a.n != n) throw std::invalid_argument("lagrange_to_coeff: wrong length");
+    check(mi355_intt_fr_dev(a.p, k, omega_inv.data(), ifft_divisor.data()));
   }
   std::vector<Fr> coeff_to_extended(const std::vector<Fr> &a) const {
     if (a.size() != n) throw std::invalid_argument("coeff_to_extended: wrong length");
@@ -204,6 +230,15 @@ class ParamsKZG {
   G1 commit_lagrange(const std::vector<Fr> &poly) const {
     if (poly.size() != n) throw std::invalid_argument("commit_lagrange: polynomial must have exactly n evaluations");
     G1 out; check(mi355_msm_g1_host(gl_, 0, poly.data(), poly.size(), out.data())); return out;
+  }
+  // commit / commit_lagrange of a resident polynomial: the scalars never leave HBM
+  G1 commit(const DevicePoly &poly) const {
+    if (poly.n > n) throw std::invalid_argument("commit: polynomial longer than the basis");
+    G1 out; check(mi355_msm_g1_dev(g_, 0, poly.p, poly.n, out.data())); return out;
+  }
+  G1 commit_lagrange(const DevicePoly &poly) const {
+    if (poly.n != n) throw std::invalid_argument("commit_lagrange: polynomial must have exactly n evaluations");
+    G1 out; check(mi355_msm_g1_dev(gl_, 0, poly.p, poly.n, out.data())); return out;
   }
   // ParamsKZG::downsize(k): g.truncate(2^k); g_lagrange = g_to_lagrange(g, k) -- an inverse DFT over G1 points, run on the device
   void downsize(uint32_t new_k) {

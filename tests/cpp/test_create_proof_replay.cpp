@@ -58,20 +58,8 @@ static int failures = 0;
 #define CK(expr) do { int _rc = (expr); if (_rc != MI355_OK) { std::printf("FAILED %s:%d  %s -> %d [%s]\n", __FILE__, __LINE__, #expr, _rc, mi355_last_error()); failures++; } } while (0)
 #define EXPECT(cond) do { if (!(cond)) { std::printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond); failures++; } } while (0)
 
-// rust: struct DevicePoly { ptr: *mut c_void, len: usize }  impl Drop { mi355_buf_free }
-struct DevicePoly {
-  void *p = nullptr; uint64_t n = 0; int slot = 0;
-  DevicePoly() = default;
-  DevicePoly(uint64_t n_, int slot_) : n(n_), slot(slot_) { CK(mi355_buf_alloc(n_ * 32, slot_, &p)); }
-  DevicePoly(const DevicePoly &) = delete;
-  DevicePoly &operator=(const DevicePoly &) = delete;
-  DevicePoly(DevicePoly &&o) noexcept : p(o.p), n(o.n), slot(o.slot) { o.p = nullptr; }
-  DevicePoly &operator=(DevicePoly &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; slot = o.slot; o.p = nullptr; } return *this; }
-  ~DevicePoly() { release(); }
-  void release() { if (p) { CK(mi355_buf_free(p)); p = nullptr; } }
-  static DevicePoly from_host(const std::vector<Fr> &v, int slot) { DevicePoly d(v.size(), slot); CK(mi355_buf_upload(d.p, v.data(), v.size() * 32)); return d; }
-  std::vector<Fr> to_host() const { std::vector<Fr> v(n); CK(mi355_buf_download(v.data(), p, n * 32)); return v; }
-};
+// rust: struct DevicePoly { ptr: *mut c_void, len: usize }  impl Drop { mi355_buf_free }; C++: mi355zk::halo2::DevicePoly (include/mi355zk_halo2.hpp)
+using mi355zk::halo2::DevicePoly;
 
 struct Layer { int id; uint32_t k; uint32_t advice, lookups, products, evals; };
 static const Layer LAYERS[] = {{4, 26, 3, 1, 3, 27}, {2, 25, 1, 1, 2, 17}, {1, 24, 17, 2, 2, 60}};

@@ -101,6 +101,16 @@ int main(int argc, char **argv) {
     EXPECT(std::memcmp(many[1].data(), wa.data(), 64) == 0);
     std::vector<Fr> shorter(n - 1);
     threw = false; try { params.commit_many({&sc, &shorter}); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
+    // resident polynomials (DevicePoly): the same commitments without the scalars crossing PCIe again; move semantics; evaluation
+    {
+      DevicePoly d = DevicePoly::from_host(sc);
+      EXPECT(params.commit(d) == c1 && params.commit_lagrange(d) == c2);
+      DevicePoly moved = std::move(d);
+      EXPECT(d.p == nullptr && moved.n == n && moved.to_host() == sc);
+      const Fr x = rand_fr(rng);
+      EXPECT(moved.eval(x) == eval_polynomial(sc, x));
+      threw = false; try { params.commit_lagrange(DevicePoly(n / 2)); } catch (const std::invalid_argument &) { threw = true; } EXPECT(threw);
+    }
   }
   // --- best_fft / EvaluationDomain against the oracle (raw Montgomery bytes)
   EvaluationDomain dom(4, k);

@@ -149,3 +149,25 @@ def test_accumulate_segment_rule_covers_every_entry():
         assert threads * sg >= total, (emax, total, threads, sg)
         if total == emax and fill <= 100:
             assert sg == seg_max or sg * threads >= emax      # nothing is lost for a column in which every digit is non-zero
+
+
+def test_build_is_content_hashed_per_translation_unit():
+    """scroll-prover_amd/build.py decides staleness by content (sha256 of every file a unit includes + the flags), so a copied tree -- the GPU
+    box's snapshot -- never rebuilds what was built here, and a header change rebuilds exactly the units that include it."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_b", os.path.join(root, "scroll-prover_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    b.build()
+    assert not b.needs_build()
+    assert b.needs_build(extra_flags=["-DSOMETHING=1"])                       # other flags = another build
+    h = {u: b._unit_hash(u, []) for u in b.UNITS}
+    assert len(set(h.values())) == len(b.UNITS)
+    closure = {}
+    b._closure(os.path.join(b.CSRC, "lib_core.hip"), closure)
+    names = {os.path.basename(p) for p in closure}
+    assert "lib_common.hpp" in names and "mi355zk.h" in names and "msm.cuh" not in names and "ntt29.cuh" not in names   # lib_core launches no kernel
+    closure = {}
+    b._closure(os.path.join(b.CSRC, "lib_ntt.hip"), closure)
+    assert "ntt29.cuh" in {os.path.basename(p) for p in closure} and "msm.cuh" not in {os.path.basename(p) for p in closure}
