@@ -242,7 +242,7 @@ def main() -> None:
     # per MSM (summed over the chunks of a pipelined MSM: the sort of chunk k + 1 runs under the accumulation of chunk k, so the
     # phases overlap and do not add up to msm_total)
     n_msm = max(1, prof("msm_total")[1])
-    phases = {p: prof(p)[0] / n_msm for p in ("msm_digits", "msm_sort", "msm_accumulate", "msm_reduce", "msm_total")}
+    phases = {p: prof(p)[0] / n_msm for p in ("msm_digits", "msm_sort", "sort_l1", "sort_hist", "sort_l2", "msm_accumulate", "msm_reduce", "msm_total")}
     chunks = max(1, round(acc_cnt / n_msm))
 
     # ---- correctness of what was timed: commit(p) = p(tau) G checked in the field (rank-local shard, oracle = checker only)

@@ -99,6 +99,7 @@ struct Ctx {
   uint32_t acc_variant = 4;     // MI355_ACC_VARIANT: 4 = limb products of k_msm_accumulate as column blocks of chained v_mad (fp29_asm_gen.inc): 57.1 vs 59.5 ms at 2^26, bit-identical; 0 = the plain C++ multiplier
   uint32_t seg_factor = 16;
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
+  uint32_t sort_split = 1;      // MI355_SORT_SPLIT: level-1 output as two streams (payload u32 + fine key u16) instead of one u64 per entry; 0 = the u64 records
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
   uint32_t seg_fill = 40, seg_fill_segfix = 40;   // MI355_SEG_FILL / MI355_SEG_FILL_SEGFIX (even, 2..100 %: above 100 the segments would no longer cover the entries): share of the launched accumulate threads the actual entries are spread over
   uint32_t seg_min = 16;             // MI355_SEG_MIN: shortest accumulate segment (entries per thread) when few digits are non-zero

@@ -196,6 +196,7 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_TAIL_COOP_MAX"); if (e) { long v = atol(e); if (v >= 0 && v <= (1l << 24)) g.tail_coop_max = (uint32_t)v; } }
   { const char *e = getenv("MI355_REDUCE_MIN_CHUNK"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) g.reduce_min_chunk = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_FB"); if (e) { int v = atoi(e); if (v >= 9 && v <= 12) g.sort_fb = (uint32_t)v; } }
+  { const char *e = getenv("MI355_SORT_SPLIT"); if (e && e[0] >= '0' && e[0] <= '2') g.sort_split = (uint32_t)(e[0] - '0'); }
   { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }

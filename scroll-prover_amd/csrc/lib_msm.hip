@@ -17,6 +17,11 @@ int msm_tu_init_device() {
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter_split<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter_split<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter_split<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter_split<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter_split<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return MI355_OK;
 }
 
@@ -153,6 +158,10 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   S.shared = shared ? 1 : 0; S.nshift = log2_ceil(n);
   S.regions = sh.regions;
   S.t1 = g.sort_t1;                           // level-1 tile: 1024 threads x 8 or 16 entries (64 / 128 KiB of LDS staging)
+  // split records (payload u32 + fine key u16 as two streams, MI355_SORT_SPLIT): 6 bytes of staging per entry -> 24 576-entry tiles where the bin
+  // bookkeeping leaves room (<= 1024 coarse bins)
+  const bool split = g.sort_split != 0;
+  if (g.sort_split == 1 && S.t1 == 16384 && (1u << S.cb_bits) <= 1024 && emax >= (1ull << 24)) S.t1 = 24576;   // MI355_SORT_SPLIT=2: split records, 16 384-entry tiles
   // level-2 tile (6 B of LDS per entry next to the 3 x 2^fb words of bin bookkeeping): 16384 entries give twice the run length in
   // `sorted` (fewer partial-line store transactions, the limiter of this kernel) at one workgroup per CU; worth it for big sorts
   S.t2 = g.sort_t2 ? g.sort_t2 : (emax >= (1ull << 27) && S.fb <= 11 ? 16384 : 8192);
@@ -163,7 +172,9 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   g1_xyzz29_t *buckets, *part; int32_t *part_id;
   // stage-A-only buffers are shared by all slots (the sort stages of successive chunks run one after the other on st.a)
   CHK(ws_get("msm.digits", emax * 4, (void **)&enc));
-  CHK(ws_get("msm.pairs", emax * 8, (void **)&pairs));
+  uint32_t *pairs_lo = nullptr; uint16_t *pairs_hi = nullptr;
+  if (g.sort_split) { CHK(ws_get("msm.pairs_lo", emax * 4 + 64, (void **)&pairs_lo)); CHK(ws_get("msm.pairs_hi", emax * 2 + 64, (void **)&pairs_hi)); pairs = nullptr; }
+  else CHK(ws_get("msm.pairs", emax * 8, (void **)&pairs));
   CHK(ws_get("msm.hist", ((size_t)nbuckets + 1) * 4, (void **)&hist));
   CHK(ws_get("msm.cursor", ((size_t)nbuckets + 1) * 4, (void **)&cursor));
   CHK(ws_get("msm.coarse_hist", ((size_t)S.regions + 1) * 4, (void **)&coarse_hist));
@@ -207,18 +218,32 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
       hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums + scan_blocks, cscan_blocks);
       hipLaunchKernelGGL(k_scan_final, dim3(cscan_blocks), dim3(SCAN_BLOCK), 0, s, coarse_hist, scan_sums + scan_blocks, coarse_off, coarse_cursor, cscan_n);
       {
+        Scope s1("sort_l1", s);
         const uint32_t CBp = ((1u << S.cb_bits) + 1) & ~1u;
-        if (S.t1 == 16384) hipLaunchKernelGGL(k_sort_l1_scatter<16>, dim3(tiles1 * vwindows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
+        if (split) {
+          const size_t lds1 = (size_t)(3 * CBp + 32 + SORT_SPLIT_TMAX) * 4 + (size_t)S.t1 * 6;
+          if (S.t1 == 24576) hipLaunchKernelGGL(k_sort_l1_scatter_split<24>, dim3(tiles1 * vwindows), dim3(1024), lds1, s, enc, coarse_cursor, pairs_lo, pairs_hi, S);
+          else if (S.t1 == 16384) hipLaunchKernelGGL(k_sort_l1_scatter_split<16>, dim3(tiles1 * vwindows), dim3(1024), lds1, s, enc, coarse_cursor, pairs_lo, pairs_hi, S);
+          else hipLaunchKernelGGL(k_sort_l1_scatter_split<8>, dim3(tiles1 * vwindows), dim3(1024), lds1, s, enc, coarse_cursor, pairs_lo, pairs_hi, S);
+        }
+        else if (S.t1 == 16384) hipLaunchKernelGGL(k_sort_l1_scatter<16>, dim3(tiles1 * vwindows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
         else hipLaunchKernelGGL(k_sort_l1_scatter<8>, dim3(tiles1 * vwindows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
       }
       hipLaunchKernelGGL(k_sort_tile_prefix, dim3(1), dim3(SCAN_BLOCK), 0, s, coarse_off, tile_start, S);
-      hipLaunchKernelGGL(k_sort_l2_hist, dim3(l2_tiles_max), dim3(256), 0, s, pairs, coarse_off, tile_start, hist, S);
+      { Scope s2("sort_hist", s);
+      if (split) hipLaunchKernelGGL(k_sort_l2_hist_split, dim3(l2_tiles_max), dim3(256), 0, s, (const uint16_t *)pairs_hi, coarse_off, tile_start, hist, S);
+      else hipLaunchKernelGGL(k_sort_l2_hist, dim3(l2_tiles_max), dim3(256), 0, s, pairs, coarse_off, tile_start, hist, S); }
       hipLaunchKernelGGL(k_scan_partial, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, scan_n);
       hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums, scan_blocks);
       hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, offsets, cursor, scan_n);
       {
+        Scope s3("sort_l2", s);
         const size_t lds2 = (size_t)(3 * (1u << S.fb) + 32) * 4 + (size_t)S.t2 * 6;   // histogram / offsets / bases + staged indices (4 B) and their bins (2 B)
-        if (S.t2 == 8192) hipLaunchKernelGGL(k_sort_l2_scatter<8>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
+        if (split) {
+          if (S.t2 == 8192) hipLaunchKernelGGL(k_sort_l2_scatter_split<8>, dim3(l2_tiles_max), dim3(1024), lds2, s, (const uint32_t *)pairs_lo, (const uint16_t *)pairs_hi, coarse_off, tile_start, cursor, sorted, S);
+          else hipLaunchKernelGGL(k_sort_l2_scatter_split<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, (const uint32_t *)pairs_lo, (const uint16_t *)pairs_hi, coarse_off, tile_start, cursor, sorted, S);
+        }
+        else if (S.t2 == 8192) hipLaunchKernelGGL(k_sort_l2_scatter<8>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
         else hipLaunchKernelGGL(k_sort_l2_scatter<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
       }
     }

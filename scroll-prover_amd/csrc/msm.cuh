@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_final(const uint32_t *__res
 //   level 2: tiles inside each coarse region, bin = fine key (2^fb bins)             -> exact bucket offsets + sorted[]
 // Order inside a bucket is arbitrary (group addition commutes), so nothing needs to be stable.
 constexpr uint32_t SORT_MAX_BINS = 4096;
+constexpr uint32_t SORT_SPLIT_TMAX = 128;   // entries of the block-start table of k_sort_l1_scatter_split (coarse bins >> spare key bits, at most 2048 >> 4)
 struct SortPlan { uint32_t n, windows /* batch * W */, wpp /* W */, nb, fb, cb_bits, t1, t2, regions, shared, nshift /* ceil(log2 n): table row of an entry = payload >> nshift */; };   // shared = 1: all windows feed ONE bucket set (precomputed 2^(cw) P tables)
 
 // Per-tile bin bookkeeping shared by both scatter kernels (1024 threads): lstart[] = exclusive scan of the tile histogram,
@@ -312,6 +313,60 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(con
     const uint64_t pr = stage[sidx];
     const uint32_t bucket = (uint32_t)(pr >> 32), bin = bucket >> S.fb;
     pairs[gbase[bin] + (sidx - lstart[bin])] = ((uint64_t)(bucket & fmask) << 32) | (uint64_t)(uint32_t)pr;
+  }
+}
+// ---- split records (round 3, MI355_SORT_SPLIT): the level-1 output as TWO streams, payload (u32) and fine key (u16), instead of one u64 per
+// entry of which 43 bits carry information.  The histogram pass then reads 2 bytes per entry instead of 8, the level-2 scatter 6 instead of 8, and
+// with 6-byte staging a level-1 tile holds 24 576 entries (147 KB of LDS) -- runs of 24 entries per (tile, coarse bin) instead of 16.  The
+// staged record no longer names its coarse bin; the write-out recovers it from the key's spare bits and a 32-entry table of block starts.
+template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter_split(const uint32_t *__restrict__ enc, uint32_t *__restrict__ coarse_cursor, uint32_t *__restrict__ pairs_lo,
+                                                                                    uint16_t *__restrict__ pairs_hi, SortPlan S) {
+  extern __shared__ uint32_t sm[];
+  const uint32_t CB = 1u << S.cb_bits, CBp = (CB + 1) & ~1u, fmask = (1u << S.fb) - 1;
+  // the 16 - fb spare bits of a staged key carry the low bits of the entry's coarse bin; T[k] = lstart[k << spare] locates the rest (see the write-out)
+  const uint32_t spare = 16u - S.fb, rmask = (1u << spare) - 1, tcount = (CB + rmask) >> spare;
+  uint32_t *h = sm, *lstart = sm + CBp, *gbase = sm + 2 * CBp, *scratch32 = sm + 3 * CBp, *T = sm + 3 * CBp + 32;
+  uint32_t *stage_lo = T + SORT_SPLIT_TMAX;
+  uint16_t *stage_hi = reinterpret_cast<uint16_t *>(stage_lo + 1024 * EPT);
+  const uint32_t tiles1 = (S.n + S.t1 - 1) / S.t1;
+  const uint32_t w = blockIdx.x / tiles1, j = blockIdx.x - w * tiles1;
+  for (uint32_t b = threadIdx.x; b < CB; b += 1024) h[b] = 0;
+  __syncthreads();
+  const uint32_t i0 = j * S.t1, i1 = min(S.n, i0 + S.t1);
+  const uint32_t *plane = enc + (uint64_t)w * S.n;
+  uint32_t e[EPT], rank[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; k++) {
+    const uint32_t i = i0 + k * 1024 + threadIdx.x;
+    e[k] = i < i1 ? plane[i] : 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every load in flight before the first returning LDS atomic (see k_sort_l1_scatter)
+#pragma unroll
+  for (int k = 0; k < EPT; k++) if (e[k]) rank[k] = atomicAdd(&h[((e[k] & 0x7fffffffu) - 1) >> S.fb], 1u);
+  __syncthreads();
+  const uint32_t m_poly = w / S.wpp, w_in = w - m_poly * S.wpp;
+  uint32_t gb[4];
+  const uint32_t total = tile_bin_offsets(h, lstart, gb, CB, coarse_cursor + (S.shared ? m_poly * CB : w * CB), scratch32);
+  const uint32_t idx_base = S.shared ? w_in << S.nshift : 0;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < tcount; k += 1024) T[k] = lstart[k << spare];
+#pragma unroll
+  for (int k = 0; k < EPT; k++) if (e[k]) {
+    const uint32_t bucket = (e[k] & 0x7fffffffu) - 1, i = i0 + k * 1024 + threadIdx.x, bin = bucket >> S.fb, pos = lstart[bin] + rank[k];
+    stage_lo[pos] = (idx_base + i) | (e[k] & 0x80000000u);
+    stage_hi[pos] = (uint16_t)((bucket & fmask) | ((bin & rmask) << S.fb));
+  }
+  tile_bin_publish(gbase, gb, CB);
+  __syncthreads();
+  // dense write-out: consecutive lanes take consecutive staged entries (coalesced runs).  The entry's coarse bin = (k << spare) | r with r from
+  // the key's spare bits and k = the last block of 2^spare bins that starts at or before the entry: lstart is monotone, so the walk over T is
+  // exact whatever the distribution (empty bins and blocks included); neighbouring lanes probe the same words (LDS broadcasts)
+  uint32_t k = 0;   // a thread's entries are 1024 apart (~1.3 blocks of a uniform tile): the block index advances by a probe or two per step
+  for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
+    const uint32_t key = stage_hi[sidx];
+    while (k + 1 < tcount && T[k + 1] <= sidx) k++;
+    const uint32_t bin = (k << spare) | (key >> S.fb), pos = gbase[bin] + (sidx - lstart[bin]);
+    pairs_lo[pos] = stage_lo[sidx]; pairs_hi[pos] = (uint16_t)(key & fmask);
   }
 }
 // tile_start[r] = sum_{r' < r} ceil(size_r' / t2); one workgroup of SCAN_BLOCK threads, regions <= 8192
@@ -382,6 +437,61 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
   const uint32_t total = tile_bin_offsets(h, lstart, gb, FB, cursor + (region << S.fb), scratch32);
   __syncthreads();
   // the bin of every staged entry travels in a 16-bit side array (fine < 4096): the write-out needs no search over lstart
+  uint16_t *stage_bin = reinterpret_cast<uint16_t *>(stage + 1024 * EPT);
+#pragma unroll
+  for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) { const uint32_t pos = lstart[fine[k]] + rank[k]; stage[pos] = idx[k]; stage_bin[pos] = (uint16_t)fine[k]; }
+  tile_bin_publish(gbase, gb, FB);
+  __syncthreads();
+  for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
+    const uint32_t b = stage_bin[sidx];
+    sorted[gbase[b] + (sidx - lstart[b])] = stage[sidx];
+  }
+}
+
+// level-2 histogram and scatter over the split records
+__global__ void __launch_bounds__(256) k_sort_l2_hist_split(const uint16_t *__restrict__ pairs_hi, const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start,
+                                                            uint32_t *__restrict__ hist, SortPlan S) {
+  __shared__ uint32_t h[SORT_MAX_BINS];
+  uint32_t region, s, e;
+  if (!sort_l2_tile(coarse_off, tile_start, S, region, s, e)) return;
+  const uint32_t FB = 1u << S.fb;
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) h[b] = 0;
+  __syncthreads();
+  // 8 keys (one 16-byte load) per lane and step over the aligned body, single keys at the ragged ends
+  const uint32_t a0 = min(e, (s + 7u) & ~7u), a1 = a0 + ((e - a0) & ~7u);
+  for (uint32_t p = s + threadIdx.x; p < a0; p += blockDim.x) atomicAdd(&h[pairs_hi[p]], 1u);
+  for (uint32_t q = a0 + 8u * threadIdx.x; q < a1; q += 8u * blockDim.x) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(pairs_hi + q);
+    atomicAdd(&h[v.x & 0xffffu], 1u); atomicAdd(&h[v.x >> 16], 1u); atomicAdd(&h[v.y & 0xffffu], 1u); atomicAdd(&h[v.y >> 16], 1u);
+    atomicAdd(&h[v.z & 0xffffu], 1u); atomicAdd(&h[v.z >> 16], 1u); atomicAdd(&h[v.w & 0xffffu], 1u); atomicAdd(&h[v.w >> 16], 1u);
+  }
+  for (uint32_t p = a1 + threadIdx.x; p < e; p += blockDim.x) atomicAdd(&h[pairs_hi[p]], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) if (h[b]) atomicAdd(&hist[(region << S.fb) + b], h[b]);
+}
+template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter_split(const uint32_t *__restrict__ pairs_lo, const uint16_t *__restrict__ pairs_hi, const uint32_t *__restrict__ coarse_off,
+                                                                                    const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted, SortPlan S) {
+  extern __shared__ uint32_t sm[];
+  const uint32_t FB = 1u << S.fb;
+  uint32_t *h = sm, *lstart = sm + FB, *gbase = sm + 2 * FB, *scratch32 = sm + 3 * FB, *stage = sm + 3 * FB + 32;
+  uint32_t region, s, e;
+  if (!sort_l2_tile(coarse_off, tile_start, S, region, s, e)) return;
+  for (uint32_t b = threadIdx.x; b < FB; b += 1024) h[b] = 0;
+  __syncthreads();
+  uint32_t idx[EPT], fine[EPT], rank[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; k++) {
+    const uint32_t p = s + k * 1024 + threadIdx.x;
+    fine[k] = 0xffffffffu;
+    if (p < e) { idx[k] = pairs_lo[p]; fine[k] = pairs_hi[p]; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) rank[k] = atomicAdd(&h[fine[k]], 1u);
+  __syncthreads();
+  uint32_t gb[4];
+  const uint32_t total = tile_bin_offsets(h, lstart, gb, FB, cursor + (region << S.fb), scratch32);
+  __syncthreads();
   uint16_t *stage_bin = reinterpret_cast<uint16_t *>(stage + 1024 * EPT);
 #pragma unroll
   for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) { const uint32_t pos = lstart[fine[k]] + rank[k]; stage[pos] = idx[k]; stage_bin[pos] = (uint16_t)fine[k]; }
