@@ -266,9 +266,11 @@ __device__ __forceinline__ uint32_t tile_bin_offsets(const uint32_t *h, uint32_t
   for (uint32_t k = 0; k < 4; k++) { gb[k] = 0; if (k < bpt && b0 + k < nbins) { lstart[b0 + k] = ex; if (local[k]) gb[k] = atomicAdd(&global_cursor[b0 + k], local[k]); ex += local[k]; } }
   return total;
 }
-__device__ __forceinline__ void tile_bin_publish(uint32_t *gbase, const uint32_t (&gb)[4], uint32_t nbins) {
+// gbase[b] = (start of this tile's run in global bin b) - lstart[b]: the write-out then places staged entry sidx at gbase[bin] + sidx with ONE
+// LDS lookup per entry (the difference wraps modulo 2^32 and un-wraps in the sum)
+__device__ __forceinline__ void tile_bin_publish(uint32_t *gbase, const uint32_t *lstart, const uint32_t (&gb)[4], uint32_t nbins) {
   const uint32_t bpt = (nbins + 1023) >> 10, b0 = threadIdx.x * bpt;
-  for (uint32_t k = 0; k < 4; k++) if (k < bpt && b0 + k < nbins) gbase[b0 + k] = gb[k];
+  for (uint32_t k = 0; k < 4; k++) if (k < bpt && b0 + k < nbins) gbase[b0 + k] = gb[k] - lstart[b0 + k];
 }
 // Level-1 scatter, LDS-staged: the tile is counting-sorted inside LDS first so that the global stores are coalesced runs
 // (the direct version wrote 8-byte records at random: 3.4x write amplification measured with WRITE_SIZE).
@@ -307,12 +309,12 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(con
     const uint32_t bucket = (e[k] & 0x7fffffffu) - 1, i = i0 + k * 1024 + threadIdx.x;
     stage[lstart[bucket >> S.fb] + rank[k]] = ((uint64_t)bucket << 32) | (uint64_t)((idx_base + i) | (e[k] & 0x80000000u));
   }
-  tile_bin_publish(gbase, gb, CB);
+  tile_bin_publish(gbase, lstart, gb, CB);
   __syncthreads();
   for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
     const uint64_t pr = stage[sidx];
     const uint32_t bucket = (uint32_t)(pr >> 32), bin = bucket >> S.fb;
-    pairs[gbase[bin] + (sidx - lstart[bin])] = ((uint64_t)(bucket & fmask) << 32) | (uint64_t)(uint32_t)pr;
+    pairs[gbase[bin] + sidx] = ((uint64_t)(bucket & fmask) << 32) | (uint64_t)(uint32_t)pr;
   }
 }
 // ---- split records (round 3, MI355_SORT_SPLIT): the level-1 output as TWO streams, payload (u32) and fine key (u16), instead of one u64 per
@@ -356,7 +358,7 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter_spl
     stage_lo[pos] = (idx_base + i) | (e[k] & 0x80000000u);
     stage_hi[pos] = (uint16_t)((bucket & fmask) | ((bin & rmask) << S.fb));
   }
-  tile_bin_publish(gbase, gb, CB);
+  tile_bin_publish(gbase, lstart, gb, CB);
   __syncthreads();
   // dense write-out: consecutive lanes take consecutive staged entries (coalesced runs).  The entry's coarse bin = (k << spare) | r with r from
   // the key's spare bits and k = the last block of 2^spare bins that starts at or before the entry: lstart is monotone, so the walk over T is
@@ -365,7 +367,7 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter_spl
   for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
     const uint32_t key = stage_hi[sidx];
     while (k + 1 < tcount && T[k + 1] <= sidx) k++;
-    const uint32_t bin = (k << spare) | (key >> S.fb), pos = gbase[bin] + (sidx - lstart[bin]);
+    const uint32_t bin = (k << spare) | (key >> S.fb), pos = gbase[bin] + sidx;
     pairs_lo[pos] = stage_lo[sidx]; pairs_hi[pos] = (uint16_t)(key & fmask);
   }
 }
@@ -440,11 +442,11 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(con
   uint16_t *stage_bin = reinterpret_cast<uint16_t *>(stage + 1024 * EPT);
 #pragma unroll
   for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) { const uint32_t pos = lstart[fine[k]] + rank[k]; stage[pos] = idx[k]; stage_bin[pos] = (uint16_t)fine[k]; }
-  tile_bin_publish(gbase, gb, FB);
+  tile_bin_publish(gbase, lstart, gb, FB);
   __syncthreads();
   for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
     const uint32_t b = stage_bin[sidx];
-    sorted[gbase[b] + (sidx - lstart[b])] = stage[sidx];
+    sorted[gbase[b] + sidx] = stage[sidx];
   }
 }
 
@@ -495,11 +497,11 @@ template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter_spl
   uint16_t *stage_bin = reinterpret_cast<uint16_t *>(stage + 1024 * EPT);
 #pragma unroll
   for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) { const uint32_t pos = lstart[fine[k]] + rank[k]; stage[pos] = idx[k]; stage_bin[pos] = (uint16_t)fine[k]; }
-  tile_bin_publish(gbase, gb, FB);
+  tile_bin_publish(gbase, lstart, gb, FB);
   __syncthreads();
   for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
     const uint32_t b = stage_bin[sidx];
-    sorted[gbase[b] + (sidx - lstart[b])] = stage[sidx];
+    sorted[gbase[b] + sidx] = stage[sidx];
   }
 }
 

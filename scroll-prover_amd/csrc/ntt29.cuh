@@ -22,6 +22,9 @@
 
 namespace zk {
 
+#ifndef ZK_NTT_ODD_FIRST
+#define ZK_NTT_ODD_FIRST 1   // see lds_dif29
+#endif
 #ifndef ZK_NTT_LAZY_LAST
 #define ZK_NTT_LAZY_LAST true   // trivial-twiddle differences of a tile's last stage stay un-reduced (see lds_dif29_round)
 #endif
@@ -134,6 +137,9 @@ template <int R, bool LAST> __device__ __forceinline__ void lds_dif29_round(cons
 // post-scaling constant (tight, < 2 r) needs the reduced value ((103 r)(2 r) / 2^261 + r would exceed the single conditional subtraction).
 template <int RMAX> __device__ __forceinline__ void lds_dif29(const Lds29 &L, uint32_t log_m, uint32_t log_c, uint32_t sm, uint32_t sc, const Tw29 &tw_m, bool col_fast, bool lazy_last) {
   uint32_t s = 0;
+  // an odd tile with radix-4 rounds takes its single radix-2 stage FIRST (round 3): the closing round is then a LAST radix-4 round, which drops the
+  // unit twiddles of the last TWO stages (0.75 multiplications per element) instead of the last one (0.5) -- the round count stays the same
+  if (ZK_NTT_ODD_FIRST && RMAX == 2 && (log_m & 1u) && log_m >= 3) { lds_dif29_round<1, false>(L, log_m, log_c, sm, sc, tw_m, col_fast, 0, false); s = 1; }
   while (s < log_m) {
     const uint32_t left = log_m - s;
     if (RMAX >= 3 && left >= 3 && left != 4) { if (left == 3) lds_dif29_round<3, true>(L, log_m, log_c, sm, sc, tw_m, col_fast, s, lazy_last); else lds_dif29_round<3, false>(L, log_m, log_c, sm, sc, tw_m, col_fast, s, false); s += 3; }
