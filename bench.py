@@ -146,7 +146,10 @@ def main() -> None:
         l2 = replay_create_proof(2, host_api=not args.no_host_api)
         l1 = replay_create_proof(1, host_api=not args.no_host_api)
         ok_all = all(r.get("ok") for r in (l4, l2, l1))
-        proof_mix = {"c_abi_resident_ms": l4.get("resident_ms"), "host_api_ms": l4.get("host_api_ms"), "layer4": l4,
+        hb = None
+        if l4.get("host_api_ms", -1) > 0 and l4.get("host_api_fft_batched_ms", -1) > 0:   # the host route with the transform loops through mi355_ntt_fr_batch_host
+            hb = round(l4["host_api_ms"] - l4["host_api_fft_ms"] + l4["host_api_fft_batched_ms"], 3)
+        proof_mix = {"c_abi_resident_ms": l4.get("resident_ms"), "host_api_ms": l4.get("host_api_ms"), "host_api_batched_fft_ms": hb, "layer4": l4,
                      "chunk_proof_proxy": {"what": "layer 1 (k = 24) + layer 2 (k = 25) compression proofs of one chunk, GPU side of create_proof; layer 0 (the k = 20 inner SuperCircuit proof, O(10^3) commitments) is not replayed",
                                            "resident_ms": (l1.get("resident_ms", 0) + l2.get("resident_ms", 0)) if ok_all else None,
                                            "host_api_ms": (l1.get("host_api_ms", 0) + l2.get("host_api_ms", 0)) if ok_all else None, "layer1": l1, "layer2": l2},

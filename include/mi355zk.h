@@ -184,8 +184,9 @@ int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n
 /* `batch` independent transforms in one call -- the loops of create_proof over columns (the iNTT of every advice column, the
  * coset NTTs of every polynomial that enters evaluate_h; 8 + 32 for a layer-4 proof [REF integration/configs/layer4.config:3-10]).
  * divisor == NULL: best_fft; divisor = n^-1: EvaluationDomain::ifft.  Host pointers are dealt round-robin over the bound devices (one
- * worker thread, staging buffer and PCIe link per device); device pointers run on the device that owns them, concurrently across
- * devices.  Results equal the serial loop's.                                                                                        */
+ * worker thread and PCIe link per device; on each device the upload of item i + 1, the transform of item i and the download of item
+ * i - 1 overlap over two staging buffers: 56 ms instead of 87 ms per 2^26 polynomial); device pointers run on the device that owns
+ * them, concurrently across devices.  Results equal the serial loop's.                                                              */
 int mi355_ntt_fr_batch_host(void *const *data_host, uint32_t batch, uint32_t log_n, const void *omega, const void *divisor);
 int mi355_ntt_fr_batch_dev(void *const *data_dev, uint32_t batch, uint32_t log_n, const void *omega, const void *divisor);
 int mi355_coset_ntt_fr_batch_dev(void *const *dst_dev, const void *const *coeffs_dev, uint32_t batch, uint32_t log_n, const void *coset_factor, const void *omega);

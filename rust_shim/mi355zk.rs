@@ -67,6 +67,7 @@ extern "C" {
     pub fn mi355_msm_g1_dev(srs: u64, base_offset: u64, scalars_dev: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_msm_g1_batch_dev(srs: u64, base_offset: u64, scalars_dev: *const *const c_void, batch: u32, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_intt_fr_dev(data_dev: *mut c_void, log_n: u32, omega_inv: *const c_void, divisor: *const c_void) -> c_int;
+    pub fn mi355_ntt_fr_batch_host(data_host: *const *mut c_void, batch: u32, log_n: u32, omega: *const c_void, divisor: *const c_void) -> c_int;
     pub fn mi355_ntt_fr_batch_dev(data_dev: *const *mut c_void, batch: u32, log_n: u32, omega: *const c_void, divisor: *const c_void) -> c_int;
     pub fn mi355_coset_ntt_fr_batch_dev(dst_dev: *const *mut c_void, coeffs_dev: *const *const c_void, batch: u32, log_n: u32,
                                         coset_factor: *const c_void, omega: *const c_void) -> c_int;
@@ -241,6 +242,14 @@ pub fn fft_many_dev(polys: &mut [&mut DevicePoly], k: u32, omega: &Fr, divisor: 
     let ptrs: Vec<*mut c_void> = polys.iter_mut().map(|p| p.as_mut_ptr()).collect();
     let d = divisor.map(|d| d as *const Fr as *const c_void).unwrap_or(std::ptr::null());
     unsafe { mi355_ntt_fr_batch_dev(ptrs.as_ptr(), ptrs.len() as u32, k, omega as *const Fr as *const c_void, d) == MI355_OK }
+}
+/// The same loop over HOST polynomials (a shim that has not adopted `DevicePoly`): uploads, transforms and downloads of neighbouring
+/// items overlap inside the library, and the items are dealt over the bound devices.
+pub fn fft_many(polys: &mut [&mut [Fr]], k: u32, omega: &Fr, divisor: Option<&Fr>) -> bool {
+    if polys.iter().any(|p| p.len() != 1usize << k) { return false; }
+    let ptrs: Vec<*mut c_void> = polys.iter_mut().map(|p| p.as_mut_ptr() as *mut c_void).collect();
+    let d = divisor.map(|d| d as *const Fr as *const c_void).unwrap_or(std::ptr::null());
+    unsafe { mi355_ntt_fr_batch_host(ptrs.as_ptr(), ptrs.len() as u32, k, omega as *const Fr as *const c_void, d) == MI355_OK }
 }
 /// One term list of `evaluate_h` on one coset part: `dst[i] (+)= sum_j coeffs[j] * prod polys[p][(i + rot) mod n]` in ONE launch.
 /// `terms[j]` = (coefficient, [(index into polys, rotation in elements)]).  At most 16 terms / 48 factors per call (split and accumulate).

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <condition_variable>
 #include <unordered_map>
 #include <vector>
 
@@ -80,6 +81,7 @@ struct Ctx {
   hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_up[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint32_t up_next = 0;   // uploads on copy_stream (ring: several threads may upload at once); the compute stream waits for each
   uint32_t host_slice_min_log = 22;   // MI355_HOST_SLICE_MIN_LOG: smallest log2(n) the host-pointer MSM cuts into slices (tests lower it)
+  uint32_t host_batch_overlap = 1;   // MI355_HOST_BATCH_OVERLAP=0: the host-pointer batch transforms copy and compute one item at a time (no helper thread)
   uint32_t host_chunks = 8;     // MI355_HOST_CHUNKS: upper bound on the point-range slices of the host-pointer MSM (1 = one copy, then compute)
   int device = -1;
   hipDeviceProp_t prop;

@@ -204,6 +204,7 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_NTT_FOLD_SCALE"); if (e) g.ntt_fold_scale = e[0] == '0' ? 0u : 1u; }
   { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
+  { const char *e = getenv("MI355_HOST_BATCH_OVERLAP"); if (e) g.host_batch_overlap = atoi(e) != 0; }
   { const char *e = getenv("MI355_HOST_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64) g.host_chunks = (uint32_t)v; } }
   { const char *e = getenv("MI355_HOST_SLICE_MIN_LOG"); if (e) { int v = atoi(e); if (v >= 4 && v <= 31) g.host_slice_min_log = (uint32_t)v; } }
   g.inited = true;

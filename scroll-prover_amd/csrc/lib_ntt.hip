@@ -214,7 +214,7 @@ using namespace mi355;
 namespace {
 struct BatchItem { uint32_t index; int slot; };
 // run(slot, index) for every item, one thread per device that has items; the first error wins
-template <class F> int run_per_device(const std::vector<BatchItem> &items, F run) {
+template <class F> int run_per_device_lists(const std::vector<BatchItem> &items, F run_list) {
   std::vector<std::vector<uint32_t>> by_slot(MAX_DEV);
   for (const auto &it : items) by_slot[it.slot].push_back(it.index);
   std::vector<int> slots; for (int s = 0; s < MAX_DEV; s++) if (!by_slot[s].empty()) slots.push_back(s);
@@ -224,7 +224,7 @@ template <class F> int run_per_device(const std::vector<BatchItem> &items, F run
     rcs[k] = guarded([&]() -> int {
       DevGuard lk(slot);
       CHK(need_init(slot));
-      for (uint32_t idx : by_slot[slot]) CHK(run(slot, idx));
+      CHK(run_list(slot, by_slot[slot]));
       HIPCHK(hipStreamSynchronize(g.stream));
       resolve_spans();
       return MI355_OK;
@@ -239,10 +239,68 @@ template <class F> int run_per_device(const std::vector<BatchItem> &items, F run
   for (size_t k = 0; k < slots.size(); k++) if (rcs[k] != MI355_OK) return fail(rcs[k], "device slot " + std::to_string(slots[k]) + ": " + errs[k]);
   return MI355_OK;
 }
+template <class F> int run_per_device(const std::vector<BatchItem> &items, F run) {
+  return run_per_device_lists(items, [&](int slot, const std::vector<uint32_t> &idx) -> int { for (uint32_t i : idx) CHK(run(slot, i)); return MI355_OK; });
+}
 int transform_in_place(fe_t *data, uint32_t log_n, const void *omega, const void *divisor) {
   if (!divisor) return ntt_dev_impl(data, 1ull << log_n, data, log_n, omega, nullptr, nullptr);
   fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], divisor, 32);
   return ntt_dev_impl(data, 1ull << log_n, data, log_n, omega, nullptr, post);
+}
+// Host-pointer batch on ONE device (called with the device's lock held): upload of item i + 1 | transform of item i | download of item i - 1.
+// PCIe is full duplex, but a copy from / to pageable memory blocks its calling thread for the whole transfer, so the downloads run on a helper
+// thread with its own stream; two staging buffers alternate.  Results are those of the serial loop.
+int ntt_host_pipeline(const std::vector<uint32_t> &idx, void *const *data_host, size_t bytes, uint32_t log_n, const void *omega, const void *divisor) {
+  const size_t n = idx.size();
+  void *dev[2] = {nullptr, nullptr};
+  CHK(ws_get("io.ntt", bytes, &dev[0]));
+  if (n < 2 || g.host_batch_overlap == 0) {
+    for (uint32_t i : idx) {
+      HIPCHK(hipMemcpyAsync(dev[0], data_host[i], bytes, hipMemcpyHostToDevice, g.stream));
+      CHK(transform_in_place((fe_t *)dev[0], log_n, omega, divisor));
+      HIPCHK(hipMemcpyAsync(data_host[i], dev[0], bytes, hipMemcpyDeviceToHost, g.stream));
+      HIPCHK(hipStreamSynchronize(g.stream));   // the staging buffer is reused by the next item
+    }
+    return MI355_OK;
+  }
+  CHK(ws_get("io.ntt.b", bytes, &dev[1]));
+  struct Events { hipEvent_t up[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    ~Events() { for (int i = 0; i < 2; i++) { if (up[i]) (void)hipEventDestroy(up[i]); if (done[i]) (void)hipEventDestroy(done[i]); } } } ev;
+  for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&ev.up[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev.done[i], hipEventDisableTiming)); }
+  struct Shared { std::mutex mu; std::condition_variable cv; size_t computed = 0, downloaded = 0; bool abort = false; hipError_t err = hipSuccess; } sh;
+  const int device = g.device; hipStream_t down_stream = g.aux_stream[0] ? g.aux_stream[0] : g.copy_stream;
+  std::thread downloader([&]() {
+    hipError_t e = hipSetDevice(device);
+    for (size_t i = 0; i < n && e == hipSuccess; i++) {
+      { std::unique_lock<std::mutex> lk(sh.mu); sh.cv.wait(lk, [&] { return sh.computed > i || sh.abort; }); if (sh.abort) return; }
+      e = hipStreamWaitEvent(down_stream, ev.done[i & 1], 0);
+      if (e == hipSuccess) e = hipMemcpyAsync(data_host[idx[i]], dev[i & 1], bytes, hipMemcpyDeviceToHost, down_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(down_stream);
+      { std::lock_guard<std::mutex> lk(sh.mu); if (e == hipSuccess) sh.downloaded = i + 1; else { sh.err = e; sh.abort = true; } }
+      sh.cv.notify_all();
+    }
+    if (e != hipSuccess) { { std::lock_guard<std::mutex> lk(sh.mu); sh.err = e; sh.abort = true; } sh.cv.notify_all(); }
+  });
+  int rc = [&]() -> int {
+    for (size_t i = 0; i < n; i++) {
+      if (i >= 2) {   // staging buffer i & 1 still holds item i - 2 until its download has finished
+        std::unique_lock<std::mutex> lk(sh.mu); sh.cv.wait(lk, [&] { return sh.downloaded + 1 >= i || sh.abort; });
+        if (sh.abort) return MI355_EHIP;
+      }
+      HIPCHK(hipMemcpyAsync(dev[i & 1], data_host[idx[i]], bytes, hipMemcpyHostToDevice, g.copy_stream));
+      HIPCHK(hipEventRecord(ev.up[i & 1], g.copy_stream));
+      HIPCHK(hipStreamWaitEvent(g.stream, ev.up[i & 1], 0));
+      CHK(transform_in_place((fe_t *)dev[i & 1], log_n, omega, divisor));
+      HIPCHK(hipEventRecord(ev.done[i & 1], g.stream));
+      { std::lock_guard<std::mutex> lk(sh.mu); sh.computed = i + 1; }
+      sh.cv.notify_all();
+    }
+    return MI355_OK;
+  }();
+  if (rc != MI355_OK) { { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; } sh.cv.notify_all(); }
+  downloader.join();
+  if (sh.err != hipSuccess) return fail(MI355_EHIP, std::string("ntt_batch download: ") + hipGetErrorString(sh.err));
+  return rc;
 }
 }  // namespace
 
@@ -388,14 +446,7 @@ int mi355_ntt_fr_batch_host(void *const *data_host, uint32_t batch, uint32_t log
   std::vector<BatchItem> items(batch);
   for (uint32_t i = 0; i < batch; i++) items[i] = {i, (int)(i % (uint32_t)D)};
   const size_t bytes = sizeof(fe_t) << log_n;
-  return run_per_device(items, [&](int, uint32_t i) -> int {
-    void *dev; CHK(ws_get("io.ntt", bytes, &dev));
-    HIPCHK(hipMemcpyAsync(dev, data_host[i], bytes, hipMemcpyHostToDevice, g.stream));
-    CHK(transform_in_place((fe_t *)dev, log_n, omega, divisor));
-    HIPCHK(hipMemcpyAsync(data_host[i], dev, bytes, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));   // the staging buffer is reused by the next item
-    return MI355_OK;
-  });
+  return run_per_device_lists(items, [&](int, const std::vector<uint32_t> &idx) -> int { return ntt_host_pipeline(idx, data_host, bytes, log_n, omega, divisor); });
   });
 }
 // the same on resident polynomials: each transform runs on the device that owns its buffer, asynchronously within a device

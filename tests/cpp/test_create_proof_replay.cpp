@@ -322,24 +322,33 @@ int main(int argc, char **argv) {
     }
   }
   // ---- the same MSM / NTT / evaluation calls through the host-pointer entry points (what a shim without DevicePoly pays)
-  double host_ms = -1;
+  double host_ms = -1, host_fft_ms = -1, host_fft_batched_ms = -1;
   if (host_api && failures == 0) {
     std::vector<Fr> hp = host_cols[1]; std::vector<Fr> hext(Q * n);
     const uint32_t n_lag = W - 1 + L.products, n_coef = 1 + Q + 2, n_intt = NP, n_ntt = NP * Q;
     const auto t1 = Clock::now();
     for (uint32_t i = 0; i < n_lag; i++) CK(mi355_msm_g1_host(hl, 0, hp.data(), n, out.data()));
     for (uint32_t i = 0; i < n_coef; i++) CK(mi355_msm_g1_host(hg, 0, hp.data(), n, out.data()));
+    const auto t2 = Clock::now();
     for (uint32_t i = 0; i < n_intt; i++) CK(mi355_intt_fr_host(hp.data(), k, dom.omega_inv.data(), dom.ifft_divisor.data()));
     for (uint32_t i = 0; i < n_ntt; i++) CK(mi355_ntt_fr_host(hp.data(), k, dom.omega.data()));
+    host_fft_ms = ms_since(t2);
     CK(mi355_extended_to_coeff_host(hext.data(), k + 2, dom.g_coset.data(), dom.g_coset_inv.data(), dom.extended_omega_inv.data(), dom.extended_ifft_divisor.data()));
     Fr e; for (uint32_t i = 0; i < L.evals; i++) CK(mi355_eval_polynomial_host(hp.data(), n, tau.data(), e.data()));
     host_ms = ms_since(t1);
+    // the same transforms as column loops through the batch entry point (upload | transform | download overlapped inside the library)
+    const uint32_t B = std::min<uint32_t>(8, W);
+    std::vector<void *> ptrs(B); for (uint32_t i = 0; i < B; i++) ptrs[i] = host_cols[i].data();
+    const auto t3 = Clock::now();
+    for (uint32_t done = 0; done < n_intt; done += B) CK(mi355_ntt_fr_batch_host(ptrs.data(), std::min(B, n_intt - done), k, dom.omega_inv.data(), dom.ifft_divisor.data()));
+    for (uint32_t done = 0; done < n_ntt; done += B) CK(mi355_ntt_fr_batch_host(ptrs.data(), std::min(B, n_ntt - done), k, dom.omega.data(), nullptr));
+    host_fft_batched_ms = ms_since(t3);
   }
   std::printf("{\"replay\": \"create_proof steps 1-10 through the C-ABI, polynomials resident (mi355_buf_*)\", \"layer\": %d, \"k\": %u, \"devices\": %d, \"window_tables\": %s, "
-              "\"msm\": %zu, \"intt\": %u, \"coset_ntt\": %u, \"evals\": %zu, \"resident_ms\": %.3f, \"host_api_ms\": %.3f, "
+              "\"msm\": %zu, \"intt\": %u, \"coset_ntt\": %u, \"evals\": %zu, \"resident_ms\": %.3f, \"host_api_ms\": %.3f, \"host_api_fft_ms\": %.3f, \"host_api_fft_batched_ms\": %.3f, "
               "\"step_ms\": {\"1_instance\": %.2f, \"2_3_advice_lookup_commits\": %.2f, \"4_products\": %.2f, \"5_random\": %.2f, \"6_to_coeff\": %.2f, \"7_quotient\": %.2f, \"8_commit_h\": %.2f, \"9_evals\": %.2f, \"10_shplonk\": %.2f}, "
               "\"checked\": %u, \"ok\": %s}\n",
-              layer_id, k, devices, tables ? "true" : "false", commits.size(), NP, NP * Q, evals.size(), resident_ms, host_ms,
+              layer_id, k, devices, tables ? "true" : "false", commits.size(), NP, NP * Q, evals.size(), resident_ms, host_ms, host_fft_ms, host_fft_batched_ms,
               step_ms[1], step_ms[2], step_ms[4], step_ms[5], step_ms[6], step_ms[7], step_ms[8], step_ms[9], step_ms[10], checked, failures == 0 ? "true" : "false");
   poly.clear(); random_poly.release(); h_ext.release(); lin.release(); quot[0].release(); quot[1].release();
   CK(mi355_srs_release(hg)); CK(mi355_srs_release(hl));

@@ -137,6 +137,27 @@ def test_batched_transforms_equal_the_serial_loop_one_device(zk):
         b.free()
 
 
+def test_host_batch_overlaps_copies_and_matches_the_serial_loop(zk):
+    """mi355_ntt_fr_batch_host pipelines upload | transform | download over two staging buffers with a helper thread: seven polynomials of
+    2^19 (three reuses of each staging buffer) must equal seven single calls, and the oracle on the first."""
+    h2 = zk.halo2
+    k = 19
+    n = 1 << k
+    rng = np.random.default_rng(11)
+    dom = h2.EvaluationDomain(2, k)
+    polys = [rand_fr(rng, n) for _ in range(7)]
+    batch = [p.copy() for p in polys]
+    h2.best_fft_many(batch, dom.omega, k)
+    for a, p in zip(batch, polys):
+        single = p.copy()
+        h2.best_fft(single, dom.omega, k)
+        assert (a == single).all()
+    assert (batch[0] == cref.best_fft(polys[0], dom.omega, k, threads=8)).all()
+    h2.best_fft_many(batch, dom.omega_inv, k, divisor=dom.ifft_divisor)
+    for a, p in zip(batch, polys):
+        assert (a == p).all()
+
+
 def test_buffers_and_batches_over_two_device_slots():
     pkg = ge.load_package()
     pkg.init(0)
