@@ -281,6 +281,9 @@ int ntt_host_pipeline(const std::vector<uint32_t> &idx, void *const *data_host, 
     }
     if (e != hipSuccess) { { std::lock_guard<std::mutex> lk(sh.mu); sh.err = e; sh.abort = true; } sh.cv.notify_all(); }
   });
+  // the helper is joined on every way out of this function (an exception from the loop below -- std::bad_alloc in the plan cache, say -- must not
+  // reach a joinable std::thread's destructor)
+  struct Joiner { std::thread &t; Shared &sh; ~Joiner() { if (!t.joinable()) return; { std::lock_guard<std::mutex> lk(sh.mu); sh.abort = true; } sh.cv.notify_all(); t.join(); } } joiner{downloader, sh};
   int rc = [&]() -> int {
     for (size_t i = 0; i < n; i++) {
       if (i >= 2) {   // staging buffer i & 1 still holds item i - 2 until its download has finished
