@@ -219,6 +219,10 @@ int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n);
  * dst == poly + 1 element (the quotient then replaces coefficients 1 .. n-1 in place).                                             */
 int mi355_fr_kate_division_dev(void *dst_dev, const void *poly_dev, uint64_t n, const void *z);
 int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host);
+/* the additive counterpart: dst[0] = 0, dst[i] = sum_{j<i} src[j] -- the running sum phi of the log-derivative (mv-lookup) argument of the
+ * scroll fork [EXT-recalled halo2_proofs src/plonk/mv_lookup/prover.rs: phi[i + 1] = phi[i] + sum_j 1 / (beta + f_j[i]) - m[i] / (beta + t[i]);
+ * SURVEY 3.2 step 4 "lookup grand-sum"].  Same aliasing and total_out_host rules (the total must be zero for a valid argument).       */
+int mi355_fr_prefix_sum_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host);
 
 /* ---- halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i  (the evaluations written to the
  *      transcript in step 9 of create_proof); out_fr_host receives 32 B.  First widening into SURVEY 8f-3.   */

@@ -490,6 +490,13 @@ void orc_prefix_product(fe *z, const fe *v, uint64_t n, fe *total) {
   for (uint64_t i = 0; i < n; i++) { fe t; fe_mul(&t, &acc, &v[i], &FR); z[i] = acc; acc = t; }
   if (total) *total = acc;
 }
+/* the running sum of the log-derivative lookup argument: phi[0] = 0, phi[i + 1] = phi[i] + v[i] [EXT-recalled halo2_proofs (scroll fork)
+ * src/plonk/mv_lookup/prover.rs]; returns phi[n] in *total (zero for a valid argument) */
+void orc_prefix_sum(fe *z, const fe *v, uint64_t n, fe *total) {
+  fe acc = {{0, 0, 0, 0}};
+  for (uint64_t i = 0; i < n; i++) { fe t; fe_add(&t, &acc, &v[i], &FR); z[i] = acc; acc = t; }
+  if (total) *total = acc;
+}
 
 /* EvaluationDomain pieces [EXT-recalled halo2_proofs src/poly/domain.rs] */
 /* ifft: best_fft(a, omega_inv, log_n) then a[i] *= divisor (= n^-1) */

@@ -252,6 +252,11 @@ def prefix_product(v):
     lib().orc_prefix_product(_p(z), _p(v), C.c_uint64(v.shape[0]), _p(t)); return z, t
 
 
+def prefix_sum(v):
+    v = np.ascontiguousarray(v, dtype=np.uint64); z = np.zeros_like(v); t = _fe()
+    lib().orc_prefix_sum(_p(z), _p(v), C.c_uint64(v.shape[0]), _p(t)); return z, t
+
+
 def ifft(a, omega_inv, log_n: int, divisor, threads: int | None = None):
     threads = threads or usable_cpus()
     a = np.array(a, dtype=np.uint64, copy=True, order="C")

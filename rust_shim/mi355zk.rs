@@ -77,6 +77,7 @@ extern "C" {
                                   term_len: *const u32, n_terms: u32, factor_poly: *const u32, factor_rot: *const i32, n: u64, accumulate: c_int) -> c_int;
     pub fn mi355_fr_batch_invert_dev(data_dev: *mut c_void, n: u64) -> c_int;
     pub fn mi355_fr_prefix_product_dev(dst_dev: *mut c_void, src_dev: *const c_void, n: u64, total_out_host: *mut c_void) -> c_int;
+    pub fn mi355_fr_prefix_sum_dev(dst_dev: *mut c_void, src_dev: *const c_void, n: u64, total_out_host: *mut c_void) -> c_int;
     pub fn mi355_fr_kate_division_dev(dst_dev: *mut c_void, poly_dev: *const c_void, n: u64, z: *const c_void) -> c_int;
     pub fn mi355_eval_polynomial_dev(poly_dev: *const c_void, n: u64, point: *const c_void, out_fr_host: *mut c_void) -> c_int;
 }

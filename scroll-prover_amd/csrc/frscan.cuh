@@ -33,23 +33,25 @@ __device__ __forceinline__ fe_t lds_get(const uint32_t *p) {
 // exclusive multiplicative scan of one value per thread across the workgroup (Hillis-Steele through LDS, 9 dwords per slot).
 // buf: 2 * 256 * 9 dwords.  Returns prod_{t' < t} x_t'; total = product of all 256 values.  REVERSE scans from the other end.
 // FQ: the same scan in the base field (k_g1_batch_normalize multiplies Z coordinates).
-template <bool REVERSE, bool FQ = false> __device__ fe_t block_exclusive_mul_scan(const fe_t &x, uint32_t *buf, fe_t &total) {
+// ADD: the additive scan of Fr (the grand SUM of the log-derivative lookup argument) with the same structure: sum_{t' < t} x_t', identity zero.
+template <bool REVERSE, bool FQ = false, bool ADD = false> __device__ fe_t block_exclusive_mul_scan(const fe_t &x, uint32_t *buf, fe_t &total) {
   const uint32_t t = REVERSE ? FRSCAN_THREADS - 1 - threadIdx.x : threadIdx.x;
   uint32_t *cur = buf, *nxt = buf + FRSCAN_THREADS * 9;
   lds_put(cur + t * 9, x);
   __syncthreads();
   fe_t v = x;
   for (uint32_t o = 1; o < FRSCAN_THREADS; o <<= 1) {
-    if (t >= o) v = FQ ? fq_mul_ps(lds_get(cur + (t - o) * 9), v) : fr_mul_ps(lds_get(cur + (t - o) * 9), v);
+    if (t >= o) v = ADD ? Fr::add(lds_get(cur + (t - o) * 9), v) : FQ ? fq_mul_ps(lds_get(cur + (t - o) * 9), v) : fr_mul_ps(lds_get(cur + (t - o) * 9), v);
     lds_put(nxt + t * 9, v);
     __syncthreads();
     uint32_t *tmp = cur; cur = nxt; nxt = tmp;
   }
   total = lds_get(cur + (FRSCAN_THREADS - 1) * 9);
-  fe_t ex = t ? lds_get(cur + (t - 1) * 9) : (FQ ? Fq::one() : Fr::one());
+  fe_t ex = t ? lds_get(cur + (t - 1) * 9) : (ADD ? Fr::zero() : FQ ? Fq::one() : Fr::one());
   __syncthreads();
   return ex;
 }
+template <bool ADD> __device__ __forceinline__ fe_t fr_scan_op(const fe_t &a, const fe_t &b) { return ADD ? Fr::add(a, b) : fr_mul_ps(a, b); }
 
 // MODE 0: self-contained (the tile product is inverted by lane 0) -- for short vectors and the last level;
 // MODE 1: tile_prod[b] = product of the tile's non-zero elements;  MODE 2: invert with tile_prod[b] already holding the INVERSE of the
@@ -90,11 +92,11 @@ template <int MODE> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_batch
 }
 
 // tile <-> registers: thread t gets elements [t * 8, t * 8 + 8) of the tile; global accesses are coalesced (lane = consecutive element)
-__device__ __forceinline__ void tile_load(const fe_t *__restrict__ src, uint64_t base, uint64_t n, uint32_t *tile, fe_t (&a)[FRSCAN_EPT]) {
+__device__ __forceinline__ void tile_load(const fe_t *__restrict__ src, uint64_t base, uint64_t n, uint32_t *tile, fe_t (&a)[FRSCAN_EPT], bool pad_zero = false) {
 #pragma unroll
   for (uint32_t j = 0; j < FRSCAN_EPT; j++) {
     const uint32_t e = j * FRSCAN_THREADS + threadIdx.x;
-    const fe_t v = base + e < n ? g_load(&src[base + e]) : Fr::one();
+    const fe_t v = base + e < n ? g_load(&src[base + e]) : (pad_zero ? Fr::zero() : Fr::one());
     lds_put(tile + (e >> 3) * 65 + (e & 7) * 8, v);
   }
   __syncthreads();
@@ -104,24 +106,26 @@ __device__ __forceinline__ void tile_load(const fe_t *__restrict__ src, uint64_t
 }
 
 // PHASE 0: tile_prod[b] = product of tile b.  PHASE 1: dst[i] = tile_prefix[b] * (product of the tile's elements before i).
-template <int PHASE> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_prefix_product(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint64_t n,
+// ADD: sums instead of products (dst[0] = 0, dst[i] = sum_{j < i} src[j]) -- the running sum phi of the log-derivative lookup argument
+// [EXT-recalled halo2_proofs (scroll fork) src/plonk/mv_lookup/prover.rs: phi[i + 1] = phi[i] + sum_j 1 / (beta + f_j[i]) - m[i] / (beta + t[i])].
+template <int PHASE, bool ADD = false> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_prefix_product(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint64_t n,
                                                                                            fe_t *__restrict__ tile_prod, const fe_t *__restrict__ tile_prefix) {
   extern __shared__ uint32_t sm[];
   uint32_t *tile = sm, *buf = sm + FRSCAN_THREADS * 65;
   const uint64_t base = (uint64_t)blockIdx.x * FRSCAN_TILE;
   fe_t a[FRSCAN_EPT];
-  tile_load(src, base, n, tile, a);
+  tile_load(src, base, n, tile, a, ADD);
   fe_t run = a[0];
 #pragma unroll
-  for (uint32_t j = 1; j < FRSCAN_EPT; j++) run = fr_mul_ps(run, a[j]);
+  for (uint32_t j = 1; j < FRSCAN_EPT; j++) run = fr_scan_op<ADD>(run, a[j]);
   fe_t total;
-  fe_t ex = block_exclusive_mul_scan<false>(run, buf, total);
+  fe_t ex = block_exclusive_mul_scan<false, false, ADD>(run, buf, total);
   if (PHASE == 0) { if (threadIdx.x == 0) g_store(&tile_prod[blockIdx.x], total); return; }
-  ex = fr_mul_ps(ex, g_load(&tile_prefix[blockIdx.x]));
+  ex = fr_scan_op<ADD>(ex, g_load(&tile_prefix[blockIdx.x]));
 #pragma unroll
   for (uint32_t j = 0; j < FRSCAN_EPT; j++) {
     lds_put(tile + threadIdx.x * 65 + j * 8, ex);
-    ex = fr_mul_ps(ex, a[j]);
+    ex = fr_scan_op<ADD>(ex, a[j]);
   }
   __syncthreads();
 #pragma unroll
@@ -130,21 +134,17 @@ template <int PHASE> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_pref
     if (base + e < n) g_store(&dst[base + e], lds_get(tile + (e >> 3) * 65 + (e & 7) * 8));
   }
 }
-
-#ifndef ZK_FRSCAN_DEVICE_ONLY   // the non-template kernels are emitted by ONE translation unit (lib_aux.hip); lib_msm.hip only uses the block scans
-// exclusive scan of the m tile products by one workgroup (thread t owns a contiguous run); total_out = product of everything
-__global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_scan_tile_products(const fe_t *__restrict__ tile_prod, fe_t *__restrict__ tile_prefix, uint32_t m, fe_t *__restrict__ total_out) {
+// exclusive scan of the m tile products (sums) by one workgroup (thread t owns a contiguous run); total_out = product (sum) of everything
+template <bool ADD> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_scan_tiles(const fe_t *__restrict__ tile_prod, fe_t *__restrict__ tile_prefix, uint32_t m, fe_t *__restrict__ total_out) {
   __shared__ uint32_t buf[2 * FRSCAN_THREADS * 9];
   const uint32_t per = (m + FRSCAN_THREADS - 1) / FRSCAN_THREADS, lo = min(m, threadIdx.x * per), hi = min(m, lo + per);
-  fe_t run = Fr::one();
-  for (uint32_t i = lo; i < hi; i++) run = fr_mul_ps(run, g_load(&tile_prod[i]));
+  fe_t run = ADD ? Fr::zero() : Fr::one();
+  for (uint32_t i = lo; i < hi; i++) run = fr_scan_op<ADD>(run, g_load(&tile_prod[i]));
   fe_t total;
-  fe_t ex = block_exclusive_mul_scan<false>(run, buf, total);
-  for (uint32_t i = lo; i < hi; i++) { g_store(&tile_prefix[i], ex); ex = fr_mul_ps(ex, g_load(&tile_prod[i])); }
+  fe_t ex = block_exclusive_mul_scan<false, false, ADD>(run, buf, total);
+  for (uint32_t i = lo; i < hi; i++) { g_store(&tile_prefix[i], ex); ex = fr_scan_op<ADD>(ex, g_load(&tile_prod[i])); }
   if (threadIdx.x == 0) g_store(total_out, total);
 }
-
-#endif  // ZK_FRSCAN_DEVICE_ONLY
 
 // ---- first-order linear recurrence with a constant multiplier: P_j = b_j + m * P_(j-1), P_(-1) = 0, j < n.
 // halo2's kate_division(a, z) = (a(X) - a(z)) / (X - z) [EXT-recalled halo2_proofs src/arithmetic.rs; the quotient polynomials of the

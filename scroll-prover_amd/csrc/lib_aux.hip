@@ -14,6 +14,8 @@ static_assert(sizeof(g2_affine_t) == 128, "G2Affine is 128 bytes (x.c0, x.c1, y.
 int aux_tu_init_device() {
   HIPCHK(hipFuncSetAttribute((const void *)k_fr_prefix_product<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_fr_prefix_product<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)(k_fr_prefix_product<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)(k_fr_prefix_product<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_fr_linrec<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_fr_linrec<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return MI355_OK;
@@ -68,6 +70,29 @@ int linrec_impl(const fe_t *src, fe_t *dst, uint64_t n, const fe_t &m, bool reve
 }  // namespace mi355
 
 using namespace mi355;
+
+// dst[i] = product (ADD: sum) of src[j], j < i: tile totals -> scan of the totals by one workgroup -> per-tile completion
+template <bool ADD> int prefix_scan_entry(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host, const char *what) {
+  return guarded([&]() -> int {
+  int slot; CHK(common_slot({dst_dev, src_dev}, &slot, what)); DevGuard lk(slot);
+  CHK(need_init(slot));
+  if (n && (!dst_dev || !src_dev)) return fail(MI355_EBADARG, std::string(what) + ": null pointer");
+  if (n >= (1ull << 40)) return fail(MI355_EBADARG, std::string(what) + ": n too large");
+  const uint32_t tiles = (uint32_t)ceil_div(n, FRSCAN_TILE);
+  fe_t *tile_prod, *tile_prefix, *total;
+  CHK(ws_get("frscan.tile_prod", ((size_t)tiles + 1) * sizeof(fe_t), (void **)&tile_prod));
+  CHK(ws_get("frscan.tile_prefix", ((size_t)tiles + 1) * sizeof(fe_t), (void **)&tile_prefix));
+  CHK(ws_get("frscan.total", sizeof(fe_t), (void **)&total));
+  const size_t lds = (size_t)(FRSCAN_THREADS * 65 + 2 * FRSCAN_THREADS * 9) * 4;
+  hipStream_t s = g.stream;
+  if (tiles) hipLaunchKernelGGL((k_fr_prefix_product<0, ADD>), dim3(tiles), dim3(FRSCAN_THREADS), lds, s, (const fe_t *)src_dev, (fe_t *)dst_dev, n, tile_prod, (const fe_t *)tile_prefix);
+  hipLaunchKernelGGL(k_fr_scan_tiles<ADD>, dim3(1), dim3(FRSCAN_THREADS), 0, s, (const fe_t *)tile_prod, tile_prefix, tiles, total);
+  if (tiles) hipLaunchKernelGGL((k_fr_prefix_product<1, ADD>), dim3(tiles), dim3(FRSCAN_THREADS), lds, s, (const fe_t *)src_dev, (fe_t *)dst_dev, n, tile_prod, (const fe_t *)tile_prefix);
+  HIPCHK(hipGetLastError());
+  if (total_out_host) { HIPCHK(hipMemcpyAsync(total_out_host, total, sizeof(fe_t), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
+  return MI355_OK;
+  });
+}
 
 extern "C" {
 
@@ -180,27 +205,8 @@ int mi355_fr_batch_invert_dev(void *data_dev, uint64_t n) {
   return MI355_OK;
   });
 }
-int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host) {
-  return guarded([&]() -> int {
-  int slot; CHK(common_slot({dst_dev, src_dev}, &slot, "fr_prefix_product")); DevGuard lk(slot);
-  CHK(need_init(slot));
-  if (n && (!dst_dev || !src_dev)) return fail(MI355_EBADARG, "fr_prefix_product: null pointer");
-  if (n >= (1ull << 40)) return fail(MI355_EBADARG, "fr_prefix_product: n too large");
-  const uint32_t tiles = (uint32_t)ceil_div(n, FRSCAN_TILE);
-  fe_t *tile_prod, *tile_prefix, *total;
-  CHK(ws_get("frscan.tile_prod", ((size_t)tiles + 1) * sizeof(fe_t), (void **)&tile_prod));
-  CHK(ws_get("frscan.tile_prefix", ((size_t)tiles + 1) * sizeof(fe_t), (void **)&tile_prefix));
-  CHK(ws_get("frscan.total", sizeof(fe_t), (void **)&total));
-  const size_t lds = (size_t)(FRSCAN_THREADS * 65 + 2 * FRSCAN_THREADS * 9) * 4;
-  hipStream_t s = g.stream;
-  if (tiles) hipLaunchKernelGGL(k_fr_prefix_product<0>, dim3(tiles), dim3(FRSCAN_THREADS), lds, s, (const fe_t *)src_dev, (fe_t *)dst_dev, n, tile_prod, (const fe_t *)tile_prefix);
-  hipLaunchKernelGGL(k_fr_scan_tile_products, dim3(1), dim3(FRSCAN_THREADS), 0, s, (const fe_t *)tile_prod, tile_prefix, tiles, total);
-  if (tiles) hipLaunchKernelGGL(k_fr_prefix_product<1>, dim3(tiles), dim3(FRSCAN_THREADS), lds, s, (const fe_t *)src_dev, (fe_t *)dst_dev, n, tile_prod, (const fe_t *)tile_prefix);
-  HIPCHK(hipGetLastError());
-  if (total_out_host) { HIPCHK(hipMemcpyAsync(total_out_host, total, sizeof(fe_t), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
-  return MI355_OK;
-  });
-}
+int mi355_fr_prefix_product_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host) { return prefix_scan_entry<false>(dst_dev, src_dev, n, total_out_host, "fr_prefix_product"); }
+int mi355_fr_prefix_sum_dev(void *dst_dev, const void *src_dev, uint64_t n, void *total_out_host) { return prefix_scan_entry<true>(dst_dev, src_dev, n, total_out_host, "fr_prefix_sum"); }
 // ---- G2: s_g2 = tau * G2 of ParamsKZG::setup (the only G2 arithmetic on the path)
 int mi355_g2_mul_host(const void *p_affine_host, const void *scalar, void *out_affine_host) {
   return guarded([&]() -> int {

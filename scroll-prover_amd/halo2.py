@@ -221,6 +221,17 @@ def prefix_product(src, dst=None, want_total: bool = False):
     return (dst, total) if want_total else dst
 
 
+def prefix_sum(src, dst=None, want_total: bool = False):
+    """the running sum phi of the log-derivative (mv-lookup) argument: dst[0] = 0, dst[i] = sum_{j<i} src[j] (device buffers; dst defaults to a
+    new tensor).  want_total: also return sum_{j<n} src[j] (zero for a valid argument)."""
+    import torch
+    if dst is None:
+        dst = torch.empty_like(src)
+    total = np.zeros(4, dtype=np.uint64) if want_total else None
+    check(lib().mi355_fr_prefix_sum_dev(ptr(dst), ptr(src), src.numel() * src.element_size() // 32, ptr(total) if want_total else None))
+    return (dst, total) if want_total else dst
+
+
 # halo2curves bn256 G2 generator (x.c0, x.c1, y.c0, y.c1) [EXT-recalled src/bn256/curve.rs]; the same four words are the first pairing
 # input of the released verifier [REF release-v0.13.1/evm_verifier.yul:1230-1233] (tests/test_oracle_golden.py)
 G2_GENERATOR = (0x1800DEEF121F1E76426A00665E5C4479674322D4F75EDADD46DEBD5CD992F6ED, 0x198E9393920D483A7260BFB731FB5D25F1AA493335A9E71297E485B7AEF312C2,

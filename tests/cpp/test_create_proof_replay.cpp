@@ -12,7 +12,7 @@
 //   step 2  advice columns: witness upload (a second host thread: the DMA of column i + 1 runs under the commitment of column i),
 //           commit_lagrange each                                                          (MSM, Lagrange basis)
 //   step 3  lookup multiplicities: upload, commit_lagrange                                (MSM)
-//   step 4  permutation / lookup products: batch inversion + running product ON the device, commit_lagrange     (scans, MSM)
+//   step 4  permutation products / lookup sums: batch inversion + running product or sum ON the device, commit_lagrange (scans, MSM)
 //   step 5  random blinding polynomial: upload, commit                                   (MSM, coefficient basis)
 //   step 6  lagrange_to_coeff of every witness polynomial                                (iNTT, one batched call)
 //   step 7  quotient: per coset part q < 4, coset NTT of every polynomial (batched), the gate / permutation-shaped expression with ROTATED
@@ -192,7 +192,9 @@ int main(int argc, char **argv) {
     DevicePoly tmp(n, poly[src].slot), zp(n, poly[src].slot);
     CK(mi355_buf_copy(tmp.p, poly[src].p, n * 32));
     CK(mi355_fr_batch_invert_dev(tmp.p, n));
-    CK(mi355_fr_prefix_product_dev(zp.p, tmp.p, n, nullptr));
+    // the permutation argument's grand products, then one running SUM per lookup (the phi of the scroll fork's log-derivative lookups)
+    if (z + L.lookups >= L.products) CK(mi355_fr_prefix_sum_dev(zp.p, tmp.p, n, nullptr));
+    else CK(mi355_fr_prefix_product_dev(zp.p, tmp.p, n, nullptr));
     CK(mi355_msm_g1_dev(hl, 0, zp.p, n, out.data())); commits.push_back(out); commit_src.push_back((int)(W + z));
     poly[W + z] = std::move(zp);
   }

@@ -73,6 +73,7 @@ def test_no_gpu_means_loud_failure_not_fallback(zk):
         lib.mi355_srs_load_params_file(b"/nonexistent", 0, C.byref(k), C.byref(h), C.byref(h), None, None),
         lib.mi355_fr_batch_invert_dev(ptr(sc), 4),
         lib.mi355_fr_prefix_product_dev(ptr(sc), ptr(sc), 4, None),
+        lib.mi355_fr_prefix_sum_dev(ptr(sc), ptr(sc), 4, None),
         lib.mi355_fr_kate_division_dev(ptr(sc), ptr(sc), 4, ptr(sc[0])),
         lib.mi355_fr_vec_axpy_dev(ptr(sc), ptr(sc), ptr(sc), ptr(sc[0]), 4),
         lib.mi355_eval_polynomial_host(ptr(sc), 4, ptr(sc[0]), ptr(sc[1])),

@@ -413,6 +413,7 @@ def test_error_paths_do_not_crash(zk, points):
     assert lib.mi355_g_to_lagrange_dev(None, None, 2, capi.ptr(sc[0]), capi.ptr(sc[1])) == capi.EBADARG
     assert lib.mi355_fr_batch_invert_dev(None, 5) == capi.EBADARG and lib.mi355_fr_batch_invert_dev(None, 0) == capi.OK
     assert lib.mi355_fr_prefix_product_dev(None, None, 5, None) == capi.EBADARG
+    assert lib.mi355_fr_prefix_sum_dev(None, None, 5, None) == capi.EBADARG
     assert lib.mi355_msm_set_pipeline(99, 0) == capi.EBADARG
     assert lib.mi355_msm_g1_batch_host(424242, 0, None, 0, 8, capi.ptr(out)) == capi.EBADARG
     assert lib.mi355_g1_sum_dev(None, 3, capi.ptr(out)) == capi.EBADARG
@@ -628,6 +629,46 @@ def test_batch_invert_and_prefix_product_match_oracle(zk, n):
         z2, t2 = h2.prefix_product(torch.from_numpy(b.view(np.int64).copy()).cuda(), want_total=True)
         z2 = z2.cpu().numpy().view(np.uint64).reshape(n, 4)
         assert (z2[:2501] == wz[:2501]).all() and (z2[2501:] == 0).all() and (t2 == 0).all()
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 256, 2047, 2048, 2049, 100003, 1 << 18])
+def test_prefix_sum_matches_oracle(zk, n):
+    """mi355_fr_prefix_sum_dev (the running sum phi of the mv-lookup argument) against the oracle: tile boundaries, ragged tails, in place."""
+    import torch
+    h2 = zk.halo2
+    rng = np.random.default_rng(7100 + n)
+    b = rand_fr(rng, n)                         # contains 0, 1, r - 1 when n >= 4: sums wrap around the modulus
+    src = torch.from_numpy(b.view(np.int64).copy()).cuda()
+    z, total = h2.prefix_sum(src, want_total=True)
+    wz, wt = cref.prefix_sum(b)
+    assert (z.cpu().numpy().view(np.uint64).reshape(n, 4) == wz).all() and (total == wt).all()
+    h2.prefix_sum(src, dst=src)
+    assert (src.cpu().numpy().view(np.uint64).reshape(n, 4) == wz).all()
+
+
+def test_log_derivative_lookup_sum_closes(zk):
+    """the identity the running sum exists for (mv-lookup / logUp): every looked-up value f[i] is in the table t, m[j] counts how often t[j] is
+    hit; then sum_i 1 / (beta + f[i]) - m[i] / (beta + t[i]) = 0 -- computed with batch_invert, vec ops and prefix_sum on the device."""
+    import torch
+    h2 = zk.halo2
+    n = 1 << 14
+    rng = np.random.default_rng(32)
+    t_int = rng.choice(1 << 40, size=n, replace=False)
+    hits = rng.integers(0, n, size=n)
+    m_int = np.bincount(hits, minlength=n)
+    beta = 0x1234567890ABCDEF1234567890ABCDEF % R
+    def col(vals):
+        return np.stack([cref.fr_mont(int(v)) for v in vals])
+    tb = col((int(x) + beta) % R for x in t_int); fb = col((int(t_int[j]) + beta) % R for j in hits); mm = col(m_int)
+    d_t = torch.from_numpy(tb.view(np.int64).copy()).cuda(); d_f = torch.from_numpy(fb.view(np.int64).copy()).cuda(); d_m = torch.from_numpy(mm.view(np.int64).copy()).cuda()
+    h2.batch_invert(d_t); h2.batch_invert(d_f)
+    h2.fr_vec_op("mul", d_t, d_t, d_m)
+    h2.fr_vec_op("sub", d_f, d_f, d_t)
+    phi, total = h2.prefix_sum(d_f, want_total=True)
+    assert (total == 0).all()
+    assert (phi[0].cpu().numpy().view(np.uint64) == 0).all()
+    want, _ = cref.prefix_sum(d_f.cpu().numpy().view(np.uint64).reshape(n, 4))
+    assert (phi.cpu().numpy().view(np.uint64).reshape(n, 4) == want).all()
 
 
 def test_permutation_grand_product_closes(zk):
