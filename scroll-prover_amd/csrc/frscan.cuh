@@ -111,7 +111,7 @@ __device__ __forceinline__ void tile_load(const fe_t *__restrict__ src, uint64_t
 template <int PHASE, bool ADD = false> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_prefix_product(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint64_t n,
                                                                                            fe_t *__restrict__ tile_prod, const fe_t *__restrict__ tile_prefix) {
   extern __shared__ uint32_t sm[];
-  uint32_t *tile = sm, *buf = sm + FRSCAN_THREADS * 65;
+  uint32_t *tile = sm, *buf = sm;   // the scan buffers (18 KB) reuse the tile (65 KB): the tile is in registers while the scan runs, and two workgroups fit a CU
   const uint64_t base = (uint64_t)blockIdx.x * FRSCAN_TILE;
   fe_t a[FRSCAN_EPT];
   tile_load(src, base, n, tile, a, ADD);
@@ -156,7 +156,7 @@ template <bool ADD> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_scan_
 template <int FINAL> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_linrec(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint64_t n, fe_t m, int reverse,
                                                                                    fe_t *__restrict__ tile_tot) {
   extern __shared__ uint32_t sm[];
-  uint32_t *tile = sm, *buf = sm + FRSCAN_THREADS * 65;
+  uint32_t *tile = sm, *buf = sm;   // scan buffers inside the tile region, as in k_fr_prefix_product
   const uint64_t base = (uint64_t)blockIdx.x * FRSCAN_TILE;
   fe_t a[FRSCAN_EPT];
 #pragma unroll
@@ -190,6 +190,7 @@ template <int FINAL> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_linr
   }
   if (!FINAL) { if (t == FRSCAN_THREADS - 1) g_store(&tile_tot[blockIdx.x], v); return; }
   fe_t P = t ? lds_get(cur + (t - 1) * 9) : Fr::zero();   // value of the recurrence just before this thread's run
+  __syncthreads();   // every thread has its carried-in value before the tile region is overwritten with the results
 #pragma unroll
   for (uint32_t j = 0; j < FRSCAN_EPT; j++) { P = Fr::add(a[j], fr_mul_ps(m, P)); lds_put(tile + threadIdx.x * 65 + j * 8, P); }
   __syncthreads();

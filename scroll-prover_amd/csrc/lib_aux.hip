@@ -56,7 +56,7 @@ int batch_invert_impl(fe_t *data, uint64_t n, int level) {
 // P_j = src_j + m * P_(j-1) over n elements (dst may alias src); reverse: index j lives at memory position n - 1 - j
 int linrec_impl(const fe_t *src, fe_t *dst, uint64_t n, const fe_t &m, bool reverse, int level) {
   const uint32_t tiles = (uint32_t)ceil_div(n, FRSCAN_TILE);
-  const size_t lds = (size_t)(FRSCAN_THREADS * 65 + 2 * FRSCAN_THREADS * 9) * 4;
+  const size_t lds = (size_t)(FRSCAN_THREADS * 65) * 4;
   hipStream_t s = g.stream;
   if (tiles <= 1) { hipLaunchKernelGGL(k_fr_linrec<1>, dim3(1), dim3(FRSCAN_THREADS), lds, s, src, dst, n, m, reverse ? 1 : 0, (fe_t *)nullptr); return MI355_OK; }
   fe_t *tile_tot; const std::string role = "frscan.linrec" + std::to_string(level);
@@ -83,7 +83,7 @@ template <bool ADD> int prefix_scan_entry(void *dst_dev, const void *src_dev, ui
   CHK(ws_get("frscan.tile_prod", ((size_t)tiles + 1) * sizeof(fe_t), (void **)&tile_prod));
   CHK(ws_get("frscan.tile_prefix", ((size_t)tiles + 1) * sizeof(fe_t), (void **)&tile_prefix));
   CHK(ws_get("frscan.total", sizeof(fe_t), (void **)&total));
-  const size_t lds = (size_t)(FRSCAN_THREADS * 65 + 2 * FRSCAN_THREADS * 9) * 4;
+  const size_t lds = (size_t)(FRSCAN_THREADS * 65) * 4;
   hipStream_t s = g.stream;
   if (tiles) hipLaunchKernelGGL((k_fr_prefix_product<0, ADD>), dim3(tiles), dim3(FRSCAN_THREADS), lds, s, (const fe_t *)src_dev, (fe_t *)dst_dev, n, tile_prod, (const fe_t *)tile_prefix);
   hipLaunchKernelGGL(k_fr_scan_tiles<ADD>, dim3(1), dim3(FRSCAN_THREADS), 0, s, (const fe_t *)tile_prod, tile_prefix, tiles, total);
