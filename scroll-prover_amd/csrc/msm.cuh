@@ -794,7 +794,7 @@ __device__ __forceinline__ void msm_emit_result(const g1_xyzz_t &acc, g1_jac_t *
   *out = r;
 }
 // ---- 7. Horner over windows + normalisation.  One lane; 255 doublings are inherently serial (none with window tables).
-template <int Q> __global__ void k_msm_final29(const g1_xyzz29_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
+template <int Q> __global__ void __launch_bounds__(64) k_msm_final29(const g1_xyzz29_t *__restrict__ window_sums, uint32_t windows, uint32_t c, g1_jac_t *__restrict__ out, int normalise) {
   if (threadIdx.x >= Q) return;
   window_sums += (uint64_t)blockIdx.x * windows; out += blockIdx.x;
   g1_xyzz29_t acc = g1_xyzz29_identity();
