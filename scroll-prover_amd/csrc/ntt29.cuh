@@ -328,6 +328,7 @@ struct GatePlan {
   int32_t factor_rot[GATE_MAX_FACTORS];
   uint8_t factor_poly[GATE_MAX_FACTORS];
   uint8_t term_len[GATE_MAX_TERMS];      // factors per term (0: the constant c_j)
+  uint8_t coeff_kind[GATE_MAX_TERMS];    // 0: general coefficient, 1: c_j = 1, 2: c_j = -1 (set by the host from the coefficient bytes)
   uint32_t n_terms, accumulate;
 };
 __global__ void __launch_bounds__(256) k_fr_gate_eval(fe_t *__restrict__ dst, GatePlan G, uint64_t n) {
@@ -340,7 +341,12 @@ __global__ void __launch_bounds__(256) k_fr_gate_eval(fe_t *__restrict__ dst, Ga
       fe29_t t;
       if (len == 0) t = Fr29::from_sat_plain(G.coeff[j]);
       else {
-        t = Fr29::mul(Fr29::from_sat_plain(g_load(&G.poly[G.factor_poly[f]][(i + (uint64_t)(int64_t)G.factor_rot[f]) & mask])), Fr29::from_sat(G.coeff[j]));
+        const fe_t x0 = g_load(&G.poly[G.factor_poly[f]][(i + (uint64_t)(int64_t)G.factor_rot[f]) & mask]);
+        // unit coefficients (the common case in halo2 gates: a - b, z(wX) prod - z(X) prod): no multiplication by c_j; -1 negates the canonical first
+        // factor instead (r - x, zero stays zero), so the term value stays a tight non-negative representative (< r) like every other
+        const uint32_t kind = G.coeff_kind[j];
+        if (kind == 0) t = Fr29::mul(Fr29::from_sat_plain(x0), Fr29::from_sat(G.coeff[j]));
+        else t = Fr29::from_sat_plain(kind == 2 ? Fr::neg(x0) : x0);
         for (uint32_t q = 1; q < len; q++)
           t = Fr29::mul(t, Fr29::from_sat(g_load(&G.poly[G.factor_poly[f + q]][(i + (uint64_t)(int64_t)G.factor_rot[f + q]) & mask])));
       }

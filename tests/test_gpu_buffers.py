@@ -260,6 +260,9 @@ def test_gate_eval_matches_oracle_on_random_term_lists(zk):
             for j in range(nt):
                 ln = 0 if (trial == 1 and j == 2) else int(rng.integers(1, 4 if nt > 9 else 6))
                 terms.append((rand_fr(rng, 1, full=False)[0], [(int(rng.integers(0, 6)), int(rng.integers(-3 * n, 3 * n)) if j % 3 else int(rng.integers(-2, 3))) for _ in range(ln)]))
+            # unit coefficients take the multiplication-free path of the kernel (1: factor as it is, -1: negated first factor), also on one-factor and constant terms
+            for j in range(0, nt, 3):
+                terms[j] = (cref.fr_mont(1) if j % 2 == 0 else cref.fr_mont(R - 1), terms[j][1])
             coeffs = np.stack([c for c, _ in terms])
             tl = [len(f) for _, f in terms]; fp = [p for _, f in terms for p, _ in f]; fr_ = [r for _, f in terms for _, r in f]
             want = cref.gate_eval(polys_h, coeffs, tl, fp, fr_, n)
