@@ -549,9 +549,9 @@ void orc_eval_polynomial_mt(fe *out, const fe *poly, uint64_t n, const fe *point
  * extended domain, sums of products of ROTATED column values, a[get_rotation_idx(i, rot, rot_scale, isize)] = a[(i + rot * rot_scale) mod isize]]:
  *   dst[i] (+)= sum_j coeffs[j] * prod_k polys[factor_poly[.]][(i + factor_rot[.]) mod n],   term j owning term_len[j] consecutive factors.
  * Plain loops over the definition (checker for mi355_fr_gate_eval_dev). */
-void orc_gate_eval(fe *dst, const fe *const *polys, const fe *coeffs, const uint32_t *term_len, uint32_t n_terms,
-                   const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate) {
-  for (uint64_t i = 0; i < n; i++) {
+static void gate_eval_rows(fe *dst, const fe *const *polys, const fe *coeffs, const uint32_t *term_len, uint32_t n_terms,
+                           const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate, uint64_t row_lo, uint64_t row_hi) {
+  for (uint64_t i = row_lo; i < row_hi; i++) {
     fe acc = {{0, 0, 0, 0}}; uint32_t f = 0;
     for (uint32_t j = 0; j < n_terms; j++) {
       fe t = coeffs[j];
@@ -564,6 +564,23 @@ void orc_gate_eval(fe *dst, const fe *const *polys, const fe *coeffs, const uint
     if (accumulate) fe_add(&acc, &acc, &dst[i], &FR);
     dst[i] = acc;
   }
+}
+void orc_gate_eval(fe *dst, const fe *const *polys, const fe *coeffs, const uint32_t *term_len, uint32_t n_terms,
+                   const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate) {
+  gate_eval_rows(dst, polys, coeffs, term_len, n_terms, factor_poly, factor_rot, n, accumulate, 0, n);
+}
+/* the same loop with the ROWS dealt over threads (row i reads operands at rotated positions but writes dst[i] only, and dst is not an
+ * operand here): the checker for 2^24 .. 2^26 rows, where the single-threaded loop takes minutes.  Same values as orc_gate_eval. */
+typedef struct { fe *dst; const fe *const *polys; const fe *coeffs; const uint32_t *term_len; uint32_t n_terms; const uint32_t *factor_poly; const int32_t *factor_rot; uint64_t n; int accumulate; uint64_t lo, hi; } gate_job;
+static void *gate_worker(void *arg) { gate_job *j = (gate_job *)arg; gate_eval_rows(j->dst, j->polys, j->coeffs, j->term_len, j->n_terms, j->factor_poly, j->factor_rot, j->n, j->accumulate, j->lo, j->hi); return NULL; }
+void orc_gate_eval_mt(fe *dst, const fe *const *polys, const fe *coeffs, const uint32_t *term_len, uint32_t n_terms,
+                      const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate, int num_threads) {
+  if (num_threads < 1) num_threads = 1;
+  if (num_threads > 256) num_threads = 256;
+  if (n < 4096 || num_threads == 1) { orc_gate_eval(dst, polys, coeffs, term_len, n_terms, factor_poly, factor_rot, n, accumulate); return; }
+  pthread_t th[256]; gate_job jobs[256]; int T = num_threads;
+  for (int t = 0; t < T; t++) { jobs[t] = (gate_job){dst, polys, coeffs, term_len, n_terms, factor_poly, factor_rot, n, accumulate, n * t / T, n * (t + 1) / T}; pthread_create(&th[t], NULL, gate_worker, &jobs[t]); }
+  for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
 }
 
 /* ParamsKZG::setup-style synthetic SRS [EXT-recalled src/poly/kzg/commitment.rs setup]:

@@ -290,7 +290,7 @@ def eval_polynomial_mt(poly, point, threads: int | None = None):
     lib().orc_eval_polynomial_mt(_p(o), _p(poly), C.c_uint64(poly.shape[0]), _p(np.ascontiguousarray(point)), C.c_int(threads)); return o
 
 
-def gate_eval(polys, coeffs, term_len, factor_poly, factor_rot, n: int, dst=None):
+def gate_eval(polys, coeffs, term_len, factor_poly, factor_rot, n: int, dst=None, threads: int = 1):
     """dst[i] (+)= sum_j coeffs[j] * prod_k polys[factor_poly[.]][(i + factor_rot[.]) mod n]  (restated evaluate_h operand shape); dst given: accumulate"""
     polys = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
     arr = (C.c_void_p * max(1, len(polys)))(*[p.ctypes.data for p in polys])
@@ -299,7 +299,10 @@ def gate_eval(polys, coeffs, term_len, factor_poly, factor_rot, n: int, dst=None
     acc = dst is not None
     out = np.array(dst, dtype=np.uint64, copy=True, order="C") if acc else np.zeros((n, 4), dtype=np.uint64)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    lib().orc_gate_eval(_p(out), arr, _p(coeffs), vp(tl), C.c_uint32(len(tl)), vp(fp), vp(fr_), C.c_uint64(n), C.c_int(1 if acc else 0))
+    if threads > 1:   # rows dealt over threads (same loop per row): the at-size checker
+        lib().orc_gate_eval_mt(_p(out), arr, _p(coeffs), vp(tl), C.c_uint32(len(tl)), vp(fp), vp(fr_), C.c_uint64(n), C.c_int(1 if acc else 0), C.c_int(threads))
+    else:
+        lib().orc_gate_eval(_p(out), arr, _p(coeffs), vp(tl), C.c_uint32(len(tl)), vp(fp), vp(fr_), C.c_uint64(n), C.c_int(1 if acc else 0))
     return out
 
 

@@ -209,6 +209,7 @@ impl DevicePoly {
     }
     /// `EvaluationDomain::lagrange_to_coeff`, in place.
     pub fn lagrange_to_coeff(&mut self, k: u32, omega_inv: &Fr, ifft_divisor: &Fr) -> bool {
+        if k > 28 || self.len != 1usize << k { return false; }   // a short block would be written past its end
         unsafe { mi355_intt_fr_dev(self.ptr, k, omega_inv as *const Fr as *const c_void, ifft_divisor as *const Fr as *const c_void) == MI355_OK }
     }
     /// `eval_polynomial(self, point)`.
@@ -221,6 +222,7 @@ impl DevicePoly {
 impl GpuBasis {
     /// commit / commit_lagrange of a resident polynomial: the scalars never leave HBM (with several devices each shard's slice crosses xGMI).
     pub fn multiexp_dev(&self, poly: &DevicePoly) -> Option<G1> {
+        // (a polynomial longer than the registered basis is rejected by the library: MI355_EBADARG -> None -> CPU path)
         let mut out = std::mem::MaybeUninit::<G1>::uninit();
         let rc = unsafe { mi355_msm_g1_dev(self.0, 0, poly.as_ptr(), poly.len() as u64, out.as_mut_ptr() as *mut c_void) };
         if rc == MI355_OK { Some(unsafe { out.assume_init() }) } else { None }
@@ -240,6 +242,7 @@ impl GpuBasis {
 /// `polys.iter_mut().for_each(|p| domain.lagrange_to_coeff(p))` (divisor = Some(n^-1)) or a loop of `best_fft` (None) over resident
 /// polynomials as ONE call: with several devices the independent transforms run concurrently where their buffers live.
 pub fn fft_many_dev(polys: &mut [&mut DevicePoly], k: u32, omega: &Fr, divisor: Option<&Fr>) -> bool {
+    if k > 28 || polys.iter().any(|p| p.len() != 1usize << k) { return false; }   // as fft_many: every operand is exactly 2^k long
     let ptrs: Vec<*mut c_void> = polys.iter_mut().map(|p| p.as_mut_ptr()).collect();
     let d = divisor.map(|d| d as *const Fr as *const c_void).unwrap_or(std::ptr::null());
     unsafe { mi355_ntt_fr_batch_dev(ptrs.as_ptr(), ptrs.len() as u32, k, omega as *const Fr as *const c_void, d) == MI355_OK }
@@ -261,6 +264,9 @@ pub fn gate_eval_dev(dst: &mut DevicePoly, polys: &[&DevicePoly], terms: &[(Fr, 
     let fp: Vec<u32> = terms.iter().flat_map(|t| t.1.iter().map(|f| f.0)).collect();
     let fr: Vec<i32> = terms.iter().flat_map(|t| t.1.iter().map(|f| f.1)).collect();
     let n = dst.len() as u64;
+    // the kernel reads polys[p][(i + rot) mod n] for every i < n: n must be a power of two and no operand may be shorter than dst
+    if n == 0 || !n.is_power_of_two() || polys.iter().any(|p| (p.len() as u64) < n) { return false; }
+    if fp.iter().any(|&p| p as usize >= polys.len()) { return false; }
     unsafe { mi355_fr_gate_eval_dev(dst.as_mut_ptr(), ptrs.as_ptr(), ptrs.len() as u32, coeffs.as_ptr() as *const c_void, term_len.as_ptr(),
                                     terms.len() as u32, fp.as_ptr(), fr.as_ptr(), n, accumulate as c_int) == MI355_OK }
 }

@@ -166,7 +166,7 @@ int mi355_srs_downsize(uint64_t g_handle, uint32_t k, const void *omega_inv, con
   for (int sl = 1; sl < g_ndev; sl++) { CHK(bind_ctx(sl)); HIPCHK(hipStreamSynchronize(g.stream)); }
   CHK(bind_ctx(0));
   const g1_affine_t *src; CHK(srs_gather_to_primary(*sp, n, &src));
-  g1_affine_t *res; HIPCHK(hipMalloc((void **)&res, n * sizeof(g1_affine_t)));
+  g1_affine_t *res; CHK(dev_malloc((void **)&res, n * sizeof(g1_affine_t), "srs_downsize"));
   int rc = g1fft_impl(src, 0, res, 0, k, omega_inv, n_inv);
   if (rc == MI355_OK) rc = finish_async();
   if (rc == MI355_OK && hipStreamSynchronize(g.stream) != hipSuccess) rc = fail(MI355_EHIP, "srs_downsize: stream synchronize failed");

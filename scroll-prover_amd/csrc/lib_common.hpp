@@ -76,6 +76,7 @@ struct Ctx {
   std::vector<Span> spans;      // profiling: (name, start, stop) event pairs resolved after the stream is idle
   void *comm = nullptr;         // ncclComm_t of this device (mi355_init_multi with distinct devices)
   hipEvent_t ev_xchg = nullptr;
+  hipEvent_t ev_xchg2 = nullptr;   // recorded behind a cross-slot mi355_buf_copy on the destination's stream; the source slot's stream waits for it
   // host-pointer MSM: chunked copy on its own stream, overlapped with the digit extraction (msm_host_single); also the stream the
   // resident-buffer uploads run on (mi355_buf_upload)
   hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -138,6 +139,7 @@ extern Ctx g_ctx[MAX_DEV];
 extern int g_ndev;
 extern bool g_dup_devices;     // test mode: the same physical device bound to several slots (exchange by device copies instead of RCCL)
 extern uint32_t g_shard_min_log;  // MI355_SHARD_MIN_LOG: a basis with fewer than 2^this points per device stays on the primary device (tests lower it)
+extern bool g_peer_ok[MAX_DEV][MAX_DEV];   // [s][t]: kernels on slot s may read memory of slot t directly
 extern bool g_force_exchange;  // MI355_MULTI_FORCE=1: take the sharded path (partials + exchange + fold) even with one device
 extern thread_local Ctx *g_cur;
 #define g (*::mi355::g_cur)
@@ -183,6 +185,8 @@ struct CallTrace {
 };
 
 int ws_get(const char *role, size_t bytes, void **out);
+// hipMalloc on the current context's device; on out-of-memory the device's pooled (free) mi355_buf blocks go back to HIP and the call is retried once
+int dev_malloc(void **out, size_t bytes, const char *what);
 
 // ---- profiling: a list of (name, start, stop) event pairs per context, resolved after the stream is idle
 struct Scope {

@@ -17,6 +17,7 @@ int g_ndev = 0;
 bool g_dup_devices = false;
 uint32_t g_shard_min_log = 14;
 bool g_force_exchange = false;
+bool g_peer_ok[MAX_DEV][MAX_DEV] = {};   // [s][t]: kernels on slot s may dereference memory of slot t (same device, or hipDeviceEnablePeerAccess succeeded)
 thread_local Ctx *g_cur = &g_ctx[0];
 // The handle table is heap-allocated and never destroyed: the destructors of its entries (SrsMem / SrsTables) call hipFree, and a process
 // that exits with bases still registered -- the Rust shim's static params_map never calls mi355_shutdown -- must not run HIP calls from
@@ -55,12 +56,33 @@ int need_init(int slot) {
   return bind_ctx(slot);
 }
 
+static size_t pool_release_slot(int slot);
+// hipMalloc on the current context's device.  HBM may be full of blocks that only sit in the library's own buffer pool (mi355_buf_free keeps
+// them for reuse): before reporting MI355_EOOM the pooled blocks of THIS device go back to HIP and the allocation is tried once more
+// (ws_get, the twiddle tables and mi355_srs_precompute used to fail while gigabytes of free pooled blocks sat idle).
+int dev_malloc(void **out, size_t bytes, const char *what) {
+  *out = nullptr;
+  hipError_t e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    if (pool_release_slot(g.slot) > 0) e = hipMalloc(out, bytes);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError(); *out = nullptr;
+    char b[256]; snprintf(b, sizeof b, "%s: hipMalloc of %zu bytes failed: %s", what, bytes, hipGetErrorString(e));
+    return fail(e == hipErrorOutOfMemory ? MI355_EOOM : MI355_EHIP, b);
+  }
+  return MI355_OK;
+}
+
 int ws_get(const char *role, size_t bytes, void **out) {
   Buf &b = g.ws[role];
   if (b.cap < bytes) {
     if (b.p) { HIPCHK(hipStreamSynchronize(g.stream)); for (int i = 0; i < 2; i++) if (g.aux_stream[i]) HIPCHK(hipStreamSynchronize(g.aux_stream[i])); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     size_t cap = bytes + bytes / 8 + 256;
-    HIPCHK(hipMalloc(&b.p, cap)); b.cap = cap;
+    // the head-room is a convenience (fewer regrowths), not a requirement: near the HBM limit the exact size is tried as well
+    if (dev_malloc(&b.p, cap, role) != MI355_OK) { cap = bytes; CHK(dev_malloc(&b.p, cap, role)); }
+    b.cap = cap;
   }
   *out = b.p; return MI355_OK;
 }
@@ -139,6 +161,17 @@ int pick_replica_slot() {
   for (int i = 0; i < D; i++) { const int s = (start + i) % D; if (g_ctx_mu[s].try_lock()) { g_ctx_mu[s].unlock(); return s; } }
   return start;
 }
+// give the pooled (free) blocks of one device slot back to HIP; the caller holds that slot's lock and is bound to its device.  Returns bytes freed.
+static size_t pool_release_slot(int slot) {
+  std::vector<BufBlock> drop;
+  { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto it = g_pool.begin(); it != g_pool.end();) { if (it->first.first == slot) { drop.push_back(it->second); it = g_pool.erase(it); } else ++it; } }
+  if (drop.empty()) return 0;
+  (void)hipStreamSynchronize(g_ctx[slot].stream);   // work queued on a block before its mi355_buf_free
+  if (g_ctx[slot].copy_stream) (void)hipStreamSynchronize(g_ctx[slot].copy_stream);
+  size_t freed = 0;
+  for (auto &b : drop) { if (b.free_ev) (void)hipEventDestroy(b.free_ev); (void)hipFree(b.p); freed += b.bytes; }
+  return freed;
+}
 static void buf_release_all_locked() {   // shutdown: every slot's lock is held, the devices are still bound
   auto drop = [](BufBlock &b) {
     if (b.slot < g_ndev && g_ctx[b.slot].inited) (void)hipSetDevice(g_ctx[b.slot].device);
@@ -170,6 +203,7 @@ static int init_ctx(int slot, int device_id) {
   }
   HIPCHK(hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&g.ev_xchg, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&g.ev_xchg2, hipEventDisableTiming));
   HIPCHK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[i], hipEventDisableTiming));
   for (int i = 0; i < 8; i++) HIPCHK(hipEventCreateWithFlags(&g.ev_up[i], hipEventDisableTiming));
@@ -229,6 +263,7 @@ static void destroy_ctx(int slot) {
   }
   if (g.ev_fork) { (void)hipEventDestroy(g.ev_fork); g.ev_fork = nullptr; }
   if (g.ev_xchg) { (void)hipEventDestroy(g.ev_xchg); g.ev_xchg = nullptr; }
+  if (g.ev_xchg2) { (void)hipEventDestroy(g.ev_xchg2); g.ev_xchg2 = nullptr; }
   for (int i = 0; i < 8; i++) if (g.ev_up[i]) { (void)hipEventDestroy(g.ev_up[i]); g.ev_up[i] = nullptr; }
   for (int i = 0; i < 4; i++) if (g.ev_copy[i]) { (void)hipEventDestroy(g.ev_copy[i]); g.ev_copy[i] = nullptr; }
   if (g.copy_stream) { (void)hipStreamDestroy(g.copy_stream); g.copy_stream = nullptr; }
@@ -265,7 +300,7 @@ int srs_alloc(SrsMem &mem, uint64_t n) {
   mem.sh = plan_shards(n);
   for (auto &sh : mem.sh) {
     CHK(bind_ctx(sh.slot));
-    HIPCHK(hipMalloc((void **)&sh.dev, sh.n * sizeof(g1_affine_t))); sh.owned = true;
+    CHK(dev_malloc((void **)&sh.dev, sh.n * sizeof(g1_affine_t), "srs shard")); sh.owned = true;
   }
   return bind_ctx(0);
 }
@@ -275,7 +310,7 @@ int srs_scatter_from_primary(SrsMem &mem, const g1_affine_t *src_dev, uint64_t n
   for (auto &sh : mem.sh) {
     if (sh.slot == 0 && alias_shard0) { sh.dev = const_cast<g1_affine_t *>(src_dev) + sh.lo; sh.owned = false; continue; }
     CHK(bind_ctx(sh.slot));
-    HIPCHK(hipMalloc((void **)&sh.dev, sh.n * sizeof(g1_affine_t))); sh.owned = true;
+    CHK(dev_malloc((void **)&sh.dev, sh.n * sizeof(g1_affine_t), "srs shard")); sh.owned = true;
     if (sh.slot == 0 || g_ctx[sh.slot].device == g_ctx[0].device) HIPCHK(hipMemcpyAsync(sh.dev, src_dev + sh.lo, sh.n * sizeof(g1_affine_t), hipMemcpyDeviceToDevice, g.stream));
     else HIPCHK(hipMemcpyPeerAsync(sh.dev, g.device, src_dev + sh.lo, g_ctx[0].device, sh.n * sizeof(g1_affine_t), g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -333,6 +368,7 @@ int mi355_init_multi(const int *device_ids, int n_devices) {
   { const char *e = getenv("MI355_MULTI_FORCE"); g_force_exchange = e && e[0] == '1'; }
   { const char *e = getenv("MI355_MSM_AUTO_MAX_C"); g_auto_max_c = 22; if (e) { int v = atoi(e); if (v >= 16 && v <= MSM_MAX_C) g_auto_max_c = v; } }
   { const char *e = getenv("MI355_SHARD_MIN_LOG"); g_shard_min_log = 14; if (e) { int v = atoi(e); if (v >= 0 && v <= 30) g_shard_min_log = (uint32_t)v; } }
+  for (int s = 0; s < MAX_DEV; s++) for (int t = 0; t < MAX_DEV; t++) g_peer_ok[s][t] = s == t;
   if (n_devices > 1 || g_force_exchange) {
     // one communicator per process over the bound devices: ncclCommInitAll.  Duplicate devices (test mode) cannot form a
     // communicator; their exchange is a device-to-device copy.
@@ -348,7 +384,16 @@ int mi355_init_multi(const int *device_ids, int n_devices) {
     for (int s = 0; s < n_devices && rc == MI355_OK; s++) {
       use_ctx(s);
       if (hipSetDevice(g.device) != hipSuccess) { rc = fail(MI355_EHIP, "hipSetDevice failed"); break; }
-      if (!dup) for (int t = 0; t < n_devices; t++) if (t != s) { int can = 0; if (hipDeviceCanAccessPeer(&can, g.device, g_ctx[t].device) == hipSuccess && can) { if (hipDeviceEnablePeerAccess(g_ctx[t].device, 0) != hipSuccess) (void)hipGetLastError(); } }
+      for (int t = 0; t < n_devices; t++) {
+        g_peer_ok[s][t] = dup || t == s;
+        if (dup || t == s) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, g.device, g_ctx[t].device) == hipSuccess && can) {
+          const hipError_t pe = hipDeviceEnablePeerAccess(g_ctx[t].device, 0);
+          if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) g_peer_ok[s][t] = true;
+          if (pe != hipSuccess) (void)hipGetLastError();
+        }
+      }
     }
     if (rc != MI355_OK) { const std::string keep = g_err; shutdown_all(); g_err = keep; return rc; }
   }
@@ -509,17 +554,7 @@ int mi355_buf_alloc(uint64_t bytes, int device_slot, void **dev_ptr_out) {
     if (it != g_pool.end()) { BufBlock b = it->second; g_pool.erase(it); b.used = false; g_bufs[(uintptr_t)b.p] = b; *dev_ptr_out = b.p; return MI355_OK; }
   }
   void *p = nullptr;
-  hipError_t e = hipMalloc(&p, want);
-  if (e == hipErrorOutOfMemory) {
-    // the pool of this device is given back to the allocator before giving up
-    (void)hipGetLastError();
-    std::vector<BufBlock> drop;
-    { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto it = g_pool.begin(); it != g_pool.end();) { if (it->first.first == device_slot) { drop.push_back(it->second); it = g_pool.erase(it); } else ++it; } }
-    (void)hipStreamSynchronize(g.stream);
-    for (auto &b : drop) { if (b.free_ev) (void)hipEventDestroy(b.free_ev); (void)hipFree(b.p); }
-    e = hipMalloc(&p, want);
-  }
-  if (e != hipSuccess) { (void)hipGetLastError(); return fail(e == hipErrorOutOfMemory ? MI355_EOOM : MI355_EHIP, std::string("buf_alloc: hipMalloc failed: ") + hipGetErrorString(e)); }
+  CHK(dev_malloc(&p, want, "buf_alloc"));   // the pool of this device is given back to the allocator before giving up
   BufBlock b; b.p = p; b.bytes = want; b.slot = device_slot;
   { std::lock_guard<std::mutex> bl(g_buf_mu); g_bufs[(uintptr_t)p] = b; }
   *dev_ptr_out = p; return MI355_OK;
@@ -617,6 +652,14 @@ int mi355_buf_copy(void *dst_dev, const void *src_dev, uint64_t bytes) {
   CHK(need_init(sd));
   if (g_ctx[sd].device == g_ctx[ss].device) HIPCHK(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, g.stream));
   else HIPCHK(hipMemcpyPeerAsync(dst_dev, g.device, src_dev, g_ctx[ss].device, bytes, g.stream));
+  if (ss != sd) {
+    // The copy is queued on the DESTINATION slot's stream only.  Whatever the source slot queues next on src -- a kernel that rewrites it, or the
+    // free_ev of mi355_buf_free after which the pool may hand the block to a fresh upload -- must come after the copy has read it: the source
+    // slot's compute stream waits for an event recorded behind the copy (both slots' locks are held here).  ADVICE r3 (medium).
+    hipEvent_t ev = g.ev_xchg2;
+    HIPCHK(hipEventRecord(ev, g.stream));
+    HIPCHK(hipStreamWaitEvent(g_ctx[ss].stream, ev, 0));
+  }
   return MI355_OK;
   });
 }

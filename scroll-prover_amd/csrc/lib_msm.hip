@@ -571,7 +571,7 @@ int mi355_srs_precompute(uint64_t handle, uint64_t n_hint, int c) {
     if (sh.lo >= sp->n) continue;
     const uint64_t cnt = std::min(sh.n, sp->n - sh.lo);   // a prefix view tabulates only its own points
     CHK(bind_ctx(sh.slot));
-    HIPCHK(hipMalloc((void **)&tab->pre[i], (size_t)W * cnt * sizeof(g1_affine_t)));
+    CHK(dev_malloc((void **)&tab->pre[i], (size_t)W * cnt * sizeof(g1_affine_t), "srs_precompute (window table)"));
     tab->stride[i] = cnt;
     hipLaunchKernelGGL(k_srs_precompute, dim3(ceil_div(cnt, 256)), dim3(256), 0, g.stream, sh.dev, tab->pre[i], cnt, (uint32_t)W, (uint32_t)c);
     HIPCHK(hipGetLastError());
@@ -712,10 +712,27 @@ static int msm_dev_dispatch(uint64_t srs_handle, uint64_t base_offset, const voi
   if (M == 0 || n == 0) { if (M) memset(out_g1_host, 0, (size_t)M * sizeof(g1_jac_t)); return MI355_OK; }
   if (!single_device_call(pieces)) return msm_multi(pieces, (const fe_t *const *)scalars_dev, SCALARS_DEV, M, n, out_g1_host);
   g_last_devices = 1; g_last_exchange = "none";
-  // several devices bound, basis on the primary only: scalars that live on another device are read through peer access, after their producer
-  if (g_ndev > 1) for (uint32_t m = 0; m < M; m++) { const int o = slot_of(scalars_dev[m]); if (o != 0) { CHK(bind_ctx(o)); HIPCHK(hipStreamSynchronize(g.stream)); } }
+  // Every scalar block is marked as used by queued work (slot_of's `touch`), with one device as with several: an upload into a block whose only
+  // use since mi355_buf_alloc was as an MSM input must wait for the compute stream, not take the "fresh block" path.
+  // Several devices bound, basis on the primary only: scalars that live on another device are read through peer access, after their producer;
+  // when peer access to that device could not be enabled they are staged on the primary first (hipMemcpyPeerAsync needs no peer mapping).
+  std::vector<const fe_t *> ptrs(M);
+  fe_t *stage = nullptr; size_t staged = 0;
+  for (uint32_t m = 0; m < M; m++) {
+    const int o = slot_of(scalars_dev[m], true);
+    ptrs[m] = (const fe_t *)scalars_dev[m];
+    if (g_ndev > 1 && o != 0) {
+      CHK(bind_ctx(o)); HIPCHK(hipStreamSynchronize(g.stream));
+      if (!g_peer_ok[0][o]) {
+        CHK(bind_ctx(0));
+        if (!stage) CHK(ws_get("io.scalars", (size_t)M * n * sizeof(fe_t), (void **)&stage));
+        HIPCHK(hipMemcpyPeerAsync(stage + staged, g.device, scalars_dev[m], g_ctx[o].device, n * sizeof(fe_t), g.stream));
+        ptrs[m] = stage + staged; staged += n;
+      }
+    }
+  }
   CHK(bind_ctx(0));
-  return msm_batch_impl(pieces[0].bases, (const fe_t *const *)scalars_dev, M, n, out_g1_host, &pieces[0].pre);
+  return msm_batch_impl(pieces[0].bases, ptrs.data(), M, n, out_g1_host, &pieces[0].pre);
 }
 
 int mi355_msm_g1_dev(uint64_t srs_handle, uint64_t base_offset, const void *scalars_dev, uint64_t n, void *out_g1_host) {
@@ -734,6 +751,7 @@ int mi355_msm_g1_dev_async(uint64_t srs_handle, uint64_t base_offset, const void
   std::vector<Piece> pieces; CHK(srs_pieces(srs_handle, base_offset, n, pieces));
   if (pieces.size() != 1 || pieces[0].slot != 0) return fail(MI355_EBADARG, "msm_g1_dev_async: the range must lie on the primary device (one process per GPU drives its own shard)");
   const fe_t *sc = (const fe_t *)scalars_dev;
+  (void)slot_of(scalars_dev, true); (void)slot_of(out_g1_dev, true);   // both blocks now carry queued work: a later upload into either waits for the compute stream
   return msm_batch_impl(pieces[0].bases, &sc, 1, n, nullptr, &pieces[0].pre, out_g1_dev);
   });
 }
@@ -844,7 +862,7 @@ int mi355_msm_last_run(int *devices_out, const char **exchange_out, int *shared_
 // ---- synthetic SRS
 static int ensure_fixed_base_table() {
   if (g.fixed_base_table) return MI355_OK;
-  HIPCHK(hipMalloc((void **)&g.fixed_base_table, 32 * 256 * sizeof(g1_affine_t)));
+  CHK(dev_malloc((void **)&g.fixed_base_table, 32 * 256 * sizeof(g1_affine_t), "fixed-base table"));
   hipLaunchKernelGGL(k_fixed_base_table, dim3(1), dim3(256), 0, g.stream, g.fixed_base_table);
   HIPCHK(hipGetLastError());
   return MI355_OK;

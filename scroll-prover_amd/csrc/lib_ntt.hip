@@ -26,7 +26,7 @@ constexpr uint32_t NTT_DIRECT_TW_MAX_LOG = 20;   // 2^20 x 36 B = 38 MB per tabl
 std::string plan_key(uint32_t log_n, const void *omega) { std::string k((const char *)omega, 32); k.push_back((char)log_n); return k; }
 
 int pow_table(fe_t **out, const fe_t &base, uint64_t step, uint32_t count) {
-  HIPCHK(hipMalloc((void **)out, (size_t)count * sizeof(fe_t)));
+  CHK(dev_malloc((void **)out, (size_t)count * sizeof(fe_t), "ntt twiddles"));
   hipLaunchKernelGGL(k_pow_table, dim3(ceil_div(count, 256)), dim3(256), 0, g.stream, *out, base, step, count);
   HIPCHK(hipGetLastError());
   return MI355_OK;
@@ -34,9 +34,9 @@ int pow_table(fe_t **out, const fe_t &base, uint64_t step, uint32_t count) {
 
 int pow_table29(NttPlan &p, Tw29 *out, const fe_t &base, uint64_t step, uint32_t count) {
   uint4 *lo, *hi; uint32_t *top;
-  HIPCHK(hipMalloc((void **)&lo, (size_t)count * 16)); p.owned.push_back(lo);
-  HIPCHK(hipMalloc((void **)&hi, (size_t)count * 16)); p.owned.push_back(hi);
-  HIPCHK(hipMalloc((void **)&top, (size_t)count * 4)); p.owned.push_back(top);
+  CHK(dev_malloc((void **)&lo, (size_t)count * 16, "ntt twiddles")); p.owned.push_back(lo);
+  CHK(dev_malloc((void **)&hi, (size_t)count * 16, "ntt twiddles")); p.owned.push_back(hi);
+  CHK(dev_malloc((void **)&top, (size_t)count * 4, "ntt twiddles")); p.owned.push_back(top);
   hipLaunchKernelGGL(k_pow_table29, dim3(ceil_div(count, 256)), dim3(256), 0, g.stream, lo, hi, top, base, step, count);
   HIPCHK(hipGetLastError());
   out->lo = lo; out->hi = hi; out->top = top;
@@ -518,6 +518,14 @@ int mi355_fr_gate_eval_dev(void *dst_dev, const void *const *polys_dev, uint32_t
     if (!polys_dev[p]) return fail(MI355_EBADARG, "fr_gate_eval: null polynomial pointer");
     int s; CHK(common_slot({dst_dev, polys_dev[p]}, &s, "fr_gate_eval"));
     G.poly[p] = (const fe_t *)polys_dev[p];
+    // dst may BE one of the operands only where every thread reads exactly the element it writes: same base address, every factor of that
+    // polynomial un-rotated.  Any other overlap is a cross-thread race (thread i would read what thread i - r is writing): rejected.
+    const uintptr_t d0 = (uintptr_t)dst_dev, d1 = d0 + n * sizeof(fe_t), p0 = (uintptr_t)polys_dev[p], p1 = p0 + n * sizeof(fe_t);
+    if (p0 < d1 && d0 < p1) {
+      if (p0 != d0) return fail(MI355_EBADARG, "fr_gate_eval: dst overlaps an operand at an offset");
+      for (uint32_t q = 0; q < nf; q++) if (factor_poly[q] == p && (((uint64_t)(int64_t)factor_rot[q]) & (n - 1)) != 0)
+        return fail(MI355_EBADARG, "fr_gate_eval: dst aliases an operand that is read with a non-zero rotation");
+    }
   }
   DevGuard lk(slot);
   CHK(need_init(slot));

@@ -331,7 +331,8 @@ struct GatePlan {
   uint8_t coeff_kind[GATE_MAX_TERMS];    // 0: general coefficient, 1: c_j = 1, 2: c_j = -1 (set by the host from the coefficient bytes)
   uint32_t n_terms, accumulate;
 };
-__global__ void __launch_bounds__(256) k_fr_gate_eval(fe_t *__restrict__ dst, GatePlan G, uint64_t n) {
+// dst carries no __restrict__: it may be one of the operands (un-rotated, checked by the host) and is read when G.accumulate is set
+__global__ void __launch_bounds__(256) k_fr_gate_eval(fe_t *dst, GatePlan G, uint64_t n) {
   const uint64_t mask = n - 1;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     fe29_t acc = Fr29::zero();

@@ -273,3 +273,23 @@ def test_gate_eval_restatement_matches_big_integer_definition():
                         t = t * vals[p][(i + r) % n] % R_
                     want = (want + t) % R_
                 assert cref.limbs_to_int(cref.f_to_canonical_vec(cref.FR, got[i:i + 1])[0]) == want
+
+
+def test_gate_eval_rows_over_threads_equals_the_serial_loop():
+    """orc_gate_eval_mt (the at-size checker of the -m gpu tests: rows dealt over threads) == orc_gate_eval == Python big integers"""
+    rng = np.random.default_rng(404)
+    n = 1 << 13
+    polys = [np.stack([cref.fr_mont(int(x)) for x in rng.integers(0, 1 << 62, size=n)]) for _ in range(3)]
+    coeffs = np.stack([cref.fr_mont(3), cref.fr_mont(pyref.R_MOD - 1), cref.fr_mont(1), cref.fr_mont(12345)])
+    tl, fp, fr_ = [2, 1, 3, 0], [0, 1, 2, 0, 1, 2], [1, -1, n - 1, -3 * n + 5, 0, 1 << 12]
+    a = cref.gate_eval(polys, coeffs, tl, fp, fr_, n)
+    b = cref.gate_eval(polys, coeffs, tl, fp, fr_, n, threads=5)
+    assert (a == b).all()
+    c = cref.gate_eval(polys, coeffs, tl, fp, fr_, n, dst=a, threads=3)
+    d = cref.gate_eval(polys, coeffs, tl, fp, fr_, n, dst=a)
+    assert (c == d).all()
+    Rinv = pow(pyref.MONT_R, -1, pyref.R_MOD)
+    val = lambda arr, i: pyref.from_limbs([int(x) for x in arr[i % n]]) * Rinv % pyref.R_MOD
+    for i in (0, 1, n - 1, 4097):
+        want = (3 * val(polys[0], i + 1) * val(polys[1], i - 1) - val(polys[2], i + n - 1) + val(polys[0], i - 3 * n + 5) * val(polys[1], i) * val(polys[2], i + (1 << 12)) + 12345) % pyref.R_MOD
+        assert val(b, i) == want
