@@ -114,13 +114,33 @@ def main() -> None:
     ap.add_argument("--host-api", action="store_true", help=argparse.SUPPRESS)   # accepted for older command lines: the leg is on by default now
     args = ap.parse_args()
 
+    single = args.single_process          # N GPUs behind this one process (the reference's shape: one prover process, one params_map)
+    if args.gpus > 1 and not single and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher (the driver starts N = 1 exactly like this): become the launch the contract describes --
+        # one rank per GPU under torch.distributed.run on 127.0.0.1 -- instead of failing on WORLD_SIZE (VERDICT r3 missing #5 / next #5)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"bench.py: --gpus {args.gpus} without WORLD_SIZE, re-launching as: {' '.join(cmd)}", file=sys.stderr, flush=True)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    single = args.single_process          # N GPUs behind this one process (the reference's shape: one prover process, one params_map)
-    assert single or world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or pass --single-process)"
-    assert not (single and world > 1), "--single-process is launched without torchrun"
+    if single and world > 1:
+        raise SystemExit("bench.py: --single-process drives all GPUs from ONE process; launch it without torchrun")
+    if not single and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; pass --gpus {world} (or --single-process)")
+    if os.environ.get("MI355_BENCH_DRYRUN") == "1":
+        # launch-path check for GPU-less boxes (tests/test_bench_launch.py): everything up to, not including, the device binding
+        print(json.dumps({"dryrun": True, "rank": rank, "world": world, "local_rank": local_rank, "gpus": args.gpus, "single_process": single,
+                          "master": os.environ.get("MASTER_ADDR"), "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none"}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if world > 1 and os.environ.get("MI355_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     # one rank per GPU.  MI355_BENCH_SHARE_GPU=1 (test only) lets several ranks share the visible GPUs and moves the
     # collective to gloo, so the N > 1 control flow can be exercised on a one-GPU box; the driver never sets it.
     share = os.environ.get("MI355_BENCH_SHARE_GPU") == "1"
@@ -228,10 +248,24 @@ def main() -> None:
     dt = time.perf_counter() - t0
     check(lib.mi355_profile_enable(0))
     result = np.array(result, copy=True)   # `out` is reused by every later leg: keep the timed steps' result for the checks below
+    multi = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
+        per_rank = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what actually ran, so that a silent single-device fallback cannot hide in an N > 1 line: every rank's own device and time
+        names = [None] * world
+        dist.all_gather_object(names, {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": torch.cuda.get_device_name(dev_index),
+                                       "pci_bus_id": getattr(torch.cuda.get_device_properties(dev_index), "pci_bus_id", None), "uuid": str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", ""))})
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl_version = None
+        multi = {"devices": names, "distinct_devices": len({(d["device_index"], d["uuid"]) for d in names}),
+                 "exchange": "gloo all_gather + host fold (MI355_BENCH_SHARE_GPU test mode)" if share else "RCCL all_gather_into_tensor of 96-B partials + device fold (mi355_g1_sum_dev)",
+                 "backend": "gloo" if share else "nccl (RCCL)", "rccl_version": rccl_version, "per_rank_ms_per_step": [float(x.item()) / args.steps * 1e3 for x in per_rank]}
 
     def prof(name):
         ms, cnt = C.c_double(), C.c_uint64()
@@ -537,6 +571,12 @@ def main() -> None:
                          "note": "algorithmic bytes = 96 B per (scalar, point) pair x pairs per launch (SURVEY 8d); the kernel is VALU-integer bound, see DESIGN.md"},
             "cpu_baseline": cpu, "ntt": ntt,
         }
+        if multi is not None:
+            line["multi_gpu"] = multi
+        if single and args.gpus > 1:
+            dv, ex, shd, sl = C.c_int(), C.c_char_p(), C.c_int(), C.c_int()
+            check(lib.mi355_msm_last_run(C.byref(dv), C.byref(ex), C.byref(shd), C.byref(sl)))
+            line["multi_gpu"] = {"devices": dv.value, "exchange": (ex.value or b"").decode(), "mode": "one process, mi355_init_multi"}
         line.update(extra)
         print(json.dumps(line), flush=True)
     if world > 1:
