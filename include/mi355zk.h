@@ -91,6 +91,11 @@ int mi355_buf_upload(void *dst_dev, const void *src_host, uint64_t bytes);
 int mi355_buf_download(void *dst_host, const void *src_dev, uint64_t bytes);   /* ordered after everything queued on the owner; synchronous */
 int mi355_buf_copy(void *dst_dev, const void *src_dev, uint64_t bytes);        /* within a device or between two bound devices (xGMI)       */
 int mi355_buf_zero(void *dst_dev, uint64_t bytes);
+/* HBM accounting of one bound device (any pointer may be NULL): what HIP reports free / in total, and what this library holds in live
+ * mi355_buf blocks, in pooled (freed, reusable) blocks and in its grow-only workspace arena.  A prover keeps the SRS of its degree set
+ * [REF bin/src/trace_prover.rs:35-36] AND the proving key's extended-coset polynomials resident: the caller budgets window tables
+ * (mi355_srs_precompute: W x the basis) against this figure and stays on the table-free schedule when they do not fit.     */
+int mi355_mem_info(int device_slot, uint64_t *free_bytes, uint64_t *total_bytes, uint64_t *live_buf_bytes, uint64_t *pooled_bytes, uint64_t *workspace_bytes);
 
 /* ---- SRS ownership: ParamsKZG { g, g_lagrange } [halo2_proofs poly/kzg/commitment.rs], held for the process
  *      lifetime by the caller's params_map [REF bin/src/trace_prover.rs:35-43], [REF integration/src/prove.rs:12,26,58].
@@ -210,6 +215,9 @@ int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_
  * 20 factors: 8.7 ms against 12.2 ms with general coefficients).                                                                                   */
 int mi355_fr_gate_eval_dev(void *dst_dev, const void *const *polys_dev, uint32_t n_polys, const void *coeffs_fr_host, const uint32_t *term_len,
                            uint32_t n_terms, const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate);
+/* the extended-domain vector from its Q <= 8 coset parts (scroll fork: evaluate_h works part by part, part q = the evaluations at
+ * zeta * extended_omega^(q + Q i), i < n): dst[i * Q + q] = parts[q][i], i.e. the natural order mi355_extended_to_coeff_dev inverts           */
+int mi355_fr_interleave_dev(void *dst_dev, const void *const *parts_dev, uint32_t q_parts, uint64_t n);
 /* the multiplicative scans of the permutation / lookup arguments [EXT-recalled halo2_proofs src/plonk/permutation/prover.rs,
  * src/plonk/lookup/prover.rs]: data[i] = data[i]^-1 with zeros left zero (ff::BatchInvert), and the grand product
  * dst[0] = 1, dst[i] = prod_{j<i} src[j] (dst may alias src; total_out_host, optional, receives prod_{j<n} src[j] and makes the

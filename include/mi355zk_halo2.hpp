@@ -278,3 +278,6 @@ class ParamsKZG {
 
 }  // namespace halo2
 }  // namespace mi355zk
+
+// create_proof_gpu_side(...): steps 1-10 of plonk::create_proof over resident polynomials, with the proving key's cosets in HBM
+#include "mi355zk_create_proof.hpp"

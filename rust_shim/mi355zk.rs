@@ -64,6 +64,7 @@ extern "C" {
     pub fn mi355_buf_download(dst_host: *mut c_void, src_dev: *const c_void, bytes: u64) -> c_int;
     pub fn mi355_buf_copy(dst_dev: *mut c_void, src_dev: *const c_void, bytes: u64) -> c_int;
     pub fn mi355_buf_zero(dst_dev: *mut c_void, bytes: u64) -> c_int;
+    pub fn mi355_mem_info(device_slot: c_int, free_bytes: *mut u64, total_bytes: *mut u64, live_buf_bytes: *mut u64, pooled_bytes: *mut u64, workspace_bytes: *mut u64) -> c_int;
     pub fn mi355_msm_g1_dev(srs: u64, base_offset: u64, scalars_dev: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_msm_g1_batch_dev(srs: u64, base_offset: u64, scalars_dev: *const *const c_void, batch: u32, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_intt_fr_dev(data_dev: *mut c_void, log_n: u32, omega_inv: *const c_void, divisor: *const c_void) -> c_int;
@@ -75,6 +76,7 @@ extern "C" {
                                        extended_omega_inv: *const c_void, extended_ifft_divisor: *const c_void) -> c_int;
     pub fn mi355_fr_gate_eval_dev(dst_dev: *mut c_void, polys_dev: *const *const c_void, n_polys: u32, coeffs_fr_host: *const c_void,
                                   term_len: *const u32, n_terms: u32, factor_poly: *const u32, factor_rot: *const i32, n: u64, accumulate: c_int) -> c_int;
+    pub fn mi355_fr_interleave_dev(dst_dev: *mut c_void, parts_dev: *const *const c_void, q_parts: u32, n: u64) -> c_int;
     pub fn mi355_fr_batch_invert_dev(data_dev: *mut c_void, n: u64) -> c_int;
     pub fn mi355_fr_prefix_product_dev(dst_dev: *mut c_void, src_dev: *const c_void, n: u64, total_out_host: *mut c_void) -> c_int;
     pub fn mi355_fr_prefix_sum_dev(dst_dev: *mut c_void, src_dev: *const c_void, n: u64, total_out_host: *mut c_void) -> c_int;

@@ -30,6 +30,7 @@ SIGNATURES = {
     "mi355_buf_download": (_int, [_vp, _vp, _u64]),
     "mi355_buf_copy": (_int, [_vp, _vp, _u64]),
     "mi355_buf_zero": (_int, [_vp, _u64]),
+    "mi355_mem_info": (_int, [_int, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "mi355_srs_register_host": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "mi355_srs_register_dev": (_int, [_vp, _u64, _int, C.POINTER(_u64)]),
     "mi355_srs_register_prefix": (_int, [_u64, _u64, C.POINTER(_u64)]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "mi355_ntt_fr_batch_dev": (_int, [C.POINTER(_vp), _u32, _u32, _vp, _vp]),
     "mi355_coset_ntt_fr_batch_dev": (_int, [C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp]),
     "mi355_fr_gate_eval_dev": (_int, [_vp, C.POINTER(_vp), _u32, _vp, C.POINTER(_u32), _u32, C.POINTER(_u32), C.POINTER(C.c_int32), _u64, _int]),
+    "mi355_fr_interleave_dev": (_int, [_vp, C.POINTER(_vp), _u32, _u64]),
     "mi355_fr_vec_axpy_dev": (_int, [_vp, _vp, _vp, _vp, _u64]),
     "mi355_fr_vec_op_dev": (_int, [_int, _vp, _vp, _vp, _u64]),
     "mi355_fr_vec_mul_periodic_dev": (_int, [_vp, _u64, _vp, _u32]),

@@ -675,6 +675,24 @@ int mi355_buf_zero(void *dst_dev, uint64_t bytes) {
   });
 }
 
+int mi355_mem_info(int device_slot, uint64_t *free_bytes, uint64_t *total_bytes, uint64_t *live_buf_bytes, uint64_t *pooled_bytes, uint64_t *workspace_bytes) {
+  return guarded([&]() -> int {
+  if (device_slot < 0 || device_slot >= MAX_DEV) return fail(MI355_EBADARG, "mem_info: device slot out of range");
+  DevGuard lk(device_slot);
+  CHK(need_init(device_slot));
+  size_t fr = 0, tot = 0;
+  HIPCHK(hipMemGetInfo(&fr, &tot));
+  uint64_t live = 0, pooled = 0, ws = 0;
+  { std::lock_guard<std::mutex> bl(g_buf_mu);
+    for (const auto &kv : g_bufs) if (kv.second.slot == device_slot) live += kv.second.bytes;
+    for (const auto &kv : g_pool) if (kv.first.first == device_slot) pooled += kv.second.bytes; }
+  for (const auto &kv : g.ws) ws += kv.second.cap;
+  if (free_bytes) *free_bytes = fr; if (total_bytes) *total_bytes = tot; if (live_buf_bytes) *live_buf_bytes = live;
+  if (pooled_bytes) *pooled_bytes = pooled; if (workspace_bytes) *workspace_bytes = ws;
+  return MI355_OK;
+  });
+}
+
 // ---- test hook: read back a workspace buffer ("msm.sorted", "msm.offsets", ...) after a call
 int mi355_debug_ws_read(const char *role, uint64_t offset, void *dst_host, uint64_t bytes) {
   return guarded([&]() -> int {

@@ -534,6 +534,27 @@ int mi355_fr_gate_eval_dev(void *dst_dev, const void *const *polys_dev, uint32_t
   return MI355_OK;
   });
 }
+// extended-domain vector from its Q coset parts: dst[i * Q + q] = parts[q][i] (dst: Q * n elements, must not overlap a part)
+int mi355_fr_interleave_dev(void *dst_dev, const void *const *parts_dev, uint32_t q_parts, uint64_t n) {
+  return guarded([&]() -> int {
+  if (!dst_dev || !parts_dev || q_parts == 0 || q_parts > 8) return fail(MI355_EBADARG, "fr_interleave: 1..8 parts");
+  InterleavePlan P; memset(&P, 0, sizeof P); P.q = q_parts;
+  int slot = slot_of(dst_dev);
+  for (uint32_t q = 0; q < q_parts; q++) {
+    if (!parts_dev[q]) return fail(MI355_EBADARG, "fr_interleave: null part pointer");
+    int s; CHK(common_slot({dst_dev, parts_dev[q]}, &s, "fr_interleave"));
+    const uintptr_t d0 = (uintptr_t)dst_dev, d1 = d0 + (uint64_t)q_parts * n * sizeof(fe_t), p0 = (uintptr_t)parts_dev[q], p1 = p0 + n * sizeof(fe_t);
+    if (p0 < d1 && d0 < p1) return fail(MI355_EBADARG, "fr_interleave: dst overlaps a part");
+    P.part[q] = (const fe_t *)parts_dev[q];
+  }
+  DevGuard lk(slot);
+  CHK(need_init(slot));
+  if (n == 0) return MI355_OK;
+  hipLaunchKernelGGL(k_fr_interleave, dim3(g.prop.multiProcessorCount * 8), dim3(256), 0, g.stream, (fe_t *)dst_dev, P, n);
+  HIPCHK(hipGetLastError());
+  return MI355_OK;
+  });
+}
 int mi355_fr_vec_axpy_dev(void *dst_dev, const void *a_dev, const void *b_dev, const void *scalar, uint64_t n) {
   return guarded([&]() -> int {
   int slot; CHK(common_slot({dst_dev, a_dev, b_dev}, &slot, "fr_vec_axpy")); DevGuard lk(slot);

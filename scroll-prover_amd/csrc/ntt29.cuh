@@ -360,6 +360,15 @@ __global__ void __launch_bounds__(256) k_fr_gate_eval(fe_t *dst, GatePlan G, uin
   }
 }
 
+// dst[i * Q + q] = parts[q][i]: the Q coset parts of the scroll fork's evaluate_h (part q = the evaluations at zeta * omega_ext^(q + Q i), i < n)
+// laid out as the extended domain's natural order, which is what extended_to_coeff inverts.  Q <= 8 pointers travel as a kernel argument; a lane
+// reads one 32-byte element per part (consecutive lanes, consecutive elements) and writes Q consecutive elements: both sides coalesced.
+struct InterleavePlan { const fe_t *part[8]; uint32_t q; };
+__global__ void __launch_bounds__(256) k_fr_interleave(fe_t *__restrict__ dst, InterleavePlan P, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    for (uint32_t q = 0; q < P.q; q++) g_store(&dst[i * P.q + q], g_load(&P.part[q][i]));
+}
+
 // sum of m canonical field elements (the per-block partials) by one workgroup
 __global__ void __launch_bounds__(256) k_fr_sum(const fe_t *__restrict__ in, uint64_t m, fe_t *__restrict__ out) {
   __shared__ fe_t lds[4];
