@@ -444,6 +444,7 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
     const uint32_t NP = (uint32_t)wrefs.size();
     std::vector<std::map<PolyRef, DevicePoly>> part_on(D), coeff_on(D), pkpart_on(D);
     std::vector<std::vector<DevicePoly>> tmp_on(D); std::vector<DevicePoly> hq_on(D);
+    std::vector<DevicePoly> hpart; for (uint32_t q = 0; q < Q; q++) hpart.emplace_back(n, 0);   // part q of h: the evaluations at zeta omega_ext^(q + Q i)
     for (int d = 0; d < D; d++) {
       for (const auto &r : wrefs) part_on[d][r] = DevicePoly(n, d);
       for (uint32_t i = 0; i < 2 * s.chunk_len; i++) tmp_on[d].emplace_back(n, d);
@@ -475,19 +476,21 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
           };
           // 1 / ((zeta omega_ext^q)^n - 1): the vanishing polynomial is constant on a coset part; it rides on the coefficients
           const Fr tq_inv = fr_inv(fr_sub(fr_pow(factor, n), fr_one()));
-          void *hq = d == 0 ? R.h.at((uint64_t)q * n) : hq_on[d].p;
+          void *hq = d == 0 ? hpart[q].p : hq_on[d].p;
           bool first = true;
           for (const auto &L : plan.quotient) {
             if (L.to_tmp) run_launch(L, tmp_on[d][L.tmp].p, n, fr_one(), false, resolve);
             else { run_launch(L, hq, n, tq_inv, !first, resolve); first = false; }
             launches[d]++;
           }
-          if (d != 0) check(mi355_buf_copy(R.h.at((uint64_t)q * n), hq, n * 32));
+          if (d != 0) check(mi355_buf_copy(hpart[q].p, hq, n * 32));
         }
       } catch (const std::exception &e) { errs[d] = e.what(); }
     };
     { std::vector<std::thread> th; for (int d = 1; d < D; d++) th.emplace_back(do_parts, d); do_parts(0); for (auto &x : th) x.join(); }
     for (int d = 0; d < D; d++) { if (!errs[d].empty()) throw Error(MI355_EHIP, "quotient part on device slot " + std::to_string(d) + ": " + errs[d]); R.gate_launches += launches[d]; R.coset_ntt += cosets[d]; }
+    // the parts interleave into the extended domain's natural order (index q + Q i), which extended_to_coeff inverts: h(X), Q n coefficients
+    { std::vector<const void *> pp(Q); for (uint32_t q = 0; q < Q; q++) pp[q] = hpart[q].p; check(mi355_fr_interleave_dev(R.h.p, pp.data(), Q, n)); }
     check(mi355_extended_to_coeff_dev(R.h.p, dom.extended_k, dom.g_coset.data(), dom.g_coset_inv.data(), dom.extended_omega_inv.data(), dom.extended_ifft_divisor.data()));
   }
   lap(7);

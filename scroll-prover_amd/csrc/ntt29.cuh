@@ -290,7 +290,8 @@ __global__ void __launch_bounds__(256) k_distribute_powers(const fe_t *src, fe_t
 // element-wise vector operations on device-resident polynomials (the pointwise steps between the transforms of the quotient
 // construction): op 0 add, 1 sub, 2 mul; and data[i] *= table[i mod period] (division by the vanishing polynomial on
 // the extended coset: halo2's t_evaluations have period 2^(extended_k - k)).  Streaming, 16 B/lane accesses, grid-stride.
-__global__ void __launch_bounds__(256) k_fr_vec_op(int op, fe_t *__restrict__ dst, const fe_t *__restrict__ a, const fe_t *__restrict__ b, uint64_t n) {
+// no __restrict__: dst may be one of the operands (each thread reads element i of both operands before it writes element i)
+__global__ void __launch_bounds__(256) k_fr_vec_op(int op, fe_t *dst, const fe_t *a, const fe_t *b, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const fe_t x = g_load(&a[i]), y = g_load(&b[i]);
     fe_t r;
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(256) k_fr_vec_op(int op, fe_t *__restrict__ ds
   }
 }
 // dst = a + s * b (s a scalar): the linear combinations sum_i v^i p_i(X) of the multi-open argument, one polynomial at a time
-__global__ void __launch_bounds__(256) k_fr_vec_axpy(fe_t *__restrict__ dst, const fe_t *__restrict__ a, const fe_t *__restrict__ b, fe_t s_sat, uint64_t n) {
+__global__ void __launch_bounds__(256) k_fr_vec_axpy(fe_t *dst, const fe_t *a, const fe_t *b, fe_t s_sat, uint64_t n) {   // dst may alias a or b
   const fe29_t s = Fr29::from_sat(s_sat);   // s * 2^261: the product with b * 2^256 lands back in the ABI domain
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const fe_t sb = fr29_finish(Fr29::mul(Fr29::from_sat_plain(g_load(&b[i])), s));

@@ -1,39 +1,27 @@
-// test_create_proof_replay.cpp -- the step order of halo2_proofs::plonk::create_proof replayed by a COMPILED caller
-// through the C-ABI with the proof's polynomials resident in HBM (mi355_buf_*: what rust_shim/mi355zk.rs wraps as DevicePoly).  The
-// reference reaches this function once per layer [REF integration/src/prove.rs:36-43,67,96]; Rust is absent from this image, so this program
-// stands in for the patched create_proof: host memory is touched only for the witness upload and for the 96-byte / 32-byte results.
+// test_create_proof_replay.cpp -- a COMPILED caller that runs halo2_proofs::plonk::create_proof's GPU side for one layer of scroll-prover's
+// proof stack through the C-ABI and then checks everything it produced.  The flow itself is mi355zk::halo2::create_proof_gpu_side
+// (include/mi355zk_create_proof.hpp: steps 1-10 of SURVEY.md 3.2 over resident polynomials, the proving key's cosets resident in HBM); this
+// program is the set-up around it (synthetic SRS with a known tau, keygen, witness synthesis, the HBM budget) and the checker after it.
+// The reference reaches create_proof once per layer [REF integration/src/prove.rs:36-43,67,95-97]; Rust is absent from this image.
 //
-//   layer 4 (k = 26, batch compression [REF integration/configs/layer4.config:3-10]; counts from test_data/full_proof_batch_agg_1.json):
-//       num_witness [3,1,4] -> 8 witness commitments + 4 quotient pieces + 2 SHPLONK = 14 MSM, 27 evaluations
-//   layer 2 (k = 25, chunk compression [REF integration/configs/layer2.config:3-10]; full_proof_1.json): [1,1,3] -> 11 MSM, 17 evaluations
-//   layer 1 (k = 24 [REF integration/configs/layer1.config:3-10]; no fixture, SURVEY 3.3 estimate [17,2,3]): 28 MSM
+//   layers 0-6: counts from mi355zk::halo2::layer_shape (configs [REF integration/configs/layer1.config:3-10] ... layer6.config, fixtures
+//   test_data/full_proof_1.json and full_proof_batch_agg_1.json; layer 0 is a stated guess, overridable: --advice / --fixed / --lookups / --perm / --chunk / --degree)
 //
-//   step 1  instance column: upload, lagrange_to_coeff                                   (iNTT)
-//   step 2  advice columns: witness upload (a second host thread: the DMA of column i + 1 runs under the commitment of column i),
-//           commit_lagrange each                                                          (MSM, Lagrange basis)
-//   step 3  lookup multiplicities: upload, commit_lagrange                                (MSM)
-//   step 4  permutation products / lookup sums: batch inversion + running product or sum ON the device, commit_lagrange (scans, MSM)
-//   step 5  random blinding polynomial: upload, commit                                   (MSM, coefficient basis)
-//   step 6  lagrange_to_coeff of every witness polynomial                                (iNTT, one batched call)
-//   step 7  quotient: per coset part q < 4, coset NTT of every polynomial (batched), the gate / permutation-shaped expression with ROTATED
-//           operands as one fused launch (mi355_fr_gate_eval_dev; the division by the vanishing polynomial, constant on a coset part, rides on
-//           the coefficients), then extended_to_coeff over 2^(k+2)                         (NTT, pointwise, inverse NTT)
-//   step 8  commit the 4 quotient pieces                                                  (MSM)
-//   step 9  evaluations at x * omega^rot                                                  (eval_polynomial)
-//   step 10 SHPLONK: linear combination (one fused launch), 2 x kate_division, 2 commitments
-//
-// What is replayed is the CALL MIX with real data flow, not a circuit: the gate expression is a stand-in of the right shape (degree-3/4 products
-// of rotated columns), the coset parts are laid out part by part, transcript hashing and witness synthesis (CPU side) are absent.
-// EVERY commitment is checked afterwards against p(tau) G (the SRS is synthetic, tau known; Horner + one scalar multiple in the CPU oracle,
-// TEST INFRASTRUCTURE) and every evaluation against Horner.  --host-api replays the MSM / NTT / evaluation calls through the host-pointer
-// entry points for comparison.  Prints one JSON line; exit code 0 = all checks passed, 2 = no GPU (mi355_init failed).
+// Checks, all AFTER the clock stops, all with the CPU oracle (oracle/, TEST INFRASTRUCTURE) on downloaded data:
+//   (1) every commitment == p(tau) G for the polynomial it commits to (Horner over the downloaded coefficients + one scalar multiple);
+//   (2) every evaluation == Horner over the downloaded coefficients;
+//   (3) SEMANTICS of the quotient: at the challenge x,  h(x) (x^n - 1) == sum_g y^g gate_g(x), the right-hand side recomputed from the
+//       EVALUATIONS alone through the same expression plan (custom gates, permutation argument with its (c + beta sigma + gamma) products,
+//       log-derivative lookups; l_active / l_0 / instance evaluated by the checker as a verifier would) -- the witness satisfies the constraints,
+//       so this fails if any coset transform, gate launch, the part interleave, the 2^(k + e) inverse or the division by the vanishing
+//       polynomial is wrong;
+//   (4) both multi-open quotients with the trapdoor, G1 operations only:  commit(q_j) (tau - z_j) == commit(lin) - lin(z_j) G.
+// --host-api additionally replays the MSM / NTT / evaluation counts through the host-pointer entry points (what a shim without DevicePoly pays).
+// Prints one JSON line; exit code 0 = all checks passed, 2 = no GPU (mi355_init failed).
 #include <chrono>
-#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -45,11 +33,15 @@ void orc_eval_polynomial_mt(void *out, const void *poly, uint64_t n, const void 
 void orc_g1_mul(void *out_jac, const void *p_affine, const void *scalar_mont);
 void orc_g1_generator(void *out_affine);
 void orc_g1_to_affine(void *o, const void *p);
+void orc_g1_add_affine(void *o_jac, const void *p_jac, const void *q_affine);
+void orc_f_add(int w, void *o, const void *a, const void *b);
+void orc_f_sub(int w, void *o, const void *a, const void *b);
+void orc_f_mul(int w, void *o, const void *a, const void *b);
+void orc_f_neg(int w, void *o, const void *a);
+void orc_f_pow(int w, void *o, const void *a, const uint64_t *e);
 }
 
-using mi355zk::halo2::Fr;
-using mi355zk::halo2::G1;
-using mi355zk::halo2::G1Affine;
+using namespace mi355zk::halo2;
 namespace h2d = mi355zk::halo2::detail;
 using Clock = std::chrono::steady_clock;
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
@@ -58,304 +50,244 @@ static int failures = 0;
 #define CK(expr) do { int _rc = (expr); if (_rc != MI355_OK) { std::printf("FAILED %s:%d  %s -> %d [%s]\n", __FILE__, __LINE__, #expr, _rc, mi355_last_error()); failures++; } } while (0)
 #define EXPECT(cond) do { if (!(cond)) { std::printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond); failures++; } } while (0)
 
-// rust: struct DevicePoly { ptr: *mut c_void, len: usize }  impl Drop { mi355_buf_free }; C++: mi355zk::halo2::DevicePoly (include/mi355zk_halo2.hpp)
-using mi355zk::halo2::DevicePoly;
-
-struct Layer { int id; uint32_t k; uint32_t advice, lookups, products, evals; };
-static const Layer LAYERS[] = {{4, 26, 3, 1, 3, 27}, {2, 25, 1, 1, 2, 17}, {1, 24, 17, 2, 2, 60}};
-
-// witness-like column: 60 % zero, 20 % < 256, 10 % 64-bit, 10 % uniform, Montgomery form
-static void fill_witness(std::vector<Fr> &v, uint64_t seed, bool uniform) {
-  std::mt19937_64 g(seed);
-  const Fr r2 = h2d::fr_from_u64(1);   // Montgomery one; small values go through fr_from_u64
-  (void)r2;
-  static thread_local std::vector<Fr> small;
-  if (small.empty()) { small.resize(256); for (uint64_t i = 0; i < 256; i++) small[i] = h2d::fr_from_u64(i); }
-  for (auto &x : v) {
-    const uint64_t u = g() % 10;
-    if (uniform || u == 9) x = Fr{{g(), g(), g(), g() & ((uint64_t(1) << 60) - 1)}};
-    else if (u < 6) x = Fr{{0, 0, 0, 0}};
-    else if (u < 8) x = small[g() & 255];
-    else x = h2d::fr_mul(small[(g() & 254) + 1], Fr{{g(), g() & 0xffff, 0, 0}});   // some mid-size value (any field element is a valid witness)
-  }
-}
-static void fill_parallel(std::vector<Fr> &v, uint64_t seed, bool uniform, int threads) {
-  const uint64_t n = v.size();
-  if (n < (1u << 16) || threads <= 1) { fill_witness(v, seed, uniform); return; }
-  std::vector<std::thread> th;
-  for (int t = 0; t < threads; t++) th.emplace_back([&, t] {
-    const uint64_t lo = n * t / threads, hi = n * (t + 1) / threads;
-    std::vector<Fr> part(hi - lo); fill_witness(part, seed * 1000003 + t, uniform); std::memcpy(v.data() + lo, part.data(), (hi - lo) * 32);
-  });
-  for (auto &t : th) t.join();
-}
+// oracle field arithmetic (Fr = selector 1)
+static Fr o_add(const Fr &a, const Fr &b) { Fr r; orc_f_add(1, r.data(), a.data(), b.data()); return r; }
+static Fr o_sub(const Fr &a, const Fr &b) { Fr r; orc_f_sub(1, r.data(), a.data(), b.data()); return r; }
+static Fr o_mul(const Fr &a, const Fr &b) { Fr r; orc_f_mul(1, r.data(), a.data(), b.data()); return r; }
+static Fr o_neg(const Fr &a) { Fr r; orc_f_neg(1, r.data(), a.data()); return r; }
+static Fr o_pow(const Fr &a, uint64_t e) { uint64_t ee[4] = {e, 0, 0, 0}; Fr r; orc_f_pow(1, r.data(), a.data(), ee); return r; }
+static Fr o_eval(const std::vector<Fr> &c, const Fr &x, int threads) { Fr r; orc_eval_polynomial_mt(r.data(), c.data(), c.size(), x.data(), threads); return r; }
 
 static G1Affine field_commit(const std::vector<Fr> &coeffs, const Fr &tau, int threads) {
-  Fr ev; orc_eval_polynomial_mt(ev.data(), coeffs.data(), coeffs.size(), tau.data(), threads);
+  const Fr ev = o_eval(coeffs, tau, threads);
   G1Affine gen, out; G1 j; orc_g1_generator(gen.data()); orc_g1_mul(j.data(), gen.data(), ev.data()); orc_g1_to_affine(out.data(), j.data());
   return out;
 }
+static bool is_identity(const G1 &g) { for (auto w : g) if (w) return false; return true; }
 static bool commit_matches(const G1 &got, const G1Affine &want) {
   bool ident = true; for (auto w : want) ident = ident && w == 0;
-  if (ident) { for (auto w : got) if (w) return false; return true; }
+  if (ident) return is_identity(got);
   return std::memcmp(got.data(), want.data(), 64) == 0;   // normalised Jacobian: (x, y, R)
 }
+static std::vector<Fr> download(const void *p, uint64_t n) { std::vector<Fr> v(n); CK(mi355_buf_download(v.data(), p, n * 32)); return v; }
+static Fr rot_point(const EvaluationDomain &dom, const Fr &x, int32_t rot) {
+  if (rot > 0) return o_mul(x, o_pow(dom.omega, (uint64_t)rot));
+  if (rot < 0) return o_mul(x, o_pow(dom.omega_inv, (uint64_t)(-(int64_t)rot)));
+  return x;
+}
+static const char *kind_name(PolyKind k) { static const char *n[] = {"instance", "advice", "m", "z", "phi", "fixed", "sigma", "id", "l_active", "l_0", "tmp", "h/shplonk"}; return n[k]; }
 
 int main(int argc, char **argv) {
-  int layer_id = 4, devices = 1, threads = (int)std::thread::hardware_concurrency(); long k_override = -1; bool host_api = false, check = true, tables = true;
+  int layer_id = 4, devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2; long k_override = -1; bool host_api = false, do_check = true;
+  std::string tables = "auto", pk_mode = "auto";
+  long o_advice = -1, o_fixed = -1, o_lookups = -1, o_perm = -1, o_chunk = -1, o_degree = -1;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto next = [&]() -> long { return i + 1 < argc ? std::atol(argv[++i]) : 0; };
+    auto nexts = [&]() -> std::string { return i + 1 < argc ? std::string(argv[++i]) : std::string(); };
     if (a == "--layer") layer_id = (int)next(); else if (a == "--k") k_override = next(); else if (a == "--devices") devices = (int)next();
-    else if (a == "--threads") threads = (int)next(); else if (a == "--host-api") host_api = true; else if (a == "--no-check") check = false; else if (a == "--no-tables") tables = false;
-    else { std::printf("usage: %s [--layer 1|2|4] [--k K] [--devices D] [--threads T] [--host-api] [--no-check] [--no-tables]\n", argv[0]); return 1; }
+    else if (a == "--threads") threads = (int)next(); else if (a == "--host-api") host_api = true; else if (a == "--no-check") do_check = false;
+    else if (a == "--no-tables") tables = "off"; else if (a == "--tables") tables = nexts(); else if (a == "--pk-cosets") pk_mode = nexts(); else if (a == "--proofs") proofs = (int)next();
+    else if (a == "--advice") o_advice = next(); else if (a == "--fixed") o_fixed = next(); else if (a == "--lookups") o_lookups = next();
+    else if (a == "--perm") o_perm = next(); else if (a == "--chunk") o_chunk = next(); else if (a == "--degree") o_degree = next();
+    else { std::printf("usage: %s [--layer 0..6] [--k K] [--advice A --fixed F --lookups L --perm P --chunk C --degree D] [--devices D] [--threads T] [--proofs N]\n"
+                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--no-check]\n", argv[0]); return 1; }
   }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;   // the GPU box's container gets 16 of the host's CPUs
   const char *tq = std::getenv("MI355_REPLAY_THREADS"); if (tq) threads = std::max(1, std::atoi(tq));
-  Layer L = LAYERS[0]; for (const auto &c : LAYERS) if (c.id == layer_id) L = c;
-  if (k_override > 0) L.k = (uint32_t)k_override;
-  const uint32_t k = L.k, Q = 4; const uint64_t n = uint64_t(1) << k;
+  if (proofs < 1) proofs = 1;
+  CircuitShape S;
+  try { S = layer_shape(layer_id); } catch (const std::exception &e) { std::printf("%s\n", e.what()); return 1; }
+  if (k_override > 0) S.k = (uint32_t)k_override;
+  if (o_advice > 0) S.advice = (uint32_t)o_advice; if (o_fixed > 0) S.fixed = (uint32_t)o_fixed; if (o_lookups >= 0) S.lookups = (uint32_t)o_lookups;
+  if (o_perm > 0) S.perm_columns = (uint32_t)o_perm; if (o_chunk > 0) S.chunk_len = (uint32_t)o_chunk; if (o_degree > 0) S.degree = (uint32_t)o_degree;
+  if (S.chunk_len > 6 || S.chunk_len + 2 > S.degree || ((S.degree - 1) & (S.degree - 2)) || S.degree < 4 || S.degree > 9) { std::printf("unsupported shape: degree - 1 must be a power of two in 4..8, chunk_len <= min(6, degree - 2)\n"); return 1; }
+  const uint32_t k = S.k, Q = S.Q(); const uint64_t n = uint64_t(1) << k;
   {
     std::vector<int> ids(devices); for (int d = 0; d < devices; d++) ids[d] = d;
     if (std::getenv("MI355_ALLOW_DUP_DEVICES")) for (auto &d : ids) d = 0;
     const int rc = devices == 1 ? mi355_init(0) : mi355_init_multi(ids.data(), devices);
     if (rc != MI355_OK) { std::printf("mi355_init failed (%d): %s\n", rc, mi355_last_error()); return 2; }
   }
-  const mi355zk::halo2::EvaluationDomain dom(5, k);   // quotient degree 4: extended_k = k + 2
+  int rc_main = 0;
+  try {
+  const EvaluationDomain dom(S.degree, k);   // quotient degree = degree - 1 = Q: extended_k = k + log2 Q
   const Fr tau = h2d::fr_from_u64(0x5343524F4C4C0001ull + layer_id);
-  // ---- ParamsKZG (setup-time, outside the timed region): synthetic SRS on the device, both bases registered, window tables
+  // ---- ParamsKZG (set-up time): synthetic SRS on the device, both bases registered
   uint64_t hg = 0, hl = 0;
   {
     DevicePoly g(2 * n, 0), gl(2 * n, 0);   // 64 bytes per point
-    CK(mi355_srs_setup_dev(g.p, gl.p, k, tau.data(), dom.omega.data()));
-    CK(mi355_srs_register_dev(g.p, n, 1, &hg)); CK(mi355_srs_register_dev(gl.p, n, 1, &hl));
-    CK(mi355_synchronize());
+    check(mi355_srs_setup_dev(g.p, gl.p, k, tau.data(), dom.omega.data()));
+    check(mi355_srs_register_dev(g.p, n, 1, &hg)); check(mi355_srs_register_dev(gl.p, n, 1, &hl));
+    check(mi355_synchronize());
   }
-  CK(mi355_buf_trim());   // the two staging blocks of the set-up go back to HIP
-  if (tables) { CK(mi355_srs_precompute(hg, 0, 0)); CK(mi355_srs_precompute(hl, 0, 0)); }
-  // ---- the witness, "synthesised" on the CPU before the proof starts (host Vec<Fr> as create_proof holds them)
-  const uint32_t W = 1 + L.advice + L.lookups;         // uploaded columns: instance, advice, lookup multiplicities
-  std::vector<std::vector<Fr>> host_cols(W + 1);        // + the random blinding polynomial
-  for (uint32_t i = 0; i <= W; i++) { host_cols[i].resize(n); fill_parallel(host_cols[i], 9000 + i, i == W || i == 1, threads); }
-  auto slot_for = [&](uint32_t i) { return devices > 1 ? (int)(i % (uint32_t)devices) : 0; };
+  check(mi355_buf_trim());   // the two staging blocks of the set-up go back to HIP
+  // ---- HBM budget: what must live in HBM for this layer's prover, and which optional residents fit on top
+  uint64_t hbm_free = 0, hbm_total = 0; check(mi355_mem_info(0, &hbm_free, &hbm_total, nullptr, nullptr, nullptr));
+  const double per = (double)n * 32, GiB = 1024.0 * 1024 * 1024;
+  const uint32_t npk = S.fixed + S.perm_columns + 3, NPW = S.witness_polys();
+  const double pk_base = per * (S.fixed * 2 + S.perm_columns * 2 + 4), pk_cosets = per * npk * Q, pk_lean_tmp = per * npk;
+  const double working = per * (2.0 * NPW + 2 * S.chunk_len + 2 * Q + 3 + (2 * S.chunk_len + 2) + 1) + per * Q + per   // polynomials, parts, temporaries, h parts + h, lin + quotients, NTT scratch
+                         + (double)n * 13 * 22 + 0.3 * GiB;                                                              // MSM workspace (digit plane, two record streams, sorted stream; ~22 B per entry, up to 13 windows) + fixed overheads
+  const double table_one = (double)n * 64 * (k >= 24 ? 12 : 15);
+  const double usable = 0.94 * (double)hbm_free;   // what is free after the SRS registration, minus allocator slack
+  bool resident = true; int n_tables = 0;
+  if (pk_mode == "on-the-fly") resident = false;
+  else if (pk_mode == "auto" && pk_base + pk_cosets + working > usable) resident = false;
+  const double fixed_need = pk_base + (resident ? pk_cosets : pk_lean_tmp) + working;
+  if (tables == "on") n_tables = 2; else if (tables == "lagrange") n_tables = 1; else if (tables == "off") n_tables = 0;
+  else n_tables = fixed_need + 2 * table_one <= usable ? 2 : fixed_need + table_one <= usable ? 1 : 0;
+  if (devices > 1 && tables == "auto") n_tables = 2;   // the estimate above is for one device; shards divide everything
+  if (n_tables >= 1) check(mi355_srs_precompute(hl, 0, 0));   // commit_lagrange carries most commitments: its basis first
+  if (n_tables >= 2) check(mi355_srs_precompute(hg, 0, 0));
+  // ---- keygen (device side) and the witness (host side, as create_proof receives it)
+  ProvingKeyDevice pk = keygen_device(S, dom, 0xC0FFEE + layer_id, resident, devices, threads);
+  Witness wit = synthesize_witness(S, dom, pk, 9000 + layer_id, threads);
+  Challenges ch;
+  ch.theta = h2d::fr_from_u64(0x7468657461ull); ch.beta = h2d::fr_from_u64(0xBE7A0000BE7A0001ull); ch.gamma = h2d::fr_from_u64(0x6A6D6D6100000003ull);
+  ch.y = h2d::fr_from_u64(0x7900000000000005ull); ch.x = h2d::fr_from_u64(0x1234567890ABCDEFull); ch.v = h2d::fr_from_u64(0xABCDEF0123456789ull);
+  ch.z0 = h2d::fr_from_u64(0x1111); ch.z1 = h2d::fr_from_u64(0x1112);
+  const ExpressionPlan plan = build_plan(S, ch);
+  ProofOptions opt; opt.devices = devices; opt.threads = threads;
+  // ---- the proofs: a prover process runs proof after proof; the first one grows the workspace arena and the buffer pool, the last one is reported
+  ProofGpuSide R; double first_ms = 0;
+  for (int it = 0; it < proofs; it++) {
+    R = ProofGpuSide();   // the previous proof's polynomials go back to the pool
+    R = create_proof_gpu_side(hg, hl, dom, pk, plan, wit, ch, opt);
+    if (it == 0) first_ms = R.total_ms;
+  }
+  uint64_t live = 0, pooled = 0, ws = 0, fr_end = 0; check(mi355_mem_info(0, &fr_end, nullptr, &live, &pooled, &ws));
 
-  std::vector<DevicePoly> poly(W + L.products);         // resident polynomials: [0] instance, advice, lookups, then products
-  DevicePoly random_poly, h_ext, lin, quot[2];
-  std::vector<G1> commits; std::vector<int> commit_src;   // commit_src: index into `poly` (>= 0), -1 random, -2-q quotient piece q, -10-j SHPLONK quotient j
-  std::vector<Fr> evals; std::vector<std::pair<int, Fr>> eval_src;
-  G1 out;
-  // warm the grow-only workspace arena (a prover runs proof after proof; the first proof of a process pays the hipMallocs once)
-  {
-    DevicePoly w0(n, 0), w1(Q * n, 0);
-    CK(mi355_buf_zero(w0.p, n * 32)); CK(mi355_buf_zero(w1.p, Q * n * 32));
-    CK(mi355_msm_g1_dev(hl, 0, w0.p, n, out.data())); CK(mi355_msm_g1_dev(hg, 0, w0.p, n, out.data()));
-    CK(mi355_extended_to_coeff_dev(w1.p, k + 2, dom.g_coset.data(), dom.g_coset_inv.data(), dom.extended_omega_inv.data(), dom.extended_ifft_divisor.data()));
-    CK(mi355_fr_batch_invert_dev(w0.p, n)); CK(mi355_fr_prefix_product_dev(w0.p, w0.p, n, nullptr)); CK(mi355_fr_kate_division_dev(w1.p, w0.p, n, tau.data()));
-    Fr e; CK(mi355_eval_polynomial_dev(w0.p, n, tau.data(), e.data()));
-    CK(mi355_synchronize());
-  }
-  {
-    // ... and the buffer pool: every DevicePoly of the proof below then comes out of mi355_buf_alloc without a hipMalloc (2 GiB allocations
-    // cost 10-40 ms each and vary from box to box); blocks return to the pool when the previous proof's polynomials drop
-    const uint32_t np = 1 + L.advice + L.lookups + L.products, nd = (uint32_t)std::max(1, devices);
-    std::vector<DevicePoly> warm;
-    for (uint32_t d = 0; d < nd; d++) for (uint32_t i = 0; i < 2 * np + 6; i++) warm.emplace_back(n, (int)d);
-    warm.emplace_back(Q * n, 0);
-    std::vector<Fr> probe(std::min<uint64_t>(n, 1u << 20));
-    CK(mi355_buf_upload(warm[0].p, probe.data(), probe.size() * 32));   // first use of the copy stream
-    CK(mi355_synchronize());
-  }
-  double step_ms[11] = {0};
-  const auto t_start = Clock::now();
-  auto lap = [&](int step, Clock::time_point &t) { step_ms[step] += ms_since(t); t = Clock::now(); };
-  auto t = t_start;
-  // ---- steps 1-3, 5: uploads on a second host thread (rayon worker in the real caller); commitments as the columns arrive
-  std::mutex mu; std::condition_variable cv; uint32_t ready = 0;
-  std::thread uploader([&] {
-    for (uint32_t i = 0; i <= W; i++) {
-      DevicePoly d = DevicePoly::from_host(host_cols[i], slot_for(i));
-      { std::lock_guard<std::mutex> lk(mu); if (i < W) poly[i] = std::move(d); else random_poly = std::move(d); ready = i + 1; }
-      cv.notify_all();
-    }
-  });
-  auto wait_for = [&](uint32_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready > i; }); };
-  wait_for(0);
-  CK(mi355_intt_fr_dev(poly[0].p, k, dom.omega_inv.data(), dom.ifft_divisor.data()));   // step 1
-  lap(1, t);
-  for (uint32_t i = 1; i < W; i++) {                                                       // steps 2, 3
-    wait_for(i);
-    CK(mi355_msm_g1_dev(hl, 0, poly[i].p, n, out.data())); commits.push_back(out); commit_src.push_back((int)i);
-  }
-  lap(2, t);
-  for (uint32_t z = 0; z < L.products; z++) {                                              // step 4
-    const uint32_t src = z == 0 ? 1 : W + z - 1;   // the uniform advice column, then the previous product (dense, non-zero values)
-    DevicePoly tmp(n, poly[src].slot), zp(n, poly[src].slot);
-    CK(mi355_buf_copy(tmp.p, poly[src].p, n * 32));
-    CK(mi355_fr_batch_invert_dev(tmp.p, n));
-    // the permutation argument's grand products, then one running SUM per lookup (the phi of the scroll fork's log-derivative lookups)
-    if (z + L.lookups >= L.products) CK(mi355_fr_prefix_sum_dev(zp.p, tmp.p, n, nullptr));
-    else CK(mi355_fr_prefix_product_dev(zp.p, tmp.p, n, nullptr));
-    CK(mi355_msm_g1_dev(hl, 0, zp.p, n, out.data())); commits.push_back(out); commit_src.push_back((int)(W + z));
-    poly[W + z] = std::move(zp);
-  }
-  lap(4, t);
-  wait_for(W);
-  uploader.join();
-  CK(mi355_msm_g1_dev(hg, 0, random_poly.p, n, out.data())); commits.push_back(out); commit_src.push_back(-1);   // step 5
-  lap(5, t);
-  const uint32_t NP = W + L.products;
-  {                                                                                         // step 6
-    std::vector<void *> ptrs; for (uint32_t i = 1; i < NP; i++) ptrs.push_back(poly[i].p);
-    CK(mi355_ntt_fr_batch_dev(ptrs.data(), (uint32_t)ptrs.size(), k, dom.omega_inv.data(), dom.ifft_divisor.data()));
-  }
-  lap(6, t);
-  // ---- step 7: the quotient, coset part by coset part
-  h_ext = DevicePoly(Q * n, 0);
-  {
-    // expression over the coset evaluations (indices into `poly`; rotations in elements of the part: rot_scale = 1).  Up to 16 terms per launch.
-    struct Term { uint64_t c; std::vector<std::pair<uint32_t, int32_t>> f; };
-    std::vector<Term> terms;
-    const uint32_t a0 = 1, a1 = 1 + (1 % (NP - 1)), a2 = 1 + (2 % (NP - 1)), zz = NP - 1, lk = W - 1;
-    terms.push_back({3, {{a0, 0}, {a1, 0}, {a2, 0}}});            // a custom gate: q * a * b * c ...
-    terms.push_back({5, {{a0, 0}, {a1, 1}}});                     // ... with a rotated operand
-    terms.push_back({7, {{a2, -1}, {a2, 0}}});
-    terms.push_back({1, {{zz, 1}, {a0, 0}, {a1, 0}}});            // permutation: z(omega X) prod(..) - z(X) prod(..)
-    terms.push_back({0xfffffffeull, {{zz, 0}, {a1, 0}, {a2, 0}}});
-    terms.push_back({11, {{lk, 0}, {a0, 0}}});                    // lookup multiplicity term
-    terms.push_back({13, {{0, 0}}});                              // instance column
-    terms.push_back({17, {{zz, 0}, {zz, 0}}});                    // l_last * (z^2 - z)
-    terms.push_back({19, {{zz, 0}}});
-    for (uint32_t i = 1; i < NP && terms.size() < 16; i++) terms.push_back({23 + i, {{i, (int32_t)(i % 3) - 1}, {1 + (i % (NP - 1)), 0}}});
-    std::vector<uint32_t> term_len, fpoly; std::vector<int32_t> frot;
-    for (auto &tm : terms) { term_len.push_back((uint32_t)tm.f.size()); for (auto &pr : tm.f) { fpoly.push_back(pr.first); frot.push_back(pr.second); } }
-    // parts live on the primary here; with several devices part q is computed on device q % D from replicas of the coefficient polynomials
-    const int D = devices > 1 ? std::min<int>(devices, (int)Q) : 1;
-    std::vector<std::vector<DevicePoly>> coeff_on(D), part_on(D);
-    std::vector<DevicePoly> hq_on(D);
-    for (int d = 0; d < D; d++) {
-      part_on[d].resize(NP);
-      for (uint32_t i = 0; i < NP; i++) part_on[d][i] = DevicePoly(n, d);
-      if (d > 0 || devices > 1) { coeff_on[d].resize(NP); for (uint32_t i = 0; i < NP; i++) if (poly[i].slot != d) { coeff_on[d][i] = DevicePoly(n, d); CK(mi355_buf_copy(coeff_on[d][i].p, poly[i].p, n * 32)); } }
-      if (d > 0) hq_on[d] = DevicePoly(n, d);
-    }
-    auto do_parts = [&](int d) {
-      for (uint32_t q = (uint32_t)d; q < Q; q += (uint32_t)D) {
-        Fr factor = dom.g_coset; Fr wq = h2d::fr_pow(dom.extended_omega, q); factor = h2d::fr_mul(factor, wq);
-        std::vector<void *> dst(NP); std::vector<const void *> src(NP);
-        for (uint32_t i = 0; i < NP; i++) { dst[i] = part_on[d][i].p; src[i] = (devices > 1 && poly[i].slot != d) ? coeff_on[d][i].p : poly[i].p; }
-        CK(mi355_coset_ntt_fr_batch_dev(dst.data(), src.data(), NP, k, factor.data(), dom.omega.data()));
-        // 1 / ((zeta omega_ext^q)^n - 1): the vanishing polynomial is constant on a coset part; it rides on the coefficients
-        const Fr tq_inv = h2d::fr_inv(mi355zk::halo2::detail::from_fe(zk::Fr::sub(h2d::to_fe(h2d::fr_pow(factor, n)), zk::Fr::one())));
-        std::vector<Fr> coeffs; for (auto &tm : terms) coeffs.push_back(h2d::fr_mul(h2d::fr_from_u64(tm.c), tq_inv));
-        std::vector<const void *> pp(NP); for (uint32_t i = 0; i < NP; i++) pp[i] = part_on[d][i].p;
-        void *hq = d == 0 ? (void *)((char *)h_ext.p + (size_t)q * n * 32) : hq_on[d].p;
-        CK(mi355_fr_gate_eval_dev(hq, pp.data(), NP, coeffs.data(), term_len.data(), (uint32_t)term_len.size(), fpoly.data(), frot.data(), n, 0));
-        if (d != 0) CK(mi355_buf_copy((char *)h_ext.p + (size_t)q * n * 32, hq, n * 32));
-      }
+  // ---- checks (outside the timing)
+  uint32_t checked = 0; bool semantic_ok = false, trapdoor_ok = false;
+  if (do_check && failures == 0) {
+    // (1) commitments
+    std::map<PolyRef, std::vector<Fr>> host_coeff;
+    auto coeffs_of = [&](const PolyRef &r) -> const std::vector<Fr> & {
+      auto it = host_coeff.find(r);
+      if (it == host_coeff.end()) it = host_coeff.emplace(r, download((r.kind >= P_FIXED && r.kind <= P_L0) ? pk.coeff(r).p : R.coeff.at(r).p, n)).first;
+      return it->second;
     };
-    std::vector<std::thread> th; for (int d = 1; d < D; d++) th.emplace_back(do_parts, d);
-    do_parts(0);
-    for (auto &x : th) x.join();
-    CK(mi355_extended_to_coeff_dev(h_ext.p, k + 2, dom.g_coset.data(), dom.g_coset_inv.data(), dom.extended_omega_inv.data(), dom.extended_ifft_divisor.data()));
-  }
-  lap(7, t);
-  for (uint32_t q = 0; q < Q; q++) {                                                       // step 8
-    CK(mi355_msm_g1_dev(hg, 0, (char *)h_ext.p + (size_t)q * n * 32, n, out.data())); commits.push_back(out); commit_src.push_back(-2 - (int)q);
-  }
-  lap(8, t);
-  {                                                                                         // step 9
-    const Fr x = h2d::fr_from_u64(0x1234567890ABCDEFull);
-    for (uint32_t e = 0; e < L.evals; e++) {
-      const int src = (int)(e % NP);
-      const Fr pt = h2d::fr_mul(x, h2d::fr_pow(dom.omega, e % 3));   // x * omega^rot
-      Fr v; CK(mi355_eval_polynomial_dev(poly[src].p, n, pt.data(), v.data())); evals.push_back(v); eval_src.push_back({src, pt});
-    }
-  }
-  lap(9, t);
-  {                                                                                         // step 10
-    lin = DevicePoly(n, 0);
-    const Fr v = h2d::fr_from_u64(0xABCDEF0123456789ull);
-    Fr pw = h2d::fr_from_u64(1);
-    std::vector<DevicePoly> moved(NP);
-    for (uint32_t base = 0; base < NP; base += 16) {   // sum_i v^i p_i(X): one fused launch per 16 polynomials
-      const uint32_t cnt = std::min<uint32_t>(16, NP - base);
-      std::vector<const void *> pp(cnt); std::vector<Fr> cs(cnt); std::vector<uint32_t> tl(cnt, 1), fp(cnt); std::vector<int32_t> fr(cnt, 0);
-      for (uint32_t i = 0; i < cnt; i++) {
-        const DevicePoly &src = poly[base + i];
-        if (src.slot != 0) { moved[base + i] = DevicePoly(n, 0); CK(mi355_buf_copy(moved[base + i].p, src.p, n * 32)); pp[i] = moved[base + i].p; } else pp[i] = src.p;
-        cs[i] = pw; pw = h2d::fr_mul(pw, v); fp[i] = i;
-      }
-      CK(mi355_fr_gate_eval_dev(lin.p, pp.data(), cnt, cs.data(), tl.data(), cnt, fp.data(), fr.data(), n, base ? 1 : 0));
-    }
-    for (int j = 0; j < 2; j++) {
-      quot[j] = DevicePoly(n, 0);
-      const Fr z = h2d::fr_from_u64(0x1111 + j);
-      CK(mi355_buf_zero(quot[j].p, n * 32));
-      CK(mi355_fr_kate_division_dev(quot[j].p, lin.p, n, z.data()));   // n - 1 coefficients, the top one stays zero
-      CK(mi355_msm_g1_dev(hg, 0, quot[j].p, n, out.data())); commits.push_back(out); commit_src.push_back(-10 - j);
-    }
-  }
-  CK(mi355_synchronize());
-  lap(10, t);
-  const double resident_ms = ms_since(t_start);
-
-  // ---- checks (outside the timing): every commitment == p(tau) G, every evaluation == Horner
-  uint32_t checked = 0;
-  if (check && failures == 0) {
-    std::vector<std::vector<Fr>> coeff_host(NP);
     std::vector<Fr> scratch;
-    auto coeffs_of = [&](int src) -> const std::vector<Fr> & {
-      if (src >= 0) { if (coeff_host[src].empty()) coeff_host[src] = poly[src].to_host(); return coeff_host[src]; }
-      if (src == -1) scratch = random_poly.to_host();
-      else if (src <= -10) scratch = quot[-10 - src].to_host();
-      else { scratch.resize(n); CK(mi355_buf_download(scratch.data(), (char *)h_ext.p + (size_t)(-2 - src) * n * 32, n * 32)); }
-      return scratch;
-    };
-    for (size_t c = 0; c < commits.size(); c++) {
-      const auto &cf = coeffs_of(commit_src[c]);
-      const bool ok = commit_matches(commits[c], field_commit(cf, tau, threads));
-      if (!ok) std::printf("commitment %zu (source %d) != p(tau) G\n", c, commit_src[c]);
+    for (size_t c = 0; c < R.commitments.size(); c++) {
+      const CommitRecord &cr = R.commitments[c];
+      const std::vector<Fr> *cf;
+      if (cr.p.kind != P_KINDS) cf = &coeffs_of(cr.p);
+      else if (cr.piece >= 0) { scratch = download(R.h.at((uint64_t)cr.piece * n), n); cf = &scratch; }
+      else { scratch = download(R.quot[-1 - cr.piece].p, n); cf = &scratch; }
+      const bool ok = commit_matches(cr.c, field_commit(*cf, tau, threads));
+      if (!ok) std::printf("commitment %zu (%s %u, piece %d) != p(tau) G\n", c, kind_name(cr.p.kind), cr.p.idx, cr.piece);
       EXPECT(ok); checked++;
+      if (cr.p.kind != P_KINDS && S.k >= 24 && S.advice + S.perm_z() > 24) host_coeff.erase(cr.p);   // wide AND big: do not keep every column on the host
     }
-    for (size_t e = 0; e < evals.size(); e++) {
-      const auto &cf = coeff_host[eval_src[e].first].empty() ? (coeff_host[eval_src[e].first] = poly[eval_src[e].first].to_host()) : coeff_host[eval_src[e].first];
-      Fr want; orc_eval_polynomial_mt(want.data(), cf.data(), n, eval_src[e].second.data(), threads);
-      EXPECT(want == evals[e]); checked++;
+    // (2) evaluations
+    std::map<Query, Fr> ev;
+    for (size_t e = 0; e < plan.queries.size(); e++) {
+      const Query &qr = plan.queries[e];
+      const Fr want = o_eval(coeffs_of(qr.p), rot_point(dom, ch.x, qr.rot), threads);
+      const bool ok = want == R.evals[e];
+      if (!ok) std::printf("evaluation %zu (%s %u, rotation %d) differs from Horner\n", e, kind_name(qr.p.kind), qr.p.idx, qr.rot);
+      EXPECT(ok); checked++; ev[qr] = R.evals[e];
+    }
+    Fr hx = h2d::fr_zero();
+    {
+      const Fr xn = o_pow(ch.x, n); Fr xq = h2d::fr_one();
+      for (uint32_t q = 0; q < Q; q++) {
+        scratch = download(R.h.at((uint64_t)q * n), n);
+        const Fr want = o_eval(scratch, ch.x, threads);
+        EXPECT(want == R.evals[plan.queries.size() + q]); checked++;
+        hx = o_add(hx, o_mul(xq, R.evals[plan.queries.size() + q])); xq = o_mul(xq, xn);
+      }
+    }
+    // (3) h(x) (x^n - 1) == sum_g y^g gate_g(x), from the evaluations through the plan
+    {
+      const std::vector<Fr> la = download(pk.l_active_coeff.p, n), l0 = download(pk.l0_coeff.p, n), inst = download(R.coeff.at({P_INSTANCE, 0}).p, n);
+      std::map<uint32_t, Fr> tmp;
+      auto value = [&](const Factor &f) -> Fr {
+        switch (f.p.kind) {
+          case P_TMP: return tmp.at(f.p.idx);
+          case P_ID: return rot_point(dom, ch.x, f.rot);
+          case P_LACTIVE: return o_eval(la, rot_point(dom, ch.x, f.rot), threads);
+          case P_L0: return o_eval(l0, rot_point(dom, ch.x, f.rot), threads);
+          case P_INSTANCE: return o_eval(inst, rot_point(dom, ch.x, f.rot), threads);
+          default: return ev.at({f.p, f.rot});
+        }
+      };
+      Fr N = h2d::fr_zero();
+      for (const auto &L : plan.quotient) {
+        Fr acc = h2d::fr_zero();
+        for (const auto &t : L.terms) { Fr v = t.coeff; for (const auto &f : t.f) v = o_mul(v, value(f)); acc = o_add(acc, v); }
+        if (L.to_tmp) tmp[L.tmp] = acc; else N = o_add(N, acc);
+      }
+      const Fr t_x = o_sub(o_pow(ch.x, n), h2d::fr_one());
+      semantic_ok = o_mul(hx, t_x) == N;
+      if (!semantic_ok) std::printf("SEMANTIC CHECK FAILED: h(x) (x^n - 1) != sum_g y^g gate_g(x)\n");
+      EXPECT(semantic_ok); checked++;
+    }
+    // (4) the multi-open quotients with the trapdoor, in the group
+    {
+      G1 c_lin; CK(mi355_msm_g1_dev(hg, 0, R.lin.p, n, c_lin.data()));
+      const std::vector<Fr> lin = download(R.lin.p, n);
+      EXPECT(commit_matches(c_lin, field_commit(lin, tau, threads)));
+      G1Affine gen; orc_g1_generator(gen.data());
+      trapdoor_ok = true;
+      for (int j = 0; j < 2; j++) {
+        const Fr z = j ? ch.z1 : ch.z0;
+        Fr lz; CK(mi355_eval_polynomial_dev(R.lin.p, n, z.data(), lz.data()));
+        EXPECT(lz == o_eval(lin, z, threads));
+        const G1 &cq = R.commitments[R.commitments.size() - 2 + j].c;
+        G1Affine lhs{}, rhs{};
+        if (!is_identity(cq)) { G1Affine cqa; std::memcpy(cqa.data(), cq.data(), 64); G1 t; const Fr d = o_sub(tau, z); orc_g1_mul(t.data(), cqa.data(), d.data()); orc_g1_to_affine(lhs.data(), t.data()); }
+        { G1 t; const Fr m = o_neg(lz); orc_g1_mul(t.data(), gen.data(), m.data()); if (!is_identity(c_lin)) { G1Affine cl; std::memcpy(cl.data(), c_lin.data(), 64); orc_g1_add_affine(t.data(), t.data(), cl.data()); } orc_g1_to_affine(rhs.data(), t.data()); }
+        const bool ok = lhs == rhs;
+        if (!ok) std::printf("TRAPDOOR CHECK FAILED for multi-open quotient %d\n", j);
+        trapdoor_ok = trapdoor_ok && ok; EXPECT(ok); checked++;
+      }
     }
   }
-  // ---- the same MSM / NTT / evaluation calls through the host-pointer entry points (what a shim without DevicePoly pays)
+  // ---- the same MSM / NTT / evaluation counts through the host-pointer entry points (what a shim without DevicePoly pays)
   double host_ms = -1, host_fft_ms = -1, host_fft_batched_ms = -1;
+  const uint32_t n_commit_lag = S.advice + 2 * S.lookups + S.perm_z(), n_commit_coef = Q + 2;
   if (host_api && failures == 0) {
-    std::vector<Fr> hp = host_cols[1]; std::vector<Fr> hext(Q * n);
-    const uint32_t n_lag = W - 1 + L.products, n_coef = 1 + Q + 2, n_intt = NP, n_ntt = NP * Q;
+    std::vector<Fr> hp = wit.advice[0]; std::vector<Fr> hext(Q * n); G1 out; std::vector<std::vector<Fr>> cols(std::min<uint32_t>(8, NPW), wit.advice[0]);
+    const uint32_t n_intt = NPW, n_ntt = NPW * Q, n_ev = (uint32_t)plan.queries.size() + Q;
     const auto t1 = Clock::now();
-    for (uint32_t i = 0; i < n_lag; i++) CK(mi355_msm_g1_host(hl, 0, hp.data(), n, out.data()));
-    for (uint32_t i = 0; i < n_coef; i++) CK(mi355_msm_g1_host(hg, 0, hp.data(), n, out.data()));
+    for (uint32_t i = 0; i < n_commit_lag; i++) CK(mi355_msm_g1_host(hl, 0, hp.data(), n, out.data()));
+    for (uint32_t i = 0; i < n_commit_coef; i++) CK(mi355_msm_g1_host(hg, 0, hp.data(), n, out.data()));
     const auto t2 = Clock::now();
     for (uint32_t i = 0; i < n_intt; i++) CK(mi355_intt_fr_host(hp.data(), k, dom.omega_inv.data(), dom.ifft_divisor.data()));
     for (uint32_t i = 0; i < n_ntt; i++) CK(mi355_ntt_fr_host(hp.data(), k, dom.omega.data()));
     host_fft_ms = ms_since(t2);
-    CK(mi355_extended_to_coeff_host(hext.data(), k + 2, dom.g_coset.data(), dom.g_coset_inv.data(), dom.extended_omega_inv.data(), dom.extended_ifft_divisor.data()));
-    Fr e; for (uint32_t i = 0; i < L.evals; i++) CK(mi355_eval_polynomial_host(hp.data(), n, tau.data(), e.data()));
+    CK(mi355_extended_to_coeff_host(hext.data(), dom.extended_k, dom.g_coset.data(), dom.g_coset_inv.data(), dom.extended_omega_inv.data(), dom.extended_ifft_divisor.data()));
+    Fr e; for (uint32_t i = 0; i < n_ev; i++) CK(mi355_eval_polynomial_host(hp.data(), n, tau.data(), e.data()));
     host_ms = ms_since(t1);
-    // the same transforms as column loops through the batch entry point (upload | transform | download overlapped inside the library)
-    const uint32_t B = std::min<uint32_t>(8, W);
-    std::vector<void *> ptrs(B); for (uint32_t i = 0; i < B; i++) ptrs[i] = host_cols[i].data();
+    const uint32_t B = (uint32_t)cols.size();
+    std::vector<void *> ptrs(B); for (uint32_t i = 0; i < B; i++) ptrs[i] = cols[i].data();
     const auto t3 = Clock::now();
     for (uint32_t done = 0; done < n_intt; done += B) CK(mi355_ntt_fr_batch_host(ptrs.data(), std::min(B, n_intt - done), k, dom.omega_inv.data(), dom.ifft_divisor.data()));
     for (uint32_t done = 0; done < n_ntt; done += B) CK(mi355_ntt_fr_batch_host(ptrs.data(), std::min(B, n_ntt - done), k, dom.omega.data(), nullptr));
     host_fft_batched_ms = ms_since(t3);
   }
-  std::printf("{\"replay\": \"create_proof steps 1-10 through the C-ABI, polynomials resident (mi355_buf_*)\", \"layer\": %d, \"k\": %u, \"devices\": %d, \"window_tables\": %s, "
-              "\"msm\": %zu, \"intt\": %u, \"coset_ntt\": %u, \"evals\": %zu, \"resident_ms\": %.3f, \"host_api_ms\": %.3f, \"host_api_fft_ms\": %.3f, \"host_api_fft_batched_ms\": %.3f, "
-              "\"step_ms\": {\"1_instance\": %.2f, \"2_3_advice_lookup_commits\": %.2f, \"4_products\": %.2f, \"5_random\": %.2f, \"6_to_coeff\": %.2f, \"7_quotient\": %.2f, \"8_commit_h\": %.2f, \"9_evals\": %.2f, \"10_shplonk\": %.2f}, "
-              "\"checked\": %u, \"ok\": %s}\n",
-              layer_id, k, devices, tables ? "true" : "false", commits.size(), NP, NP * Q, evals.size(), resident_ms, host_ms, host_fft_ms, host_fft_batched_ms,
-              step_ms[1], step_ms[2], step_ms[4], step_ms[5], step_ms[6], step_ms[7], step_ms[8], step_ms[9], step_ms[10], checked, failures == 0 ? "true" : "false");
-  poly.clear(); random_poly.release(); h_ext.release(); lin.release(); quot[0].release(); quot[1].release();
+  std::printf("{\"replay\": \"create_proof_gpu_side (include/mi355zk_create_proof.hpp): steps 1-10 through the C-ABI, polynomials and proving-key cosets resident\", \"layer\": %d, \"k\": %u, \"devices\": %d, "
+              "\"shape\": {\"advice\": %u, \"fixed\": %u, \"lookups\": %u, \"perm_columns\": %u, \"chunk_len\": %u, \"perm_z\": %u, \"degree\": %u, \"quotient_pieces\": %u, \"source\": \"%s\"}, "
+              "\"window_tables\": %s, \"window_table_bases\": %d, \"pk_cosets\": \"%s\", "
+              "\"msm\": %zu, \"intt\": %u, \"coset_ntt\": %u, \"gate_launches\": %u, \"gates\": %u, \"gate_terms\": %u, \"evals\": %zu, \"resident_ms\": %.3f, \"first_proof_ms\": %.3f, \"proofs\": %d, "
+              "\"host_api_ms\": %.3f, \"host_api_fft_ms\": %.3f, \"host_api_fft_batched_ms\": %.3f, "
+              "\"step_ms\": {\"1_instance\": %.2f, \"2_3_advice_lookup_commits\": %.2f, \"4_products\": %.2f, \"5_random\": 0.0, \"6_to_coeff\": %.2f, \"7_quotient\": %.2f, \"8_commit_h\": %.2f, \"9_evals\": %.2f, \"10_shplonk\": %.2f}, "
+              "\"hbm\": {\"total_gib\": %.1f, \"peak_used_gib\": %.1f, \"proving_key_gib\": %.1f, \"live_buffers_gib\": %.1f, \"pooled_gib\": %.1f, \"workspace_gib\": %.1f, \"planned\": {\"pk_base_gib\": %.1f, \"pk_cosets_gib\": %.1f, \"working_set_gib\": %.1f, \"one_table_gib\": %.1f, \"usable_gib\": %.1f}}, "
+              "\"checked\": %u, \"semantic_check\": %s, \"trapdoor_check\": %s, \"ok\": %s}\n",
+              layer_id, k, devices, S.advice, S.fixed, S.lookups, S.perm_columns, S.chunk_len, S.perm_z(), S.degree, Q, S.source,
+              n_tables ? "true" : "false", n_tables, resident ? "resident" : "on-the-fly",
+              R.commitments.size(), R.intt, R.coset_ntt, R.gate_launches, plan.gates, plan.terms, R.evals.size(), R.total_ms, first_ms, proofs,
+              host_ms, host_fft_ms, host_fft_batched_ms,
+              R.step_ms[1], R.step_ms[2], R.step_ms[4], R.step_ms[6], R.step_ms[7], R.step_ms[8], R.step_ms[9], R.step_ms[10],
+              hbm_total / GiB, (hbm_total - fr_end) / GiB, pk.bytes / GiB, live / GiB, pooled / GiB, ws / GiB, pk_base / GiB, pk_cosets / GiB, working / GiB, table_one / GiB, usable / GiB,
+              checked, semantic_ok ? "true" : "false", trapdoor_ok ? "true" : "false", failures == 0 ? "true" : "false");
+  R = ProofGpuSide(); pk = ProvingKeyDevice();
   CK(mi355_srs_release(hg)); CK(mi355_srs_release(hl));
+  } catch (const std::exception &e) { std::printf("FAILED with exception: %s\n", e.what()); failures++; rc_main = 1; }
   CK(mi355_shutdown());
   if (failures) { std::printf("%d check(s) FAILED\n", failures); return 1; }
   std::printf("all checks passed\n");
-  return 0;
+  return rc_main;
 }

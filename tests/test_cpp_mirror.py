@@ -67,20 +67,31 @@ def test_create_proof_replay_compiles_and_fails_loudly_without_a_gpu():
     (["--layer", "4", "--k", "13"], {}),
     (["--layer", "2", "--k", "12", "--host-api"], {}),
     (["--layer", "1", "--k", "10", "--no-tables"], {}),
+    (["--layer", "6", "--k", "11", "--pk-cosets", "on-the-fly"], {}),
+    (["--layer", "3", "--k", "9", "--tables", "lagrange"], {}),
+    (["--layer", "5", "--k", "10"], {}),
+    (["--layer", "0", "--k", "9", "--advice", "70", "--fixed", "9", "--lookups", "6", "--perm", "20"], {}),
+    (["--layer", "0", "--k", "8", "--advice", "12", "--fixed", "3", "--lookups", "2", "--perm", "7", "--chunk", "3", "--degree", "5", "--proofs", "3"], {}),
     (["--layer", "4", "--k", "12", "--devices", "2"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "8"}),
-    (["--layer", "2", "--k", "11", "--devices", "3"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "6"}),
+    (["--layer", "2", "--k", "11", "--devices", "3", "--pk-cosets", "on-the-fly"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "6"}),
 ])
 def test_create_proof_replay_on_gpu(args, env):
-    """SURVEY 3.2 steps 1-10 for the layer-4 / layer-2 / layer-1 counts at test sizes, polynomials resident, every commitment checked against
-    p(tau) G and every evaluation against Horner (oracle); two and three device slots: columns live round-robin on the devices, coset parts
-    are computed on different devices by different host threads, commitments take scalars from whichever device holds them."""
+    """create_proof_gpu_side (include/mi355zk_create_proof.hpp) for the counts of all seven layers at test sizes: polynomials
+    and proving-key cosets resident (or recomputed per part), every commitment checked against p(tau) G, every evaluation against Horner, the
+    quotient SEMANTICALLY (h(x) (x^n - 1) == sum_g y^g gate_g(x) from the evaluations) and both multi-open quotients with the trapdoor; two and
+    three device slots: coset parts are computed on different devices by different host threads."""
     import json
     exe = build_exe("test_create_proof_replay")
     e = dict(os.environ); e.update(env)
-    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=e)
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=e)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed" in out.stdout
     line = next(l for l in out.stdout.splitlines() if l.startswith("{"))
     rec = json.loads(line)
-    counts = {4: (14, 27), 2: (11, 17), 1: (28, 60)}[rec["layer"]]
-    assert rec["ok"] and rec["msm"] == counts[0] and rec["evals"] == counts[1] and rec["checked"] == counts[0] + counts[1], rec
+    sh = rec["shape"]
+    msm = sh["advice"] + 2 * sh["lookups"] + sh["perm_z"] + sh["quotient_pieces"] + 2
+    assert rec["ok"] and rec["semantic_check"] and rec["trapdoor_check"], rec
+    assert rec["msm"] == msm and rec["checked"] == msm + rec["evals"] + 1 + 2, rec
+    if rec["layer"] in (2, 4) and "--k" in args and len(args) <= 5:
+        assert rec["msm"] == {4: 14, 2: 11}[rec["layer"]]          # the fixtures' proof word counts (SURVEY 3.3)
+    assert rec["coset_ntt"] >= (1 + sh["advice"] + 2 * sh["lookups"] + sh["perm_z"]) * sh["quotient_pieces"]
