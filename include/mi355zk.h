@@ -236,6 +236,9 @@ int mi355_fr_prefix_sum_dev(void *dst_dev, const void *src_dev, uint64_t n, void
 /* ---- halo2_proofs::arithmetic::eval_polynomial(poly, point) = sum_i poly[i] * point^i  (the evaluations written to the
  *      transcript in step 9 of create_proof); out_fr_host receives 32 B.  First widening into SURVEY 8f-3.   */
 int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *point, void *out_fr_host);
+/* `batch` evaluations with one device synchronisation (step 9 of create_proof: every queried (polynomial, rotation) pair): polys_dev[i] has n
+ * coefficients, points = batch x 32 B (Montgomery), out_fr_host = batch x 32 B.  Same values as `batch` calls of mi355_eval_polynomial_dev.      */
+int mi355_eval_polynomial_batch_dev(const void *const *polys_dev, uint32_t batch, uint64_t n, const void *points, void *out_fr_host);
 int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *point, void *out_fr_host);
 
 /* ---- synthetic SRS: ParamsKZG::setup(k, rng) restated on the device [poly/kzg/commitment.rs]:

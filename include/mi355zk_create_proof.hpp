@@ -497,12 +497,17 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
   for (uint32_t q = 0; q < Q; q++) commit_one(h_g, R.h, {P_KINDS, 0}, (int)q, R.h.at((uint64_t)q * n));   // step 8
   lap(8);
   auto coeff_of = [&](const PolyRef &r) -> const DevicePoly & { return (r.kind >= P_FIXED && r.kind <= P_L0) ? pk.coeff(r) : poly.at(r); };
-  for (const auto &qr : plan.queries) {                                                 // step 9
-    Fr pt = ch.x;
-    if (qr.rot > 0) pt = fr_mul(pt, fr_pow(dom.omega, (uint64_t)qr.rot)); else if (qr.rot < 0) pt = fr_mul(pt, fr_pow(dom.omega_inv, (uint64_t)(-(int64_t)qr.rot)));
-    R.evals.push_back(coeff_of(qr.p).eval(pt));
+  {                                                                                     // step 9: every queried (polynomial, rotation), one synchronisation
+    std::vector<const void *> ptrs; std::vector<Fr> pts;
+    for (const auto &qr : plan.queries) {
+      Fr pt = ch.x;
+      if (qr.rot > 0) pt = fr_mul(pt, fr_pow(dom.omega, (uint64_t)qr.rot)); else if (qr.rot < 0) pt = fr_mul(pt, fr_pow(dom.omega_inv, (uint64_t)(-(int64_t)qr.rot)));
+      ptrs.push_back(coeff_of(qr.p).p); pts.push_back(pt);
+    }
+    for (uint32_t q = 0; q < Q; q++) { ptrs.push_back(R.h.at((uint64_t)q * n)); pts.push_back(ch.x); }
+    R.evals.resize(ptrs.size());
+    check(mi355_eval_polynomial_batch_dev(ptrs.data(), (uint32_t)ptrs.size(), n, pts.data(), R.evals.data()));
   }
-  for (uint32_t q = 0; q < Q; q++) { Fr v; check(mi355_eval_polynomial_dev(R.h.at((uint64_t)q * n), n, ch.x.data(), v.data())); R.evals.push_back(v); }
   lap(9);
   {                                                                                     // step 10
     R.lin = DevicePoly(n, 0);

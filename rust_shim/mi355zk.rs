@@ -81,6 +81,7 @@ extern "C" {
     pub fn mi355_fr_prefix_product_dev(dst_dev: *mut c_void, src_dev: *const c_void, n: u64, total_out_host: *mut c_void) -> c_int;
     pub fn mi355_fr_prefix_sum_dev(dst_dev: *mut c_void, src_dev: *const c_void, n: u64, total_out_host: *mut c_void) -> c_int;
     pub fn mi355_fr_kate_division_dev(dst_dev: *mut c_void, poly_dev: *const c_void, n: u64, z: *const c_void) -> c_int;
+    pub fn mi355_eval_polynomial_batch_dev(polys_dev: *const *const c_void, batch: u32, n: u64, points: *const c_void, out_fr_host: *mut c_void) -> c_int;
     pub fn mi355_eval_polynomial_dev(poly_dev: *const c_void, n: u64, point: *const c_void, out_fr_host: *mut c_void) -> c_int;
 }
 

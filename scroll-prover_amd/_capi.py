@@ -81,6 +81,7 @@ SIGNATURES = {
     "mi355_fr_prefix_product_dev": (_int, [_vp, _vp, _u64, _vp]),
     "mi355_fr_prefix_sum_dev": (_int, [_vp, _vp, _u64, _vp]),
     "mi355_eval_polynomial_dev": (_int, [_vp, _u64, _vp, _vp]),
+    "mi355_eval_polynomial_batch_dev": (_int, [C.POINTER(_vp), _u32, _u64, _vp, _vp]),
     "mi355_eval_polynomial_host": (_int, [_vp, _u64, _vp, _vp]),
     "mi355_srs_setup_dev": (_int, [_vp, _vp, _u32, _vp, _vp]),
     "mi355_g1_fixed_base_mul_dev": (_int, [_vp, _vp, _u64]),

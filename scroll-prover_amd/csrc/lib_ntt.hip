@@ -609,6 +609,44 @@ int mi355_eval_polynomial_dev(const void *poly_dev, uint64_t n, const void *poin
   return eval_polynomial_locked(poly_dev, n, point, out_fr_host);
   });
 }
+// `batch` x eval_polynomial with ONE device synchronisation: step 9 of create_proof evaluates every queried (polynomial, rotation) pair -- dozens
+// for a compression layer, thousands for the k = 20 inner circuit -- and a copy-back + stream synchronisation per value (~100 us) would cost more than
+// the evaluations.  polys_dev[i] has n coefficients, points holds batch x 32 bytes, out_fr_host receives batch x 32 bytes.  All on one device.
+int mi355_eval_polynomial_batch_dev(const void *const *polys_dev, uint32_t batch, uint64_t n, const void *points, void *out_fr_host) {
+  return guarded([&]() -> int {
+  if (batch == 0) return MI355_OK;
+  if (!polys_dev || !points || !out_fr_host) return fail(MI355_EBADARG, "eval_polynomial_batch: null pointer");
+  int slot = -1;
+  for (uint32_t i = 0; i < batch; i++) {
+    if (n && !polys_dev[i]) return fail(MI355_EBADARG, "eval_polynomial_batch: null polynomial pointer");
+    const int s = slot_of(polys_dev[i]);
+    if (slot < 0) slot = s; else if (s != slot && g_ctx[s].device != g_ctx[slot].device) return fail(MI355_EBADARG, "eval_polynomial_batch: the polynomials live on different devices");
+  }
+  DevGuard lk(slot);
+  CHK(need_init(slot));
+  if (n == 0) { memset(out_fr_host, 0, (size_t)batch * 32); return MI355_OK; }
+  const uint32_t blocks = ceil_div(n, (uint64_t)EVAL_RUN * 256);
+  const size_t stride = (size_t)blocks + 1;
+  // chunks of at most 256 evaluations share one scratch area and one copy-back
+  const uint32_t CH = 256;
+  fe_t *partial; CHK(ws_get("eval.partial", stride * std::min(batch, CH) * sizeof(fe_t), (void **)&partial));
+  fe_t *res; CHK(ws_get("eval.results", (size_t)std::min(batch, CH) * sizeof(fe_t), (void **)&res));
+  for (uint32_t base = 0; base < batch; base += CH) {
+    const uint32_t cnt = std::min(CH, batch - base);
+    Scope sc("eval_poly");
+    for (uint32_t i = 0; i < cnt; i++) {
+      fe_t x; memcpy(&x, (const char *)points + 32 * (size_t)(base + i), 32);
+      hipLaunchKernelGGL(k_eval_poly_partial, dim3(blocks), dim3(256), 0, g.stream, (const fe_t *)polys_dev[base + i], n, x, partial + stride * i);
+      hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, g.stream, partial + stride * i, (uint64_t)blocks, res + i);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync((char *)out_fr_host + 32 * (size_t)base, res, (size_t)cnt * sizeof(fe_t), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+  }
+  resolve_spans();
+  return MI355_OK;
+  });
+}
 int mi355_eval_polynomial_host(const void *poly_host, uint64_t n, const void *point, void *out_fr_host) {
   return guarded([&]() -> int {
   const int slot = pick_replica_slot(); DevGuard lk(slot);   // host-pointer calls may run on any bound device (replicas): callers on different threads land on different devices

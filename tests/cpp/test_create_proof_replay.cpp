@@ -127,22 +127,28 @@ int main(int argc, char **argv) {
   const double per = (double)n * 32, GiB = 1024.0 * 1024 * 1024;
   const uint32_t npk = S.fixed + S.perm_columns + 3, NPW = S.witness_polys();
   const double pk_base = per * (S.fixed * 2 + S.perm_columns * 2 + 4), pk_cosets = per * npk * Q, pk_lean_tmp = per * npk;
-  const double working = per * (2.0 * NPW + 2 * S.chunk_len + 2 * Q + 3 + (2 * S.chunk_len + 2) + 1) + per * Q + per   // polynomials, parts, temporaries, h parts + h, lin + quotients, NTT scratch
-                         + (double)n * 13 * 22 + 0.3 * GiB;                                                              // MSM workspace (digit plane, two record streams, sorted stream; ~22 B per entry, up to 13 windows) + fixed overheads
+  // a proof's own blocks: coefficients + one part of every witness polynomial, the permutation temporaries, h as parts and as one vector, the opened
+  // combination and its two quotients (the step-4 temporaries are pooled and reused by the parts); the NTT scratch of the 2^(k + e) inverse;
+  // the MSM workspace (digit plane, two record streams, sorted stream: ~22 B per entry, up to 13 windows); fixed overheads
+  const double working = per * (2.0 * NPW + 2 * S.chunk_len + 2 * Q + 3) + per * Q + per + (double)n * 13 * 22 + 0.5 * GiB;
   const double table_one = (double)n * 64 * (k >= 24 ? 12 : 15);
   const double usable = 0.94 * (double)hbm_free;   // what is free after the SRS registration, minus allocator slack
   bool resident = true; int n_tables = 0;
   if (pk_mode == "on-the-fly") resident = false;
   else if (pk_mode == "auto" && pk_base + pk_cosets + working > usable) resident = false;
-  const double fixed_need = pk_base + (resident ? pk_cosets : pk_lean_tmp) + working;
-  if (tables == "on") n_tables = 2; else if (tables == "lagrange") n_tables = 1; else if (tables == "off") n_tables = 0;
-  else n_tables = fixed_need + 2 * table_one <= usable ? 2 : fixed_need + table_one <= usable ? 1 : 0;
-  if (devices > 1 && tables == "auto") n_tables = 2;   // the estimate above is for one device; shards divide everything
-  if (n_tables >= 1) check(mi355_srs_precompute(hl, 0, 0));   // commit_lagrange carries most commitments: its basis first
-  if (n_tables >= 2) check(mi355_srs_precompute(hg, 0, 0));
   // ---- keygen (device side) and the witness (host side, as create_proof receives it)
   ProvingKeyDevice pk = keygen_device(S, dom, 0xC0FFEE + layer_id, resident, devices, threads);
   Witness wit = synthesize_witness(S, dom, pk, 9000 + layer_id, threads);
+  check(mi355_buf_trim());
+  // window tables (W x a basis) only where they fit next to the proving key that is now resident and the working set of a proof: the measured
+  // free memory decides, the Lagrange basis first (commit_lagrange carries most commitments); otherwise the table-free schedule (+ ~8 % per MSM)
+  uint64_t free_after_pk = 0; check(mi355_mem_info(0, &free_after_pk, nullptr, nullptr, nullptr, nullptr));
+  const double room = 0.97 * (double)free_after_pk - working - (resident ? 0.0 : pk_lean_tmp);
+  if (tables == "on") n_tables = 2; else if (tables == "lagrange") n_tables = 1; else if (tables == "off") n_tables = 0;
+  else n_tables = room >= 2 * table_one ? 2 : room >= table_one ? 1 : 0;
+  if (devices > 1 && tables == "auto") n_tables = 2;   // the estimate above is for one device; shards divide everything
+  if (n_tables >= 1 && mi355_srs_precompute(hl, 0, 0) != MI355_OK) { std::printf("window tables for g_lagrange did not fit (%s): table-free schedule\n", mi355_last_error()); n_tables = 0; }
+  if (n_tables >= 2 && mi355_srs_precompute(hg, 0, 0) != MI355_OK) { std::printf("window tables for g did not fit (%s): Lagrange basis only\n", mi355_last_error()); n_tables = 1; }
   Challenges ch;
   ch.theta = h2d::fr_from_u64(0x7468657461ull); ch.beta = h2d::fr_from_u64(0xBE7A0000BE7A0001ull); ch.gamma = h2d::fr_from_u64(0x6A6D6D6100000003ull);
   ch.y = h2d::fr_from_u64(0x7900000000000005ull); ch.x = h2d::fr_from_u64(0x1234567890ABCDEFull); ch.v = h2d::fr_from_u64(0xABCDEF0123456789ull);

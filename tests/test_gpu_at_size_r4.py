@@ -229,3 +229,24 @@ def test_coset_and_plain_batches_on_resident_buffers_2_22(zk):
     for b, hsrc in zip(bufs, hosts[1:]):
         assert (as_host(b, n) == hsrc).all()
     torch.cuda.empty_cache()
+
+
+def test_eval_polynomial_batch_equals_single_calls_and_oracle(zk):
+    """mi355_eval_polynomial_batch_dev (step 9 of create_proof with one synchronisation): 300 evaluations (two scratch chunks) over 7 polynomials of
+    2^18 + a ragged tail check at n = 1000, against single calls and the oracle's Horner"""
+    h2 = zk.halo2
+    lib, capi = zk._capi.lib(), zk._capi
+    for n in (1 << 18, 1000):
+        polys = [dev_scalars(n, 1800 + i) for i in range(7)]
+        hosts = [as_host(p, n) for p in polys]
+        rng = np.random.default_rng(18)
+        B = 300 if n > 1000 else 9
+        which = [int(rng.integers(0, 7)) for _ in range(B)]
+        pts = np.ascontiguousarray(np.stack([h2.fr(int(rng.integers(1, 1 << 62)) * 0x9E3779B97F4A7C15 % R) for _ in range(B)]))
+        out = np.zeros((B, 4), dtype=np.uint64)
+        arr = (C.c_void_p * B)(*[polys[w].data_ptr() for w in which])
+        capi.check(lib.mi355_eval_polynomial_batch_dev(arr, B, n, capi.ptr(pts), capi.ptr(out)))
+        for i in range(0, B, 37):
+            assert (out[i] == h2.eval_polynomial(polys[which[i]], pts[i])).all()
+            assert (out[i] == cref.eval_polynomial(hosts[which[i]], pts[i])).all()
+    capi.check(lib.mi355_eval_polynomial_batch_dev(None, 0, 0, None, None))
