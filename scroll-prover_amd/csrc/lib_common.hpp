@@ -116,6 +116,7 @@ struct Ctx {
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
   uint32_t ntt_direct2_max_log = 25;   // MI355_NTT_DIRECT2_MAX_LOG: levels up to 2^this elements read their inter-level twiddles from a full table (36 B per element of the level: 2^24 transform 2.41 -> 2.28 ms for 0.6 GB; at 2^26 the 2.4 GB table only buys 1.7 %, so the default stops at 2^25); 0 disables
   uint32_t ntt_fold_scale = 1;  // MI355_NTT_FOLD_SCALE=0: the inverse transform's divisor stays a multiplication in the closing pass
+  uint32_t ntt_two_level_max_log = 18;   // MI355_NTT_TWO_LEVEL_MAX_LOG (18..20): transforms up to 2^this run as two passes instead of three
   uint32_t ntt_radix_log = 2;   // MI355_NTT_RADIX_LOG
   uint32_t ntt_tile_log = 11;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
   bool ntt29 = true;   // unsaturated 29-bit NTT kernels (MI355_NTT_SAT=1 selects the saturated 8x32 ones for A/B runs)
@@ -203,7 +204,19 @@ inline uint32_t log2_ceil(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) 
 
 // No exception may cross the C boundary (the Rust callers are `extern "C"` and would abort): every multi-line entry point runs inside
 // this guard, which turns allocation failures and anything else the host-side C++ might throw into error codes.
-template <class F> int guarded(F body) {
+// MI355_TRACE=2: every entry point runs inside a roctx range named after it ("wrap every FFI call in a roctx range"), so a
+// rocprofv3 --marker-trace timeline of a real proof shows which create_proof call each kernel belongs to.  The marker library
+// (librocprofiler-sdk-roctx.so.1, else libroctx64.so.4) is dlopen()ed on first use; without it, or with MI355_TRACE != 2, this costs one load.
+struct Roctx { int state = 0; int (*push)(const char *) = nullptr; int (*pop)() = nullptr; };
+extern Roctx g_roctx;
+void roctx_bind();
+struct ApiRange {
+  bool on;
+  explicit ApiRange(const char *name) : on(false) { if (g_roctx.state == 0) roctx_bind(); if (g_roctx.state == 2) { g_roctx.push(name); on = true; } }
+  ~ApiRange() { if (on) g_roctx.pop(); }
+};
+template <class F> int guarded(F body, const char *who = __builtin_FUNCTION()) {
+  ApiRange range(who);
   try { return body(); }
   catch (const std::bad_alloc &) { return fail(MI355_EOOM, "host allocation failed"); }
   catch (const std::exception &e) { return fail(MI355_EHIP, std::string("unexpected host exception: ") + e.what()); }

@@ -95,6 +95,18 @@ void resolve_spans() {
   g.spans.clear();
 }
 
+Roctx g_roctx;
+void roctx_bind() {   // state 1: off (default, or the library is absent), 2: ranges on
+  static std::mutex mu; std::lock_guard<std::mutex> lk(mu);
+  if (g_roctx.state != 0) return;
+  const char *e = getenv("MI355_TRACE");
+  if (!(e && e[0] == '2')) { g_roctx.state = 1; return; }
+  void *h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+  if (h) { g_roctx.push = (int (*)(const char *))dlsym(h, "roctxRangePushA"); g_roctx.pop = (int (*)())dlsym(h, "roctxRangePop"); }
+  if (!h || !g_roctx.push || !g_roctx.pop) { fprintf(stderr, "[mi355zk] MI355_TRACE=2: no roctx library found, ranges stay off\n"); g_roctx.state = 1; return; }
+  g_roctx.state = 2;
+}
 int rccl_fail(const char *what, int rc) { return fail(MI355_ERCCL, std::string(what) + " failed: " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?")); }
 // librccl.so.1 is dlopen()ed by mi355_init_multi only when it needs a communicator, so single-device users (and the CPU-only symbol checks)
 // carry no RCCL dependency; a process that imported torch first gets torch's copy (same SONAME), as with libamdhip64.
@@ -236,6 +248,7 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
   { const char *e = getenv("MI355_NTT_DIRECT2_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 0 && v <= 28) g.ntt_direct2_max_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_FOLD_SCALE"); if (e) g.ntt_fold_scale = e[0] == '0' ? 0u : 1u; }
+  { const char *e = getenv("MI355_NTT_TWO_LEVEL_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 9 && v <= 20) g.ntt_two_level_max_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_HOST_BATCH_OVERLAP"); if (e) g.host_batch_overlap = atoi(e) != 0; }

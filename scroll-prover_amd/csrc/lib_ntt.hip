@@ -65,7 +65,7 @@ static bool alloc_tw29(uint64_t cnt, uint4 **lo, uint4 **hi, uint32_t **top) {
 }
 static int build_plan(NttPlan &p, uint32_t log_n, const void *omega) {
   if (log_n <= 8) { p.levels = 1; p.log_m[0] = log_n; }
-  else if (log_n <= 18) { p.levels = 2; p.log_m[0] = (log_n + 1) / 2; p.log_m[1] = log_n / 2; }
+  else if (log_n <= g.ntt_two_level_max_log) { p.levels = 2; p.log_m[0] = (log_n + 1) / 2; p.log_m[1] = log_n / 2; }   // two passes up to 2^18 (2^20 as an A/B knob: 1024-point columns, two adjacent columns per tile)
   else { p.levels = 3; p.log_m[0] = (log_n + 2) / 3; p.log_m[1] = (log_n + 1) / 3; p.log_m[2] = log_n / 3; }
   fe_t w; memcpy(&w, omega, 32);
   const uint64_t N = 1ull << log_n;

@@ -61,7 +61,7 @@ def parse_rust_type(t: str):
         chain.append(mm.group(1) == "const")
         t = mm.group(2).strip()
     # rust writes the outermost pointer first; the C parse lists the innermost pointee first
-    return RUST_SCALARS[t], tuple(reversed(chain))
+    return RUST_SCALARS[t.split("::")[-1]], tuple(reversed(chain))   # std::os::raw::c_int -> c_int
 
 
 def parse_rust(path: str):
@@ -109,7 +109,7 @@ def test_every_rust_extern_matches_the_header():
                 if rp[1]:
                     assert rp[1][0] == hp[1][0], f"{name} argument {i}: pointee constness differs (rust const={rp[1][0]}, header const={hp[1][0]})"
             bound += 1
-    assert bound >= 37
+    assert bound >= 40
 
 
 def test_ctypes_table_names_exactly_the_header_functions():
