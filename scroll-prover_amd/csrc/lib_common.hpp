@@ -80,6 +80,7 @@ struct Ctx {
   // host-pointer MSM: chunked copy on its own stream, overlapped with the digit extraction (msm_host_single); also the stream the
   // resident-buffer uploads run on (mi355_buf_upload)
   hipStream_t copy_stream = nullptr; hipEvent_t ev_copy[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_up_fork = nullptr;   // mi355_buf_upload into a block in use: recorded on the compute stream, awaited by the copy stream (upload mutex)
   hipEvent_t ev_up[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint32_t up_next = 0;   // uploads on copy_stream (ring: several threads may upload at once); the compute stream waits for each
   uint32_t host_slice_min_log = 22;   // MI355_HOST_SLICE_MIN_LOG: smallest log2(n) the host-pointer MSM cuts into slices (tests lower it)
   uint32_t host_batch_overlap = 1;   // MI355_HOST_BATCH_OVERLAP=0: the host-pointer batch transforms copy and compute one item at a time (no helper thread)
@@ -136,6 +137,7 @@ struct Ctx {
 // worker threads of sharded MSMs / batched transforms each have their own.
 constexpr int MAX_DEV = 16;
 extern std::mutex g_ctx_mu[MAX_DEV];
+extern std::mutex g_upload_mu[MAX_DEV];
 extern Ctx g_ctx[MAX_DEV];
 extern int g_ndev;
 extern bool g_dup_devices;     // test mode: the same physical device bound to several slots (exchange by device copies instead of RCCL)

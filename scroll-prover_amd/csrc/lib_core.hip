@@ -12,6 +12,7 @@ thread_local std::string g_err;
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 std::mutex g_ctx_mu[MAX_DEV];
+std::mutex g_upload_mu[MAX_DEV];   // mi355_buf_upload's bookkeeping (event ring, fork event): uploads never take the device lock
 Ctx g_ctx[MAX_DEV];
 int g_ndev = 0;
 bool g_dup_devices = false;
@@ -219,6 +220,7 @@ static int init_ctx(int slot, int device_id) {
   HIPCHK(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&g.ev_copy[i], hipEventDisableTiming));
   for (int i = 0; i < 8; i++) HIPCHK(hipEventCreateWithFlags(&g.ev_up[i], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&g.ev_up_fork, hipEventDisableTiming));
   { const char *e = getenv("MI355_MSM_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 16) g.msm_chunks = (uint32_t)v; } }
   // dynamic-LDS limits are per device and per kernel: each translation unit sets the ones of the kernels it launches
   CHK(msm_tu_init_device());
@@ -278,6 +280,7 @@ static void destroy_ctx(int slot) {
   if (g.ev_xchg) { (void)hipEventDestroy(g.ev_xchg); g.ev_xchg = nullptr; }
   if (g.ev_xchg2) { (void)hipEventDestroy(g.ev_xchg2); g.ev_xchg2 = nullptr; }
   for (int i = 0; i < 8; i++) if (g.ev_up[i]) { (void)hipEventDestroy(g.ev_up[i]); g.ev_up[i] = nullptr; }
+  if (g.ev_up_fork) { (void)hipEventDestroy(g.ev_up_fork); g.ev_up_fork = nullptr; }
   for (int i = 0; i < 4; i++) if (g.ev_copy[i]) { (void)hipEventDestroy(g.ev_copy[i]); g.ev_copy[i] = nullptr; }
   if (g.copy_stream) { (void)hipStreamDestroy(g.copy_stream); g.copy_stream = nullptr; }
   g.own_stream = g.stream = nullptr; g.inited = false; g.device = -1;
@@ -619,22 +622,28 @@ int mi355_buf_upload(void *dst_dev, const void *src_host, uint64_t bytes) {
   if (bytes == 0) return MI355_OK;
   if (!dst_dev || !src_host) return fail(MI355_EBADARG, "buf_upload: null pointer");
   const int slot = slot_of(dst_dev, false);
-  hipStream_t cs = nullptr; hipEvent_t done = nullptr;
+  // Round 4: the upload takes the device's UPLOAD mutex only, never the device lock.  An MSM over a batch of columns holds the device lock for tens
+  // of milliseconds; with the lock also needed here, column i + 1 could not start (or finish) crossing PCIe until that MSM had returned, and the
+  // many-column layers ran upload and commitment back to back (layer 0: 0.85 s for steps 2-3 = 0.55 s of DMA + 0.30 s of MSM).  What the lock
+  // protected is replaced: the event ring and the fork event are this path's own (upload mutex), HIP streams accept work from several threads,
+  // and the ordering is by events -- the copy waits for the work queued on the block, the compute stream waits for the copy.
+  CHK(need_init(slot));
+  Ctx &c = g_ctx[slot];
+  hipEvent_t done = nullptr;
   {
-    DevGuard lk(slot);
-    CHK(need_init(slot));
+    std::lock_guard<std::mutex> ul(g_upload_mu[slot]);
     bool fresh = false; hipEvent_t free_ev = nullptr;
     { std::lock_guard<std::mutex> bl(g_buf_mu); if (BufBlock *b = buf_find_locked(dst_dev)) { if ((uintptr_t)dst_dev + bytes > (uintptr_t)b->p + b->bytes) return fail(MI355_EBADARG, "buf_upload: range exceeds the block"); fresh = !b->used; free_ev = b->free_ev; b->used = true; } }
-    if (fresh) { if (free_ev) HIPCHK(hipStreamWaitEvent(g.copy_stream, free_ev, 0)); }
-    else { HIPCHK(hipEventRecord(g.ev_fork, g.stream)); HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_fork, 0)); }
-    cs = g.copy_stream; done = g.ev_up[g.up_next++ & 7];
+    if (fresh) { if (free_ev) HIPCHK(hipStreamWaitEvent(c.copy_stream, free_ev, 0)); }
+    else { HIPCHK(hipEventRecord(c.ev_up_fork, c.stream)); HIPCHK(hipStreamWaitEvent(c.copy_stream, c.ev_up_fork, 0)); }   // everything queued on the compute stream so far
+    done = c.ev_up[c.up_next++ & 7];
+    HIPCHK(hipEventSynchronize(done));   // the ring slot's previous use (eight uploads ago) has long completed; an unrecorded event returns at once
   }
-  HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, cs));   // this thread stays bound to the device (need_init above)
-  HIPCHK(hipEventRecord(done, cs));
+  HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c.copy_stream));   // pageable source: blocks this thread for the transfer
   {
-    DevGuard lk(slot);
-    CHK(need_init(slot));
-    HIPCHK(hipStreamWaitEvent(g.stream, done, 0));
+    std::lock_guard<std::mutex> ul(g_upload_mu[slot]);
+    HIPCHK(hipEventRecord(done, c.copy_stream));
+    HIPCHK(hipStreamWaitEvent(c.stream, done, 0));   // later work on the compute stream sees the data
   }
   HIPCHK(hipEventSynchronize(done));   // pinned sources return from hipMemcpyAsync at once
   return MI355_OK;

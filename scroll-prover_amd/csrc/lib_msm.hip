@@ -644,7 +644,7 @@ static int msm_multi(const std::vector<Piece> &pieces, const fe_t *const *polys,
       }
       return msm_batch_impl(p->bases, ptrs.data(), M, p->cnt, nullptr, &p->pre, send);
     };
-    rcs[slot] = guarded(body);
+    rcs[slot] = guarded(body, "msm shard worker");
     if (rcs[slot] != MI355_OK) errs[slot] = g_err;
   };
   {

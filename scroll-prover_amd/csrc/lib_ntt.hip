@@ -228,7 +228,7 @@ template <class F> int run_per_device_lists(const std::vector<BatchItem> &items,
       HIPCHK(hipStreamSynchronize(g.stream));
       resolve_spans();
       return MI355_OK;
-    });
+    }, "batch worker (one per device)");
     if (rcs[k] != MI355_OK) errs[k] = g_err;
   };
   {
@@ -408,12 +408,32 @@ int mi355_extended_to_coeff_host(void *data_host, uint32_t log_ext, const void *
 }
 
 // ---- distribute_powers / coset NTT
+static DistFactors dist_factors(const void *factor) {   // f, f^256, f^(256 EVAL_RUN): a few dozen host multiplications per call
+  DistFactors F; memcpy(&F.f, factor, 32);
+  F.f256 = Fr::pow_u64(F.f, 256); F.fblock = Fr::pow_u64(F.f256, EVAL_RUN);
+  return F;
+}
 static int distribute_powers_locked(void *data_dev, uint64_t n, const void *factor, const void *src_dev = nullptr) {
   if (!factor || (n && !data_dev)) return fail(MI355_EBADARG, "distribute_powers: null pointer");
   if (n == 0) return MI355_OK;
-  fe_t f; memcpy(&f, factor, 32);
-  hipLaunchKernelGGL(k_distribute_powers, dim3(ceil_div(n, (uint64_t)EVAL_RUN * 256)), dim3(256), 0, g.stream, (const fe_t *)(src_dev ? src_dev : data_dev), (fe_t *)data_dev, n, f);
+  hipLaunchKernelGGL(k_distribute_powers, dim3(ceil_div(n, (uint64_t)EVAL_RUN * 256)), dim3(256), 0, g.stream, (const fe_t *)(src_dev ? src_dev : data_dev), (fe_t *)data_dev, n, dist_factors(factor));
   HIPCHK(hipGetLastError());
+  return MI355_OK;
+}
+// the coset shift of `cnt` polynomials in one launch: dst[i][j] = src[i][j] * factor^j.  The pointer tables travel through a workspace buffer; the
+// caller synchronises the stream before `ptrs` (host) goes away (the batch entry points end with a stream synchronisation).
+static int distribute_powers_batch_locked(const std::vector<const void *> &src, const std::vector<void *> &dst, uint64_t n, const void *factor) {
+  const size_t cnt = src.size();
+  if (cnt == 0 || n == 0) return MI355_OK;
+  void **tab; CHK(ws_get("batch.ptrs", 2 * cnt * sizeof(void *), (void **)&tab));
+  for (size_t base = 0; base < cnt; base += 65535) {   // grid.y limit
+    const size_t c = std::min<size_t>(65535, cnt - base);
+    HIPCHK(hipMemcpyAsync(tab, src.data() + base, c * sizeof(void *), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(tab + cnt, dst.data() + base, c * sizeof(void *), hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_distribute_powers_batch, dim3(ceil_div(n, (uint64_t)EVAL_RUN * 256), (uint32_t)c), dim3(256), 0, g.stream, (const fe_t *const *)tab, (fe_t *const *)(tab + cnt), n, dist_factors(factor));
+    HIPCHK(hipGetLastError());
+    if (base + c < cnt) HIPCHK(hipStreamSynchronize(g.stream));   // the table is reused by the next slice
+  }
   return MI355_OK;
 }
 int mi355_distribute_powers_fr_dev(void *data_dev, uint64_t n, const void *factor) {
@@ -472,9 +492,14 @@ int mi355_coset_ntt_fr_batch_dev(void *const *dst_dev, const void *const *coeffs
     if (!dst_dev[i] || !coeffs_dev[i]) return fail(MI355_EBADARG, "coset_ntt_batch: null polynomial pointer");
     int slot; CHK(common_slot({dst_dev[i], coeffs_dev[i]}, &slot, "coset_ntt_batch")); items[i] = {i, slot};
   }
-  return run_per_device(items, [&](int, uint32_t i) -> int {
-    CHK(distribute_powers_locked(dst_dev[i], 1ull << log_n, coset_factor, coeffs_dev[i]));
-    return ntt_dev_impl((const fe_t *)dst_dev[i], 1ull << log_n, (fe_t *)dst_dev[i], log_n, omega, nullptr, nullptr);
+  // per device: ONE launch scales every polynomial of the list by the powers of the coset factor (round 4: 946 separate 64-block launches of
+  // ~110 us each per coset part of the k = 20 inner circuit were latency, not work), then the transforms run in place one after the other
+  return run_per_device_lists(items, [&](int, const std::vector<uint32_t> &idx) -> int {
+    std::vector<const void *> src; std::vector<void *> dst;
+    for (uint32_t i : idx) { src.push_back(coeffs_dev[i]); dst.push_back(dst_dev[i]); }
+    CHK(distribute_powers_batch_locked(src, dst, 1ull << log_n, coset_factor));
+    for (uint32_t i : idx) CHK(ntt_dev_impl((const fe_t *)dst_dev[i], 1ull << log_n, (fe_t *)dst_dev[i], log_n, omega, nullptr, nullptr));
+    return MI355_OK;
   });
   });
 }
@@ -593,7 +618,7 @@ static int eval_polynomial_locked(const void *poly_dev, uint64_t n, const void *
   {
     Scope sc("eval_poly");
     hipLaunchKernelGGL(k_eval_poly_partial, dim3(blocks), dim3(256), 0, g.stream, (const fe_t *)poly_dev, n, x, partial);
-    hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, g.stream, partial, (uint64_t)blocks, partial + blocks);
+    hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, g.stream, (const fe_t *)partial, (uint64_t)blocks, partial + blocks, (uint64_t)0);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(&res, partial + blocks, sizeof res, hipMemcpyDeviceToHost, g.stream));
@@ -626,19 +651,20 @@ int mi355_eval_polynomial_batch_dev(const void *const *polys_dev, uint32_t batch
   CHK(need_init(slot));
   if (n == 0) { memset(out_fr_host, 0, (size_t)batch * 32); return MI355_OK; }
   const uint32_t blocks = ceil_div(n, (uint64_t)EVAL_RUN * 256);
-  const size_t stride = (size_t)blocks + 1;
-  // chunks of at most 256 evaluations share one scratch area and one copy-back
-  const uint32_t CH = 256;
-  fe_t *partial; CHK(ws_get("eval.partial", stride * std::min(batch, CH) * sizeof(fe_t), (void **)&partial));
-  fe_t *res; CHK(ws_get("eval.results", (size_t)std::min(batch, CH) * sizeof(fe_t), (void **)&res));
+  const size_t stride = (size_t)blocks;
+  // slices of at most 4096 evaluations (and at most 256 MiB of partial sums) share one scratch area, one pair of launches and one copy-back
+  const uint32_t CH = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4096, (256ull << 20) / (stride * sizeof(fe_t))));
+  const uint32_t chunk = std::min(batch, CH);
+  fe_t *partial; CHK(ws_get("eval.partial", stride * chunk * sizeof(fe_t), (void **)&partial));
+  char *tab; CHK(ws_get("eval.batch", (size_t)chunk * (sizeof(void *) + 2 * sizeof(fe_t)), (void **)&tab));
+  const fe_t **ptab = (const fe_t **)tab; fe_t *xtab = (fe_t *)(tab + (size_t)chunk * sizeof(void *)); fe_t *res = xtab + chunk;
   for (uint32_t base = 0; base < batch; base += CH) {
     const uint32_t cnt = std::min(CH, batch - base);
     Scope sc("eval_poly");
-    for (uint32_t i = 0; i < cnt; i++) {
-      fe_t x; memcpy(&x, (const char *)points + 32 * (size_t)(base + i), 32);
-      hipLaunchKernelGGL(k_eval_poly_partial, dim3(blocks), dim3(256), 0, g.stream, (const fe_t *)polys_dev[base + i], n, x, partial + stride * i);
-      hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, g.stream, partial + stride * i, (uint64_t)blocks, res + i);
-    }
+    HIPCHK(hipMemcpyAsync(ptab, polys_dev + base, (size_t)cnt * sizeof(void *), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(xtab, (const char *)points + 32 * (size_t)base, (size_t)cnt * sizeof(fe_t), hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_eval_poly_partial_batch, dim3(blocks, cnt), dim3(256), 0, g.stream, (const fe_t *const *)ptab, n, (const fe_t *)xtab, partial, (uint64_t)stride);
+    hipLaunchKernelGGL(k_fr_sum, dim3(cnt), dim3(256), 0, g.stream, (const fe_t *)partial, (uint64_t)blocks, res, (uint64_t)stride);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync((char *)out_fr_host + 32 * (size_t)base, res, (size_t)cnt * sizeof(fe_t), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));

@@ -227,7 +227,7 @@ __device__ __forceinline__ fe29_t fr29_pow_u64(const fe29_t &x, uint64_t e) {
 // Thread t of a block takes the coefficients base + t + 256 k (k < EVAL_RUN): loads are coalesced (consecutive lanes, consecutive
 // 32-byte coefficients) and every thread runs Horner in the SAME y = x^256, so the per-coefficient cost is one multiplication;
 // the thread-specific factor x^t and the block factor x^base (computed once per block, broadcast through LDS) are applied at the end.
-__global__ void __launch_bounds__(256) k_eval_poly_partial(const fe_t *__restrict__ poly, uint64_t n, fe_t x_sat, fe_t *__restrict__ partial) {
+__device__ __forceinline__ void eval_poly_partial_body(const fe_t *__restrict__ poly, uint64_t n, const fe_t &x_sat, fe_t *__restrict__ partial) {
   __shared__ uint32_t lds[5][9];
   const uint64_t base = (uint64_t)blockIdx.x * 256 * EVAL_RUN;
   const fe29_t x = Fr29::reduce_small(Fr29::from_sat(x_sat));          // x * 2^261, tight
@@ -265,17 +265,24 @@ __global__ void __launch_bounds__(256) k_eval_poly_partial(const fe_t *__restric
     g_store(&partial[blockIdx.x], fr29_finish(Fr29::reduce_small(Fr29::normalise(acc))));   // canonical, ABI domain
   }
 }
+__global__ void __launch_bounds__(256) k_eval_poly_partial(const fe_t *__restrict__ poly, uint64_t n, fe_t x_sat, fe_t *__restrict__ partial) { eval_poly_partial_body(poly, n, x_sat, partial); }
+// blockIdx.y = evaluation: step 9 of create_proof evaluates thousands of (polynomial, point) pairs at k = 20, each a 64-block launch whose ~100 us are
+// latency (a serial Horner chain of 64 multiplications per thread behind a power ladder); one launch over all pairs is throughput-bound instead
+__global__ void __launch_bounds__(256) k_eval_poly_partial_batch(const fe_t *const *__restrict__ polys, uint64_t n, const fe_t *__restrict__ points, fe_t *__restrict__ partial, uint64_t stride) {
+  eval_poly_partial_body(polys[blockIdx.y], n, g_load(&points[blockIdx.y]), partial + stride * blockIdx.y);
+}
 // a[i] *= f^i  (halo2_proofs distribute_powers: the coset shift of coeff_to_extended_part / general coset FFTs).
 // Same tiling as k_eval_poly_partial: thread t walks i = base + t + 256 k with a running power stepped by f^256.
 // src == a: in place; otherwise a = src scaled (the coset transforms write the scaled copy straight into their destination: no separate copy)
-__global__ void __launch_bounds__(256) k_distribute_powers(const fe_t *src, fe_t *a, uint64_t n, fe_t f_sat) {
+// DistFactors: f, f^256 and f^(256 EVAL_RUN) in Montgomery (ABI) form, the two powers computed by the host (round 4: the in-kernel ladder
+// f^base with a 64-bit exponent cost every block ~40 dependent multiplications before its first store -- 108 us for a 2^16-element call)
+struct DistFactors { fe_t f, f256, fblock; };
+__device__ __forceinline__ void distribute_powers_body(const fe_t *src, fe_t *a, uint64_t n, const DistFactors &F) {
   __shared__ uint32_t lds[9];
   const uint64_t base = (uint64_t)blockIdx.x * 256 * EVAL_RUN;
-  const fe29_t f = Fr29::reduce_small(Fr29::from_sat(f_sat));
-  if (threadIdx.x < 64) { const fe29_t fb = fr29_pow_u64(f, base); if (threadIdx.x == 0) for (int k = 0; k < 9; k++) lds[k] = fb.l[k]; }
-  fe29_t y = f;
-#pragma unroll
-  for (int i = 0; i < 8; i++) y = Fr29::sqr(y);                        // f^256
+  const fe29_t f = Fr29::reduce_small(Fr29::from_sat(F.f));
+  if (threadIdx.x < 64) { const fe29_t fb = fr29_pow_u64(Fr29::reduce_small(Fr29::from_sat(F.fblock)), blockIdx.x); if (threadIdx.x == 0) for (int k = 0; k < 9; k++) lds[k] = fb.l[k]; }   // (f^(256 EVAL_RUN))^block: a short exponent
+  const fe29_t y = Fr29::reduce_small(Fr29::from_sat(F.f256));         // f^256
   fe29_t pw = fr29_pow_u64(f, threadIdx.x);
   __syncthreads();
   { fe29_t fb; for (int k = 0; k < 9; k++) fb.l[k] = lds[k]; pw = Fr29::mul(pw, fb); }   // f^(base + t), tight
@@ -286,6 +293,9 @@ __global__ void __launch_bounds__(256) k_distribute_powers(const fe_t *src, fe_t
     pw = Fr29::mul(pw, y);
   }
 }
+__global__ void __launch_bounds__(256) k_distribute_powers(const fe_t *src, fe_t *a, uint64_t n, DistFactors F) { distribute_powers_body(src, a, n, F); }
+// blockIdx.y = polynomial: the coset shift of every polynomial of a coset part in ONE launch (mi355_coset_ntt_fr_batch_dev)
+__global__ void __launch_bounds__(256) k_distribute_powers_batch(const fe_t *const *srcs, fe_t *const *dsts, uint64_t n, DistFactors F) { distribute_powers_body(srcs[blockIdx.y], dsts[blockIdx.y], n, F); }
 
 // element-wise vector operations on device-resident polynomials (the pointwise steps between the transforms of the quotient
 // construction): op 0 add, 1 sub, 2 mul; and data[i] *= table[i mod period] (division by the vanishing polynomial on
@@ -370,8 +380,9 @@ __global__ void __launch_bounds__(256) k_fr_interleave(fe_t *__restrict__ dst, I
     for (uint32_t q = 0; q < P.q; q++) g_store(&dst[i * P.q + q], g_load(&P.part[q][i]));
 }
 
-// sum of m canonical field elements (the per-block partials) by one workgroup
-__global__ void __launch_bounds__(256) k_fr_sum(const fe_t *__restrict__ in, uint64_t m, fe_t *__restrict__ out) {
+// sum of m canonical field elements (the per-block partials) by one workgroup; blockIdx.x = which vector (stride elements apart) of a batch
+__global__ void __launch_bounds__(256) k_fr_sum(const fe_t *__restrict__ in_all, uint64_t m, fe_t *__restrict__ out_all, uint64_t stride = 0) {
+  const fe_t *__restrict__ in = in_all + stride * blockIdx.x; fe_t *__restrict__ out = out_all + blockIdx.x;
   __shared__ fe_t lds[4];
   fe_t acc = Fr::zero();
   for (uint64_t i = threadIdx.x; i < m; i += blockDim.x) acc = Fr::add(acc, g_load(&in[i]));
