@@ -320,7 +320,7 @@ inline Witness synthesize_witness(const CircuitShape &s, const EvaluationDomain 
 }
 
 // ------------------------------------------------------------------------------------------------ create_proof, GPU side
-struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; bool warm = true; };
+struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 2; };
 struct CommitRecord { PolyRef p; int piece; G1 c; };   // piece >= 0: quotient piece; p.kind == P_KINDS with piece -1 - j: SHPLONK quotient j
 struct ProofGpuSide {
   std::vector<CommitRecord> commitments;              // in transcript order
@@ -365,18 +365,23 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
   for (uint32_t i = 0; i < s.advice; i++) uploads.push_back({{P_ADVICE, i}, &wit.advice[i]});
   for (uint32_t l = 0; l < s.lookups; l++) uploads.push_back({{P_M, l}, &wit.m[l]});
   for (const auto &u : uploads) poly[u.first];   // every entry exists before the uploader starts: the map's structure does not change under the readers
-  std::mutex mu; std::condition_variable cv; size_t ready = 0; std::string upload_error;
-  std::thread uploader([&] {
+  // opt.upload_threads host threads (rayon workers in the real caller) share the columns round-robin: a copy from pageable memory is staged by the
+  // calling thread, and one thread alone moves ~33 GB/s of the link's ~55 (mi355_buf_upload takes no device lock, so the copies also run under the
+  // commitments of earlier columns)
+  std::mutex mu; std::condition_variable cv; std::vector<char> arrived(uploads.size(), 0); std::string upload_error;
+  const size_t UT = (size_t)std::max(1, std::min<int>(opt.upload_threads, (int)uploads.size()));
+  auto upload_worker = [&](size_t first) {
     try {
-      for (size_t i = 0; i < uploads.size(); i++) {
+      for (size_t i = first; i < uploads.size(); i += UT) {
         DevicePoly d = DevicePoly::from_host(*uploads[i].second, 0);
-        { std::lock_guard<std::mutex> lk(mu); poly.at(uploads[i].first) = std::move(d); ready = i + 1; }
+        { std::lock_guard<std::mutex> lk(mu); poly.at(uploads[i].first) = std::move(d); arrived[i] = 1; }
         cv.notify_all();
       }
-    } catch (const std::exception &e) { { std::lock_guard<std::mutex> lk(mu); upload_error = e.what(); ready = uploads.size(); } cv.notify_all(); }
-  });
-  struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_uploader{uploader};
-  auto wait_for = [&](size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready > i; }); if (!upload_error.empty()) throw Error(MI355_EHIP, "witness upload: " + upload_error); };
+    } catch (const std::exception &e) { { std::lock_guard<std::mutex> lk(mu); upload_error = e.what(); std::fill(arrived.begin(), arrived.end(), 1); } cv.notify_all(); }
+  };
+  struct Joiner { std::vector<std::thread> th; void join() { for (auto &t : th) if (t.joinable()) t.join(); } ~Joiner() { join(); } } uploaders;
+  for (size_t w = 0; w < UT; w++) uploaders.th.emplace_back(upload_worker, w);
+  auto wait_for = [&](size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return arrived[i] != 0; }); if (!upload_error.empty()) throw Error(MI355_EHIP, "witness upload: " + upload_error); };
   wait_for(0);
   DevicePoly inst_lagrange = clone(poly.at({P_INSTANCE, 0}), 0);                        // the permutation argument reads the instance VALUES in step 4
   check(mi355_intt_fr_dev(poly.at({P_INSTANCE, 0}).p, k, dom.omega_inv.data(), dom.ifft_divisor.data())); R.intt++;   // step 1
@@ -390,7 +395,7 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
       else { pending.push_back(uploads[i].first); if (pending.size() == 32 || i + 1 == uploads.size() || uploads[i + 1].first.kind != uploads[i].first.kind) { commit_many(h_g_lagrange, pending, poly); pending.clear(); } }
     }
   }
-  uploader.join();
+  uploaders.join();
   lap(2);
   // ---- step 4: grand products and running sums, built on the device from the Lagrange values
   {

@@ -79,7 +79,7 @@ static const char *kind_name(PolyKind k) { static const char *n[] = {"instance",
 
 int main(int argc, char **argv) {
   int layer_id = 4, devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2; long k_override = -1; bool host_api = false, do_check = true;
-  std::string tables = "auto", pk_mode = "auto";
+  std::string tables = "auto", pk_mode = "auto"; int upload_threads = 2;
   long o_advice = -1, o_fixed = -1, o_lookups = -1, o_perm = -1, o_chunk = -1, o_degree = -1;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -88,9 +88,10 @@ int main(int argc, char **argv) {
     if (a == "--layer") layer_id = (int)next(); else if (a == "--k") k_override = next(); else if (a == "--devices") devices = (int)next();
     else if (a == "--threads") threads = (int)next(); else if (a == "--host-api") host_api = true; else if (a == "--no-check") do_check = false;
     else if (a == "--no-tables") tables = "off"; else if (a == "--tables") tables = nexts(); else if (a == "--pk-cosets") pk_mode = nexts(); else if (a == "--proofs") proofs = (int)next();
+    else if (a == "--upload-threads") upload_threads = (int)next();
     else if (a == "--advice") o_advice = next(); else if (a == "--fixed") o_fixed = next(); else if (a == "--lookups") o_lookups = next();
     else if (a == "--perm") o_perm = next(); else if (a == "--chunk") o_chunk = next(); else if (a == "--degree") o_degree = next();
-    else { std::printf("usage: %s [--layer 0..6] [--k K] [--advice A --fixed F --lookups L --perm P --chunk C --degree D] [--devices D] [--threads T] [--proofs N]\n"
+    else { std::printf("usage: %s [--layer 0..6] [--k K] [--advice A --fixed F --lookups L --perm P --chunk C --degree D] [--devices D] [--threads T] [--proofs N] [--upload-threads U]\n"
                        "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--no-check]\n", argv[0]); return 1; }
   }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;   // the GPU box's container gets 16 of the host's CPUs
@@ -154,7 +155,7 @@ int main(int argc, char **argv) {
   ch.y = h2d::fr_from_u64(0x7900000000000005ull); ch.x = h2d::fr_from_u64(0x1234567890ABCDEFull); ch.v = h2d::fr_from_u64(0xABCDEF0123456789ull);
   ch.z0 = h2d::fr_from_u64(0x1111); ch.z1 = h2d::fr_from_u64(0x1112);
   const ExpressionPlan plan = build_plan(S, ch);
-  ProofOptions opt; opt.devices = devices; opt.threads = threads;
+  ProofOptions opt; opt.devices = devices; opt.threads = threads; opt.upload_threads = upload_threads;
   // ---- the proofs: a prover process runs proof after proof; the first one grows the workspace arena and the buffer pool, the last one is reported
   ProofGpuSide R; double first_ms = 0;
   for (int it = 0; it < proofs; it++) {
@@ -277,14 +278,14 @@ int main(int argc, char **argv) {
   std::printf("{\"replay\": \"create_proof_gpu_side (include/mi355zk_create_proof.hpp): steps 1-10 through the C-ABI, polynomials and proving-key cosets resident\", \"layer\": %d, \"k\": %u, \"devices\": %d, "
               "\"shape\": {\"advice\": %u, \"fixed\": %u, \"lookups\": %u, \"perm_columns\": %u, \"chunk_len\": %u, \"perm_z\": %u, \"degree\": %u, \"quotient_pieces\": %u, \"source\": \"%s\"}, "
               "\"window_tables\": %s, \"window_table_bases\": %d, \"pk_cosets\": \"%s\", "
-              "\"msm\": %zu, \"intt\": %u, \"coset_ntt\": %u, \"gate_launches\": %u, \"gates\": %u, \"gate_terms\": %u, \"evals\": %zu, \"resident_ms\": %.3f, \"first_proof_ms\": %.3f, \"proofs\": %d, "
+              "\"upload_threads\": %d, \"msm\": %zu, \"intt\": %u, \"coset_ntt\": %u, \"gate_launches\": %u, \"gates\": %u, \"gate_terms\": %u, \"evals\": %zu, \"resident_ms\": %.3f, \"first_proof_ms\": %.3f, \"proofs\": %d, "
               "\"host_api_ms\": %.3f, \"host_api_fft_ms\": %.3f, \"host_api_fft_batched_ms\": %.3f, "
               "\"step_ms\": {\"1_instance\": %.2f, \"2_3_advice_lookup_commits\": %.2f, \"4_products\": %.2f, \"5_random\": 0.0, \"6_to_coeff\": %.2f, \"7_quotient\": %.2f, \"8_commit_h\": %.2f, \"9_evals\": %.2f, \"10_shplonk\": %.2f}, "
               "\"hbm\": {\"total_gib\": %.1f, \"peak_used_gib\": %.1f, \"proving_key_gib\": %.1f, \"live_buffers_gib\": %.1f, \"pooled_gib\": %.1f, \"workspace_gib\": %.1f, \"planned\": {\"pk_base_gib\": %.1f, \"pk_cosets_gib\": %.1f, \"working_set_gib\": %.1f, \"one_table_gib\": %.1f, \"usable_gib\": %.1f}}, "
               "\"checked\": %u, \"semantic_check\": %s, \"trapdoor_check\": %s, \"ok\": %s}\n",
               layer_id, k, devices, S.advice, S.fixed, S.lookups, S.perm_columns, S.chunk_len, S.perm_z(), S.degree, Q, S.source,
               n_tables ? "true" : "false", n_tables, resident ? "resident" : "on-the-fly",
-              R.commitments.size(), R.intt, R.coset_ntt, R.gate_launches, plan.gates, plan.terms, R.evals.size(), R.total_ms, first_ms, proofs,
+              upload_threads, R.commitments.size(), R.intt, R.coset_ntt, R.gate_launches, plan.gates, plan.terms, R.evals.size(), R.total_ms, first_ms, proofs,
               host_ms, host_fft_ms, host_fft_batched_ms,
               R.step_ms[1], R.step_ms[2], R.step_ms[4], R.step_ms[6], R.step_ms[7], R.step_ms[8], R.step_ms[9], R.step_ms[10],
               hbm_total / GiB, (hbm_total - fr_end) / GiB, pk.bytes / GiB, live / GiB, pooled / GiB, ws / GiB, pk_base / GiB, pk_cosets / GiB, working / GiB, table_one / GiB, usable / GiB,
