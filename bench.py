@@ -39,6 +39,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # ALU-side ceiling of the dominant kernel: the 29-bit XYZZ mixed-addition chain of tools/microbench.hip at this kernel's occupancy
 # (3 waves/SIMD, operands cache-resident), profiles/r01_microbench_final.log.  Reported next to the HBM roofline, never instead of it.
 MADD_CHAIN_PEAK = 15.9e9
+MADS_PER_MADD = 1467   # v_mad_[ui]64 on the common path of one XYZZ mixed addition (tools/isa_block_census.py)
 
 
 def rand_scalars(n: int, seed: int, device) -> torch.Tensor:
@@ -584,7 +585,13 @@ def main() -> None:
                          "pairs_per_launch": pairs_per_launch,
                          "alu": {"achieved": (pairs_per_launch * W / (acc_avg_ms * 1e-3)) if acc_avg_ms > 0 else None, "peak": MADD_CHAIN_PEAK, "unit": "G1 mixed additions/s",
                                  "frac": (pairs_per_launch * W / (acc_avg_ms * 1e-3) / MADD_CHAIN_PEAK) if acc_avg_ms > 0 else None,
-                                 "source": "profiles/r02_microbench.log (xyzz29 madd chain, 3 waves/SIMD, boost clock); SQ counters: VALU 98 % busy at the sustained 1.93 GHz, 2 193 VALU instructions per addition, profiles/r03_sq_counters.md"},
+                                 "source": "profiles/r02_microbench.log (xyzz29 madd chain, 3 waves/SIMD, boost clock); SQ counters: VALU 98 % busy at the sustained 1.93 GHz, 2 193 VALU instructions per addition, profiles/r03_sq_counters.md",
+                                 # SURVEY 8d's own definition, next to the chain ceiling: multiplier instructions executed / time / the
+                                 # machine's v_mad_u64_u32 issue rate (one per lane per 4 cycles: CUs x 4 SIMDs x 16 lanes x clock, nominal 2.4 GHz)
+                                 "mad_rate": {"mads_per_addition": MADS_PER_MADD, "achieved": (MADS_PER_MADD * pairs_per_launch * W / (acc_avg_ms * 1e-3)) if acc_avg_ms > 0 else None,
+                                              "peak": torch.cuda.get_device_properties(dev).multi_processor_count * 4 * 16 * 2.4e9, "unit": "v_mad_[ui]64 per second",
+                                              "frac": (MADS_PER_MADD * pairs_per_launch * W / (acc_avg_ms * 1e-3) / (torch.cuda.get_device_properties(dev).multi_processor_count * 4 * 16 * 2.4e9)) if acc_avg_ms > 0 else None,
+                                              "source": "profiles/r04_accumulate_isa_blocks.md (1 467 multiplier instructions on the common path of one mixed addition); the sustained clock under this kernel is 1.93 GHz, at which the fraction is 0.65"}},
                          "note": "algorithmic bytes = 96 B per (scalar, point) pair x pairs per launch (SURVEY 8d); the kernel is VALU-integer bound, see DESIGN.md"},
             "cpu_baseline": cpu, "ntt": ntt,
         }
