@@ -6,7 +6,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 CSRC := scroll-prover_amd/csrc
 LIB := scroll-prover_amd/libmi355zk.so
-DEPS := $(wildcard $(CSRC)/*.cuh $(CSRC)/*.hpp $(CSRC)/*.inc) include/mi355zk.h
+DEPS := $(wildcard $(CSRC)/*.hpp $(CSRC)/*.hpp $(CSRC)/*.inc) include/mi355zk.h
 
 .PHONY: lib oracle test-cpu test-gpu bench clean
 OBJDIR := scroll-prover_amd/build

@@ -13,7 +13,7 @@
 //
 // Header-only; link with -lmi355zk.  Types are the in-memory forms of halo2curves::bn256 (4 x u64 LE Montgomery limbs).
 // Host arithmetic here is limited to the domain constants (omega, n^-1, ...), exactly what EvaluationDomain::new computes;
-// it reuses the product's own limb code (scroll-prover_amd/csrc/fp.cuh compiles for the host).
+// it reuses the product's own limb code (scroll-prover_amd/csrc/fp.hpp compiles for the host).
 #pragma once
 #include <array>
 #include <cstdint>
@@ -24,7 +24,7 @@
 #include <vector>
 
 #include "mi355zk.h"
-#include "../scroll-prover_amd/csrc/fp.cuh"
+#include "../scroll-prover_amd/csrc/fp.hpp"
 
 namespace mi355zk {
 namespace halo2 {

@@ -1,4 +1,4 @@
-// fp.cuh -- BN254 Fq / Fr arithmetic for gfx950 (MI355X), 8 x 32-bit limbs, Montgomery form R = 2^256.
+// fp.hpp -- BN254 Fq / Fr arithmetic for gfx950 (MI355X), 8 x 32-bit limbs, Montgomery form R = 2^256.
 //
 // In-memory element = 32 bytes little-endian = exactly halo2curves' `Fr([u64;4])` / `Fq([u64;4])`
 // (fixture KAT A1/A2 prove the Montgomery/LE/fully-reduced convention), so data crosses

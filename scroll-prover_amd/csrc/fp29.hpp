@@ -1,4 +1,4 @@
-// fp29.cuh -- BN254 Fq / Fr in 9 x 29-bit UNSATURATED limbs for the compute-bound inner loops on gfx950.
+// fp29.hpp -- BN254 Fq / Fr in 9 x 29-bit UNSATURATED limbs for the compute-bound inner loops on gfx950.
 //
 // Why: on MI355X v_mad_u64_u32 issues in ~4.5 cycles but so does every carry instruction
 // (v_addc_co_u32, v_lshl_add_u64), so in the saturated 8 x 32 form each limb product costs two 4-cycle instructions.
@@ -12,7 +12,7 @@
 // The ABI (and HBM) keep the saturated 8 x 32, R = 2^256 form; from_sat()/to_sat() convert at load/store:
 // x * 2^256 (stored) -> limbs of (stored << 5) = x * 2^261 (loose, no reduction needed).
 #pragma once
-#include "fp.cuh"
+#include "fp.hpp"
 
 namespace zk {
 

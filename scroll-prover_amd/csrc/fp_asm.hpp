@@ -1,6 +1,6 @@
-// fp_asm.cuh -- product-scanning (FIPS) Montgomery multiplier tuned for the gfx950 ISA.
+// fp_asm.hpp -- product-scanning (FIPS) Montgomery multiplier tuned for the gfx950 ISA.
 //
-// Why: hipcc turns the textbook CIOS loop of fp.cuh into mad_u64_u32 + v_lshl_add_u64 + 2 x v_mov per
+// Why: hipcc turns the textbook CIOS loop of fp.hpp into mad_u64_u32 + v_lshl_add_u64 + 2 x v_mov per
 // limb product (~540 VALU instructions per field multiplication).  CDNA4's v_mad_u64_u32 is a VOP3B
 // instruction with a carry-out SGPR, so a column accumulator {acc64, ex32} can absorb one 32x32 product in
 // exactly two instructions (v_mad_u64_u32 ; v_addc_co_u32) with no register shuffling: ~300 instructions
@@ -9,8 +9,8 @@
 //
 // The host build of the same functions (plain C, for tests/hostcheck) uses 128-bit integers in `mac`.
 #pragma once
-#include "fp.cuh"
-#include "g1.cuh"
+#include "fp.hpp"
+#include "g1.hpp"
 #include "fp_asm_gen.inc"
 
 namespace zk {

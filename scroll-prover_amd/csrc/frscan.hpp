@@ -1,18 +1,18 @@
-// frscan.cuh -- multiplicative scans over device-resident Fr vectors: the grand products and the batch inversion of the permutation and
+// frscan.hpp -- multiplicative scans over device-resident Fr vectors: the grand products and the batch inversion of the permutation and
 // lookup arguments of create_proof [EXT-recalled halo2_proofs src/plonk/permutation/prover.rs,
 // src/plonk/lookup/prover.rs: `modified_values.batch_invert()`, then z[0] = 1, z[i + 1] = z[i] * modified_values[i]].
 //
 //   k_fr_batch_invert     data[i] = data[i]^-1, zeros stay zero (ff::BatchInvert semantics).  A thread multiplies its 8 (strided,
 //                         coalesced) elements, the 256 thread products are scanned from both ends through LDS; the products of the
 //                         2048-element tiles are themselves batch-inverted (recursion on the host side), so the whole vector costs a
-//                         handful of one-lane inversions (division steps, fp.cuh inv_sgcd).
+//                         handful of one-lane inversions (division steps, fp.hpp inv_sgcd).
 //   k_fr_prefix_product   dst[i] = prod_{j < i} src[j]  (dst[0] = 1): tile products -> scan of the tile products -> tile-local rescan
 //                         with the carried-in prefix.  Order matters here, so tiles go through LDS to turn coalesced 16-byte-per-lane
 //                         global accesses into 8 consecutive elements per thread (chunk stride 65 dwords: conflict-free).
 // Both are streaming kernels (one read + one write of the vector, plus one re-read for the prefix product) with ~5 multiplications
 // per element; Montgomery form in, Montgomery form out, fully reduced.
 #pragma once
-#include "fp_asm.cuh"
+#include "fp_asm.hpp"
 
 namespace zk {
 #ifdef __HIPCC__
@@ -77,7 +77,7 @@ template <int MODE> __global__ void __launch_bounds__(FRSCAN_THREADS) k_fr_batch
   const fe_t right = block_exclusive_mul_scan<true>(run, buf, total_r);
   fe_t inv_t;
   if (MODE == 0) {
-    if (threadIdx.x == 0) lds_put(inv_total, Fr::inv_sgcd(total));   // division-step inverse (fp.cuh): a fraction of the Fermat ladder's latency
+    if (threadIdx.x == 0) lds_put(inv_total, Fr::inv_sgcd(total));   // division-step inverse (fp.hpp): a fraction of the Fermat ladder's latency
     __syncthreads();
     inv_t = lds_get(inv_total);
   } else inv_t = g_load(&tile_prod[blockIdx.x]);

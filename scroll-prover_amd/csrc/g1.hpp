@@ -1,4 +1,4 @@
-// g1.cuh -- BN254 G1 (y^2 = x^3 + 3 over Fq) point arithmetic for the MSM kernels.
+// g1.hpp -- BN254 G1 (y^2 = x^3 + 3 over Fq) point arithmetic for the MSM kernels.
 //
 // ABI types (halo2curves bn256 [EXT-recalled]):
 //   g1_affine_t  {x, y}      64 B, Montgomery, identity = (0, 0)          == halo2curves G1Affine
@@ -8,7 +8,7 @@
 // and the accumulator is what the bucket kernels keep in registers (32 VGPRs).
 // Formulas: EFD "madd-2008-s", "add-2008-s", "dbl-2008-s-1", "mdbl-2008-s".
 #pragma once
-#include "fp.cuh"
+#include "fp.hpp"
 
 namespace zk {
 
@@ -83,7 +83,7 @@ ZK_HD g1_affine_t g1_xyzz_to_affine(const g1_xyzz_t &p) {
   g1_affine_t r;
   if (g1_xyzz_is_identity(p)) { r.x = Fq::zero(); r.y = Fq::zero(); return r; }
   // 1/ZZZ, then 1/ZZ = ZZZ^-1 * ZZZ / ZZ ... cheaper: i = (ZZ*ZZZ)^-1; 1/ZZ = i*ZZZ; 1/ZZZ = i*ZZ
-  fe_t i = Fq::inv_sgcd(Fq::mul(p.zz, p.zzz));   // division-step inverse (fp.cuh): no multiword borrow chains, no divergence when every lane converts a point
+  fe_t i = Fq::inv_sgcd(Fq::mul(p.zz, p.zzz));   // division-step inverse (fp.hpp): no multiword borrow chains, no divergence when every lane converts a point
   r.x = Fq::mul(p.x, Fq::mul(i, p.zzz));
   r.y = Fq::mul(p.y, Fq::mul(i, p.zz));
   return r;

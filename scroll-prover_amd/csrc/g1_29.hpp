@@ -1,13 +1,13 @@
-// g1_29.cuh -- XYZZ bucket accumulator on the 9 x 29-bit unsaturated field (fp29.cuh); used by k_msm_accumulate, whose
-// time is entirely field multiplications.  Same formulas and exceptional cases as g1.cuh (madd-2008-s / mdbl-2008-s); what
+// g1_29.hpp -- XYZZ bucket accumulator on the 9 x 29-bit unsaturated field (fp29.hpp); used by k_msm_accumulate, whose
+// time is entirely field multiplications.  Same formulas and exceptional cases as g1.hpp (madd-2008-s / mdbl-2008-s); what
 // changes is the bookkeeping of lazy values.  Invariants of an accumulator between additions (p = Fq modulus):
 //     x   limbs <= 2^29 + 8, value < 14 p          zz, zzz   tight (mul outputs), value < 1.1 p
 //     y   limbs <= 2^30 - 2, value < 6.1 p         identity  <=> all limbs of zz are 0
 // Bases arrive in the ABI form (8 x 32, R = 2^256) and are re-sliced on the fly (from_sat: value < 2^259, limbs < 2^29:
 // only ever used as a multiplication operand).  Bounds of every intermediate are written next to it.
 #pragma once
-#include "fp29.cuh"
-#include "g1.cuh"
+#include "fp29.hpp"
+#include "g1.hpp"
 
 namespace zk {
 
@@ -46,7 +46,7 @@ ZK_HD g1_xyzz29_t g1_xyzz29_dbl_affine(const fe29_t &xt, const fe29_t &yt) {
   return r;
 }
 
-// acc += (+-) q, q in the ABI form.  madd-2008-s.  CHAIN: limb products as explicitly chained v_mad (fp29.cuh mac_*), bit-identical.
+// acc += (+-) q, q in the ABI form.  madd-2008-s.  CHAIN: limb products as explicitly chained v_mad (fp29.hpp mac_*), bit-identical.
 #ifndef ZK_MADD_CHAIN_DEFAULT
 #define ZK_MADD_CHAIN_DEFAULT false
 #endif

@@ -1,4 +1,4 @@
-// g1fft.cuh -- DFT over G1 points: best_fft::<Fr, G1> of halo2_proofs [EXT-recalled src/arithmetic.rs], the transform behind
+// g1fft.hpp -- DFT over G1 points: best_fft::<Fr, G1> of halo2_proofs [EXT-recalled src/arithmetic.rs], the transform behind
 // g_to_lagrange / ParamsKZG::downsize [REF integration/tests/integration.rs:12-22; SURVEY 8a row a3, 8f-2]:
 //     a'[i] = sum_j omega^(ij) a[j]      (natural order in, natural order out, no scaling)
 //
@@ -10,10 +10,10 @@
 //     stage s (m = 2^s):  t = w^j * a[g + j + m];  a[g + j + m] = a[g + j] - t;  a[g + j] += t,   w = omega^(n / 2m)
 // Butterflies with j == 0 (all of stage 0) skip the scalar multiple.
 #pragma once
-#include "fp_asm.cuh"
-#include "g1.cuh"
-#include "g1_29.cuh"
-#include "glv.cuh"
+#include "fp_asm.hpp"
+#include "g1.hpp"
+#include "g1_29.hpp"
+#include "glv.hpp"
 
 namespace zk {
 #ifdef __HIPCC__
@@ -92,7 +92,7 @@ __device__ __noinline__ g1_xyzz29_t g1_xyzz29_mul_fr(const g1_xyzz29_t &p, const
   return acc;
 }
 
-// GLV form of the same multiple (glv.cuh): k = k1 + lambda k2, one joint double-and-add over 64 signed 2-bit digits with the tables
+// GLV form of the same multiple (glv.hpp): k = k1 + lambda k2, one joint double-and-add over 64 signed 2-bit digits with the tables
 // {P, 2P} and their images under phi(x, y) = (beta x, y) -- 128 doublings + ~96 additions instead of 256 + ~96 (-31 % of the field
 // multiplications).  ZK_G1FFT_GLV=false keeps the plain ladder for A/B runs.
 #ifndef ZK_G1FFT_GLV

@@ -1,10 +1,10 @@
-// g2.cuh -- BN254 G2 (the sextic twist y^2 = x^3 + 3 / (9 + u) over Fq2 = Fq[u] / (u^2 + 1)) for the ONE place the proving path
+// g2.hpp -- BN254 G2 (the sextic twist y^2 = x^3 + 3 / (9 + u) over Fq2 = Fq[u] / (u^2 + 1)) for the ONE place the proving path
 // touches it: ParamsKZG::setup's s_g2 = tau * G2 (there is no G2 MSM in create_proof).
 // g2_affine_t = {x: {c0, c1}, y: {c0, c1}} = 128 B of Montgomery limbs == halo2curves bn256::G2Affine == the `g2` / `s_g2`
-// fields of a RawBytes params file; identity = all zero.  Same XYZZ formulas as g1.cuh with Fq2 in the place of Fq
+// fields of a RawBytes params file; identity = all zero.  Same XYZZ formulas as g1.hpp with Fq2 in the place of Fq
 // (madd-2008-s / dbl-2008-s-1 / mdbl-2008-s); one scalar multiplication per SRS, so a single lane and the plain C++ multiplier.
 #pragma once
-#include "fp.cuh"
+#include "fp.hpp"
 
 namespace zk {
 

@@ -1,11 +1,11 @@
-// glv.cuh -- the GLV endomorphism of BN254 G1 for the scalar multiples of the G1 DFT (g1fft.cuh: best_fft::<Fr, G1>, g_to_lagrange,
+// glv.hpp -- the GLV endomorphism of BN254 G1 for the scalar multiples of the G1 DFT (g1fft.hpp: best_fft::<Fr, G1>, g_to_lagrange,
 // ParamsKZG::downsize).  phi(x, y) = (beta x, y) acts as multiplication by lambda (lambda^2 + lambda + 1 = 0 mod r; lambda is halo2curves'
 // Fr::ZETA), so a 254-bit scalar k = k1 + lambda k2 with |k1|, |k2| < 2^127 turns k P into k1 P + k2 phi(P): one joint double-and-add over
 // 127 bits instead of 254 (Gallant, Lambert, Vanstone, CRYPTO 2001).  Constants: tools/gen_glv_constants.py, which derives them from r and p;
 // tests/test_device_limb_code_on_host.py re-runs that derivation and holds this header's decomposition and scalar multiple (compiled for the
 // host) to the same integers and to big-integer curve arithmetic.
 #pragma once
-#include "g1_29.cuh"
+#include "g1_29.hpp"
 
 namespace zk {
 

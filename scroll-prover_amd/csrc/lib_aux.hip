@@ -1,10 +1,10 @@
 // lib_aux.hip -- libmi355zk.so, the translation unit of the kernels either side of MSM / NTT: the DFT over G1 points
-// (g1fft.cuh: g_to_lagrange, ParamsKZG::downsize), the multiplicative scans of the permutation / lookup arguments and kate_division
-// (frscan.cuh), Curve::batch_normalize, and the one G2 scalar multiple of ParamsKZG::setup (g2.cuh).  Host logic only.
+// (g1fft.hpp: g_to_lagrange, ParamsKZG::downsize), the multiplicative scans of the permutation / lookup arguments and kate_division
+// (frscan.hpp), Curve::batch_normalize, and the one G2 scalar multiple of ParamsKZG::setup (g2.hpp).  Host logic only.
 // kernel headers first: lib_common.hpp defines the macro `g` (the calling thread's device context), a name the kernels use for locals
-#include "g1fft.cuh"
-#include "frscan.cuh"
-#include "g2.cuh"
+#include "g1fft.hpp"
+#include "frscan.hpp"
+#include "g2.hpp"
 #include "lib_common.hpp"
 
 namespace mi355 {
@@ -21,7 +21,7 @@ int aux_tu_init_device() {
   return MI355_OK;
 }
 
-// DFT over G1 points (g1fft.cuh).  in: n x (96 B Jacobian | 64 B affine), out likewise (may alias in); scale: optional Fr (Montgomery).
+// DFT over G1 points (g1fft.hpp).  in: n x (96 B Jacobian | 64 B affine), out likewise (may alias in); scale: optional Fr (Montgomery).
 int g1fft_impl(const void *in, int in_jac, void *out, int out_jac, uint32_t log_n, const void *omega, const void *scale_host) {
   const uint32_t n = 1u << log_n, half = std::max(1u, n / 2);
   g1_xyzz_t *work; fe_t *tw; fe_t scale = Fr::zero(); if (scale_host) memcpy(&scale, scale_host, 32);
@@ -30,7 +30,7 @@ int g1fft_impl(const void *in, int in_jac, void *out, int out_jac, uint32_t log_
   hipStream_t s = g.stream;
   fe_t w; memcpy(&w, omega, 32);
   Scope total("g1_fft");
-  CHK(launch_pow_table(tw, w, 1, half));   // kernel of ntt.cuh, launched by lib_ntt.hip on this context's stream
+  CHK(launch_pow_table(tw, w, 1, half));   // kernel of ntt.hpp, launched by lib_ntt.hip on this context's stream
   if (in_jac) hipLaunchKernelGGL(k_g1fft_load<1>, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, work, log_n);
   else hipLaunchKernelGGL(k_g1fft_load<0>, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, work, log_n);
   for (uint32_t st = 0; st < log_n; st++) hipLaunchKernelGGL(k_g1fft_stage, dim3(ceil_div(n / 2, 256)), dim3(256), 0, s, work, tw, log_n, st);
@@ -96,7 +96,7 @@ template <bool ADD> int prefix_scan_entry(void *dst_dev, const void *src_dev, ui
 
 extern "C" {
 
-// Curve::batch_normalize: n Jacobian points (96 B, any representative) -> n affine points (64 B); k_g1_batch_normalize (frscan.cuh)
+// Curve::batch_normalize: n Jacobian points (96 B, any representative) -> n affine points (64 B); k_g1_batch_normalize (frscan.hpp)
 int mi355_g1_batch_normalize_dev(const void *jac_dev, void *affine_dev, uint64_t n) {
   return guarded([&]() -> int {
   int slot; CHK(common_slot({jac_dev, affine_dev}, &slot, "g1_batch_normalize")); DevGuard lk(slot);

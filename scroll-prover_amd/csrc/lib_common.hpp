@@ -20,10 +20,10 @@
 #include <vector>
 
 #include "../../include/mi355zk.h"
-#include "fp.cuh"
-#include "g1.cuh"
-#include "g1_29.cuh"
-#include "ntt_types.cuh"
+#include "fp.hpp"
+#include "g1.hpp"
+#include "g1_29.hpp"
+#include "ntt_types.hpp"
 
 namespace mi355 {
 using namespace zk;
@@ -60,7 +60,7 @@ struct NttPlan {
   uint32_t split[2] = {0, 0};
   uint32_t direct2[2] = {0, 0};
   std::map<std::string, Tw29> scaled;   // the last strided level's direct twiddle table times a constant (key: the 32 bytes of the constant)
-  // the same tables as w * 2^261 mod r in 29-bit limbs (SoA) for the unsaturated kernels (ntt29.cuh); tw29_s_lo[l] of a big level is the
+  // the same tables as w * 2^261 mod r in 29-bit limbs (SoA) for the unsaturated kernels (ntt29.hpp); tw29_s_lo[l] of a big level is the
   // 2^log_s-entry table [k][column]
   Tw29 tw29_m[3] = {}, tw29_s_lo[2] = {}, tw29_s_hi[2] = {};
   std::vector<void *> owned;
@@ -259,7 +259,7 @@ int pick_replica_slot();
 int msm_tu_init_device();
 int ntt_tu_init_device();
 int aux_tu_init_device();
-// twiddle table out[i] = (base^step)^i on the current context's stream (kernel in ntt.cuh; used by the G1 DFT as well)
+// twiddle table out[i] = (base^step)^i on the current context's stream (kernel in ntt.hpp; used by the G1 DFT as well)
 int launch_pow_table(fe_t *out, const fe_t &base, uint64_t step, uint32_t count);
 // window-cost model shared by the MSM launch code and mi355_srs_precompute
 constexpr int MSM_SCALAR_BITS = 255, MSM_MAX_C = 24;   // hard limit of the sorter (23 key bits); the automatic choices stop at g_auto_max_c

@@ -1,10 +1,10 @@
-// lib_msm.hip -- libmi355zk.so, the MSM translation unit: launch orchestration of msm.cuh (digits -> two-level LDS counting sort ->
+// lib_msm.hip -- libmi355zk.so, the MSM translation unit: launch orchestration of msm.hpp (digits -> two-level LDS counting sort ->
 // segmented accumulation -> fix-up -> reduction tail), the host-pointer and sharded (multi-device) schedules, the C-ABI entry points
-// mi355_msm_* / mi355_g1_sum_*, and the SRS entry points that launch kernels of msm.cuh (params-file loader with on-device validation,
+// mi355_msm_* / mi355_g1_sum_*, and the SRS entry points that launch kernels of msm.hpp (params-file loader with on-device validation,
 // window-table build, synthetic SRS).  Host logic only; all arithmetic runs in the kernels.
 // kernel headers first: lib_common.hpp defines the macro `g` (the calling thread's device context), a name the kernels use for locals
-#define ZK_FRSCAN_DEVICE_ONLY 1   // msm.cuh needs the block scans of frscan.cuh, not its kernels (those belong to lib_aux.hip)
-#include "msm.cuh"
+#define ZK_FRSCAN_DEVICE_ONLY 1   // msm.hpp needs the block scans of frscan.hpp, not its kernels (those belong to lib_aux.hip)
+#include "msm.hpp"
 #include "lib_common.hpp"
 
 namespace mi355 {
@@ -257,7 +257,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
       Scope sc("msm_accumulate", s);
       HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
 #define ACC_LAUNCH(V) hipLaunchKernelGGL(k_msm_accumulate<V>, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, seg_arg, S.nshift, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask)
-      if (g.acc_variant & 4) ACC_LAUNCH(4); else ACC_LAUNCH(0);   // 4: limb products as explicitly chained v_mad (fp29.cuh mac_*); the older A/B variants (index stream further ahead, prefetched bucket ends) did not help and are no longer instantiated
+      if (g.acc_variant & 4) ACC_LAUNCH(4); else ACC_LAUNCH(0);   // 4: limb products as explicitly chained v_mad (fp29.hpp mac_*); the older A/B variants (index stream further ahead, prefetched bucket ends) did not help and are no longer instantiated
 #undef ACC_LAUNCH
     }
     if (piped) { HIPCHK(hipEventRecord(slot.acc_done, s)); HIPCHK(hipStreamWaitEvent(st.c, slot.acc_done, 0)); }

@@ -1,10 +1,10 @@
-// lib_ntt.hip -- libmi355zk.so, the Fr translation unit: launch orchestration of ntt.cuh / ntt29.cuh (plan cache, <= 3 global passes), the
+// lib_ntt.hip -- libmi355zk.so, the Fr translation unit: launch orchestration of ntt.hpp / ntt29.hpp (plan cache, <= 3 global passes), the
 // EvaluationDomain wrappers (ifft, coset extension and its inverse), distribute_powers, the element-wise vector operations, the gate-shaped
 // fused evaluation (mi355_fr_gate_eval_dev), eval_polynomial, and the batched / replicated entry points that spread independent transforms
 // over the bound devices.  Host logic only; all arithmetic runs in the kernels.
 // kernel headers first: lib_common.hpp defines the macro `g` (the calling thread's device context), a name the kernels use for locals
-#include "ntt.cuh"
-#include "ntt29.cuh"
+#include "ntt.hpp"
+#include "ntt29.hpp"
 #include "lib_common.hpp"
 
 namespace mi355 {

@@ -1,4 +1,4 @@
-// msm.cuh -- BN254 G1 multi-scalar multiplication (Pippenger / bucket method) for gfx950.
+// msm.hpp -- BN254 G1 multi-scalar multiplication (Pippenger / bucket method) for gfx950.
 // Stands in for halo2_proofs::arithmetic::best_multiexp and the ParamsKZG::commit / commit_lagrange wrappers
 // (SURVEY.md §8a a1/a2).  The result is a group element, so any correct schedule is bit-exact with the CPU
 // path after normalisation; what differs from the CPU reference is the schedule:
@@ -22,9 +22,9 @@
 // Algorithmic HBM bytes: 96 B per (scalar, point) pair.  The accumulation is VALU-integer bound
 // (10 field multiplications = ~1650 v_mad_u64_u32 + ~700 other instructions per mixed addition), see DESIGN.md section 4.
 #pragma once
-#include "fp_asm.cuh"
-#include "g1_29.cuh"
-#include "frscan.cuh"
+#include "fp_asm.hpp"
+#include "g1_29.hpp"
+#include "frscan.hpp"
 
 namespace zk {
 
@@ -76,7 +76,7 @@ __device__ __forceinline__ g1_xyzz29_t load_xyzz29(const g1_xyzz29_t *p) {
 // broadcast inside the quad with DPP quad_perm moves (full-rate VALU, no LDS).  The dependent chain of an addition drops from 14 field
 // multiplications to 4 (a doubling: 9 -> 3): ~1 250 instructions per wavefront instead of ~2 900, i.e. the latency of every step of the
 // ~60-step serial chain of a small MSM's tail.  It costs 4x the lanes and ~1.7x the total instructions, so the launch code only uses it where
-// the kernels are latency-bound (few logical threads).  Same formulas, bounds and exceptional cases as g1_xyzz29_add / _dbl (g1_29.cuh); the
+// the kernels are latency-bound (few logical threads).  Same formulas, bounds and exceptional cases as g1_xyzz29_add / _dbl (g1_29.hpp); the
 // only difference is Y3 = A - B + 4p as two products instead of one fused reduction (value < 5.6 p, inside the accumulator invariant).
 template <int J> __device__ __forceinline__ fe29_t quad_bcast(const fe29_t &v) {
   fe29_t r;
@@ -536,7 +536,7 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
   uint32_t b = lo, b_start = offsets[b], b_end = offsets[b + 1];
   uint32_t next_end = (b + 2 <= nbuckets) ? offsets[b + 2] : b_end;   // end of bucket b+1, fetched one bucket ahead so that a crossing does not stall on a load
   int32_t id_first = -1, id_last = -1;
-  // the accumulator lives in the 9 x 29-bit unsaturated field (g1_29.cuh): one v_mad_u64_u32 per limb product, no carry chain;
+  // the accumulator lives in the 9 x 29-bit unsaturated field (g1_29.hpp): one v_mad_u64_u32 per limb product, no carry chain;
   // it is flushed as a raw 144-byte record
   g1_xyzz29_t acc = g1_xyzz29_identity();
   // row_stride != 0: entry payload (w << nshift) | i names row w of the precomputed table T[w][.] = 2^(c w) P (rows row_stride points apart)
@@ -593,7 +593,7 @@ template <int VARIANT> __global__ void __launch_bounds__(256) k_msm_accumulate(c
 //         reduced by a whole workgroup (wavefront-shuffle tree + LDS) in k_msm_fixup_big.
 constexpr uint32_t FIXUP_SERIAL_MAX = 32, FIXUP_HUGE_MIN = 2048, FIXUP_SLICES = 64;   // SLICES <= 64: one wavefront folds the slice sums
 // The fix-up and the whole reduction tail stay in the 29-bit field (g1_xyzz29_add / _dbl): no conversion of the 144-byte records to the
-// saturated form (4 multiplications each) and the faster multiplier; records always hold valid accumulators (g1_29.cuh invariants).
+// saturated form (4 multiplications each) and the faster multiplier; records always hold valid accumulators (g1_29.hpp invariants).
 template <int Q = 1> __device__ __forceinline__ void fixup_take29(g1_xyzz29_t &acc, const g1_xyzz29_t *__restrict__ part, const int32_t *__restrict__ part_id, uint32_t t, uint32_t b) {
   if (part_id[2 * t] == (int32_t)b) g1_vadd<Q>(acc, load_xyzz29(&part[2 * (uint64_t)t]));
   else if (part_id[2 * t + 1] == (int32_t)b) g1_vadd<Q>(acc, load_xyzz29(&part[2 * (uint64_t)t + 1]));
@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(256) k_g1_validate(const g1_affine_t *__restri
 
 // ---- window precomputation for a registered basis: T[w][i] = 2^(c w) * P_i, affine, w < W (row 0 = the basis itself).
 // One thread per point and c doublings per row; the conversion back to affine coordinates shares ONE inversion per row among the 256
-// points of a workgroup (Montgomery's trick through the LDS scans of frscan.cuh, the tile product inverted by lane 0's Euclidean
+// points of a workgroup (Montgomery's trick through the LDS scans of frscan.hpp, the tile product inverted by lane 0's Euclidean
 // inverse): ~210 field multiplications per point and row instead of ~550 with a Fermat ladder per point (3.05 s per 2^26 basis before).
 // One-off cost at registration.
 __global__ void __launch_bounds__(FRSCAN_THREADS) k_srs_precompute(const g1_affine_t *__restrict__ base, g1_affine_t *__restrict__ table, uint64_t n, uint32_t W, uint32_t c) {

@@ -1,4 +1,4 @@
-// ntt.cuh -- BN254 Fr number-theoretic transform for gfx950: LDS-tiled Cooley-Tukey in at most three
+// ntt.hpp -- BN254 Fr number-theoretic transform for gfx950: LDS-tiled Cooley-Tukey in at most three
 // global passes.  Stands in for halo2_proofs::arithmetic::best_fft (natural order in -> natural order out,
 // a'[i] = sum_j a[j] w^(ij), no scaling) and the EvaluationDomain wrappers around it.
 //
@@ -14,7 +14,7 @@
 // Element layout in LDS: two 16-byte planes (lo = limbs 0..3, hi = limbs 4..7) so that consecutive lanes touch
 // consecutive 16-B slots (conflict-free ds_read_b128 / ds_write_b128).
 #pragma once
-#include "fp_asm.cuh"
+#include "fp_asm.hpp"
 
 namespace zk {
 

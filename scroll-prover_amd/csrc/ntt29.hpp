@@ -1,6 +1,6 @@
-// ntt29.cuh -- the NTT passes of ntt.cuh on the 9 x 29-bit unsaturated field (fp29.cuh).
+// ntt29.hpp -- the NTT passes of ntt.hpp on the 9 x 29-bit unsaturated field (fp29.hpp).
 //
-// Same decomposition, tiling and global access pattern as ntt.cuh (strided passes + digit-reversing final pass); what
+// Same decomposition, tiling and global access pattern as ntt.hpp (strided passes + digit-reversing final pass); what
 // changes is the arithmetic inside the tile: one v_mad_u64_u32 per limb product and lazy additions.
 //   * data stay in the ABI domain (x * 2^256): they are only re-sliced (from_sat_plain) on load; twiddles are kept as
 //     w * 2^261 mod r (canonical, SoA tables), so Montgomery products with R' = 2^261 land back in the x * 2^256 domain
@@ -15,10 +15,10 @@
 //     leave the tight multiplication output (< 1.4 r) in the scratch buffer as it is.
 // LDS: 36 B per element as two 16-byte planes + one 4-byte plane (4096-element tile = 144 KiB of the 160 KiB).
 #pragma once
-#include "fp29.cuh"
-#include "fp_asm.cuh"
-#include "ntt.cuh"
-#include "ntt_types.cuh"
+#include "fp29.hpp"
+#include "fp_asm.hpp"
+#include "ntt.hpp"
+#include "ntt_types.hpp"
 
 namespace zk {
 
@@ -29,7 +29,7 @@ namespace zk {
 #define ZK_NTT_LAZY_LAST true   // trivial-twiddle differences of a tile's last stage stay un-reduced (see lds_dif29_round)
 #endif
 #ifndef ZK_NTT_CHAIN
-#define ZK_NTT_CHAIN true    // limb products of the NTT butterflies as column blocks of chained v_mad (fp29.cuh mul_c): 8.61 vs 8.86 ms at 2^26 in round 3 (round 2 measured no gain; false restores the C++ multiplier for A/B builds)
+#define ZK_NTT_CHAIN true    // limb products of the NTT butterflies as column blocks of chained v_mad (fp29.hpp mul_c): 8.61 vs 8.86 ms at 2^26 in round 3 (round 2 measured no gain; false restores the C++ multiplier for A/B builds)
 #endif
 struct Ntt29Level { uint32_t log_m, log_t, split; Tw29 tw_m, tw_s_lo, tw_s_hi; uint32_t direct; };   // direct 1: tw_s_lo holds every inter-level twiddle w_S^e (small levels), no lo x hi product; direct 2: tw_s_lo is the table [k][column] = w_S^(column k) of a big level, read like the data (8 adjacent columns per row)
 

@@ -1,4 +1,4 @@
-// ntt_types.cuh -- the twiddle-table descriptor of the 29-bit NTT kernels (ntt29.cuh), split out so that the host-side plan cache
+// ntt_types.hpp -- the twiddle-table descriptor of the 29-bit NTT kernels (ntt29.hpp), split out so that the host-side plan cache
 // (lib_common.hpp) can hold it without pulling in the kernels.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -146,7 +146,7 @@ int main(int argc, char **argv) {
   uint64_t free_after_pk = 0; check(mi355_mem_info(0, &free_after_pk, nullptr, nullptr, nullptr, nullptr));
   const double room = 0.97 * (double)free_after_pk - working - (resident ? 0.0 : pk_lean_tmp);
   if (tables == "on") n_tables = 2; else if (tables == "lagrange") n_tables = 1; else if (tables == "off") n_tables = 0;
-  else n_tables = room >= 2 * table_one ? 2 : room >= table_one ? 1 : 0;
+  else { const double margin = 0.08 * (double)hbm_total; n_tables = room >= 2 * table_one + margin ? 2 : room >= table_one + margin ? 1 : 0; }   // 8 % of the device stays unplanned: a table is worth 5 ms per commitment, an out-of-memory proof is worth nothing
   if (devices > 1 && tables == "auto") n_tables = 2;   // the estimate above is for one device; shards divide everything
   if (n_tables >= 1 && mi355_srs_precompute(hl, 0, 0) != MI355_OK) { std::printf("window tables for g_lagrange did not fit (%s): table-free schedule\n", mi355_last_error()); n_tables = 0; }
   if (n_tables >= 2 && mi355_srs_precompute(hg, 0, 0) != MI355_OK) { std::printf("window tables for g did not fit (%s): Lagrange basis only\n", mi355_last_error()); n_tables = 1; }

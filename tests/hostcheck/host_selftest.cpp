@@ -1,12 +1,12 @@
 // host_selftest.cpp -- TEST INFRASTRUCTURE: compiles the product's __host__ __device__ limb code
-// (scroll-prover_amd/csrc/fp.cuh, g1.cuh) for the CPU with plain g++ so that the 8x32-bit Montgomery
+// (scroll-prover_amd/csrc/fp.hpp, g1.hpp) for the CPU with plain g++ so that the 8x32-bit Montgomery
 // and XYZZ formulas can be checked against the oracle in the GPU-less container.  Never shipped,
 // never linked into libmi355zk.so.
-#include "../../scroll-prover_amd/csrc/g1.cuh"
-#include "../../scroll-prover_amd/csrc/fp_asm.cuh"
-#include "../../scroll-prover_amd/csrc/fp29.cuh"
-#include "../../scroll-prover_amd/csrc/g1_29.cuh"
-#include "../../scroll-prover_amd/csrc/glv.cuh"
+#include "../../scroll-prover_amd/csrc/g1.hpp"
+#include "../../scroll-prover_amd/csrc/fp_asm.hpp"
+#include "../../scroll-prover_amd/csrc/fp29.hpp"
+#include "../../scroll-prover_amd/csrc/g1_29.hpp"
+#include "../../scroll-prover_amd/csrc/glv.hpp"
 #include <string.h>
 using namespace zk;
 
@@ -48,7 +48,7 @@ extern "C" void hs_xyzz_mul_small(void *out, const void *p, uint32_t k) { *(g1_x
 extern "C" void hs_xyzz_madd_ps(void *acc_xyzz, const void *affine) { g1_xyzz_madd_ps(*(g1_xyzz_t *)acc_xyzz, *(const g1_affine_t *)affine); }
 extern "C" void hs_xyzz_add_ps(void *acc_xyzz, const void *q) { g1_xyzz_add_ps(*(g1_xyzz_t *)acc_xyzz, *(const g1_xyzz_t *)q); }
 
-// ---- 29-bit unsaturated arithmetic (fp29.cuh): every op takes/returns saturated ABI elements so the test can use the oracle
+// ---- 29-bit unsaturated arithmetic (fp29.hpp): every op takes/returns saturated ABI elements so the test can use the oracle
 template <class F29> static void op29(int op, fe_t *o, const fe_t *a, const fe_t *b) {
   fe29_t x = F29::from_sat(*a), y = F29::from_sat(*b), r;
   switch (op) {
@@ -88,7 +88,7 @@ extern "C" void hs_f29_reduce_small(int which, uint32_t *out9, const uint32_t *i
   for (int i = 0; i < 9; i++) out9[i] = r.l[i];
 }
 
-// ---- 29-bit full addition / doubling (g1_29.cuh): groups of mixed additions are combined with g1_xyzz29_add (loose inputs), and
+// ---- 29-bit full addition / doubling (g1_29.hpp): groups of mixed additions are combined with g1_xyzz29_add (loose inputs), and
 // a double-and-add ladder runs on g1_xyzz29_dbl / g1_xyzz29_add; results leave as saturated XYZZ for the oracle comparison
 extern "C" void hs_xyzz29_grouped_sum(void *out_xyzz, const void *affine, const uint8_t *signs, uint64_t n, uint64_t group) {
   const g1_affine_t *p = (const g1_affine_t *)affine;
@@ -109,7 +109,7 @@ extern "C" void hs_xyzz29_ladder(void *out_xyzz, const void *affine, const uint8
   *(g1_xyzz_t *)out_xyzz = g1_xyzz29_to_sat(acc);
 }
 
-// ---- GLV (glv.cuh): decomposition of a canonical scalar and the joint scalar multiple k * P on the 29-bit field
+// ---- GLV (glv.hpp): decomposition of a canonical scalar and the joint scalar multiple k * P on the 29-bit field
 extern "C" void hs_glv_decompose(const void *k_canonical, uint32_t *k1, int *neg1, uint32_t *k2, int *neg2) {
   uint32_t a[4], b[4]; bool n1, n2;
   glv_decompose(*(const fe_t *)k_canonical, a, n1, b, n2);

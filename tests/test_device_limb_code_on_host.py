@@ -1,5 +1,5 @@
 """
-Runs the product's __host__ __device__ limb code (fp.cuh 8x32-bit Montgomery, g1.cuh XYZZ formulas) on the CPU
+Runs the product's __host__ __device__ limb code (fp.hpp 8x32-bit Montgomery, g1.hpp XYZZ formulas) on the CPU
 via tests/hostcheck/host_selftest.cpp and checks it bit-exactly against the oracle.  This is a check OF the
 device arithmetic, compiled for x86 -- it is not a product path.  CPU only.
 """
@@ -47,7 +47,7 @@ def test_field_ops_bit_exact(hs):
             a, b = mont[i], mont[(i * 7 + 3) % len(vals)]
             assert (op(hs, w, 2, a, b) == cref.f_mul(w, a, b)).all()
             assert (op(hs, w, 0, a, b) == cref.f_add(w, a, b)).all()
-            assert (op(hs, w, 7, a, b) == cref.f_mul(w, a, b)).all()      # product-scanning multiplier (fp_asm.cuh, host form)
+            assert (op(hs, w, 7, a, b) == cref.f_mul(w, a, b)).all()      # product-scanning multiplier (fp_asm.hpp, host form)
             assert (op(hs, w, 8, a) == cref.f_mul(w, a, a)).all()         # dedicated squaring
             assert (op(hs, w, 1, a, b) == cref.f_sub(w, a, b)).all()
             assert (op(hs, w, 5, np.array(pyref.to_limbs(vals[i]), dtype=np.uint64)) == a).all()
@@ -119,7 +119,7 @@ def test_xyzz_special_cases(hs):
 
 
 def test_unsaturated_29bit_arithmetic(hs):
-    """fp29.cuh (9 x 29-bit limbs, R' = 2^261): conversions from/to the ABI form, lazy add/sub chains, mul/sqr, zero test."""
+    """fp29.hpp (9 x 29-bit limbs, R' = 2^261): conversions from/to the ABI form, lazy add/sub chains, mul/sqr, zero test."""
     rng = random.Random(29)
     for w, m in ((cref.FQ, P), (cref.FR, R)):
         edge = [0, 1, 2, m - 1, m - 2, (1 << 253) % m, (1 << 29) - 1, 1 << 29, (1 << 232), (1 << 232) - 1]
@@ -147,7 +147,7 @@ def test_unsaturated_29bit_arithmetic(hs):
 
 
 def test_xyzz29_bucket_accumulator(hs):
-    """g1_29.cuh: long chains of mixed additions with lazy values, negation, identity bases, P+P and P+(-P) inside a bucket."""
+    """g1_29.hpp: long chains of mixed additions with lazy values, negation, identity bases, P+P and P+(-P) inside a bucket."""
     rng = random.Random(31)
     G = pyref.G1_GEN
     pool = [pyref.g1_mul(G, rng.randrange(1, R)) for _ in range(12)]
@@ -242,7 +242,7 @@ def test_xyzz29_full_addition_and_doubling(hs):
 
 
 def test_glv_decomposition_and_joint_scalar_multiple(hs):
-    """glv.cuh: k = k1 + lambda k2 (mod r) with |k_i| < 2^127 for random and extreme scalars, and k * P by the joint double-and-add
+    """glv.hpp: k = k1 + lambda k2 (mod r) with |k_i| < 2^127 for random and extreme scalars, and k * P by the joint double-and-add
     (phi(P) = (beta x, y), signed 2-bit digits) against the big-integer oracle."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_glv", os.path.join(os.path.dirname(HERE), "tools", "gen_glv_constants.py"))

@@ -250,3 +250,37 @@ def test_eval_polynomial_batch_equals_single_calls_and_oracle(zk):
             assert (out[i] == h2.eval_polynomial(polys[which[i]], pts[i])).all()
             assert (out[i] == cref.eval_polynomial(hosts[which[i]], pts[i])).all()
     capi.check(lib.mi355_eval_polynomial_batch_dev(None, 0, 0, None, None))
+
+
+def test_interleave_and_mem_info(zk):
+    """mi355_fr_interleave_dev: dst[i * Q + q] = parts[q][i] for Q = 1, 4, 8 (numpy as the checker), overlap and argument rules;
+    mi355_mem_info: the library's own accounting moves with mi355_buf_alloc / _free / _trim"""
+    h2 = zk.halo2
+    lib, capi = zk._capi.lib(), zk._capi
+    n = (1 << 16) + 3                       # not a power of two: the kernel has no such requirement
+    for Q in (1, 4, 8):
+        parts = [dev_scalars(n, 700 + q) for q in range(Q)]
+        dst = torch.empty((Q * n, 4), dtype=torch.int64, device="cuda")
+        arr = (C.c_void_p * Q)(*[p.data_ptr() for p in parts])
+        capi.check(lib.mi355_fr_interleave_dev(C.c_void_p(dst.data_ptr()), arr, Q, n))
+        want = np.stack([as_host(p, n) for p in parts], axis=1).reshape(Q * n, 4)
+        assert (as_host(dst, Q * n) == want).all()
+    arr9 = (C.c_void_p * 9)(*([parts[0].data_ptr()] * 9))
+    assert lib.mi355_fr_interleave_dev(C.c_void_p(dst.data_ptr()), arr9, 9, n) == capi.EBADARG              # more than 8 parts
+    arr1 = (C.c_void_p * 1)(dst.data_ptr())
+    assert lib.mi355_fr_interleave_dev(C.c_void_p(dst.data_ptr()), arr1, 1, n) == capi.EBADARG              # dst overlaps a part
+    free0, tot, live0, pool0, ws0 = (C.c_uint64() for _ in range(5))
+    capi.check(lib.mi355_buf_trim())
+    capi.check(lib.mi355_mem_info(0, C.byref(free0), C.byref(tot), C.byref(live0), C.byref(pool0), C.byref(ws0)))
+    assert tot.value > (200 << 30) and free0.value <= tot.value and pool0.value == 0
+    b = h2.DeviceBuffer(1 << 30)
+    free1, live1, pool1 = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    capi.check(lib.mi355_mem_info(0, C.byref(free1), None, C.byref(live1), C.byref(pool1), None))
+    assert live1.value == live0.value + (1 << 30) and free1.value <= free0.value - (1 << 30) + (64 << 20)
+    b.free()
+    capi.check(lib.mi355_mem_info(0, None, None, C.byref(live1), C.byref(pool1), None))
+    assert live1.value == live0.value and pool1.value == 1 << 30                                              # freed = pooled, still held
+    capi.check(lib.mi355_buf_trim())
+    capi.check(lib.mi355_mem_info(0, C.byref(free1), None, None, C.byref(pool1), None))
+    assert pool1.value == 0 and free1.value >= free0.value - (64 << 20)
+    assert lib.mi355_mem_info(99, None, None, None, None, None) == capi.EBADARG

@@ -125,7 +125,7 @@ def test_signed_digit_recoding_algorithm():
 
 
 def test_accumulate_segment_rule_covers_every_entry():
-    """msm_seg_eff (msm.cuh), restated in integers: the accumulate launch is sized for the worst case (threads = ceil(emax / seg_max) rounded to
+    """msm_seg_eff (msm.hpp), restated in integers: the accumulate launch is sized for the worst case (threads = ceil(emax / seg_max) rounded to
     workgroups), and every kernel derives the segment from the actual entry count as clamp(ceil(total / (fill % of the threads)), seg_min,
     seg_max).  Whatever the count, threads * segment must cover it, and a full column must get the worst-case segment back."""
     import random
@@ -167,7 +167,7 @@ def test_build_is_content_hashed_per_translation_unit():
     closure = {}
     b._closure(os.path.join(b.CSRC, "lib_core.hip"), closure)
     names = {os.path.basename(p) for p in closure}
-    assert "lib_common.hpp" in names and "mi355zk.h" in names and "msm.cuh" not in names and "ntt29.cuh" not in names   # lib_core launches no kernel
+    assert "lib_common.hpp" in names and "mi355zk.h" in names and "msm.hpp" not in names and "ntt29.hpp" not in names   # lib_core launches no kernel
     closure = {}
     b._closure(os.path.join(b.CSRC, "lib_ntt.hip"), closure)
-    assert "ntt29.cuh" in {os.path.basename(p) for p in closure} and "msm.cuh" not in {os.path.basename(p) for p in closure}
+    assert "ntt29.hpp" in {os.path.basename(p) for p in closure} and "msm.hpp" not in {os.path.basename(p) for p in closure}

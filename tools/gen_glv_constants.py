@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gen_glv_constants.py -- derives the GLV constants of BN254 G1 used by scroll-prover_amd/csrc/glv.cuh and prints them as C++ initialisers.
+"""gen_glv_constants.py -- derives the GLV constants of BN254 G1 used by scroll-prover_amd/csrc/glv.hpp and prints them as C++ initialisers.
 
   lambda : primitive cube root of unity in Fr,  beta : primitive cube root of unity in Fq,  with  lambda * (x, y) = (beta x, y)  on G1
   (a1, b1), (a2, b2) : short basis of the lattice {(a, b) : a + b lambda = 0 mod r}  (extended Euclid on (r, lambda), Gallant-Lambert-Vanstone)
@@ -52,7 +52,7 @@ def derive():
 
 
 def decompose(k, c):
-    """the integer formulas of glv_decompose (glv.cuh): magnitudes of g1 / g2 with their signs applied afterwards"""
+    """the integer formulas of glv_decompose (glv.hpp): magnitudes of g1 / g2 with their signs applied afterwards"""
     c1 = (k * abs(c["g1"])) >> 256
     c2 = (k * abs(c["g2"])) >> 256
     if c["g1"] < 0: c1 = -c1

@@ -6,9 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "../scroll-prover_amd/csrc/g1.cuh"
-#include "../scroll-prover_amd/csrc/fp_asm.cuh"
-#include "../scroll-prover_amd/csrc/fp29.cuh"
+#include "../scroll-prover_amd/csrc/g1.hpp"
+#include "../scroll-prover_amd/csrc/fp_asm.hpp"
+#include "../scroll-prover_amd/csrc/fp29.hpp"
 using namespace zk;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -90,7 +90,7 @@ template <int VARIANT> __global__ void k_fq29mul(fe_t *io) {
   io[2 * t] = Fq29::to_sat(a); io[2 * t + 1] = Fq29::to_sat(b);
 }
 // madd chain on the 29-bit accumulator, to see the ALU ceiling of k_msm_accumulate at its real occupancy
-#include "../scroll-prover_amd/csrc/g1_29.cuh"
+#include "../scroll-prover_amd/csrc/g1_29.hpp"
 template <bool FUSED, bool CHAIN = false> __global__ void __launch_bounds__(256) k_madd29(g1_xyzz_t *accs, const g1_affine_t *pts, int npts, int iters) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   g1_xyzz29_t acc = g1_xyzz29_identity();

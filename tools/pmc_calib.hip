@@ -1,6 +1,6 @@
 // pmc_calib.hip -- calibrates rocprofv3 FETCH_SIZE on gfx950 for the two access patterns of the MSM:
 //  (a) k_stream: coalesced 16 B/lane streaming read of B bytes; (b) k_gather: random 64-byte record gathers
-//  (two 32-byte halves, each as two dwordx4 loads -- exactly load_affine() of msm.cuh) with a known record count.
+//  (two 32-byte halves, each as two dwordx4 loads -- exactly load_affine() of msm.hpp) with a known record count.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
