@@ -294,7 +294,8 @@ int main(int argc, char **argv) {
   CK(mi355_srs_release(hg)); CK(mi355_srs_release(hl));
   } catch (const std::exception &e) { std::printf("FAILED with exception: %s\n", e.what()); failures++; rc_main = 1; }
   CK(mi355_shutdown());
-  if (failures) { std::printf("%d check(s) FAILED\n", failures); return 1; }
+  if (failures) { std::printf("%d check(s) FAILED\n", failures); std::fflush(stdout); return 1; }
   std::printf("all checks passed\n");
+  std::fflush(stdout);   // exit handlers of the HIP / sanitizer runtimes run after main: what was printed must not depend on them
   return rc_main;
 }
