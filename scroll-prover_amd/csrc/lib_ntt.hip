@@ -531,6 +531,7 @@ int mi355_fr_gate_eval_dev(void *dst_dev, const void *const *polys_dev, uint32_t
     if (term_len[j] > 8 || nf + term_len[j] > GATE_MAX_FACTORS) return fail(MI355_EBADARG, "fr_gate_eval: at most 8 factors per term and 48 per launch");
     G.term_len[j] = (uint8_t)term_len[j]; nf += term_len[j];
     memcpy(&G.coeff[j], (const char *)coeffs + 32 * (size_t)j, 32);
+    G.coeff29[j] = Fr29::from_sat(G.coeff[j]);
     { const fe_t one = Fr::one(), minus_one = Fr::neg(Fr::one()); G.coeff_kind[j] = memcmp(&G.coeff[j], &one, 32) == 0 ? 1 : memcmp(&G.coeff[j], &minus_one, 32) == 0 ? 2 : 0; }
   }
   if (nf && (!factor_poly || !factor_rot)) return fail(MI355_EBADARG, "fr_gate_eval: null factor list");

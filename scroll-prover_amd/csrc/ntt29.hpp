@@ -335,7 +335,8 @@ __global__ void __launch_bounds__(256) k_fr_vec_mul_periodic(fe_t *__restrict__ 
 constexpr uint32_t GATE_MAX_TERMS = 16, GATE_MAX_FACTORS = 48, GATE_MAX_POLYS = 24;
 struct GatePlan {
   const fe_t *poly[GATE_MAX_POLYS];
-  fe_t coeff[GATE_MAX_TERMS];            // Montgomery (ABI) form
+  fe_t coeff[GATE_MAX_TERMS];            // Montgomery (ABI) form (constant terms)
+  fe29_t coeff29[GATE_MAX_TERMS];        // the same coefficient as c * 2^261 in 29-bit limbs (Fr29::from_sat, done once on the host: round 4 -- the kernel used to re-slice every general coefficient for every row)
   int32_t factor_rot[GATE_MAX_FACTORS];
   uint8_t factor_poly[GATE_MAX_FACTORS];
   uint8_t term_len[GATE_MAX_TERMS];      // factors per term (0: the constant c_j)
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(256) k_fr_gate_eval(fe_t *dst, GatePlan G, uin
         // unit coefficients (the common case in halo2 gates: a - b, z(wX) prod - z(X) prod): no multiplication by c_j; -1 negates the canonical first
         // factor instead (r - x, zero stays zero), so the term value stays a tight non-negative representative (< r) like every other
         const uint32_t kind = G.coeff_kind[j];
-        if (kind == 0) t = Fr29::mul(Fr29::from_sat_plain(x0), Fr29::from_sat(G.coeff[j]));
+        if (kind == 0) t = Fr29::mul(Fr29::from_sat_plain(x0), G.coeff29[j]);
         else t = Fr29::from_sat_plain(kind == 2 ? Fr::neg(x0) : x0);
         for (uint32_t q = 1; q < len; q++)
           t = Fr29::mul(t, Fr29::from_sat(g_load(&G.poly[G.factor_poly[f + q]][(i + (uint64_t)(int64_t)G.factor_rot[f + q]) & mask])));
