@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <set>
 
 #include "mi355zk_halo2.hpp"
 
@@ -62,6 +63,39 @@ int main(int argc, char **argv) {
     int rejected = 0;                                                          // about half of all x are not on the curve
     for (uint8_t v = 1; v < 40; v++) { G1Bytes t{}; t[0] = v; G1Affine o1, o2; const bool a = g1_from_bytes(t, o1); const int b = orc_g1_decompress(o2.data(), t.data()); EXPECT(a == (b == 1)); if (a) EXPECT(o1 == o2); else rejected++; }
     EXPECT(rejected > 5);
+  }
+  // --- the expression plans of create_proof_gpu_side (include/mi355zk_create_proof.hpp), host logic only: every launch of every layer's plan stays
+  // inside the limits of mi355_fr_gate_eval_dev, intermediates are written before they are read, the counts follow from the shapes
+  {
+    Challenges ch; ch.theta = detail::fr_from_u64(2); ch.beta = detail::fr_from_u64(3); ch.gamma = detail::fr_from_u64(5); ch.y = detail::fr_from_u64(7);
+    ch.x = detail::fr_from_u64(11); ch.v = detail::fr_from_u64(13); ch.z0 = detail::fr_from_u64(17); ch.z1 = detail::fr_from_u64(19);
+    const uint32_t want_commitments[7] = {955, 37, 11, 163, 14, 17, 12};   // layers 2 and 4: the fixtures' proof word counts
+    for (int layer = 0; layer <= 6; layer++) {
+      const CircuitShape sh = layer_shape(layer);
+      EXPECT(sh.commitments() == want_commitments[layer]);
+      EXPECT(sh.chunk_len + 2 <= sh.degree && sh.chunk_len <= 6 && ((sh.Q() & (sh.Q() - 1)) == 0));
+      const ExpressionPlan P = build_plan(sh, ch);
+      EXPECT(P.gates == 1 + (sh.advice > 2 ? sh.advice - 2 : 0) + sh.lookups + 2 * sh.perm_z());
+      EXPECT(P.perm_product.size() == sh.perm_z());
+      std::set<uint32_t> written; uint32_t quotient_launches = 0;
+      for (const auto &L : P.quotient) {
+        std::set<PolyRef> polys; uint32_t nf = 0;
+        EXPECT(L.terms.size() >= 1 && L.terms.size() <= PLAN_MAX_TERMS);
+        for (const auto &t : L.terms) {
+          EXPECT(t.f.size() <= 8); nf += (uint32_t)t.f.size();
+          for (const auto &f : t.f) { polys.insert(f.p); if (f.p.kind == P_TMP) EXPECT(written.count(f.p.idx) == 1); EXPECT(t.f.size() <= sh.degree); }
+        }
+        EXPECT(nf <= PLAN_MAX_FACTORS && polys.size() <= PLAN_MAX_POLYS);
+        if (L.to_tmp) { EXPECT(L.tmp < 2 * sh.chunk_len); written.insert(L.tmp); } else quotient_launches++;
+      }
+      EXPECT(quotient_launches >= 1);
+      for (size_t q = 1; q < P.queries.size(); q++) EXPECT(P.queries[q - 1] < P.queries[q]);   // sorted, no duplicates
+      for (const auto &qr : P.queries) EXPECT(qr.p.kind != P_TMP && qr.p.kind != P_INSTANCE && qr.p.kind != P_ID);
+    }
+    // the 16-term limit really cuts: layer 0's 798 custom gates of 3 terms cannot share fewer than 160 launches
+    const ExpressionPlan P0 = build_plan(layer_shape(0), ch);
+    uint32_t non_tmp = 0; for (const auto &L : P0.quotient) if (!L.to_tmp) non_tmp++;
+    EXPECT(non_tmp >= 160 && P0.terms > 2500);
   }
   if (host_only) {
     // without a GPU every compute entry point must fail loudly (no CPU fallback)
