@@ -320,7 +320,7 @@ inline Witness synthesize_witness(const CircuitShape &s, const EvaluationDomain 
 }
 
 // ------------------------------------------------------------------------------------------------ create_proof, GPU side
-struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 2; };
+struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 2; int early_intt = -1 /* -1: by column count, 0 / 1: off / on */; };
 struct CommitRecord { PolyRef p; int piece; G1 c; };   // piece >= 0: quotient piece; p.kind == P_KINDS with piece -1 - j: SHPLONK quotient j
 struct ProofGpuSide {
   std::vector<CommitRecord> commitments;              // in transcript order
@@ -387,12 +387,23 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
   check(mi355_intt_fr_dev(poly.at({P_INSTANCE, 0}).p, k, dom.omega_inv.data(), dom.ifft_divisor.data())); R.intt++;   // step 1
   lap(1);
   const bool batch_cols = s.advice >= 16;
+  // With many columns steps 2-3 are bound by PCIe (layer 0: 28.9 GB of witness at ~34 GB/s from pageable memory = 0.85 s against 0.42 s of MSM kernels),
+  // so the device idles half of that time.  lagrange_to_coeff of a column needs nothing but the column: the inverse transforms of the columns already
+  // committed run in those gaps, into coefficient copies (step 4 still reads the Lagrange values), and step 6 only transforms what is left.
+  const bool early_intt = opt.early_intt < 0 ? s.advice >= 8 : opt.early_intt != 0;
+  std::map<PolyRef, DevicePoly> coeff_early;
+  auto to_coeff_early = [&](const std::vector<PolyRef> &refs) {
+    if (!early_intt) return;
+    std::vector<void *> ptrs;
+    for (const auto &r : refs) { DevicePoly c = clone(poly.at(r), 0); ptrs.push_back(c.p); coeff_early[r] = std::move(c); }
+    check(mi355_ntt_fr_batch_dev(ptrs.data(), (uint32_t)ptrs.size(), k, dom.omega_inv.data(), dom.ifft_divisor.data())); R.intt += (uint32_t)ptrs.size();
+  };
   {                                                                                     // steps 2, 3
     std::vector<PolyRef> pending;
     for (size_t i = 1; i < uploads.size(); i++) {
       wait_for(i);
-      if (!batch_cols) commit_one(h_g_lagrange, poly.at(uploads[i].first), uploads[i].first, -1000);
-      else { pending.push_back(uploads[i].first); if (pending.size() == 32 || i + 1 == uploads.size() || uploads[i + 1].first.kind != uploads[i].first.kind) { commit_many(h_g_lagrange, pending, poly); pending.clear(); } }
+      if (!batch_cols) { commit_one(h_g_lagrange, poly.at(uploads[i].first), uploads[i].first, -1000); to_coeff_early({uploads[i].first}); }
+      else { pending.push_back(uploads[i].first); if (pending.size() == 32 || i + 1 == uploads.size() || uploads[i + 1].first.kind != uploads[i].first.kind) { commit_many(h_g_lagrange, pending, poly); to_coeff_early(pending); pending.clear(); } }
     }
   }
   uploaders.join();
@@ -437,9 +448,11 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
   // ---- step 6: every witness polynomial to coefficients, one batched call
   {
     std::vector<void *> ptrs;
-    for (auto &kv : poly) if (kv.first.kind != P_INSTANCE) ptrs.push_back(kv.second.p);
-    check(mi355_ntt_fr_batch_dev(ptrs.data(), (uint32_t)ptrs.size(), k, dom.omega_inv.data(), dom.ifft_divisor.data()));
+    for (auto &kv : poly) if (kv.first.kind != P_INSTANCE && !coeff_early.count(kv.first)) ptrs.push_back(kv.second.p);
+    if (!ptrs.empty()) check(mi355_ntt_fr_batch_dev(ptrs.data(), (uint32_t)ptrs.size(), k, dom.omega_inv.data(), dom.ifft_divisor.data()));
     R.intt += (uint32_t)ptrs.size();
+    for (auto &kv : coeff_early) poly.at(kv.first) = std::move(kv.second);   // the Lagrange values of those columns go back to the pool
+    coeff_early.clear();
   }
   lap(6);
   // ---- step 7: the quotient, coset part by coset part; part q on device q % D (pk cosets of that part live there)

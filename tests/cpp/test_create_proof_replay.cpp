@@ -79,7 +79,7 @@ static const char *kind_name(PolyKind k) { static const char *n[] = {"instance",
 
 int main(int argc, char **argv) {
   int layer_id = 4, devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2; long k_override = -1; bool host_api = false, do_check = true;
-  std::string tables = "auto", pk_mode = "auto"; int upload_threads = 2;
+  std::string tables = "auto", pk_mode = "auto"; int upload_threads = 2, early_intt = -1;
   long o_advice = -1, o_fixed = -1, o_lookups = -1, o_perm = -1, o_chunk = -1, o_degree = -1;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -88,10 +88,10 @@ int main(int argc, char **argv) {
     if (a == "--layer") layer_id = (int)next(); else if (a == "--k") k_override = next(); else if (a == "--devices") devices = (int)next();
     else if (a == "--threads") threads = (int)next(); else if (a == "--host-api") host_api = true; else if (a == "--no-check") do_check = false;
     else if (a == "--no-tables") tables = "off"; else if (a == "--tables") tables = nexts(); else if (a == "--pk-cosets") pk_mode = nexts(); else if (a == "--proofs") proofs = (int)next();
-    else if (a == "--upload-threads") upload_threads = (int)next();
+    else if (a == "--upload-threads") upload_threads = (int)next(); else if (a == "--early-intt") early_intt = (int)next();
     else if (a == "--advice") o_advice = next(); else if (a == "--fixed") o_fixed = next(); else if (a == "--lookups") o_lookups = next();
     else if (a == "--perm") o_perm = next(); else if (a == "--chunk") o_chunk = next(); else if (a == "--degree") o_degree = next();
-    else { std::printf("usage: %s [--layer 0..6] [--k K] [--advice A --fixed F --lookups L --perm P --chunk C --degree D] [--devices D] [--threads T] [--proofs N] [--upload-threads U]\n"
+    else { std::printf("usage: %s [--layer 0..6] [--k K] [--advice A --fixed F --lookups L --perm P --chunk C --degree D] [--devices D] [--threads T] [--proofs N] [--upload-threads U] [--early-intt 0|1]\n"
                        "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--no-check]\n", argv[0]); return 1; }
   }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;   // the GPU box's container gets 16 of the host's CPUs
@@ -155,7 +155,7 @@ int main(int argc, char **argv) {
   ch.y = h2d::fr_from_u64(0x7900000000000005ull); ch.x = h2d::fr_from_u64(0x1234567890ABCDEFull); ch.v = h2d::fr_from_u64(0xABCDEF0123456789ull);
   ch.z0 = h2d::fr_from_u64(0x1111); ch.z1 = h2d::fr_from_u64(0x1112);
   const ExpressionPlan plan = build_plan(S, ch);
-  ProofOptions opt; opt.devices = devices; opt.threads = threads; opt.upload_threads = upload_threads;
+  ProofOptions opt; opt.devices = devices; opt.threads = threads; opt.upload_threads = upload_threads; opt.early_intt = early_intt;
   // ---- the proofs: a prover process runs proof after proof; the first one grows the workspace arena and the buffer pool, the last one is reported
   ProofGpuSide R; double first_ms = 0;
   for (int it = 0; it < proofs; it++) {
