@@ -561,7 +561,9 @@ int mi355_buf_alloc(uint64_t bytes, int device_slot, void **dev_ptr_out) {
   return guarded([&]() -> int {
   if (!dev_ptr_out || bytes == 0) return fail(MI355_EBADARG, "buf_alloc: null pointer or zero size");
   if (device_slot < 0 || device_slot >= MAX_DEV) return fail(MI355_EBADARG, "buf_alloc: device slot out of range");
-  DevGuard lk(device_slot);
+  // No device lock (round 4): a pool hit is bookkeeping under the registry mutex, a miss is hipMalloc on the calling thread (thread-safe in HIP).
+  // With the lock, a witness uploader's next allocation waited for whatever call held the device -- a 12 ms batched MSM, say -- and the many-column
+  // layers uploaded at 34 GB/s instead of the link's 53 (kernel timeline in profiles/r04_kernel_vs_wall_L0_L3.md: 18.6 ms of idle device per batch).
   CHK(need_init(device_slot));
   const size_t want = ((size_t)bytes + 255) & ~(size_t)255;
   {
@@ -583,12 +585,13 @@ int mi355_buf_free(void *dev_ptr) {
   if (!dev_ptr) return MI355_OK;
   int slot;
   { std::lock_guard<std::mutex> bl(g_buf_mu); auto it = g_bufs.find((uintptr_t)dev_ptr); if (it == g_bufs.end()) return fail(MI355_EBADARG, "buf_free: not the base pointer of a live mi355_buf_alloc block"); slot = it->second.slot; }
-  DevGuard lk(slot);
+  // no device lock either: the event below marks "everything queued on the owner's compute stream so far", which includes every use the freeing
+  // thread issued before this call (HIP streams take work from several threads); nobody may use the block after its free
   CHK(need_init(slot));
   BufBlock b;
   { std::lock_guard<std::mutex> bl(g_buf_mu); auto it = g_bufs.find((uintptr_t)dev_ptr); if (it == g_bufs.end()) return fail(MI355_EBADARG, "buf_free: block freed twice"); b = it->second; g_bufs.erase(it); }
   if (!b.free_ev) HIPCHK(hipEventCreateWithFlags(&b.free_ev, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(b.free_ev, g.stream));
+  HIPCHK(hipEventRecord(b.free_ev, g_ctx[slot].stream));
   { std::lock_guard<std::mutex> bl(g_buf_mu); g_pool.insert({{b.slot, b.bytes}, b}); }
   return MI355_OK;
   });
