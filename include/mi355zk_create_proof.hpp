@@ -319,6 +319,53 @@ inline Witness synthesize_witness(const CircuitShape &s, const EvaluationDomain 
   return w;
 }
 
+// ------------------------------------------------------------------------------------------------ what stays resident
+// A prover process holds several layers at once (a chunk prover the degrees {20, 24, 25}, a batch prover {21, 26} [REF bin/src/trace_prover.rs:35-36]): the
+// SRS of every degree, every layer's proving key, and the working set of the ONE proof that runs.  Everything resident does not fit 288 GiB; this is the
+// rule of section 7c as code.  What each optional resident buys per proof: window tables of a basis ~8 % of every commitment on it (W x the basis of HBM);
+// the Q coset parts of a proving key one coset transform per polynomial and part (layer 4: 0.33 s of 1.65 s measured).  So cosets are kept before tables,
+// the keys with the most transforms per byte first, then tables go to the Lagrange bases (they carry most commitments), largest saving per byte first.
+struct LayerResidency { CircuitShape shape; bool cosets_resident = false; bool table_lagrange = false, table_coeff = false; };
+struct ResidencyPlan {
+  std::vector<LayerResidency> layers; double srs_gib = 0, keys_gib = 0, tables_gib = 0, working_gib = 0, total_gib = 0, budget_gib = 0; bool fits = false;
+};
+inline double gib_per_poly(uint32_t k) { return (double)(uint64_t(32) << k) / (1024.0 * 1024 * 1024); }
+inline double working_set_gib(const CircuitShape &s) {   // as measured in profiles/r04_replay_layers.md: polynomials + one part of each, temporaries, h twice, openings, NTT scratch, MSM workspace
+  const double per = gib_per_poly(s.k), n = (double)(uint64_t(1) << s.k);
+  return per * (2.0 * s.witness_polys() + 2 * s.chunk_len + 2 * s.Q() + 3) + per * s.Q() + per + n * 13 * 22 / (1024.0 * 1024 * 1024) + 0.5;
+}
+inline ResidencyPlan plan_residency(const std::vector<CircuitShape> &shapes, double hbm_gib, double reserve_fraction = 0.08) {
+  ResidencyPlan P; P.budget_gib = hbm_gib * (1.0 - reserve_fraction);
+  std::set<uint32_t> degrees;
+  for (const auto &s : shapes) { P.layers.push_back({s}); degrees.insert(s.k); P.working_gib = std::max(P.working_gib, working_set_gib(s)); }
+  for (uint32_t k : degrees) P.srs_gib += 2 * 2 * gib_per_poly(k);                                   // two bases of 64-byte points
+  auto key_base = [](const CircuitShape &s) { return gib_per_poly(s.k) * (s.fixed * 2 + s.perm_columns * 2 + 4); };
+  auto key_cosets = [](const CircuitShape &s) { return gib_per_poly(s.k) * (s.fixed + s.perm_columns + 3) * s.Q(); };
+  auto key_lean_tmp = [](const CircuitShape &s) { return gib_per_poly(s.k) * (s.fixed + s.perm_columns + 3); };
+  for (const auto &s : shapes) P.keys_gib += key_base(s);
+  double used = P.srs_gib + P.keys_gib + P.working_gib, lean_tmp = 0;   // lean_tmp: one part's worth of temporaries for the largest key whose cosets are recomputed
+  // 1. cosets: every part of a resident key saves one transform per proof; a transform costs ~ 2^k, a part holds 32 * 2^k bytes: the saving per byte is the
+  //    same for every layer, so the order only matters when not all fit -- smaller keys first keeps more layers fully resident
+  std::vector<size_t> order(shapes.size()); for (size_t i = 0; i < order.size(); i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key_cosets(shapes[a]) < key_cosets(shapes[b]); });
+  for (size_t i : order) {
+    const double c = key_cosets(shapes[i]);
+    if (used + c + lean_tmp <= P.budget_gib) { P.layers[i].cosets_resident = true; used += c; P.keys_gib += c; }
+    else lean_tmp = std::max(lean_tmp, key_lean_tmp(shapes[i]));
+  }
+  used += lean_tmp;
+  // 2. window tables: W x 64 bytes per point (W = 12 at k >= 24, 15 below); Lagrange bases first, the largest degree first (its commitments are the longest)
+  std::vector<uint32_t> ks(degrees.rbegin(), degrees.rend());
+  for (int pass = 0; pass < 2; pass++) for (uint32_t k : ks) {
+    const double t = 2 * gib_per_poly(k) * (k >= 24 ? 12 : 15);
+    if (used + t > P.budget_gib) continue;
+    used += t; P.tables_gib += t;
+    for (auto &L : P.layers) if (L.shape.k == k) (pass == 0 ? L.table_lagrange : L.table_coeff) = true;
+  }
+  P.total_gib = used; P.fits = used <= P.budget_gib;
+  return P;
+}
+
 // ------------------------------------------------------------------------------------------------ create_proof, GPU side
 struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 2; int early_intt = -1 /* -1: by column count, 0 / 1: off / on */; };
 struct CommitRecord { PolyRef p; int piece; G1 c; };   // piece >= 0: quotient piece; p.kind == P_KINDS with piece -1 - j: SHPLONK quotient j

@@ -97,6 +97,22 @@ int main(int argc, char **argv) {
     uint32_t non_tmp = 0; for (const auto &L : P0.quotient) if (!L.to_tmp) non_tmp++;
     EXPECT(non_tmp >= 160 && P0.terms > 2500);
   }
+  // --- the residency rule of DESIGN.md 7c as code: one layer alone keeps its cosets and (below k = 26) both tables; a chunk prover {0, 1, 2} and a batch
+  // prover {3, 4} fit 288 GiB only by giving things up, cosets before tables
+  {
+    auto one = [&](int l) { return plan_residency({layer_shape(l)}, 288.0); };
+    for (int l : {0, 1, 2, 3, 5}) { const ResidencyPlan P = one(l); EXPECT(P.fits && P.layers[0].cosets_resident && P.layers[0].table_lagrange && P.layers[0].table_coeff); }
+    { const ResidencyPlan P = one(4); EXPECT(P.fits && P.layers[0].cosets_resident && !P.layers[0].table_coeff); EXPECT(P.total_gib <= 288.0 * 0.92 + 1e-9); }
+    const ResidencyPlan C = plan_residency({layer_shape(0), layer_shape(1), layer_shape(2)}, 288.0);
+    EXPECT(C.fits && C.total_gib <= 265.0);
+    int resident = 0; for (const auto &L : C.layers) resident += L.cosets_resident;
+    EXPECT(resident >= 2);                                            // not everything (354 GiB) fits, but most keys keep their cosets
+    const ResidencyPlan B = plan_residency({layer_shape(3), layer_shape(4)}, 288.0);
+    EXPECT(B.fits && B.layers[0].cosets_resident && B.layers[1].cosets_resident);   // 38 + 116 GiB of keys resident ...
+    EXPECT(!B.layers[1].table_lagrange && !B.layers[1].table_coeff);               // ... and the k = 26 bases table-free (section 7c: 246 GiB)
+    const ResidencyPlan T = plan_residency({layer_shape(4)}, 80.0);                  // a smaller card: the key's cosets no longer fit
+    EXPECT(!T.layers[0].cosets_resident);
+  }
   if (host_only) {
     // without a GPU every compute entry point must fail loudly (no CPU fallback)
     threw = false; try { init(0); } catch (const Error &e) { threw = e.code == MI355_ENODEVICE; } 
