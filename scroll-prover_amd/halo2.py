@@ -167,6 +167,41 @@ def eval_polynomial(poly, point: np.ndarray) -> np.ndarray:
     return out
 
 
+def eval_polynomial_many(polys, points) -> np.ndarray:
+    """[eval_polynomial(p, x) for p, x in zip(polys, points)] on device-resident coefficient vectors of equal length with ONE synchronisation
+    (mi355_eval_polynomial_batch_dev): step 9 of create_proof evaluates every queried (polynomial, rotation) pair.  -> [len(polys), 4] u64."""
+    m = len(polys)
+    out = np.zeros((m, 4), dtype=np.uint64)
+    if m == 0:
+        return out
+    n = polys[0].numel() * polys[0].element_size() // 32
+    assert all(q.numel() * q.element_size() // 32 == n for q in polys), "eval_polynomial_many: polynomials of equal length"
+    pts = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.uint64) for x in points]))
+    arr = (C.c_void_p * m)(*[q.data_ptr() for q in polys])
+    check(lib().mi355_eval_polynomial_batch_dev(arr, m, n, ptr(pts), ptr(out)))
+    return out
+
+
+def interleave(parts, out=None):
+    """the extended-domain vector from its Q coset parts (scroll fork: part q = the evaluations at zeta * extended_omega^(q + Q i)):
+    out[i * Q + q] = parts[q][i] (mi355_fr_interleave_dev); what extended_to_coeff inverts."""
+    import torch
+    q = len(parts)
+    n = parts[0].numel() * parts[0].element_size() // 32
+    if out is None:
+        out = torch.empty((q * n, 4), dtype=torch.int64, device=parts[0].device)
+    arr = (C.c_void_p * q)(*[p_.data_ptr() for p_ in parts])
+    check(lib().mi355_fr_interleave_dev(ptr(out), arr, q, n))
+    return out
+
+
+def mem_info(slot: int = 0) -> dict:
+    """HBM accounting of one bound device (mi355_mem_info): what HIP reports free / in total and what the library holds, in bytes."""
+    v = [C.c_uint64() for _ in range(5)]
+    check(lib().mi355_mem_info(slot, *[C.byref(x) for x in v]))
+    return dict(zip(("free", "total", "live_buffers", "pooled", "workspace"), (x.value for x in v)))
+
+
 def fr_vec_op(op: str, dst, a, b):
     """element-wise add / sub / mul of device-resident Fr vectors (pointwise steps of the quotient construction)."""
     n = a.numel() * a.element_size() // 32

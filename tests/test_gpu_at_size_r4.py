@@ -246,6 +246,7 @@ def test_eval_polynomial_batch_equals_single_calls_and_oracle(zk):
         out = np.zeros((B, 4), dtype=np.uint64)
         arr = (C.c_void_p * B)(*[polys[w].data_ptr() for w in which])
         capi.check(lib.mi355_eval_polynomial_batch_dev(arr, B, n, capi.ptr(pts), capi.ptr(out)))
+        assert (h2.eval_polynomial_many([polys[w] for w in which], pts) == out).all()      # the halo2.py wrapper of the same call
         for i in range(0, B, 37):
             assert (out[i] == h2.eval_polynomial(polys[which[i]], pts[i])).all()
             assert (out[i] == cref.eval_polynomial(hosts[which[i]], pts[i])).all()
@@ -265,6 +266,7 @@ def test_interleave_and_mem_info(zk):
         capi.check(lib.mi355_fr_interleave_dev(C.c_void_p(dst.data_ptr()), arr, Q, n))
         want = np.stack([as_host(p, n) for p in parts], axis=1).reshape(Q * n, 4)
         assert (as_host(dst, Q * n) == want).all()
+        assert (as_host(h2.interleave(parts), Q * n) == want).all()
     arr9 = (C.c_void_p * 9)(*([parts[0].data_ptr()] * 9))
     assert lib.mi355_fr_interleave_dev(C.c_void_p(dst.data_ptr()), arr9, 9, n) == capi.EBADARG              # more than 8 parts
     arr1 = (C.c_void_p * 1)(dst.data_ptr())
@@ -284,3 +286,5 @@ def test_interleave_and_mem_info(zk):
     capi.check(lib.mi355_mem_info(0, C.byref(free1), None, None, C.byref(pool1), None))
     assert pool1.value == 0 and free1.value >= free0.value - (64 << 20)
     assert lib.mi355_mem_info(99, None, None, None, None, None) == capi.EBADARG
+    mi = h2.mem_info()
+    assert mi["total"] == tot.value and mi["pooled"] == 0
