@@ -16,6 +16,9 @@ int ntt_tu_init_device() {
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)(k_ntt29_strided<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)(k_ntt29_strided<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void *)(k_ntt29_final<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return MI355_OK;
@@ -174,7 +177,10 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     if (g.ntt29) NTT29_LAUNCH(k_ntt29_final, 1u, tile, (size_t)36 * (tile + 1), src, dst, lm, 0u, 0u, 0u, p->tw29_m[0], src_len, pre3, post3);
     else hipLaunchKernelGGL(k_ntt_final, dim3(1), dim3(threads), lds, s, src, dst, lm, 0u, 0u, 0u, p->tw_m[0], src_len, pre3, post3);
   } else {
-    fe_t *scratch; CHK(ws_get("ntt.scratch", N * sizeof(fe_t), (void **)&scratch));
+    // raw scratch (A/B knob): 36 bytes per element in three planes; only with the 29-bit kernels at the default radix
+    const bool raw_mode = g.ntt_raw_scratch && g.ntt29 && g.ntt_radix_log == 2;
+    fe_t *scratch; CHK(ws_get("ntt.scratch", N * (raw_mode ? 36 : sizeof(fe_t)), (void **)&scratch));
+    Raw29 raw{(uint4 *)scratch, (uint4 *)scratch + N, (uint32_t *)((uint4 *)scratch + 2 * N)};
     uint32_t log_s = log_n;
     const fe_t *cur = src; uint64_t cur_len = src_len; const fe_t *cur_pre = pre3;
     for (uint32_t l = 0; l + 1 < p->levels; l++) {
@@ -187,6 +193,11 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
       if (g.ntt29) {
         Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l]; L9.direct = p->direct2[l] ? 2u : (p->split[l] == log_s) ? 1u : 0u;
         if (fold_tw && l + 2 == p->levels) L9.tw_s_lo = *fold_tw;
+        if (raw_mode) {
+          const uint32_t th = std::max(64u, std::min(512u, tile / 4));
+          if (l == 0) hipLaunchKernelGGL((k_ntt29_strided<2, 1>), dim3((uint32_t)blocks), dim3(th), (size_t)36 * tile, s, cur, scratch, L9, lc, cur_len, cur_pre, raw);
+          else hipLaunchKernelGGL((k_ntt29_strided<2, 2>), dim3((uint32_t)blocks), dim3(th), (size_t)36 * tile, s, cur, scratch, L9, lc, cur_len, cur_pre, raw);
+        } else
         NTT29_LAUNCH(k_ntt29_strided, (uint32_t)blocks, tile, (size_t)36 * tile, cur, scratch, L9, lc, cur_len, cur_pre);
       } else
       hipLaunchKernelGGL(k_ntt_strided, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, scratch, L, lc, cur_len, cur_pre);
@@ -198,7 +209,8 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     const size_t lds = (size_t)2 * 16 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc);
     const uint64_t blocks = ((uint64_t)1 << log_b) << (log_a - lc);
     Scope sc("ntt_pass");
-    if (g.ntt29) NTT29_LAUNCH(k_ntt29_final, (uint32_t)blocks, tile, (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
+    if (raw_mode) hipLaunchKernelGGL((k_ntt29_final<2, 2>), dim3((uint32_t)blocks), dim3(std::max(64u, std::min(512u, tile / 4))), (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), s, cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3, raw);
+    else if (g.ntt29) NTT29_LAUNCH(k_ntt29_final, (uint32_t)blocks, tile, (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
     else hipLaunchKernelGGL(k_ntt_final, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, dst, lm, log_a, log_b, lc, p->tw_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
   }
   HIPCHK(hipGetLastError());

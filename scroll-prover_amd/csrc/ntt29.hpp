@@ -154,8 +154,20 @@ __device__ __forceinline__ fe29_t load_input29(const fe_t *__restrict__ src, uin
   return v;
 }
 
-template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_ntt29_strided(const fe_t *__restrict__ src, fe_t *__restrict__ dst, Ntt29Level L, uint32_t log_c,
-                                                        uint64_t src_len, const fe_t *__restrict__ pre3) {
+// Raw scratch (round 4 experiment, MI355_NTT_RAW_SCRATCH=1): between passes an element stays in its 9 x 29-bit limbs, as three planes (two 16-byte, one
+// 4-byte: 36 B per element) instead of being re-sliced to 8 x 32 bits on the way out and back on the way in (~55 VALU instructions per element and
+// pass boundary).  The strided passes' multiplication output is normalised (limbs < 2^29), so from_sat_plain(to_sat_plain(t)) == t: same bits either way.
+struct Raw29 { uint4 *lo; uint4 *hi; uint32_t *top; };
+__device__ __forceinline__ fe29_t raw29_load(const Raw29 &R, uint64_t i) {
+  const uint4 a = R.lo[i], b = R.hi[i]; fe29_t r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = R.top[i]; return r;
+}
+__device__ __forceinline__ void raw29_store(const Raw29 &R, uint64_t i, const fe29_t &v) {
+  R.lo[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]); R.hi[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]); R.top[i] = v.l[8];
+}
+// MODE 0: source and destination in the ABI form (8 x 32); 1: ABI source, raw destination (first pass); 2: raw source and destination (second strided pass, in place)
+template <int RMAX, int MODE = 0> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_ntt29_strided(const fe_t *__restrict__ src, fe_t *__restrict__ dst, Ntt29Level L, uint32_t log_c,
+                                                        uint64_t src_len, const fe_t *__restrict__ pre3, Raw29 raw = Raw29{nullptr, nullptr, nullptr}) {
   extern __shared__ uint4 lds[];
   const uint32_t M = 1u << L.log_m, C = 1u << log_c, tile = M << log_c;
   const Lds29 S = lds29_carve(lds, tile);
@@ -165,7 +177,7 @@ template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_
   const uint64_t base = (sub << (L.log_m + L.log_t)) + ((uint64_t)cb << log_c);
   for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
     const uint32_t c = e & (C - 1), m = e >> log_c;
-    lds29_put(S, e, load_input29(src, base + ((uint64_t)m << L.log_t) + c, src_len, pre3));
+    lds29_put(S, e, MODE == 2 ? raw29_load(raw, base + ((uint64_t)m << L.log_t) + c) : load_input29(src, base + ((uint64_t)m << L.log_t) + c, src_len, pre3));
   }
   __syncthreads();
   lds_dif29<RMAX>(S, L.log_m, log_c, C, 1, L.tw_m, true, true);
@@ -181,12 +193,13 @@ template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_
     // the strided passes only ever write the library's scratch buffer: their outputs stay the multiplication's tight value (< 1.4 r < 2^256, exact
     // limbs) re-sliced to 8 x 32 bits -- no conditional subtraction; the next pass starts from < 1.4 r (five doublings: < 45 r < the 64 r limit) and
     // only the closing pass, whose output the caller sees, makes everything canonical
-    g_store(&dst[base + ((uint64_t)k << L.log_t) + c], Fr29::to_sat_plain(Fr29::mul_t<ZK_NTT_CHAIN>(v, w)));
+    if (MODE == 0) g_store(&dst[base + ((uint64_t)k << L.log_t) + c], Fr29::to_sat_plain(Fr29::mul_t<ZK_NTT_CHAIN>(v, w)));
+    else raw29_store(raw, base + ((uint64_t)k << L.log_t) + c, Fr29::mul_t<ZK_NTT_CHAIN>(v, w));
   }
 }
 
-template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_ntt29_final(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint32_t log_m, uint32_t log_a, uint32_t log_b,
-                                                      uint32_t log_c, Tw29 tw_m, uint64_t src_len, const fe_t *__restrict__ pre3, const fe_t *__restrict__ post3) {
+template <int RMAX, int MODE = 0> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_ntt29_final(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint32_t log_m, uint32_t log_a, uint32_t log_b,
+                                                      uint32_t log_c, Tw29 tw_m, uint64_t src_len, const fe_t *__restrict__ pre3, const fe_t *__restrict__ post3, Raw29 raw = Raw29{nullptr, nullptr, nullptr}) {
   extern __shared__ uint4 lds[];
   const uint32_t M = 1u << log_m, C = 1u << log_c, seg = M + 1, tile = M << log_c;
   const Lds29 S = lds29_carve(lds, seg << log_c);
@@ -195,7 +208,7 @@ template <int RMAX> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_
   for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
     const uint32_t m = e & (M - 1), c = e >> log_m;
     const uint64_t q = ((uint64_t)(k1_0 + c) << log_b) + k2;
-    lds29_put(S, c * seg + m, load_input29(src, (q << log_m) + m, src_len, pre3));
+    lds29_put(S, c * seg + m, MODE == 2 ? raw29_load(raw, (q << log_m) + m) : load_input29(src, (q << log_m) + m, src_len, pre3));
   }
   __syncthreads();
   lds_dif29<RMAX>(S, log_m, log_c, 1, seg, tw_m, false, post3 == nullptr);
