@@ -91,6 +91,11 @@ int mi355_buf_upload(void *dst_dev, const void *src_host, uint64_t bytes);
 int mi355_buf_download(void *dst_host, const void *src_dev, uint64_t bytes);   /* ordered after everything queued on the owner; synchronous */
 int mi355_buf_copy(void *dst_dev, const void *src_dev, uint64_t bytes);        /* within a device or between two bound devices (xGMI)       */
 int mi355_buf_zero(void *dst_dev, uint64_t bytes);
+/* Page-locked host memory for buffers that cross PCIe more than once, or once but on the critical path (the witness columns of the many-column layers):
+ * a first copy out of ordinary (pageable) memory runs at ~34 GB/s on this platform, out of page-locked memory at the link's ~56 GB/s.  The caller writes
+ * its column into the block (witness synthesis can write there directly) and passes it to mi355_buf_upload / any `*_host` entry point like any pointer. */
+int mi355_host_alloc(uint64_t bytes, void **host_ptr_out);
+int mi355_host_free(void *host_ptr);
 /* HBM accounting of one bound device (any pointer may be NULL): what HIP reports free / in total, and what this library holds in live
  * mi355_buf blocks, in pooled (freed, reusable) blocks and in its grow-only workspace arena.  A prover keeps the SRS of its degree set
  * [REF bin/src/trace_prover.rs:35-36] AND the proving key's extended-coset polynomials resident: the caller budgets window tables

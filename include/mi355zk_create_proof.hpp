@@ -194,8 +194,25 @@ struct ProvingKeyDevice {
 };
 inline Fr coset_factor(const EvaluationDomain &dom, uint32_t q) { return detail::fr_mul(dom.g_coset, detail::fr_pow(dom.extended_omega, q)); }
 
+// A host column whose storage is either ordinary memory or page-locked memory of the library (mi355_host_alloc): the choice is the caller's, per column
+// vector, at run time.  A first copy out of pageable memory crosses PCIe at ~34 GB/s, out of page-locked memory at ~56 GB/s; for the many-column
+// layers that is the difference between steps 2-3 being bound by the link or by their commitments.
+template <class T> struct ColumnAllocator {
+  using value_type = T; bool pinned = false;
+  ColumnAllocator() = default; explicit ColumnAllocator(bool p) : pinned(p) {}
+  template <class U> ColumnAllocator(const ColumnAllocator<U> &o) : pinned(o.pinned) {}
+  T *allocate(size_t n) {
+    if (!pinned) return static_cast<T *>(::operator new(n * sizeof(T)));
+    void *p = nullptr; check(mi355_host_alloc(n * sizeof(T), &p)); return static_cast<T *>(p);
+  }
+  void deallocate(T *p, size_t) noexcept { if (pinned) (void)mi355_host_free(p); else ::operator delete(p); }
+  template <class U> bool operator==(const ColumnAllocator<U> &o) const { return pinned == o.pinned; }
+  template <class U> bool operator!=(const ColumnAllocator<U> &o) const { return pinned != o.pinned; }
+};
+using Column = std::vector<Fr, ColumnAllocator<Fr>>;
+
 // witness-like values: 60 % zero, 20 % < 256, 10 % 64-bit, 10 % uniform; uniform = every element random
-inline void fill_column(std::vector<Fr> &v, uint64_t seed, bool uniform, int threads) {
+template <class Vec> inline void fill_column(Vec &v, uint64_t seed, bool uniform, int threads) {
   static const std::vector<Fr> small = [] { std::vector<Fr> t(256); for (uint64_t i = 0; i < 256; i++) t[i] = detail::fr_from_u64(i); return t; }();
   const uint64_t n = v.size();
   auto work = [&](uint64_t lo, uint64_t hi, uint64_t sd) {
@@ -287,26 +304,29 @@ inline ProvingKeyDevice keygen_device(const CircuitShape &s, const EvaluationDom
 // The witness a real prover synthesises on the CPU before create_proof starts: instance, advice columns, lookup multiplicities, all Lagrange
 // values in host memory.  Dependent columns are computed so that every gate of build_plan holds on every row (the device is used as a
 // calculator here, outside any timed region; fixed_lagrange is dropped afterwards).
-struct Witness { std::vector<Fr> instance; std::vector<std::vector<Fr>> advice, m; };
-inline Witness synthesize_witness(const CircuitShape &s, const EvaluationDomain &dom, ProvingKeyDevice &pk, uint64_t seed, int threads) {
+struct Witness { Column instance; std::vector<Column> advice, m; };
+inline Witness synthesize_witness(const CircuitShape &s, const EvaluationDomain &dom, ProvingKeyDevice &pk, uint64_t seed, int threads, bool pinned = false) {
   using namespace detail;
   Witness w; const uint64_t n = dom.n;
-  w.advice.resize(s.advice); w.m.resize(s.lookups);
+  const ColumnAllocator<Fr> alloc(pinned);
+  w.instance = Column(alloc);
+  for (uint32_t i = 0; i < s.advice; i++) w.advice.emplace_back(alloc);
+  for (uint32_t l = 0; l < s.lookups; l++) w.m.emplace_back(alloc);
   std::vector<DevicePoly> adv(s.advice);
   const Fr one = fr_one();
-  for (uint32_t i = 0; i < std::min<uint32_t>(2, s.advice); i++) { w.advice[i].resize(n); fill_column(w.advice[i], seed + 7 * i, i == 0, threads); adv[i] = DevicePoly::from_host(w.advice[i], 0); }
+  for (uint32_t i = 0; i < std::min<uint32_t>(2, s.advice); i++) { w.advice[i].resize(n); fill_column(w.advice[i], seed + 7 * i, i == 0, threads); adv[i] = DevicePoly(n, 0); check(mi355_buf_upload(adv[i].p, w.advice[i].data(), n * 32)); }
   auto resolve = [&](const PolyRef &r) -> const void * { return r.kind == P_ADVICE ? adv[r.idx].p : pk.fixed_lagrange[r.idx].p; };
   for (uint32_t i = 2; i < s.advice; i++) {   // a_i = f a_0(omega^s X) a_1 + c_i f a_(i-1)(omega^-1 X)
     const PolyRef f{P_FIXED, i % s.fixed};
     Launch L{true, 0, {{one, {{f, 0}, {{P_ADVICE, 0}, gate_rot(i)}, {{P_ADVICE, 1}, 0}}}, {fr_from_u64(3 + i), {{f, 0}, {{P_ADVICE, i - 1}, -1}}}}};
     adv[i] = DevicePoly(n, 0);
     run_launch(L, adv[i].p, n, one, false, resolve);
-    w.advice[i] = adv[i].to_host();
+    w.advice[i].resize(n); check(mi355_buf_download(w.advice[i].data(), adv[i].p, n * 32));
     if (i >= 3) adv[i - 1].release();   // only a_0, a_1 and the previous column are read again
   }
   { // instance = f_0 a_0 a_0(omega X) + 7 a_0(omega^-1 X)
     Launch L{true, 0, {{one, {{{P_FIXED, 0}, 0}, {{P_ADVICE, 0}, 0}, {{P_ADVICE, 0}, 1}}}, {fr_from_u64(7), {{{P_ADVICE, 0}, -1}}}}};
-    DevicePoly inst(n, 0); run_launch(L, inst.p, n, one, false, resolve); w.instance = inst.to_host();
+    DevicePoly inst(n, 0); run_launch(L, inst.p, n, one, false, resolve); w.instance.resize(n); check(mi355_buf_download(w.instance.data(), inst.p, n * 32));
   }
   for (uint32_t l = 0; l < s.lookups; l++) {   // multiplicities: small counts
     w.m[l].resize(n);
@@ -407,7 +427,7 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
   };
   std::map<PolyRef, DevicePoly> &poly = R.coeff;   // Lagrange values until step 6, coefficients afterwards
   // ---- steps 1-3: the witness crosses PCIe on a second host thread (a rayon worker in the real caller); commitments as the columns arrive
-  std::vector<std::pair<PolyRef, const std::vector<Fr> *>> uploads;
+  std::vector<std::pair<PolyRef, const Column *>> uploads;
   uploads.push_back({{P_INSTANCE, 0}, &wit.instance});
   for (uint32_t i = 0; i < s.advice; i++) uploads.push_back({{P_ADVICE, i}, &wit.advice[i]});
   for (uint32_t l = 0; l < s.lookups; l++) uploads.push_back({{P_M, l}, &wit.m[l]});
@@ -420,7 +440,7 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
   auto upload_worker = [&](size_t first) {
     try {
       for (size_t i = first; i < uploads.size(); i += UT) {
-        DevicePoly d = DevicePoly::from_host(*uploads[i].second, 0);
+        DevicePoly d(uploads[i].second->size(), 0); check(mi355_buf_upload(d.p, uploads[i].second->data(), uploads[i].second->size() * 32));
         { std::lock_guard<std::mutex> lk(mu); poly.at(uploads[i].first) = std::move(d); arrived[i] = 1; }
         cv.notify_all();
       }

@@ -64,6 +64,8 @@ extern "C" {
     pub fn mi355_buf_download(dst_host: *mut c_void, src_dev: *const c_void, bytes: u64) -> c_int;
     pub fn mi355_buf_copy(dst_dev: *mut c_void, src_dev: *const c_void, bytes: u64) -> c_int;
     pub fn mi355_buf_zero(dst_dev: *mut c_void, bytes: u64) -> c_int;
+    pub fn mi355_host_alloc(bytes: u64, host_ptr_out: *mut *mut c_void) -> c_int;
+    pub fn mi355_host_free(host_ptr: *mut c_void) -> c_int;
     pub fn mi355_mem_info(device_slot: c_int, free_bytes: *mut u64, total_bytes: *mut u64, live_buf_bytes: *mut u64, pooled_bytes: *mut u64, workspace_bytes: *mut u64) -> c_int;
     pub fn mi355_msm_g1_dev(srs: u64, base_offset: u64, scalars_dev: *const c_void, n: u64, out_g1_host: *mut c_void) -> c_int;
     pub fn mi355_msm_g1_batch_dev(srs: u64, base_offset: u64, scalars_dev: *const *const c_void, batch: u32, n: u64, out_g1_host: *mut c_void) -> c_int;

@@ -30,6 +30,8 @@ SIGNATURES = {
     "mi355_buf_download": (_int, [_vp, _vp, _u64]),
     "mi355_buf_copy": (_int, [_vp, _vp, _u64]),
     "mi355_buf_zero": (_int, [_vp, _u64]),
+    "mi355_host_alloc": (_int, [_u64, C.POINTER(_vp)]),
+    "mi355_host_free": (_int, [_vp]),
     "mi355_mem_info": (_int, [_int, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "mi355_srs_register_host": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "mi355_srs_register_dev": (_int, [_vp, _u64, _int, C.POINTER(_u64)]),

@@ -701,6 +701,24 @@ int mi355_buf_zero(void *dst_dev, uint64_t bytes) {
   });
 }
 
+int mi355_host_alloc(uint64_t bytes, void **host_ptr_out) {
+  return guarded([&]() -> int {
+  if (!host_ptr_out || bytes == 0) return fail(MI355_EBADARG, "host_alloc: null pointer or zero size");
+  CHK(need_init(0));   // page-locking goes through the bound device's runtime; no device lock: nothing of the library's state is touched
+  void *p = nullptr;
+  const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(e == hipErrorOutOfMemory ? MI355_EOOM : MI355_EHIP, std::string("host_alloc: hipHostMalloc failed: ") + hipGetErrorString(e)); }
+  *host_ptr_out = p; return MI355_OK;
+  });
+}
+int mi355_host_free(void *host_ptr) {
+  return guarded([&]() -> int {
+  if (!host_ptr) return MI355_OK;
+  CHK(need_init(0));
+  HIPCHK(hipHostFree(host_ptr));
+  return MI355_OK;
+  });
+}
 int mi355_mem_info(int device_slot, uint64_t *free_bytes, uint64_t *total_bytes, uint64_t *live_buf_bytes, uint64_t *pooled_bytes, uint64_t *workspace_bytes) {
   return guarded([&]() -> int {
   if (device_slot < 0 || device_slot >= MAX_DEV) return fail(MI355_EBADARG, "mem_info: device slot out of range");

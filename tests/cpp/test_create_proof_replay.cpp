@@ -79,7 +79,7 @@ static const char *kind_name(PolyKind k) { static const char *n[] = {"instance",
 
 int main(int argc, char **argv) {
   int layer_id = 4, devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2; long k_override = -1; bool host_api = false, do_check = true;
-  std::string tables = "auto", pk_mode = "auto"; int upload_threads = 2, early_intt = -1;
+  std::string tables = "auto", pk_mode = "auto"; int upload_threads = 2, early_intt = -1; bool pinned_witness = false;
   long o_advice = -1, o_fixed = -1, o_lookups = -1, o_perm = -1, o_chunk = -1, o_degree = -1;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -88,10 +88,10 @@ int main(int argc, char **argv) {
     if (a == "--layer") layer_id = (int)next(); else if (a == "--k") k_override = next(); else if (a == "--devices") devices = (int)next();
     else if (a == "--threads") threads = (int)next(); else if (a == "--host-api") host_api = true; else if (a == "--no-check") do_check = false;
     else if (a == "--no-tables") tables = "off"; else if (a == "--tables") tables = nexts(); else if (a == "--pk-cosets") pk_mode = nexts(); else if (a == "--proofs") proofs = (int)next();
-    else if (a == "--upload-threads") upload_threads = (int)next(); else if (a == "--early-intt") early_intt = (int)next();
+    else if (a == "--upload-threads") upload_threads = (int)next(); else if (a == "--early-intt") early_intt = (int)next(); else if (a == "--pinned-witness") pinned_witness = true;
     else if (a == "--advice") o_advice = next(); else if (a == "--fixed") o_fixed = next(); else if (a == "--lookups") o_lookups = next();
     else if (a == "--perm") o_perm = next(); else if (a == "--chunk") o_chunk = next(); else if (a == "--degree") o_degree = next();
-    else { std::printf("usage: %s [--layer 0..6] [--k K] [--advice A --fixed F --lookups L --perm P --chunk C --degree D] [--devices D] [--threads T] [--proofs N] [--upload-threads U] [--early-intt 0|1]\n"
+    else { std::printf("usage: %s [--layer 0..6] [--k K] [--advice A --fixed F --lookups L --perm P --chunk C --degree D] [--devices D] [--threads T] [--proofs N] [--upload-threads U] [--early-intt 0|1] [--pinned-witness]\n"
                        "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--no-check]\n", argv[0]); return 1; }
   }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;   // the GPU box's container gets 16 of the host's CPUs
@@ -139,7 +139,7 @@ int main(int argc, char **argv) {
   else if (pk_mode == "auto" && pk_base + pk_cosets + working > usable) resident = false;
   // ---- keygen (device side) and the witness (host side, as create_proof receives it)
   ProvingKeyDevice pk = keygen_device(S, dom, 0xC0FFEE + layer_id, resident, devices, threads);
-  Witness wit = synthesize_witness(S, dom, pk, 9000 + layer_id, threads);
+  Witness wit = synthesize_witness(S, dom, pk, 9000 + layer_id, threads, pinned_witness);
   check(mi355_buf_trim());
   // window tables (W x a basis) only where they fit next to the proving key that is now resident and the working set of a proof: the measured
   // free memory decides, the Lagrange basis first (commit_lagrange carries most commitments); otherwise the table-free schedule (+ ~8 % per MSM)
@@ -256,7 +256,7 @@ int main(int argc, char **argv) {
   double host_ms = -1, host_fft_ms = -1, host_fft_batched_ms = -1;
   const uint32_t n_commit_lag = S.advice + 2 * S.lookups + S.perm_z(), n_commit_coef = Q + 2;
   if (host_api && failures == 0) {
-    std::vector<Fr> hp = wit.advice[0]; std::vector<Fr> hext(Q * n); G1 out; std::vector<std::vector<Fr>> cols(std::min<uint32_t>(8, NPW), wit.advice[0]);
+    std::vector<Fr> hp(wit.advice[0].begin(), wit.advice[0].end()); std::vector<Fr> hext(Q * n); G1 out; std::vector<std::vector<Fr>> cols(std::min<uint32_t>(8, NPW), hp);
     const uint32_t n_intt = NPW, n_ntt = NPW * Q, n_ev = (uint32_t)plan.queries.size() + Q;
     const auto t1 = Clock::now();
     for (uint32_t i = 0; i < n_commit_lag; i++) CK(mi355_msm_g1_host(hl, 0, hp.data(), n, out.data()));
@@ -278,14 +278,14 @@ int main(int argc, char **argv) {
   std::printf("{\"replay\": \"create_proof_gpu_side (include/mi355zk_create_proof.hpp): steps 1-10 through the C-ABI, polynomials and proving-key cosets resident\", \"layer\": %d, \"k\": %u, \"devices\": %d, "
               "\"shape\": {\"advice\": %u, \"fixed\": %u, \"lookups\": %u, \"perm_columns\": %u, \"chunk_len\": %u, \"perm_z\": %u, \"degree\": %u, \"quotient_pieces\": %u, \"source\": \"%s\"}, "
               "\"window_tables\": %s, \"window_table_bases\": %d, \"pk_cosets\": \"%s\", "
-              "\"upload_threads\": %d, \"msm\": %zu, \"intt\": %u, \"coset_ntt\": %u, \"gate_launches\": %u, \"gates\": %u, \"gate_terms\": %u, \"evals\": %zu, \"resident_ms\": %.3f, \"first_proof_ms\": %.3f, \"proofs\": %d, "
+              "\"upload_threads\": %d, \"pinned_witness\": %s, \"msm\": %zu, \"intt\": %u, \"coset_ntt\": %u, \"gate_launches\": %u, \"gates\": %u, \"gate_terms\": %u, \"evals\": %zu, \"resident_ms\": %.3f, \"first_proof_ms\": %.3f, \"proofs\": %d, "
               "\"host_api_ms\": %.3f, \"host_api_fft_ms\": %.3f, \"host_api_fft_batched_ms\": %.3f, "
               "\"step_ms\": {\"1_instance\": %.2f, \"2_3_advice_lookup_commits\": %.2f, \"4_products\": %.2f, \"5_random\": 0.0, \"6_to_coeff\": %.2f, \"7_quotient\": %.2f, \"8_commit_h\": %.2f, \"9_evals\": %.2f, \"10_shplonk\": %.2f}, "
               "\"hbm\": {\"total_gib\": %.1f, \"peak_used_gib\": %.1f, \"proving_key_gib\": %.1f, \"live_buffers_gib\": %.1f, \"pooled_gib\": %.1f, \"workspace_gib\": %.1f, \"planned\": {\"pk_base_gib\": %.1f, \"pk_cosets_gib\": %.1f, \"working_set_gib\": %.1f, \"one_table_gib\": %.1f, \"usable_gib\": %.1f}}, "
               "\"checked\": %u, \"semantic_check\": %s, \"trapdoor_check\": %s, \"ok\": %s}\n",
               layer_id, k, devices, S.advice, S.fixed, S.lookups, S.perm_columns, S.chunk_len, S.perm_z(), S.degree, Q, S.source,
               n_tables ? "true" : "false", n_tables, resident ? "resident" : "on-the-fly",
-              upload_threads, R.commitments.size(), R.intt, R.coset_ntt, R.gate_launches, plan.gates, plan.terms, R.evals.size(), R.total_ms, first_ms, proofs,
+              upload_threads, pinned_witness ? "true" : "false", R.commitments.size(), R.intt, R.coset_ntt, R.gate_launches, plan.gates, plan.terms, R.evals.size(), R.total_ms, first_ms, proofs,
               host_ms, host_fft_ms, host_fft_batched_ms,
               R.step_ms[1], R.step_ms[2], R.step_ms[4], R.step_ms[6], R.step_ms[7], R.step_ms[8], R.step_ms[9], R.step_ms[10],
               hbm_total / GiB, (hbm_total - fr_end) / GiB, pk.bytes / GiB, live / GiB, pooled / GiB, ws / GiB, pk_base / GiB, pk_cosets / GiB, working / GiB, table_one / GiB, usable / GiB,

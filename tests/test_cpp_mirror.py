@@ -70,6 +70,7 @@ def test_create_proof_replay_compiles_and_fails_loudly_without_a_gpu():
     (["--layer", "6", "--k", "11", "--pk-cosets", "on-the-fly"], {}),
     (["--layer", "3", "--k", "9", "--tables", "lagrange"], {}),
     (["--layer", "5", "--k", "10"], {}),
+    (["--layer", "3", "--k", "10", "--pinned-witness", "--upload-threads", "3", "--early-intt", "1"], {}),
     (["--layer", "0", "--k", "9", "--advice", "70", "--fixed", "9", "--lookups", "6", "--perm", "20"], {}),
     (["--layer", "0", "--k", "8", "--advice", "12", "--fixed", "3", "--lookups", "2", "--perm", "7", "--chunk", "3", "--degree", "5", "--proofs", "3"], {}),
     (["--layer", "4", "--k", "12", "--devices", "2"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "8"}),

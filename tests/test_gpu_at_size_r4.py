@@ -288,3 +288,27 @@ def test_interleave_and_mem_info(zk):
     assert lib.mi355_mem_info(99, None, None, None, None, None) == capi.EBADARG
     mi = h2.mem_info()
     assert mi["total"] == tot.value and mi["pooled"] == 0
+
+
+def test_host_alloc_is_page_locked_memory_the_entry_points_accept(zk):
+    """mi355_host_alloc / _free: the block is ordinary addressable host memory (numpy can wrap it), uploads and host-pointer calls take it like any
+    pointer, results equal those from pageable memory"""
+    h2 = zk.halo2
+    lib, capi = zk._capi.lib(), zk._capi
+    k = 16
+    n = 1 << k
+    p = C.c_void_p()
+    capi.check(lib.mi355_host_alloc(32 * n, C.byref(p)))
+    arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n, 4))
+    vals = as_host(dev_scalars(n, 1616), n)
+    arr[:] = vals
+    dom = h2.EvaluationDomain(2, k)
+    capi.check(lib.mi355_ntt_fr_host(p, k, capi.ptr(dom.omega)))                       # in place, through the pinned block
+    assert (arr == cref.best_fft(vals, dom.omega, k, threads=4)).all()
+    buf = h2.DeviceBuffer(32 * n)
+    capi.check(lib.mi355_buf_upload(C.c_void_p(buf.data_ptr()), p, 32 * n))
+    assert (buf.fr() == arr).all()
+    buf.free()
+    capi.check(lib.mi355_host_free(p))
+    capi.check(lib.mi355_host_free(None))
+    assert lib.mi355_host_alloc(0, C.byref(p)) == capi.EBADARG
