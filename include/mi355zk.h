@@ -84,9 +84,9 @@ int mi355_buf_alloc(uint64_t bytes, int device_slot, void **dev_ptr_out);
 int mi355_buf_free(void *dev_ptr);
 int mi355_buf_trim(void);                                   /* give every pooled (free) block back to HIP                                  */
 int mi355_buf_slot(const void *dev_ptr, int *slot_out);     /* which device slot owns this pointer                                         */
-/* host -> device on the owner's COPY stream: overlaps the compute already queued; an upload into a block no call has used since
- * mi355_buf_alloc waits only for the work queued on it before its last mi355_buf_free.  Later calls see the data; on return the host buffer
- * may be reused.                                                                                                                          */
+/* host -> device on the owner's COPY stream: overlaps the compute queued before AND after it; an upload into a block no call has used since
+ * mi355_buf_alloc waits only for the work queued on it before its last mi355_buf_free.  Synchronous: on return the data is in HBM (calls
+ * issued afterwards see it) and the host buffer may be reused.  Takes no device lock.                                                   */
 int mi355_buf_upload(void *dst_dev, const void *src_host, uint64_t bytes);
 int mi355_buf_download(void *dst_host, const void *src_dev, uint64_t bytes);   /* ordered after everything queued on the owner; synchronous */
 int mi355_buf_copy(void *dst_dev, const void *src_dev, uint64_t bytes);        /* within a device or between two bound devices (xGMI)       */
