@@ -387,7 +387,7 @@ inline ResidencyPlan plan_residency(const std::vector<CircuitShape> &shapes, dou
 }
 
 // ------------------------------------------------------------------------------------------------ create_proof, GPU side
-struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 2; int early_intt = -1 /* -1: by column count, 0 / 1: off / on */; };
+struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 1 /* one thread moves pageable memory at the link's rate; more only delay the first column */; int early_intt = -1 /* -1: by column count, 0 / 1: off / on */; };
 struct CommitRecord { PolyRef p; int piece; G1 c; };   // piece >= 0: quotient piece; p.kind == P_KINDS with piece -1 - j: SHPLONK quotient j
 struct ProofGpuSide {
   std::vector<CommitRecord> commitments;              // in transcript order
@@ -416,7 +416,7 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
     G1 out; check(mi355_msm_g1_dev(basis, 0, ptr ? ptr : p.p, n, out.data())); R.commitments.push_back({ref, piece, out});
   };
   auto commit_many = [&](uint64_t basis, const std::vector<PolyRef> &refs, std::map<PolyRef, DevicePoly> &store) {
-    const uint32_t B = opt.commit_batch ? opt.commit_batch : 32;
+    const uint32_t B = opt.commit_batch ? opt.commit_batch : 32;   // resident polynomials: nothing to wait for, 32 per pass
     for (size_t base = 0; base < refs.size(); base += B) {
       const uint32_t cnt = (uint32_t)std::min<size_t>(B, refs.size() - base);
       std::vector<const void *> ptrs(cnt); std::vector<G1> outs(cnt);
@@ -428,9 +428,11 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
   std::map<PolyRef, DevicePoly> &poly = R.coeff;   // Lagrange values until step 6, coefficients afterwards
   // ---- steps 1-3: the witness crosses PCIe on a second host thread (a rayon worker in the real caller); commitments as the columns arrive
   std::vector<std::pair<PolyRef, const Column *>> uploads;
-  uploads.push_back({{P_INSTANCE, 0}, &wit.instance});
+  // order: what is committed first crosses PCIe first; the instance column is not committed and is read from step 4 on, so it goes last
+  // (at k = 26 every column in front of the first commitment is 40 ms of idle device)
   for (uint32_t i = 0; i < s.advice; i++) uploads.push_back({{P_ADVICE, i}, &wit.advice[i]});
   for (uint32_t l = 0; l < s.lookups; l++) uploads.push_back({{P_M, l}, &wit.m[l]});
+  uploads.push_back({{P_INSTANCE, 0}, &wit.instance});
   for (const auto &u : uploads) poly[u.first];   // every entry exists before the uploader starts: the map's structure does not change under the readers
   // opt.upload_threads host threads (rayon workers in the real caller) share the columns round-robin: a copy from pageable memory is staged by the
   // calling thread, and one thread alone moves ~33 GB/s of the link's ~55 (mi355_buf_upload takes no device lock, so the copies also run under the
@@ -449,11 +451,10 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
   struct Joiner { std::vector<std::thread> th; void join() { for (auto &t : th) if (t.joinable()) t.join(); } ~Joiner() { join(); } } uploaders;
   for (size_t w = 0; w < UT; w++) uploaders.th.emplace_back(upload_worker, w);
   auto wait_for = [&](size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return arrived[i] != 0; }); if (!upload_error.empty()) throw Error(MI355_EHIP, "witness upload: " + upload_error); };
-  wait_for(0);
-  DevicePoly inst_lagrange = clone(poly.at({P_INSTANCE, 0}), 0);                        // the permutation argument reads the instance VALUES in step 4
-  check(mi355_intt_fr_dev(poly.at({P_INSTANCE, 0}).p, k, dom.omega_inv.data(), dom.ifft_divisor.data())); R.intt++;   // step 1
-  lap(1);
-  const bool batch_cols = s.advice >= 16;
+  // columns per batched commitment: as many as cross PCIe in ~20 ms (1 GiB of scalars), at most 32 -- a batch is only committed once its last column has
+  // arrived, so with big columns (layer 1: 17 x 512 MiB) a 32-column batch would wait for the whole witness before the first kernel (162 ms of idle device)
+  const uint32_t batch_cap = opt.commit_batch ? opt.commit_batch : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (uint64_t(1) << 25) / n));
+  const bool batch_cols = s.advice >= 16 && batch_cap > 1;
   // With many columns steps 2-3 are bound by PCIe (layer 0: 28.9 GB of witness at ~34 GB/s from pageable memory = 0.85 s against 0.42 s of MSM kernels),
   // so the device idles half of that time.  lagrange_to_coeff of a column needs nothing but the column: the inverse transforms of the columns already
   // committed run in those gaps, into coefficient copies (step 4 still reads the Lagrange values), and step 6 only transforms what is left.
@@ -467,14 +468,18 @@ inline ProofGpuSide create_proof_gpu_side(uint64_t h_g, uint64_t h_g_lagrange, c
   };
   {                                                                                     // steps 2, 3
     std::vector<PolyRef> pending;
-    for (size_t i = 1; i < uploads.size(); i++) {
+    for (size_t i = 0; i + 1 < uploads.size(); i++) {
       wait_for(i);
       if (!batch_cols) { commit_one(h_g_lagrange, poly.at(uploads[i].first), uploads[i].first, -1000); to_coeff_early({uploads[i].first}); }
-      else { pending.push_back(uploads[i].first); if (pending.size() == 32 || i + 1 == uploads.size() || uploads[i + 1].first.kind != uploads[i].first.kind) { commit_many(h_g_lagrange, pending, poly); to_coeff_early(pending); pending.clear(); } }
+      else { pending.push_back(uploads[i].first); if (pending.size() == batch_cap || i + 2 == uploads.size() || uploads[i + 1].first.kind != uploads[i].first.kind) { commit_many(h_g_lagrange, pending, poly); to_coeff_early(pending); pending.clear(); } }
     }
   }
-  uploaders.join();
   lap(2);
+  wait_for(uploads.size() - 1);
+  uploaders.join();
+  DevicePoly inst_lagrange = clone(poly.at({P_INSTANCE, 0}), 0);                        // the permutation argument reads the instance VALUES in step 4
+  check(mi355_intt_fr_dev(poly.at({P_INSTANCE, 0}).p, k, dom.omega_inv.data(), dom.ifft_divisor.data())); R.intt++;   // step 1 (placed here: its column arrives last)
+  lap(1);
   // ---- step 4: grand products and running sums, built on the device from the Lagrange values
   {
     std::vector<PolyRef> made;

@@ -79,7 +79,7 @@ static const char *kind_name(PolyKind k) { static const char *n[] = {"instance",
 
 int main(int argc, char **argv) {
   int layer_id = 4, devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2; long k_override = -1; bool host_api = false, do_check = true;
-  std::string tables = "auto", pk_mode = "auto"; int upload_threads = 2, early_intt = -1; bool pinned_witness = false;
+  std::string tables = "auto", pk_mode = "auto"; int upload_threads = 1, early_intt = -1; bool pinned_witness = false;
   long o_advice = -1, o_fixed = -1, o_lookups = -1, o_perm = -1, o_chunk = -1, o_degree = -1;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
