@@ -295,3 +295,63 @@ def test_gate_eval_matches_oracle_on_random_term_lists(zk):
     tl1 = (C.c_uint32 * 1)(1); fp_bad = (C.c_uint32 * 1)(3)
     assert lib.mi355_fr_gate_eval_dev(C.c_void_p(d0.data_ptr()), arr, 1, capi.ptr(one), tl1, 1, fp_bad, fr1, 8, 0) == capi.EBADARG   # factor outside the list
     d0.free()
+
+
+def test_uploads_allocations_and_frees_race_the_compute_of_other_threads(zk):
+    """round 4: mi355_buf_alloc / _free / _upload take no device lock and an upload no longer orders the compute stream behind itself.  Three threads
+    recycle pool blocks (alloc -> upload -> consume on the device -> download -> free, contents checked every time, sizes drawn from a small set so that
+    blocks are handed from thread to thread) while a fourth keeps the device busy with commitments and transforms whose results are checked too."""
+    h2 = zk.halo2
+    lib, capi = zk._capi.lib(), zk._capi
+    k = 16
+    n = 1 << k
+    dom = h2.EvaluationDomain(2, k)
+    params = h2.ParamsKZG.setup(k, TAU + 77)
+    base = rand_fr(np.random.default_rng(70), n)
+    want_commit = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.eval_polynomial(base, cref.fr_mont(TAU + 77))))
+    want_fft = cref.best_fft(base, dom.omega, k, threads=4)
+    errs, stop = [], threading.Event()
+
+    def compute():
+        try:
+            buf = h2.DeviceBuffer.from_host(base)
+            while not stop.is_set():
+                if not (affine_of(params.commit(buf)) == want_commit).all():
+                    errs.append("commit")
+                w = h2.DeviceBuffer.from_host(base)
+                dom.coeff_to_lagrange(w)
+                if not (w.fr() == want_fft).all():
+                    errs.append("fft")
+                w.free()
+            buf.free()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    def recycler(seed):
+        try:
+            r = np.random.default_rng(seed)
+            for it in range(60):
+                m = int(r.choice([1 << 12, 1 << 14, 1 << 16]))
+                v = np.ascontiguousarray(r.integers(0, 2**62, size=(m, 4), dtype=np.uint64))
+                b = h2.DeviceBuffer.from_host(v)                                   # alloc (pool hit or hipMalloc) + upload, no device lock
+                d = h2.DeviceBuffer(32 * m)
+                capi.check(lib.mi355_fr_vec_op_dev(0, C.c_void_p(d.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(b.data_ptr()), m))   # consumer queued right after the upload
+                got = d.fr()
+                if not (got[::97] == np.stack([cref.f_add(cref.FR, x, x) for x in v[::97]])).all():
+                    errs.append(f"recycler {seed} iteration {it}: doubled values differ")
+                if it % 3 == 0:
+                    b.upload(v[::-1].copy())                                        # second upload into a block in use: must wait for the add above
+                    if not (b.fr() == v[::-1]).all():
+                        errs.append(f"recycler {seed} iteration {it}: re-upload")
+                b.free(); d.free()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=compute)] + [threading.Thread(target=recycler, args=(200 + i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th[1:]:
+        t.join()
+    stop.set(); th[0].join()
+    assert not errs, errs[:5]
+    params.release()
