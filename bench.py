@@ -167,7 +167,7 @@ def main() -> None:
         # Each replay is create_proof_gpu_side (include/mi355zk_create_proof.hpp) with that layer's column counts, the proving key's cosets resident
         # (or recomputed per part when they do not fit next to the window tables: the replay's HBM plan decides and reports), two proofs per process
         # (the second, steady-state one is reported), every result checked -- commitments, evaluations, the quotient identity at x, the openings.
-        host_layers = () if args.no_host_api else (1, 2, 4)          # the host-pointer route is replayed for the layers round 3 reported
+        host_layers = () if args.no_host_api else (0, 1, 2, 3, 4, 5, 6)   # the host-pointer route (every operand crosses PCIe both ways) next to the resident one, for every layer
         L = {}
         for lay in (4, 6, 2, 1, 3, 5, 0):
             L[lay] = replay_create_proof(lay, host_api=lay in host_layers)
