@@ -127,6 +127,33 @@ int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
 
 uint32_t cols_for(uint32_t log_m) { uint32_t lc = 3; while (lc > 0 && log_m + lc > g.ntt_tile_log) lc--; return lc; }
 
+// an inverse transform's divisor (the three post-scaling constants equal) is folded into the inter-level twiddles of the last strided
+// pass: one table of 2^log_s entries per (plan, divisor), and the closing pass ends with reduce_small instead of a multiplication.
+// On success *fold_tw names the scaled table and *post3_dev is cleared; otherwise both stay as they were (the divisor remains a multiplication).
+static int fold_divisor(NttPlan *p, uint32_t log_n, const fe_t *pre3_host, const fe_t *post3_host, const Tw29 **fold_tw, fe_t **post3_dev) {
+  hipStream_t s = g.stream;
+  if (post3_host && !pre3_host && g.ntt29 && g.ntt_fold_scale && p->levels >= 2 && memcmp(&post3_host[0], &post3_host[1], 32) == 0 && memcmp(&post3_host[0], &post3_host[2], 32) == 0) {
+    const uint32_t l = p->levels - 2;
+    uint32_t log_sl = log_n; for (uint32_t q = 0; q < l; q++) log_sl -= p->log_m[q];
+    if (p->split[l] == log_sl && !p->direct2[l]) {   // that level reads ONE direct table
+      const std::string key((const char *)&post3_host[0], 32);
+      auto it = p->scaled.find(key);
+      if (it == p->scaled.end()) {
+        const uint32_t cnt = 1u << log_sl; uint4 *lo, *hi; uint32_t *top;
+        if (alloc_tw29(cnt, &lo, &hi, &top)) {
+          p->owned.push_back(lo); p->owned.push_back(hi); p->owned.push_back(top);
+          hipLaunchKernelGGL(k_scale_table29, dim3(ceil_div(cnt, 256)), dim3(256), 0, s, p->tw29_s_lo[l].lo, p->tw29_s_lo[l].hi, p->tw29_s_lo[l].top, lo, hi, top, post3_host[0], cnt);
+          HIPCHK(hipGetLastError());
+          Tw29 t; t.lo = lo; t.hi = hi; t.top = top;
+          it = p->scaled.emplace(key, t).first;
+        }
+      }
+      if (it != p->scaled.end()) { *fold_tw = &it->second; *post3_dev = nullptr; }   // allocation failed: the divisor stays a multiplication in the closing pass
+    }
+  }
+  return MI355_OK;
+}
+
 // dst[2^log_n] = NTT_omega( pre3-scaled, zero-padded src[src_len] ), then optional post3 scaling.  src may equal dst.
 int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, const void *omega, const fe_t *pre3_host, const fe_t *post3_host) {
   if (log_n > 28) return fail(MI355_EBADARG, "ntt: log_n > 28 (BN254 Fr two-adicity)");
@@ -145,28 +172,8 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
     }
   }
   NttPlan *p; CHK(get_plan(log_n, omega, &p));
-  // an inverse transform's divisor (the three post-scaling constants equal) is folded into the inter-level twiddles of the last strided
-  // pass: one table of 2^log_s entries per (plan, divisor), and the closing pass ends with reduce_small instead of a multiplication
   const Tw29 *fold_tw = nullptr;
-  if (post3_host && !pre3_host && g.ntt29 && g.ntt_fold_scale && p->levels >= 2 && memcmp(&post3_host[0], &post3_host[1], 32) == 0 && memcmp(&post3_host[0], &post3_host[2], 32) == 0) {
-    const uint32_t l = p->levels - 2;
-    uint32_t log_sl = log_n; for (uint32_t q = 0; q < l; q++) log_sl -= p->log_m[q];
-    if (p->split[l] == log_sl && !p->direct2[l]) {   // that level reads ONE direct table
-      const std::string key((const char *)&post3_host[0], 32);
-      auto it = p->scaled.find(key);
-      if (it == p->scaled.end()) {
-        const uint32_t cnt = 1u << log_sl; uint4 *lo, *hi; uint32_t *top;
-        if (alloc_tw29(cnt, &lo, &hi, &top)) {
-          p->owned.push_back(lo); p->owned.push_back(hi); p->owned.push_back(top);
-          hipLaunchKernelGGL(k_scale_table29, dim3(ceil_div(cnt, 256)), dim3(256), 0, s, p->tw29_s_lo[l].lo, p->tw29_s_lo[l].hi, p->tw29_s_lo[l].top, lo, hi, top, post3_host[0], cnt);
-          HIPCHK(hipGetLastError());
-          Tw29 t; t.lo = lo; t.hi = hi; t.top = top;
-          it = p->scaled.emplace(key, t).first;
-        }
-      }
-      if (it != p->scaled.end()) { fold_tw = &it->second; post3 = nullptr; }   // allocation failed: the divisor stays a multiplication in the closing pass
-    }
-  }
+  CHK(fold_divisor(p, log_n, pre3_host, post3_host, &fold_tw, &post3));
   CallTrace tr("ntt_fr", N, 64.0);
   Scope total("ntt_total");
   if (p->levels == 1) {
@@ -215,6 +222,68 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
   }
   HIPCHK(hipGetLastError());
   total.close();
+  tr.done();
+  return MI355_OK;
+}
+
+
+// `data.size()` in-place transforms of 2^log_n elements (optionally times a divisor) as batched launches: blockIdx.y = vector.  Used by the batch entry
+// points for small transforms; falls back to the loop of single transforms where the batched kernels do not apply.  Same results.
+int ntt_batch_inplace(const std::vector<fe_t *> &data, uint32_t log_n, const void *omega, const void *divisor) {
+  const size_t cnt = data.size();
+  auto single_loop = [&]() -> int {
+    for (fe_t *d : data) {
+      if (!divisor) CHK(ntt_dev_impl(d, 1ull << log_n, d, log_n, omega, nullptr, nullptr));
+      else { fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], divisor, 32); CHK(ntt_dev_impl(d, 1ull << log_n, d, log_n, omega, nullptr, post)); }
+    }
+    return MI355_OK;
+  };
+  if (cnt < 2 || !g.ntt29 || g.ntt_radix_log != 2 || g.ntt_raw_scratch || log_n > g.ntt_batch_max_log || log_n > 28) return single_loop();
+  NttPlan *p; CHK(get_plan(log_n, omega, &p));
+  if (p->levels < 2) return single_loop();
+  const uint64_t N = 1ull << log_n;
+  hipStream_t s = g.stream;
+  fe_t post_host[3]; fe_t *post3 = nullptr; const Tw29 *fold_tw = nullptr;
+  if (divisor) {
+    for (int i = 0; i < 3; i++) memcpy(&post_host[i], divisor, 32);
+    fe_t *c; CHK(ws_get("ntt.consts", 6 * sizeof(fe_t), (void **)&c));
+    HIPCHK(hipMemcpyAsync(c + 3, post_host, 3 * sizeof(fe_t), hipMemcpyHostToDevice, s)); HIPCHK(hipStreamSynchronize(s));
+    post3 = c + 3;
+    CHK(fold_divisor(p, log_n, nullptr, post_host, &fold_tw, &post3));
+  }
+  const size_t chunk = std::min<size_t>(cnt, std::max<size_t>(1, (size_t)((1ull << 30) / (N * sizeof(fe_t)))));   // at most 1 GiB of scratch
+  fe_t *scratch; CHK(ws_get("ntt.scratch.batch", chunk * N * sizeof(fe_t), (void **)&scratch));
+  // pointer tables for the whole list: data[i] and the scratch slot of i (slots repeat chunk by chunk; the stream orders their reuse)
+  std::vector<const fe_t *> tab(2 * cnt);
+  for (size_t i = 0; i < cnt; i++) { tab[i] = data[i]; tab[cnt + i] = scratch + (i % chunk) * N; }
+  const fe_t **dtab; CHK(ws_get("ntt.batch.ptrs", 2 * cnt * sizeof(void *), (void **)&dtab));
+  HIPCHK(hipMemcpyAsync(dtab, tab.data(), 2 * cnt * sizeof(void *), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));   // `tab` is a stack-lifetime vector
+  CallTrace tr("ntt_fr_batch", N * cnt, 64.0);
+  for (size_t base = 0; base < cnt; base += chunk) {
+    const uint32_t c = (uint32_t)std::min(chunk, cnt - base);
+    const fe_t *const *d_data = dtab + base; fe_t *const *d_scr = (fe_t *const *)(dtab + cnt + base);
+    uint32_t log_s = log_n;
+    for (uint32_t l = 0; l + 1 < p->levels; l++) {
+      Ntt29Level L9; L9.log_m = p->log_m[l]; L9.log_t = log_s - L9.log_m; L9.split = p->split[l]; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l];
+      L9.direct = p->direct2[l] ? 2u : (p->split[l] == log_s) ? 1u : 0u;
+      if (fold_tw && l + 2 == p->levels) L9.tw_s_lo = *fold_tw;
+      const uint32_t lc = std::min(cols_for(L9.log_m), L9.log_t), tile = 1u << (L9.log_m + lc);
+      const uint64_t blocks = (N >> log_s) << (L9.log_t - lc);
+      Scope sc("ntt_pass");
+      const NttBatch B{l == 0 ? d_data : (const fe_t *const *)d_scr, d_scr};
+      hipLaunchKernelGGL((k_ntt29_strided<2, 0>), dim3((uint32_t)blocks, c), dim3(std::max(64u, std::min(512u, tile / 4))), (size_t)36 * tile, s, (const fe_t *)nullptr, (fe_t *)nullptr, L9, lc, N, (const fe_t *)nullptr, Raw29{nullptr, nullptr, nullptr}, B);
+      log_s -= L9.log_m;
+    }
+    const uint32_t lm = p->log_m[p->levels - 1], log_a = p->log_m[0], log_b = p->levels == 3 ? p->log_m[1] : 0;
+    const uint32_t lc = std::min(cols_for(lm), log_a), tile = 1u << (lm + lc);
+    const uint64_t blocks = ((uint64_t)1 << log_b) << (log_a - lc);
+    Scope sc("ntt_pass");
+    const NttBatch B{(const fe_t *const *)d_scr, (fe_t *const *)d_data};
+    hipLaunchKernelGGL((k_ntt29_final<2, 0>), dim3((uint32_t)blocks, c), dim3(std::max(64u, std::min(512u, tile / 4))), (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), s, (const fe_t *)nullptr, (fe_t *)nullptr, lm, log_a, log_b, lc,
+                       p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, (const fe_t *)post3, Raw29{nullptr, nullptr, nullptr}, B);
+    HIPCHK(hipGetLastError());
+  }
   tr.done();
   return MI355_OK;
 }
@@ -491,7 +560,10 @@ int mi355_ntt_fr_batch_dev(void *const *data_dev, uint32_t batch, uint32_t log_n
   if (!data_dev || !omega || log_n > 28) return fail(MI355_EBADARG, "ntt_batch: bad argument");
   std::vector<BatchItem> items(batch);
   for (uint32_t i = 0; i < batch; i++) { if (!data_dev[i]) return fail(MI355_EBADARG, "ntt_batch: null polynomial pointer"); items[i] = {i, slot_of(data_dev[i])}; }
-  return run_per_device(items, [&](int, uint32_t i) -> int { return transform_in_place((fe_t *)data_dev[i], log_n, omega, divisor); });
+  return run_per_device_lists(items, [&](int, const std::vector<uint32_t> &idx) -> int {
+    std::vector<fe_t *> list; for (uint32_t i : idx) list.push_back((fe_t *)data_dev[i]);
+    return ntt_batch_inplace(list, log_n, omega, divisor);   // small transforms: batched launches (blockIdx.y = polynomial); otherwise the loop of single transforms
+  });
   });
 }
 // `batch` x coeff_to_extended_part: dst[i] = best_fft(coeffs[i][j] * coset_factor^j, omega); dst[i] and coeffs[i] must live on one device
@@ -510,8 +582,8 @@ int mi355_coset_ntt_fr_batch_dev(void *const *dst_dev, const void *const *coeffs
     std::vector<const void *> src; std::vector<void *> dst;
     for (uint32_t i : idx) { src.push_back(coeffs_dev[i]); dst.push_back(dst_dev[i]); }
     CHK(distribute_powers_batch_locked(src, dst, 1ull << log_n, coset_factor));
-    for (uint32_t i : idx) CHK(ntt_dev_impl((const fe_t *)dst_dev[i], 1ull << log_n, (fe_t *)dst_dev[i], log_n, omega, nullptr, nullptr));
-    return MI355_OK;
+    std::vector<fe_t *> list; for (void *d : dst) list.push_back((fe_t *)d);
+    return ntt_batch_inplace(list, log_n, omega, nullptr);
   });
   });
 }

@@ -158,6 +158,10 @@ __device__ __forceinline__ fe29_t load_input29(const fe_t *__restrict__ src, uin
 // 4-byte: 36 B per element) instead of being re-sliced to 8 x 32 bits on the way out and back on the way in (~55 VALU instructions per element and
 // pass boundary).  The strided passes' multiplication output is normalised (limbs < 2^29), so from_sat_plain(to_sat_plain(t)) == t: same bits either way.
 struct Raw29 { uint4 *lo; uint4 *hi; uint32_t *top; };
+// Several equal-size transforms in one launch (round 4): blockIdx.y picks the vector.  Small transforms (2^19 .. 2^22: the many-column layers run
+// thousands per proof) are one round of workgroups each, so between two launches the device ramps down and up again; batched, workgroups of the next
+// vector start as those of the previous one finish.  srcs == nullptr: the single-vector launch.
+struct NttBatch { const fe_t *const *srcs; fe_t *const *dsts; };
 __device__ __forceinline__ fe29_t raw29_load(const Raw29 &R, uint64_t i) {
   const uint4 a = R.lo[i], b = R.hi[i]; fe29_t r;
   r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = R.top[i]; return r;
@@ -167,8 +171,9 @@ __device__ __forceinline__ void raw29_store(const Raw29 &R, uint64_t i, const fe
 }
 // MODE 0: source and destination in the ABI form (8 x 32); 1: ABI source, raw destination (first pass); 2: raw source and destination (second strided pass, in place)
 template <int RMAX, int MODE = 0> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_ntt29_strided(const fe_t *__restrict__ src, fe_t *__restrict__ dst, Ntt29Level L, uint32_t log_c,
-                                                        uint64_t src_len, const fe_t *__restrict__ pre3, Raw29 raw = Raw29{nullptr, nullptr, nullptr}) {
+                                                        uint64_t src_len, const fe_t *__restrict__ pre3, Raw29 raw = Raw29{nullptr, nullptr, nullptr}, NttBatch batch = NttBatch{nullptr, nullptr}) {
   extern __shared__ uint4 lds[];
+  if (batch.srcs) { src = batch.srcs[blockIdx.y]; dst = batch.dsts[blockIdx.y]; }
   const uint32_t M = 1u << L.log_m, C = 1u << log_c, tile = M << log_c;
   const Lds29 S = lds29_carve(lds, tile);
   const uint32_t cb_per_sub = 1u << (L.log_t - log_c);
@@ -199,8 +204,9 @@ template <int RMAX, int MODE = 0> __global__ void __launch_bounds__(RMAX >= 2 ? 
 }
 
 template <int RMAX, int MODE = 0> __global__ void __launch_bounds__(RMAX >= 2 ? 512 : 1024) k_ntt29_final(const fe_t *__restrict__ src, fe_t *__restrict__ dst, uint32_t log_m, uint32_t log_a, uint32_t log_b,
-                                                      uint32_t log_c, Tw29 tw_m, uint64_t src_len, const fe_t *__restrict__ pre3, const fe_t *__restrict__ post3, Raw29 raw = Raw29{nullptr, nullptr, nullptr}) {
+                                                      uint32_t log_c, Tw29 tw_m, uint64_t src_len, const fe_t *__restrict__ pre3, const fe_t *__restrict__ post3, Raw29 raw = Raw29{nullptr, nullptr, nullptr}, NttBatch batch = NttBatch{nullptr, nullptr}) {
   extern __shared__ uint4 lds[];
+  if (batch.srcs) { src = batch.srcs[blockIdx.y]; dst = batch.dsts[blockIdx.y]; }
   const uint32_t M = 1u << log_m, C = 1u << log_c, seg = M + 1, tile = M << log_c;
   const Lds29 S = lds29_carve(lds, seg << log_c);
   const uint32_t k2 = blockIdx.x & ((1u << log_b) - 1);
