@@ -136,6 +136,35 @@ pub fn open_combination(all: &[&DevicePoly], v: Fr, z: &[Fr], g: &Arc<GpuBasis>,
     Some((lin, commitments))
 }
 
+/// What stays resident for a process that holds several layers (hpp: `plan_residency`).  `shapes[i]` = (k, fixed + sigma + 3 proving-key
+/// polynomials, witness polynomials, quotient parts Q); returns for each layer whether its proving key keeps its Q coset parts in HBM, then which degrees
+/// get window tables on (Lagrange basis, coefficient basis).  Cosets first (a recomputed part costs one coset transform per polynomial, ~4.8 us per MiB at
+/// every k), then tables (8 % per commitment), the Lagrange bases before the coefficient bases, 8 % of the device left unplanned.
+pub fn plan_residency(shapes: &[(u32, u32, u32, u32)], hbm_gib: f64) -> (Vec<bool>, Vec<(u32, bool, bool)>) {
+    let gib = |k: u32| (32u64 << k) as f64 / (1u64 << 30) as f64;
+    let budget = hbm_gib * 0.92;
+    let mut degrees: Vec<u32> = shapes.iter().map(|s| s.0).collect(); degrees.sort_unstable(); degrees.dedup();
+    let srs: f64 = degrees.iter().map(|&k| 4.0 * gib(k)).sum();
+    let keys: f64 = shapes.iter().map(|s| gib(s.0) * (2.0 * (s.1 as f64 - 3.0) + 4.0)).sum();
+    let working = shapes.iter().map(|s| gib(s.0) * (2.0 * s.2 as f64 + 3.0 * s.3 as f64 + 8.0) + (1u64 << s.0) as f64 * 286.0 / (1u64 << 30) as f64 + 0.5).fold(0.0, f64::max);
+    let mut used = srs + keys + working;
+    let mut order: Vec<usize> = (0..shapes.len()).collect();
+    order.sort_by(|&a, &b| (gib(shapes[a].0) * (shapes[a].1 * shapes[a].3) as f64).partial_cmp(&(gib(shapes[b].0) * (shapes[b].1 * shapes[b].3) as f64)).unwrap());
+    let (mut resident, mut lean_tmp) = (vec![false; shapes.len()], 0.0f64);
+    for i in order {
+        let c = gib(shapes[i].0) * (shapes[i].1 * shapes[i].3) as f64;
+        if used + c + lean_tmp <= budget { resident[i] = true; used += c; } else { lean_tmp = lean_tmp.max(gib(shapes[i].0) * shapes[i].1 as f64); }
+    }
+    used += lean_tmp;
+    let mut tables: Vec<(u32, bool, bool)> = degrees.iter().rev().map(|&k| (k, false, false)).collect();
+    for pass in 0..2 { for t in tables.iter_mut() {
+        let w = if t.0 >= 24 { 12.0 } else { 15.0 };
+        let bytes = 2.0 * gib(t.0) * w;
+        if used + bytes <= budget { used += bytes; if pass == 0 { t.1 = true } else { t.2 = true } }
+    } }
+    (resident, tables)
+}
+
 /// one `GateSlice` through `mi355_fr_gate_eval_dev` (hpp: `detail::run_launch`): operands are deduplicated into the launch's polynomial list
 fn run_slice(s: &GateSlice, dst: *mut c_void, n: usize, scale: Option<Fr>, accumulate: bool, resolve: &dyn Fn(Operand) -> *const c_void, _tmp: &[DevicePoly]) -> Option<()> {
     let mut ptrs: Vec<*const c_void> = Vec::new();
