@@ -199,6 +199,9 @@ inline Fr coset_factor(const EvaluationDomain &dom, uint32_t q) { return detail:
 // layers that is the difference between steps 2-3 being bound by the link or by their commitments.
 template <class T> struct ColumnAllocator {
   using value_type = T; bool pinned = false;
+  using propagate_on_container_move_assignment = std::true_type;   // `column = Column(alloc)` must carry the page-locked choice with it
+  using propagate_on_container_copy_assignment = std::true_type;
+  using propagate_on_container_swap = std::true_type;
   ColumnAllocator() = default; explicit ColumnAllocator(bool p) : pinned(p) {}
   template <class U> ColumnAllocator(const ColumnAllocator<U> &o) : pinned(o.pinned) {}
   T *allocate(size_t n) {

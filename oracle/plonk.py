@@ -1,0 +1,641 @@
+"""
+oracle/plonk.py -- TEST INFRASTRUCTURE (checker only; never imported by the product path): a CPU restatement of halo2's
+`plonk::create_proof` and `plonk::verify_proof` (KZG, SHPLONK multi-open, scroll fork with the log-derivative lookup) driven by a
+snark-verifier `PlonkProtocol` JSON -- the files the reference ships with its proofs [REF release-v0.13.1/chunk.protocol],
+[REF integration/tests/test_data/full_proof_batch_agg_1.json `protocol`] -- in Python big integers, with the C oracle (oracle/cref.py) for the
+transforms and the curve.  Shares no code with include/mi355zk_plonk.hpp: it WALKS THE JSON EXPRESSION TREE directly (no expression plan, no
+sum-of-products compiler, no launches), which is what makes it an independent check of the prover's quotient.
+
+  Protocol            parsed protocol + the structure the argument provers need (permutation chunks, lookups), recognised from the numerator
+  evaluate()          the expression tree over scalars (verifier: at the challenge x) or numpy object arrays (prover: over the extended domain)
+  Transcript          halo2's Blake2bWrite / Blake2bRead [EXT-recalled halo2_proofs src/transcript/blake2b.rs]: Blake2b-512, personalisation
+                      "Halo2-Transcript", prefix bytes 0 / 1 / 2 for challenge / point / scalar, challenges = 64 output bytes reduced mod r
+  prove()             create_proof's steps by definition: commit, grand products, quotient over the whole extended coset domain at
+                      once, evaluations in the protocol's order, SHPLONK over the rotation sets the protocol's `queries` imply
+  verify()            verify_proof from the proof BYTES (the reference's layout: compressed G1 commitments, canonical Fr evaluations, two
+                      SHPLONK points): recomputes every challenge, evaluates the numerator from the evaluations,
+                      checks h(x) (x^n - 1) == numerator(x) through the opening, and the final pairing equation with the synthetic SRS's
+                      trapdoor in G1 (e(W, [tau]_2) == e(E, [1]_2)  <=>  tau W == E)
+
+Parity: no halo2 source is in the container, so the conventions that do not show in the fixtures (which power of y / v meets which polynomial in
+SHPLONK, the vk's transcript representation) are this file's, stated where they are made; what the fixtures do pin -- the constraint system, the
+opened (polynomial, rotation) pairs, the order of commitments and evaluations in the proof, the byte layout -- is followed exactly.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+
+import numpy as np
+
+from . import cref, pyref
+
+R = pyref.R_MOD
+FR = cref.FR
+
+
+# ------------------------------------------------------------------------------------------------ conversions
+def ints_to_mont(v):
+    a = np.zeros((len(v), 4), dtype=np.uint64)
+    for i, x in enumerate(v):
+        x = int(x) % R
+        a[i, 0], a[i, 1], a[i, 2], a[i, 3] = x & 0xFFFFFFFFFFFFFFFF, (x >> 64) & 0xFFFFFFFFFFFFFFFF, (x >> 128) & 0xFFFFFFFFFFFFFFFF, x >> 192
+    return cref.f_from_canonical_vec(FR, a) if len(v) else a
+
+
+def mont_to_ints(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    c = cref.f_to_canonical_vec(FR, a) if a.shape[0] else a
+    raw = c.tobytes()
+    return [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(a.shape[0])]
+
+
+def limbs_mont_to_int(l):
+    return pyref.from_mont(sum(int(v) << (64 * i) for i, v in enumerate(l)), R)
+
+
+def inv(x):
+    return pow(x % R, -1, R)
+
+
+# ------------------------------------------------------------------------------------------------ protocol
+class Protocol:
+    def __init__(self, d: dict):
+        self.d = d
+        self.k = d["domain"]["k"]
+        self.n = 1 << self.k
+        self.omega = limbs_mont_to_int(d["domain"]["gen"])
+        assert pow(self.omega, self.n, R) == 1 and pow(self.omega, self.n // 2, R) != 1
+        self.num_pre = d["num_preprocessed"] if "num_preprocessed" in d else len(d["preprocessed"])
+        self.num_instance = list(d["num_instance"])
+        self.num_witness = list(d["num_witness"])
+        self.num_challenge = list(d["num_challenge"])
+        self.inst0 = self.num_pre
+        self.wit0 = self.inst0 + len(self.num_instance)
+        self.phase0 = [self.wit0 + sum(self.num_witness[:i]) for i in range(len(self.num_witness))]
+        self.quotient_poly = self.wit0 + sum(self.num_witness)
+        self.Q = d["quotient"]["num_chunk"]
+        self.numerator = d["quotient"]["numerator"]
+        self.evaluations = [(e["poly"], e["rotation"]) for e in d["evaluations"]]
+        self.queries = [(e["poly"], e["rotation"]) for e in d["queries"]]
+        lag = []
+        _walk_common(self.numerator, lag)
+        self.last = min(lag)                        # l_last = Lagrange(last); rows last+1 .. -1 are the blinding rows
+        self.blind = -self.last - 1
+        self.usable = self.n + self.last            # rows 0 .. usable-1 are active, row `usable` is the l_last row
+        self.ext_k = self.k + (self.Q - 1).bit_length()
+        self._recognise()
+
+    # ---- the argument structure, recognised from the numerator (what halo2 reads off its ConstraintSystem)
+    def _recognise(self):
+        cons = self.numerator["DistributePowers"][0]
+        assert self.numerator["DistributePowers"][1] == {"Challenge": sum(self.num_challenge) - 1}
+        self.gates, self.perm, self.lookups = [], [], []
+        for c in cons:
+            a, b = c["Product"]
+            if _is_lagrange(a) is not None:
+                continue                                                    # l_0 / l_last boundary constraints: implied by how z and phi are built
+            if _is_common_linear(a):                                        # l_active * (...)
+                s0, s1 = b["Sum"]
+                l0, l1 = s0["Product"]
+                if "Polynomial" in l0 and l0["Polynomial"]["rotation"] == 1:   # z(wX) prod(c + beta sigma + gamma) - z(X) prod(c + beta delta^j X + gamma)
+                    z = l0["Polynomial"]["poly"]
+                    r0, r1 = s1["Negated"]["Product"]
+                    assert r0 == {"Polynomial": {"poly": z, "rotation": 0}}
+                    cols = []
+                    for fs, fi in zip(_flatten_product(l1), _flatten_product(r1)):
+                        (cs, bs), g = fs["Sum"][0]["Sum"], fs["Sum"][1]
+                        (ci, bi), g2 = fi["Sum"][0]["Sum"], fi["Sum"][1]
+                        assert cs == ci and g == g2 == {"Challenge": 2} and bs["Product"][0] == {"Challenge": 1} and bi["Product"][1] == {"CommonPolynomial": "Identity"}
+                        assert bi["Product"][0]["Product"][0] == {"Challenge": 1}
+                        cols.append((cs["Polynomial"]["poly"], bs["Product"][1]["Polynomial"]["poly"], limbs_mont_to_int(bi["Product"][0]["Product"][1]["Constant"])))
+                        assert cs["Polynomial"]["rotation"] == 0
+                    self.perm.append({"z": z, "columns": cols})
+                else:                                                       # (T + b)(I + b)(phi(wX) - phi(X)) - ((T + b) - m (I + b))
+                    (tb, ib), dphi = l0["Product"], l1
+                    phi = dphi["Sum"][0]["Polynomial"]["poly"]
+                    assert dphi == {"Sum": [{"Polynomial": {"poly": phi, "rotation": 1}}, {"Negated": {"Polynomial": {"poly": phi, "rotation": 0}}}]}
+                    tb2, mib = s1["Negated"]["Sum"]
+                    m = mib["Negated"]["Product"][0]["Polynomial"]["poly"]
+                    assert tb2 == tb and mib["Negated"]["Product"][1] == ib and tb["Sum"][1] == ib["Sum"][1] == {"Challenge": 1}
+                    self.lookups.append({"phi": phi, "m": m, "table": tb["Sum"][0], "input": ib["Sum"][0]})
+            else:                                                           # selector * (P - target)
+                self.gates.append(c)
+
+    def poly_kind(self, i):
+        if i < self.num_pre:
+            return "preprocessed"
+        if i < self.wit0:
+            return "instance"
+        if i < self.quotient_poly:
+            return "witness"
+        return "quotient"
+
+
+def _walk_common(e, lag):
+    if isinstance(e, dict):
+        for k, v in e.items():
+            if k == "CommonPolynomial":
+                if isinstance(v, dict):
+                    lag.append(v["Lagrange"])
+            else:
+                _walk_common(v, lag)
+    elif isinstance(e, list):
+        for v in e:
+            _walk_common(v, lag)
+
+
+def _is_lagrange(e):
+    if isinstance(e, dict) and "CommonPolynomial" in e and isinstance(e["CommonPolynomial"], dict):
+        return e["CommonPolynomial"]["Lagrange"]
+    return None
+
+
+def _is_common_linear(e):
+    (k, v), = e.items()
+    if k in ("Constant", "CommonPolynomial"):
+        return True
+    if k == "Sum":
+        return _is_common_linear(v[0]) and _is_common_linear(v[1])
+    if k == "Negated":
+        return _is_common_linear(v)
+    return False
+
+
+def _flatten_product(e):
+    """the factors of a left-associated product of sums ((f0 f1) f2): every factor of the permutation products is a `Sum` node"""
+    if "Product" in e:
+        return _flatten_product(e["Product"][0]) + _flatten_product(e["Product"][1])
+    return [e]
+
+
+# ------------------------------------------------------------------------------------------------ the expression tree
+def evaluate(e, poly, challenge, identity, lagrange):
+    """e over any ring whose elements support + * - and % R (Python ints, numpy object arrays).  poly(i, rot), challenge(i), identity(),
+    lagrange(i) supply the leaves.  DistributePowers is Horner in its base, the first expression taking the highest power
+    [EXT-recalled snark-verifier util/protocol.rs Expression::evaluate; halo2 folds its gates with y the same way]."""
+    (k, v), = e.items()
+    ev = lambda x: evaluate(x, poly, challenge, identity, lagrange)
+    if k == "Polynomial":
+        return poly(v["poly"], v["rotation"])
+    if k == "Constant":
+        return limbs_mont_to_int(v)
+    if k == "Challenge":
+        return challenge(v)
+    if k == "CommonPolynomial":
+        return identity() if v == "Identity" else lagrange(v["Lagrange"])
+    if k == "Negated":
+        return (-ev(v)) % R
+    if k == "Sum":
+        return (ev(v[0]) + ev(v[1])) % R
+    if k == "Product":
+        return (ev(v[0]) * ev(v[1])) % R
+    if k == "Scaled":
+        return (ev(v[0]) * limbs_mont_to_int(v[1])) % R
+    if k == "DistributePowers":
+        exprs, base = v
+        b = ev(base)
+        acc = ev(exprs[0])
+        for x in exprs[1:]:
+            acc = (acc * b + ev(x)) % R
+        return acc
+    raise ValueError("unknown expression node " + k)
+
+
+# ------------------------------------------------------------------------------------------------ transcript
+class Transcript:
+    """Blake2b transcript of halo2 (Blake2bWrite / Blake2bRead with Challenge255)."""
+
+    def __init__(self, proof: bytes | None = None):
+        self.h = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        self.out = bytearray()
+        self.inp = proof
+        self.pos = 0
+
+    def squeeze(self) -> int:
+        self.h.update(b"\x00")
+        return int.from_bytes(self.h.copy().digest(), "little") % R
+
+    def common_point(self, p_affine_int):
+        assert p_affine_int is not None, "halo2's transcript refuses the identity (coordinates() is None)"
+        x, y = p_affine_int
+        self.h.update(b"\x01" + int(x).to_bytes(32, "little") + int(y).to_bytes(32, "little"))
+
+    def common_scalar(self, s: int):
+        self.h.update(b"\x02" + int(s % R).to_bytes(32, "little"))
+
+    def write_point(self, p_affine_int):
+        self.common_point(p_affine_int)
+        self.out += pyref.g1_compress(p_affine_int)
+
+    def write_scalar(self, s: int):
+        self.common_scalar(s)
+        self.out += int(s % R).to_bytes(32, "little")
+
+    def read_point(self):
+        b = self.inp[self.pos:self.pos + 32]; self.pos += 32
+        p = pyref.g1_decompress(bytes(b))
+        assert p is not None and pyref.g1_is_on_curve(p), "proof holds an invalid point"
+        self.common_point(p)
+        return p
+
+    def read_scalar(self):
+        v = int.from_bytes(self.inp[self.pos:self.pos + 32], "little"); self.pos += 32
+        assert v < R, "proof holds a non-canonical scalar"
+        self.common_scalar(v)
+        return v
+
+
+def vk_transcript_repr(vk_bytes: bytes) -> int:
+    """halo2 hashes the Debug rendering of the pinned verifying key (Blake2b-512, personalisation "Halo2-Verify-Key") into one scalar; that string is
+    not reproducible outside Rust, so the bytes hashed here are the .vkey serialisation (u32 BE k | u32 BE fixed columns | compressed commitments,
+    the layout of [REF release-v0.13.1/vk_chunk.vkey])."""
+    return int.from_bytes(hashlib.blake2b(vk_bytes, digest_size=64, person=b"Halo2-Verify-Key").digest(), "little") % R
+
+
+# ------------------------------------------------------------------------------------------------ group helpers (trapdoor SRS: g[i] = tau^i G)
+def g1_of_scalar(s: int):
+    if s % R == 0:
+        return None
+    a = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), cref.fr_mont(s)))
+    return pyref.g1_affine_from_limbs(a[:4], a[4:])
+
+
+def g1_mul(p, s: int):
+    return pyref.g1_mul(p, s % R)
+
+
+def g1_add(p, q):
+    return pyref.g1_add(p, q)
+
+
+# ------------------------------------------------------------------------------------------------ domain helpers
+def lagrange_at(pr: Protocol, i: int, x: int) -> int:
+    """L_i(x) for row i (negative: from the end):  omega^i (x^n - 1) / (n (x - omega^i))"""
+    wi = pow(pr.omega, i % pr.n, R)
+    return wi * (pow(x, pr.n, R) - 1) % R * inv(pr.n * (x - wi)) % R
+
+
+def rotation_sets(queries):
+    """SHPLONK's grouping [EXT-recalled halo2_proofs poly/kzg/multiopen/shplonk.rs construct_intermediate_sets]: polynomials opened at the same SET of
+    rotations share one rotation set.  Order here: first appearance in `queries` (halo2 orders the sets by a BTreeSet of the evaluation POINTS, which
+    depends on the challenge; the order only permutes powers of v)."""
+    rots = {}
+    order = []
+    for p, r in queries:
+        if p not in rots:
+            rots[p] = []
+            order.append(p)
+        if r not in rots[p]:
+            rots[p].append(r)
+    sets = []
+    for p in order:
+        key = frozenset(rots[p])
+        for s in sets:
+            if s["key"] == key:
+                s["polys"].append(p)
+                break
+        else:
+            sets.append({"key": key, "rots": list(rots[p]), "polys": [p]})
+    return sets
+
+
+def interpolate(points, values):
+    """coefficients (low first) of the polynomial of degree < len(points) through (points[i], values[i])"""
+    m = len(points)
+    coeffs = [0] * m
+    for i in range(m):
+        num = [1]
+        den = 1
+        for j in range(m):
+            if j == i:
+                continue
+            num = [(a - points[j] * b) % R for a, b in zip([0] + num, num + [0])]
+            den = den * (points[i] - points[j]) % R
+        s = values[i] * inv(den) % R
+        for t in range(len(num)):
+            coeffs[t] = (coeffs[t] + s * num[t]) % R
+    return coeffs
+
+
+def horner(coeffs, x):
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % R
+    return acc
+
+
+# ------------------------------------------------------------------------------------------------ inputs
+class ProofInputs:
+    """what create_proof is handed: the proving key's columns, the instance values, the synthesised witness and the randomness it would draw"""
+
+    def __init__(self, pr: Protocol, pre, instances, advice, m, z_blind, phi_blind, random_coeffs, tau: int):
+        self.pr, self.pre, self.instances, self.advice, self.m = pr, pre, instances, advice, m
+        self.z_blind, self.phi_blind, self.random_coeffs, self.tau = z_blind, phi_blind, random_coeffs, tau
+
+    @staticmethod
+    def load(directory: str):
+        import os
+        man = json.load(open(os.path.join(directory, "manifest.json")))
+        pr = Protocol(json.load(open(os.path.join(directory, "protocol.json"))))
+        n = pr.n
+
+        def rd(name, rows):
+            a = np.fromfile(os.path.join(directory, name), dtype=np.uint64)
+            return a.reshape(-1, rows, 4) if rows else a.reshape(-1, 4)
+        pre = [mont_to_ints(c) for c in rd("pre.bin", n)]
+        advice = [mont_to_ints(c) for c in rd("advice.bin", n)]
+        m = [mont_to_ints(c) for c in rd("m.bin", n)] if pr.num_witness[1] else []
+        inst = mont_to_ints(rd("instance.bin", 0))
+        zb = [mont_to_ints(c) for c in rd("z_blind.bin", pr.blind)]
+        pb = [mont_to_ints(c) for c in rd("phi_blind.bin", pr.blind)] if pr.num_witness[1] else []
+        rnd = mont_to_ints(rd("random.bin", 0))
+        return ProofInputs(pr, pre, inst, advice, m, zb, pb, rnd, int(man["tau"], 16)), man
+
+
+class _Domain:
+    def __init__(self, pr: Protocol):
+        k, ek = pr.k, pr.ext_k
+        self.k, self.ek, self.n, self.ne = k, ek, pr.n, 1 << ek
+        self.w = pr.omega
+        self.we = pow(pyref.FR_ROOT_OF_UNITY, 1 << (pyref.FR_S - ek), R)
+        assert pow(self.we, 1 << (ek - k), R) == self.w
+        self.zeta = pyref.FR_ZETA
+        m = cref.fr_mont
+        self.m_w, self.m_winv, self.m_ninv = m(self.w), m(inv(self.w)), m(inv(self.n))
+        self.m_we, self.m_weinv, self.m_neinv = m(self.we), m(inv(self.we)), m(inv(self.ne))
+        self.m_zeta, self.m_zeta_inv = m(self.zeta), m(self.zeta * self.zeta % R)
+
+    def to_coeff(self, lagrange_ints):
+        return mont_to_ints(cref.ifft(ints_to_mont(lagrange_ints), self.m_winv, self.k, self.m_ninv))
+
+    def to_extended(self, coeff_ints):
+        a = cref.coeff_to_extended(ints_to_mont(coeff_ints), self.k, self.ek, self.m_zeta, self.m_zeta_inv, self.m_we)
+        return np.array(mont_to_ints(a), dtype=object)
+
+    def from_extended(self, ext_vals):
+        return mont_to_ints(cref.extended_to_coeff(ints_to_mont(list(ext_vals)), self.ek, self.m_zeta, self.m_zeta_inv, self.m_weinv, self.m_neinv))
+
+
+def eval_poly(coeffs, x):
+    return mont_to_ints(cref.eval_polynomial_mt(ints_to_mont(coeffs), cref.fr_mont(x))[None, :])[0] if len(coeffs) > 64 else horner(coeffs, x)
+
+
+def kate_division(coeffs, z):
+    return mont_to_ints(cref.kate_division(ints_to_mont(coeffs), cref.fr_mont(z)))
+
+
+# ------------------------------------------------------------------------------------------------ keygen (vk) and the prover
+def keygen_vk(pr: Protocol, pre, tau: int) -> bytes:
+    """commit_lagrange of every fixed / sigma column, serialised like the reference's .vkey files"""
+    dom = _Domain(pr)
+    n_sigma = sum(len(c["columns"]) for c in pr.perm)
+    out = pr.k.to_bytes(4, "big") + (pr.num_pre - n_sigma).to_bytes(4, "big")
+    for col in pre:
+        out += pyref.g1_compress(g1_of_scalar(eval_poly(dom.to_coeff(col), tau)))
+    return out
+
+
+def prove(inp: ProofInputs, vk_bytes: bytes) -> bytes:
+    pr = inp.pr
+    n, w, u, tau = pr.n, pr.omega, pr.usable, inp.tau
+    dom = _Domain(pr)
+    T = Transcript()
+    T.common_scalar(vk_transcript_repr(vk_bytes))
+    for v in inp.instances:
+        T.common_scalar(v)
+    lag = {}                                   # polynomial index -> Lagrange values (witness, instance, preprocessed)
+    coeff = {}
+    for i, c in enumerate(inp.pre):
+        lag[i] = c
+    inst_col = list(inp.instances) + [0] * (n - len(inp.instances))
+    lag[pr.inst0] = inst_col
+    commit_lagrange = lambda vals: g1_of_scalar(eval_poly(dom.to_coeff(vals), tau))
+    commit = lambda cf: g1_of_scalar(eval_poly(cf, tau))
+    # phase 0: advice
+    for j, col in enumerate(inp.advice):
+        lag[pr.phase0[0] + j] = col
+        T.write_point(commit_lagrange(col))
+    ch = [T.squeeze() for _ in range(pr.num_challenge[0])]                   # theta
+    for j, col in enumerate(inp.m):
+        lag[pr.phase0[1] + j] = col
+        T.write_point(commit_lagrange(col))
+    ch += [T.squeeze() for _ in range(pr.num_challenge[1])]                  # beta, gamma
+    theta, beta, gamma = ch[0], ch[1], ch[2]
+    wpow = [1] * n
+    for i in range(1, n):
+        wpow[i] = wpow[i - 1] * w % R
+    # permutation grand products, chunk after chunk; chunk c starts where chunk c - 1 ended (its value at the l_last row)
+    acc = 1
+    for c, chunk in enumerate(pr.perm):
+        z = [0] * n
+        for i in range(u + 1):
+            z[i] = acc
+            if i == u:
+                break
+            num = den = 1
+            for (col, sigma, dj) in chunk["columns"]:
+                v = lag[col][i]
+                num = num * (v + beta * dj % R * wpow[i] + gamma) % R
+                den = den * (v + beta * lag[sigma][i] + gamma) % R
+            acc = acc * num % R * inv(den) % R
+        z[u + 1:] = inp.z_blind[c]
+        lag[chunk["z"]] = z
+    assert acc == 1, "the copy constraints do not hold: the grand product does not return to 1"
+    # log-derivative sums
+    leaf = lambda i_row: dict(poly=lambda p, r: lag[p][(i_row + r) % n], challenge=lambda j: ch[j], identity=lambda: wpow[i_row], lagrange=lambda j: 1 if (j % n) == i_row else 0)
+    for l, lk in enumerate(pr.lookups):
+        phi = [0] * n
+        s = 0
+        for i in range(u + 1):
+            phi[i] = s
+            if i == u:
+                break
+            tb = (evaluate(lk["table"], **leaf(i)) + beta) % R
+            ib = (evaluate(lk["input"], **leaf(i)) + beta) % R
+            s = (s + inv(ib) - lag[lk["m"]][i] * inv(tb)) % R
+        assert s == 0, "the lookup does not hold: the running sum does not return to 0"
+        phi[u + 1:] = inp.phi_blind[l]
+        lag[lk["phi"]] = phi
+    for chunk in pr.perm:
+        T.write_point(commit_lagrange(lag[chunk["z"]]))
+    for lk in pr.lookups:
+        T.write_point(commit_lagrange(lag[lk["phi"]]))
+    rnd = pr.quotient_poly - 1
+    coeff[rnd] = list(inp.random_coeffs)
+    T.write_point(commit(coeff[rnd]))                                        # step 5: the random polynomial of the vanishing argument
+    ch += [T.squeeze() for _ in range(pr.num_challenge[2])]                  # y
+    # coefficient forms, extended-coset evaluations
+    for i in range(pr.quotient_poly - 1):
+        coeff[i] = dom.to_coeff(lag[i])
+    ext = {i: dom.to_extended(coeff[i]) for i in range(pr.quotient_poly - 1)}
+    step = dom.ne // n
+    pts = np.empty(dom.ne, dtype=object)
+    p = dom.zeta
+    for i in range(dom.ne):
+        pts[i] = p
+        p = p * dom.we % R
+    xn_minus_1 = np.array([(pow(int(x), n, R) - 1) % R for x in pts], dtype=object)
+    lag_cache = {}
+
+    def lagrange_ext(i):
+        if i not in lag_cache:
+            wi = pow(w, i % n, R)
+            lag_cache[i] = np.array([wi * int(xn_minus_1[t]) % R * inv(n * (int(pts[t]) - wi)) % R for t in range(dom.ne)], dtype=object)
+        return lag_cache[i]
+    num = evaluate(pr.numerator, poly=lambda p_, r: np.roll(ext[p_], -r * step), challenge=lambda j: ch[j], identity=lambda: pts, lagrange=lagrange_ext)
+    h_ext = [int(num[t]) * inv(int(xn_minus_1[t])) % R for t in range(dom.ne)]
+    h = dom.from_extended(h_ext)
+    assert all(v == 0 for v in h[pr.Q * n:]), "the quotient does not fit Q pieces: the constraints do not vanish on the domain"
+    pieces = [h[q * n:(q + 1) * n] for q in range(pr.Q)]
+    for pc in pieces:
+        T.write_point(commit(pc))
+    x = T.squeeze()
+    xn = pow(x, n, R)
+    rot_pt = lambda r: x * pow(w, r % n, R) % R
+    evals = {}
+    for (p_, r) in pr.evaluations:
+        evals[(p_, r)] = eval_poly(coeff[p_], rot_pt(r))
+        T.write_scalar(evals[(p_, r)])
+    # the vanishing argument opens ONE combined quotient polynomial  h_0 + x^n h_1 + ... ; the verifier derives its value at x
+    hq = [0] * n
+    f = 1
+    for pc in pieces:
+        hq = [(a + f * b) % R for a, b in zip(hq, pc)]
+        f = f * xn % R
+    coeff[pr.quotient_poly] = hq
+    evals[(pr.quotient_poly, 0)] = eval_poly(hq, x)
+    # SHPLONK
+    ys, v = T.squeeze(), T.squeeze()
+    sets = rotation_sets(pr.queries)
+    H = [0] * n
+    for s in sets:
+        points = [rot_pt(r) for r in s["rots"]]
+        N = [0] * n
+        for p_ in s["polys"]:
+            rcoef = interpolate(points, [evals[(p_, r)] for r in s["rots"]])
+            npoly = list(coeff[p_])
+            for t, c_ in enumerate(rcoef):
+                npoly[t] = (npoly[t] - c_) % R
+            N = [(a * ys + b) % R for a, b in zip(N, npoly)]                # fold(acc * y + poly)
+        for pt in points:
+            N = kate_division(N, pt)
+        N = N + [0] * (n - len(N))
+        H = [(a * v + b) % R for a, b in zip(H, N)]                          # fold(acc * v + quotient)
+    T.write_point(commit(H))
+    uu = T.squeeze()
+    super_pts = []
+    for s in sets:
+        for r in s["rots"]:
+            if rot_pt(r) not in super_pts:
+                super_pts.append(rot_pt(r))
+    zt = 1
+    for pt in super_pts:
+        zt = zt * (uu - pt) % R
+    L = [0] * n
+    zd0 = None
+    for s in sets:
+        points = [rot_pt(r) for r in s["rots"]]
+        zd = 1
+        for pt in super_pts:
+            if pt not in points:
+                zd = zd * (uu - pt) % R
+        if zd0 is None:
+            zd0 = zd
+        inner = [0] * n
+        for p_ in s["polys"]:
+            r_u = horner(interpolate(points, [evals[(p_, r)] for r in s["rots"]]), uu)
+            lp = list(coeff[p_])
+            lp[0] = (lp[0] - r_u) % R
+            inner = [(a * ys + b) % R for a, b in zip(inner, lp)]
+        L = [(a * v + zd * b) % R for a, b in zip(L, inner)]
+    L = [(a - zt * b) % R for a, b in zip(L, H)]
+    assert horner(L, uu) == 0
+    zi = inv(zd0)
+    L = [a * zi % R for a in L]
+    Wp = kate_division(L, uu)
+    T.write_point(commit(Wp + [0] * (n - len(Wp))))
+    return bytes(T.out)
+
+
+# ------------------------------------------------------------------------------------------------ the verifier
+def verify(pr: Protocol, vk_bytes: bytes, instances, proof: bytes, tau: int) -> dict:
+    """returns {"ok": bool, ...}; every failed check is named"""
+    n, w = pr.n, pr.omega
+    res = {"ok": False}
+    assert int.from_bytes(vk_bytes[:4], "big") == pr.k and len(vk_bytes) == 8 + 32 * pr.num_pre
+    pre_c = [pyref.g1_decompress(vk_bytes[8 + 32 * i:8 + 32 * i + 32]) for i in range(pr.num_pre)]
+    T = Transcript(proof)
+    T.common_scalar(vk_transcript_repr(vk_bytes))
+    for v_ in instances:
+        T.common_scalar(v_)
+    com = {i: c for i, c in enumerate(pre_c)}
+    ch = []
+    idx = pr.wit0
+    for ph in range(len(pr.num_witness)):
+        for _ in range(pr.num_witness[ph]):
+            com[idx] = T.read_point(); idx += 1
+        ch += [T.squeeze() for _ in range(pr.num_challenge[ph])]
+    pieces = [T.read_point() for _ in range(pr.Q)]
+    x = T.squeeze()
+    xn = pow(x, n, R)
+    evals = {}
+    for (p_, r) in pr.evaluations:
+        evals[(p_, r)] = T.read_scalar()
+    ys, v = T.squeeze(), T.squeeze()
+    c_h = T.read_point()
+    uu = T.squeeze()
+    c_w = T.read_point()
+    if T.pos != len(proof):
+        res["error"] = f"proof has {len(proof)} bytes, the protocol reads {T.pos}"
+        return res
+    res["proof_words"] = {"commitments": sum(pr.num_witness) + pr.Q, "evaluations": len(pr.evaluations), "multiopen": 2}
+    # instance polynomials are not committed: the verifier evaluates them from the public values
+    for j in range(len(pr.num_instance)):
+        evals[(pr.inst0 + j, 0)] = sum(int(v_) * lagrange_at(pr, i, x) for i, v_ in enumerate(instances)) % R
+    rot_pt = lambda r: x * pow(w, r % n, R) % R
+    numer = evaluate(pr.numerator, poly=lambda p_, r: evals[(p_, r)], challenge=lambda j: ch[j], identity=lambda: x, lagrange=lambda i: lagrange_at(pr, i, x))
+    evals[(pr.quotient_poly, 0)] = numer * inv(xn - 1) % R                 # the value the combined quotient polynomial MUST take at x
+    res["numerator_at_x"] = numer
+    hc = None
+    f = 1
+    for pc in pieces:
+        hc = g1_add(hc, g1_mul(pc, f)); f = f * xn % R
+    com[pr.quotient_poly] = hc
+    # SHPLONK verification:  E = sum_i v^(m-1-i) (zd_i / zd_0) sum_j y^(..) (C_ij - r_ij(u) G) - (Z_T(u) / zd_0) C_H;  check  E + u C_W == tau C_W
+    sets = rotation_sets(pr.queries)
+    super_pts = []
+    for s in sets:
+        for r in s["rots"]:
+            if rot_pt(r) not in super_pts:
+                super_pts.append(rot_pt(r))
+    zt = 1
+    for pt in super_pts:
+        zt = zt * (uu - pt) % R
+    E = None
+    r_acc = 0
+    zd0 = None
+    for s in sets:
+        points = [rot_pt(r) for r in s["rots"]]
+        zd = 1
+        for pt in super_pts:
+            if pt not in points:
+                zd = zd * (uu - pt) % R
+        if zd0 is None:
+            zd0 = zd
+        inner_c, inner_r = None, 0
+        for p_ in s["polys"]:
+            r_u = horner(interpolate(points, [evals[(p_, r)] for r in s["rots"]]), uu)
+            inner_c = g1_add(g1_mul(inner_c, ys), com[p_])
+            inner_r = (inner_r * ys + r_u) % R
+        E = g1_add(g1_mul(E, v), g1_mul(inner_c, zd))
+        r_acc = (r_acc * v + zd * inner_r) % R
+    zi = inv(zd0)
+    E = g1_add(g1_mul(E, zi), g1_of_scalar((-r_acc * zi) % R))
+    E = g1_add(E, g1_mul(c_h, (-zt * zi) % R))
+    lhs = g1_add(E, g1_mul(c_w, uu))
+    rhs = g1_mul(c_w, tau)
+    res["pairing_with_trapdoor"] = lhs == rhs
+    res["ok"] = lhs == rhs
+    res["challenges"] = {"theta": ch[0], "beta": ch[1], "gamma": ch[2], "y": ch[3], "x": x}
+    return res

@@ -15,6 +15,13 @@ Sources:
   [REF integration/tests/test_data/full_proof_batch_agg_1.json]  batch proof (1312 B), vk, protocol (k=26)
   [REF release-v0.13.1/evm_verifier.yul:17-18,1230-1239]    moduli, g2, s_g2 words
   [REF release-v0.13.1/proof.data, pi.data]                 bundle EVM proof words
+
+Also writes tests/golden/protocol_layer2.json / protocol_layer4.json: the COMPLETE snark-verifier PlonkProtocol of the chunk proof
+(layer 2, k = 25: [REF release-v0.13.1/chunk.protocol] == [REF integration/tests/test_data/chunk_chunk_0.protocol] == the base64
+`protocol` of full_proof_1.json) and of the batch proof (layer 4, k = 26: the base64 `protocol` of
+[REF integration/tests/test_data/full_proof_batch_agg_1.json]) -- quotient.numerator (the constraint system as an expression tree),
+queries, evaluations, num_witness, num_challenge, domain -- re-serialised compactly, nothing added or changed, plus the six
+layer configs [REF integration/configs/layer{1..6}.config] as tests/golden/layer_configs.json.
 """
 import base64, json, os, re, sys
 
@@ -52,6 +59,16 @@ out["yul"] = {"f_p": re.search(r"0x[0-9a-f]+", yul[16]).group(0), "f_q": re.sear
               "s_g2_words": [re.search(r", (0x[0-9a-f]+)\)", yul[i]).group(1) for i in range(1235, 1239)]}
 out["bundle_proof_data"] = rd("release-v0.13.1/proof.data").hex()
 out["bundle_pi_data"] = rd("release-v0.13.1/pi.data").hex()
+l2 = json.loads(rd("release-v0.13.1/chunk.protocol", "r"))
+assert l2 == json.loads(rd("integration/tests/test_data/chunk_chunk_0.protocol", "r")) == json.loads(base64.b64decode(cp["protocol"]))
+l4 = json.loads(base64.b64decode(bp["protocol"]))
+assert l4 == json.loads(base64.b64decode(json.loads(rd("integration/tests/test_data/full_proof_batch_agg_2.json", "r"))["protocol"]))
+for name, pr in (("protocol_layer2.json", l2), ("protocol_layer4.json", l4)):
+    with open(os.path.join(HERE, name), "w") as f:
+        json.dump(pr, f, separators=(",", ":"))
+    print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+with open(os.path.join(HERE, "layer_configs.json"), "w") as f:
+    json.dump({str(i): json.loads(rd(f"integration/configs/layer{i}.config", "r")) for i in range(1, 7)}, f, indent=1)
 with open(os.path.join(HERE, "kat.json"), "w") as f:
     json.dump(out, f, indent=1)
 print("wrote", os.path.join(HERE, "kat.json"), os.path.getsize(os.path.join(HERE, "kat.json")), "bytes")
