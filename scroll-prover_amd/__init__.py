@@ -14,3 +14,5 @@ from . import _capi  # noqa: F401
 from ._capi import Mi355Error, lib, init, shutdown  # noqa: F401
 from . import halo2  # noqa: F401
 from . import distributed  # noqa: F401
+from . import protocols  # noqa: F401
+from . import replay  # noqa: F401
