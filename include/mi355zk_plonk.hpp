@@ -188,11 +188,23 @@ inline std::set<uint32_t> lagrange_needed(const Protocol &P) {
   for (const auto &l : P.lookups) { std::vector<std::pair<int32_t, int32_t>> r; collect_polys(*l.table, r); collect_polys(*l.input, r); for (const auto &x : r) if (P.is_pre((uint32_t)x.first)) s.insert((uint32_t)x.first); }
   return s;
 }
-struct PkSizes { uint32_t polys, lagrange; double base_bytes, coset_bytes, lean_tmp_bytes; };
-inline PkSizes pk_sizes(const Protocol &P, uint32_t n_commons = 4) {
+// HBM a layer's prover needs, from the protocol alone: a dry compile gives the plan's temporaries and the common polynomials
+struct PkSizes { uint32_t polys, lagrange, commons, plan_tmps; double base_bytes, coset_bytes, lean_tmp_bytes, working_bytes; };
+inline PkSizes pk_sizes(const Protocol &P) {
   const double per = (double)P.n * 32; PkSizes s;
-  s.polys = P.num_pre + n_commons; s.lagrange = (uint32_t)lagrange_needed(P).size() + 1;
+  CommonRegistry reg; { Expr id; id.kind = Expr::IDENTITY; reg.id_of(id, true); }
+  Compiler cmp(reg, true, std::vector<Fr>(4, fr_one())); cmp.compile_numerator(P.numerator);
+  s.commons = (uint32_t)reg.defs.size(); s.plan_tmps = cmp.tmp_max;
+  s.polys = P.num_pre + s.commons; s.lagrange = (uint32_t)lagrange_needed(P).size() + 1;
   s.base_bytes = per * (s.polys + s.lagrange); s.coset_bytes = per * s.polys * P.Q; s.lean_tmp_bytes = per * s.polys;
+  uint32_t NW = 1; for (auto w : P.num_witness) NW += w;                     // instance + witness polynomials
+  uint32_t max_chunk = 0; for (const auto &c : P.perm) max_chunk = std::max<uint32_t>(max_chunk, (uint32_t)c.columns.size());
+  // the peak is step 7: every polynomial's coefficients + one coset part of each (the random polynomial has none), the plan's temporaries, h as Q parts and as one
+  // vector; step 4 (Lagrange values + 2 + 2 chunk temporaries) and step 10 (one combination per rotation set + H, L, work, the combined quotient) stay below it when
+  // the early coefficient copies of a many-column layer are counted (one more copy of every advice column).  Plus the scratch of the 2^(k + e) inverse transform,
+  // the MSM workspace (~22 B per entry, up to 13 windows) and fixed overheads.
+  const double step7 = per * (2.0 * NW - 1 + s.plan_tmps + 2.0 * P.Q), step4 = per * (NW + (P.num_advice() >= 8 ? P.num_advice() : 0) + 3.0 + 2.0 * max_chunk), step10 = per * (NW + P.Q + 10.0);
+  s.working_bytes = std::max(step7, std::max(step4, step10)) + per * P.Q + (double)P.n * 13 * 22 + 0.5 * 1024.0 * 1024 * 1024;
   return s;
 }
 
@@ -253,7 +265,7 @@ inline std::unique_ptr<ProvingKey> keygen(const Protocol &P, const Circuit &C, u
   }
   for (size_t i = 0; i < pk->common_lagrange.size(); i++) if (i != pk->identity_common) pk->common_lagrange[i].release();   // step 4 reads X only
   check(mi355_synchronize());
-  const PkSizes sz = pk_sizes(P, (uint32_t)pk->commons.defs.size());
+  const PkSizes sz = pk_sizes(P);
   pk->bytes = (uint64_t)(sz.base_bytes + (resident_cosets ? sz.coset_bytes : 0));
   return pk;
 }

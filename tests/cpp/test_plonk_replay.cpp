@@ -25,7 +25,7 @@ static void write_file(const std::string &path, const void *p, size_t bytes) { s
 int main(int argc, char **argv) {
   std::string protocol_path, out_dir, tables = "auto", pk_mode = "auto";
   int devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2, upload_threads = 1, early_intt = -1;
-  bool host_api = false, builder_only = false, dump_inputs = false, pinned_witness = false; uint64_t seed = 1; double fill = 0.9;
+  bool host_api = false, builder_only = false, dump_inputs = false, pinned_witness = false, corrupt = false; uint64_t seed = 1; double fill = 0.9;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto next = [&]() -> long { return i + 1 < argc ? std::atol(argv[++i]) : 0; };
@@ -34,9 +34,19 @@ int main(int argc, char **argv) {
     else if (a == "--threads") threads = (int)next(); else if (a == "--host-api") host_api = true; else if (a == "--builder-only") builder_only = true; else if (a == "--dump-inputs") dump_inputs = true;
     else if (a == "--no-tables") tables = "off"; else if (a == "--tables") tables = nexts(); else if (a == "--pk-cosets") pk_mode = nexts(); else if (a == "--proofs") proofs = (int)next();
     else if (a == "--upload-threads") upload_threads = (int)next(); else if (a == "--early-intt") early_intt = (int)next(); else if (a == "--pinned-witness") pinned_witness = true;
-    else if (a == "--seed") seed = (uint64_t)next(); else if (a == "--fill") fill = std::atof(nexts().c_str());
+    else if (a == "--seed") seed = (uint64_t)next(); else if (a == "--fill") fill = std::atof(nexts().c_str()); else if (a == "--corrupt-witness") corrupt = true;
+    else if (a == "--transcript-selftest") {   // host only: a fixed byte stream through the Blake2b transcript (tests compare with hashlib)
+      Transcript T; T.common_scalar(fr_u64(5)); const Fr c1 = fr_to_canonical(T.squeeze_challenge());
+      G1 g{}; { const Fr one = fr_one(); (void)one; mi355zk::halo2::G1Affine gen{}; zk::fe_t x = zk::Fq::one(), y = zk::Fq::add(zk::Fq::one(), zk::Fq::one()); std::memcpy(gen.data(), &x, 32); std::memcpy(gen.data() + 4, &y, 32); std::memcpy(g.data(), gen.data(), 64); std::memcpy(g.data() + 8, &x, 32); }
+      T.write_point(g); T.write_scalar(fr_u64(0xDEADBEEFull)); const Fr c2 = fr_to_canonical(T.squeeze_challenge());
+      std::vector<uint8_t> vkb(40, 7); const Fr c3 = fr_to_canonical(vk_transcript_repr(vkb));
+      auto hex = [](const Fr &c) { char b[65]; std::snprintf(b, sizeof b, "%016llx%016llx%016llx%016llx", (unsigned long long)c[3], (unsigned long long)c[2], (unsigned long long)c[1], (unsigned long long)c[0]); return std::string(b); };
+      std::string ph; for (uint8_t b : T.proof) { char t[3]; std::snprintf(t, sizeof t, "%02x", b); ph += t; }
+      std::printf("{\"c1\": \"%s\", \"c2\": \"%s\", \"vk_repr\": \"%s\", \"proof\": \"%s\"}\n", hex(c1).c_str(), hex(c2).c_str(), hex(c3).c_str(), ph.c_str());
+      return 0;
+    }
     else { std::printf("usage: %s --protocol FILE --out DIR [--builder-only] [--dump-inputs] [--devices D] [--threads T] [--proofs N] [--upload-threads U] [--early-intt 0|1] [--pinned-witness]\n"
-                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F]\n", argv[0]); return 1; }
+                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] | --transcript-selftest\n", argv[0]); return 1; }
   }
   if (protocol_path.empty() || out_dir.empty()) { std::printf("--protocol and --out are required\n"); return 1; }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;
@@ -75,13 +85,10 @@ int main(int argc, char **argv) {
     check(mi355_buf_trim());
     // ---- HBM plan: what must live in HBM for this layer's prover, and which optional residents fit on top
     uint64_t hbm_free = 0, hbm_total = 0; check(mi355_mem_info(0, &hbm_free, &hbm_total, nullptr, nullptr, nullptr));
-    const double per = (double)n * 32, GiB = 1024.0 * 1024 * 1024;
+    const double GiB = 1024.0 * 1024 * 1024;
     const PkSizes sz = pk_sizes(P);
     uint32_t NW = 1; for (auto w : P.num_witness) NW += w;   // instance + witness polynomials
-    uint32_t max_chunk = 0; for (const auto &c : P.perm) max_chunk = std::max<uint32_t>(max_chunk, (uint32_t)c.columns.size());
-    // a proof's own blocks: coefficients + one part of every witness polynomial, the plan's temporaries, h as parts and as one vector, SHPLONK's combinations (one per
-    // rotation set + H, L, work); the NTT scratch of the 2^(k + e) inverse; the MSM workspace (~22 B per entry, up to 13 windows); fixed overheads
-    const double working = per * (2.0 * NW + 2 * max_chunk + 4 + 2 * Q + 8) + per * Q + per + (double)n * 13 * 22 + 0.5 * GiB;
+    const double working = sz.working_bytes;                  // a proof's own blocks at their peak (mi355zk_plonk.hpp pk_sizes)
     const double table_one = (double)n * 64 * (k >= 24 ? 12 : 15);
     const double usable = 0.94 * (double)hbm_free;
     bool resident = true; int n_tables = 0;
@@ -92,6 +99,7 @@ int main(int argc, char **argv) {
     CircuitOptions co; co.seed = seed; co.threads = threads; co.pinned = pinned_witness; co.fill = fill;
     auto C = build_circuit(P, co);
     const double build_ms = ms_since(t_build);
+    if (corrupt) C->advice[0][3] = fr_add(C->advice[0][3], fr_one());   // one cell off: the first gate no longer holds, the verifier must reject what comes out
     if (dump_inputs) dump_circuit(*C, out_dir, tau, protocol_path);
     const auto t_keygen = Clock::now();
     auto pk = keygen(P, *C, hl, resident, devices);
