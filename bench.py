@@ -74,22 +74,32 @@ def witness_like_scalars(n: int, seed: int, device, h2) -> torch.Tensor:
     return a.contiguous()
 
 
-def replay_create_proof(layer: int, k: int | None = None, host_api: bool = True, timeout: int = 900, devices: int = 1):
-    """tests/cpp/test_create_proof_replay: SURVEY 3.2 steps 1-10 for one layer's counts, a COMPILED caller of the C-ABI with the proof's
-    polynomials resident in HBM (mi355_buf_*), witness uploads overlapped, every commitment and evaluation checked afterwards.  Run as its own
-    process BEFORE this process binds the GPU (each needs the window tables of both bases: 96 GiB at k = 26).  Returns the program's JSON record."""
-    import subprocess
-    exe = ge.build_cpp("test_create_proof_replay")
-    cmd = [exe, "--layer", str(layer)] + (["--k", str(k)] if k else []) + (["--host-api"] if host_api else []) + (["--devices", str(devices)] if devices > 1 else [])
+def replay_create_proof(layer: int, k: int | None = None, host_api: bool = False, timeout: int = 1500, devices: int = 1, **shape):
+    """One layer of scroll-prover's proof stack, proven on the device from the layer's PlonkProtocol by the compiled caller tests/cpp/test_plonk_replay.cpp
+    (mi355zk::plonk::create_proof, include/mi355zk_plonk.hpp; its own process, run BEFORE this process binds the GPU), then VERIFIED here from the bytes it
+    wrote: oracle/plonk.py (checker only) re-derives every challenge, walks the protocol's JSON expression tree for h(x) (x^n - 1) == numerator(x) and checks
+    the SHPLONK opening with the synthetic SRS's trapdoor.  Layers 2 and 4 run the reference's OWN protocol files (tests/golden/protocol_layer{2,4}.json =
+    [REF release-v0.13.1/chunk.protocol], the `protocol` of [REF integration/tests/test_data/full_proof_batch_agg_1.json])."""
+    zk = ge.load_package()
+    fx = os.path.join(ROOT, "tests", "golden", f"protocol_layer{layer}.json")
+    args = (["--host-api"] if host_api else []) + (["--devices", str(devices)] if devices > 1 else [])
+    rec = zk.replay.run(layer, k, args=args, timeout=timeout, protocol_file=fx if (os.path.exists(fx) and not k and not shape) else None, **shape)
+    if not rec.get("ok"):
+        return {"layer": layer, "ok": False, "error": rec.get("error")}
+    from oracle import plonk
     t0 = time.perf_counter()
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
-    wall = time.perf_counter() - t0
-    line = next((l for l in out.stdout.splitlines() if l.startswith("{")), None)
-    if out.returncode != 0 or line is None:
-        return {"layer": layer, "ok": False, "error": (out.stdout + out.stderr)[-400:]}
-    rec = json.loads(line)
-    rec["process_wall_s"] = wall
-    return rec
+    pr = plonk.Protocol(json.load(open(rec["protocol_path"])))
+    inst = plonk.mont_to_ints(np.frombuffer(rec["instances"], dtype=np.uint64).reshape(-1, 4))
+    try:
+        ver = plonk.verify(pr, rec["vk"], inst, rec["proof"], 0x5343524F4C4C0001 + (rec["layer"] if rec["layer"] >= 0 else 0))
+    except AssertionError as e:
+        ver = {"ok": False, "error": str(e)}
+    out = {k_: v for k_, v in rec.items() if k_ not in ("proof", "vk", "instances", "out_dir", "protocol_path", "returncode")}
+    out.update({"layer": layer, "verified": bool(ver["ok"]), "verify_s": round(time.perf_counter() - t0, 2), "ok": bool(ver["ok"]),
+                "protocol_source": "reference fixture" if rec["protocol_path"].startswith(os.path.join(ROOT, "tests", "golden")) else pr.d.get("source")})
+    import shutil
+    shutil.rmtree(rec["out_dir"], ignore_errors=True)
+    return out
 
 
 def main() -> None:
@@ -105,7 +115,7 @@ def main() -> None:
     ap.add_argument("--no-batch-legs", action="store_true", help="skip the many-column legs (110 x 2^21, 256 x 2^20 through mi355_msm_g1_batch_dev)")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-precompute", action="store_true", help="skip the registration-time window tables (mi355_srs_precompute)")
-    ap.add_argument("--no-proof-mix", action="store_true", help="skip the compiled create_proof replays (layer 4, and layers 1 + 2 as the chunk-proof proxy; resident and through the host API)")
+    ap.add_argument("--no-proof-mix", action="store_true", help="skip the compiled create_proof replays (all seven layers from their PlonkProtocols, each proof verified from its bytes)")
     ap.add_argument("--proxy-chunk-proof", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--single-process", action="store_true", help="N GPUs behind ONE process (mi355_init_multi: shards, worker threads, ncclAllGather inside the library) instead of one rank per GPU")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer leg (mi355_msm_g1_host: scalars cross PCIe inside the call; reported next to, never as, the headline value)")
@@ -156,18 +166,15 @@ def main() -> None:
         else:
             dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" == RCCL on ROCm
 
-    # ---- "chunk-proof wall-clock" (third part of the BASELINE metric): not producible here (no Rust / Go / SRS / trace), so the stated stand-in is
-    # the compiled replay of create_proof's GPU-side step order per layer: layer 4 (k = 26, the batch proof: 14 MSM, 8 iNTT,
-    # 32 coset NTT, 2^28 inverse, scans, 27 evaluations, multi-open) and the two compression layers a CHUNK proof runs, layer 1 (k = 24) +
-    # layer 2 (k = 25: 11 MSM, [1,1,3] witness polynomials, Q = 4, 17 evaluations).  Each replay is its own
-    # process and runs before this one binds the GPU; resident = polynomials stay in HBM between calls, host_api = every operand crosses PCIe.
+    # ---- "chunk-proof wall-clock" (third part of the BASELINE metric): not producible here (no Rust / Go / SRS / trace).  The stand-in: every layer of the proof
+    # stack [REF integration/src/prove.rs:36-43,67,95-97] (chunk proof = layers 0 + 1 + 2, batch proof = 3 + 4, bundle = 5 + 6) is PROVEN on the device from the
+    # layer's PlonkProtocol -- layers 2 and 4 from the reference's own protocol files: 11 / 14 commitments, 5 / 8 inverse transforms, 20 / 32 coset transforms,
+    # 17 / 27 evaluations, 896 / 1 312 proof bytes -- by mi355zk::plonk::create_proof (include/mi355zk_plonk.hpp), and each proof is VERIFIED from its bytes.
+    # Each replay is its own process and runs before this one binds the GPU; two proofs per process, the second (steady-state) one is reported;
+    # resident = polynomials stay in HBM between the C-ABI calls, host_api = every operand crosses PCIe.
     proof_mix = None
     if world == 1 and not single and rank == 0 and not args.no_proof_mix and args.logn == 26:
-        # all seven layers of the proof stack [REF integration/src/prove.rs:36-43,67,95-97]: chunk proof = layers 0 + 1 + 2, batch proof = 3 + 4, bundle = 5 + 6.
-        # Each replay is create_proof_gpu_side (include/mi355zk_create_proof.hpp) with that layer's column counts, the proving key's cosets resident
-        # (or recomputed per part when they do not fit next to the window tables: the replay's HBM plan decides and reports), two proofs per process
-        # (the second, steady-state one is reported), every result checked -- commitments, evaluations, the quotient identity at x, the openings.
-        host_layers = () if args.no_host_api else (0, 1, 2, 3, 4, 5, 6)   # the host-pointer route (every operand crosses PCIe both ways) next to the resident one, for every layer
+        host_layers = () if args.no_host_api else (0, 2, 4)   # the host-pointer route (every operand crosses PCIe both ways) next to the resident one: the reference's two protocols and the many-column layer
         L = {}
         for lay in (4, 6, 2, 1, 3, 5, 0):
             L[lay] = replay_create_proof(lay, host_api=lay in host_layers)
@@ -185,14 +192,14 @@ def main() -> None:
                     "first_proof_ms": sum(r.get("first_proof_ms", 0) for r in rs) if good else None,
                     "host_api_ms": sum(host) if good and all(h is not None and h > 0 for h in host) else None,
                     "commitments": sum(r.get("msm", 0) for r in rs), "peak_hbm_gib": {f"layer{x}": (L[x].get("hbm") or {}).get("peak_used_gib") for x in layers},
-                    "semantic_and_trapdoor_checks": all(r.get("semantic_check") and r.get("trapdoor_check") for r in rs),
+                    "every_proof_verified": all(r.get("verified") for r in rs),
                     **{f"layer{x}": L[x] for x in layers}}
         proof_mix = {"c_abi_resident_ms": l4.get("resident_ms"), "host_api_ms": l4.get("host_api_ms"), "host_api_batched_fft_ms": hb, "layer4": l4,
-                     "chunk_proof_proxy": proxy("layer 0 (k = 20 inner circuit; column counts are a stated guess: 800 advice, 60 lookups, 150 permutation columns, degree 9) + layer 1 (k = 24) + layer 2 (k = 25): GPU side of the three create_proof calls of gen_halo2_chunk_proof", (0, 1, 2)),
-                     "batch_proof_proxy": proxy("layer 3 (k = 21, 93 advice, 8 lookups) + layer 4 (k = 26): gen_batch_proof", (3, 4)),
-                     "bundle_proof_proxy": proxy("layer 5 (k = 21) + layer 6 (k = 26): gen_bundle_proof", (5, 6)),
-                     "all_commitments_and_evaluations_checked": ok_all,
-                     "excludes": "witness synthesis of the real circuits, transcript hashing (CPU side of create_proof); the circuits are synthetic ones with each layer's counts and halo2's operand shapes (custom gates on rotated columns, permutation products, log-derivative lookups) whose witness satisfies them"}
+                     "chunk_proof_proxy": proxy("layer 0 (k = 20 inner circuit: a stated-shape stand-in, 800 advice / 60 lookups / 150 permuted columns / degree 9) + layer 1 (k = 24, halo2-base rule on layer1.config) + layer 2 (k = 25, the reference's chunk.protocol): the three create_proof calls of gen_halo2_chunk_proof", (0, 1, 2)),
+                     "batch_proof_proxy": proxy("layer 3 (k = 21, halo2-base rule on layer3.config: 93 advice, 8 lookups, 32 grand products) + layer 4 (k = 26, the reference's batch protocol): gen_batch_proof", (3, 4)),
+                     "bundle_proof_proxy": proxy("layer 5 (k = 21) + layer 6 (k = 26, layer 2's constraint system at the bundle's degree): gen_bundle_proof", (5, 6)),
+                     "every_proof_verified": ok_all,
+                     "excludes": "witness synthesis of the real circuits (the circuit instances are built to satisfy each protocol), the Poseidon / Keccak transcripts (halo2's Blake2b transcript stands in)"}
     if single and args.gpus > 1 and not args.no_proof_mix and args.logn == 26:
         # N devices behind ONE prover process: witness columns live round-robin on the devices, commitments take scalars from whichever device
         # holds them (shards of the basis everywhere), the iNTT batch and the coset parts of the quotient run concurrently on different devices
@@ -602,6 +609,19 @@ def main() -> None:
             check(lib.mi355_msm_last_run(C.byref(dv), C.byref(ex), C.byref(shd), C.byref(sl)))
             line["multi_gpu"] = {"devices": dv.value, "exchange": (ex.value or b"").decode(), "mode": "one process, mi355_init_multi"}
         line.update(extra)
+        # the other two legs of BASELINE.json's metric where the driver's record keeps them: the NTT at 2^k and the three proof proxies,
+        # plus one flag that every check of this run passed (MSM field check, NTT round trip / CPU equality, every proof verified from its bytes)
+        cfg = line["config"]
+        checks = [verified is not False]
+        if ntt is not None:
+            cfg["ntt_k%d_ms" % k] = round(ntt["ms_per_transform"], 3); cfg["ntt_k%d_butterflies_per_s" % k] = ntt["butterflies_per_s"]; cfg["ntt_roofline_frac_hbm"] = round(ntt["roofline"]["frac"], 4)
+            checks += [ntt["roundtrip_ok"], ntt.get("full_vector_equals_cpu_baseline", True)]
+        if proof_mix is not None and "chunk_proof_proxy" in proof_mix:
+            cfg["proxies_ms"] = [proof_mix[x]["resident_ms"] for x in ("chunk_proof_proxy", "batch_proof_proxy", "bundle_proof_proxy")]
+            cfg["proxies"] = "create_proof per layer from its PlonkProtocol (layers 2 / 4: the reference's own), proof verified from its bytes: [chunk = L0 + L1 + L2, batch = L3 + L4, bundle = L5 + L6]"
+            cfg["layer_ms"] = {str(x): (proof_mix[p_][f"layer{x}"].get("resident_ms")) for p_, xs in (("chunk_proof_proxy", (0, 1, 2)), ("batch_proof_proxy", (3, 4)), ("bundle_proof_proxy", (5, 6))) for x in xs}
+            checks.append(bool(proof_mix["every_proof_verified"]))
+        cfg["all_checks"] = all(bool(c) for c in checks)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

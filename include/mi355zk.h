@@ -215,7 +215,7 @@ int mi355_fr_vec_mul_periodic_dev(void *data_dev, uint64_t n, const void *table_
  * in ONE launch instead of a chain of mi355_fr_vec_op_dev calls (each a full HBM round trip).  Term j owns term_len[j] consecutive entries
  * of factor_poly / factor_rot (host arrays); coeffs: n_terms x 32 B Montgomery (host); rotations in ELEMENTS, already scaled by the caller,
  * negative values allowed; n a power of two (the extended domain, or one 2^k coset part).  Limits per launch: 24 polynomials, 16 terms,
- * 8 factors per term, 48 factors in all (larger expressions are split, accumulate = 1 adds to dst).  dst may alias a polynomial only
+ * 16 factors per term, 48 factors in all (larger expressions are split, accumulate = 1 adds to dst).  dst may alias a polynomial only
  * when every rotation of that polynomial is zero.  Terms with c_j = 1 or c_j = -1 cost no multiplication for the coefficient (2^26, 9 terms /
  * 20 factors: 8.7 ms against 12.2 ms with general coefficients).                                                                                   */
 int mi355_fr_gate_eval_dev(void *dst_dev, const void *const *polys_dev, uint32_t n_polys, const void *coeffs_fr_host, const uint32_t *term_len,

@@ -21,6 +21,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "mi355zk.h"
@@ -145,6 +146,28 @@ struct DevicePoly {
   void *at(uint64_t i) const { return static_cast<char *>(p) + i * 32; }
   Fr eval(const Fr &point) const { Fr out; check(mi355_eval_polynomial_dev(p, n, point.data(), out.data())); return out; }
 };
+
+
+// A host column whose storage is either ordinary memory or page-locked memory of the library (mi355_host_alloc): the choice is the caller's, per column
+// vector, at run time.  A first copy out of pageable memory crosses PCIe at ~34 GB/s, out of page-locked memory at ~56 GB/s; for the many-column
+// layers that is the difference between create_proof's steps 2-3 being bound by the link or by their commitments.
+template <class T> struct ColumnAllocator {
+  using value_type = T; bool pinned = false;
+  using propagate_on_container_move_assignment = std::true_type;   // `column = Column(alloc)` must carry the page-locked choice with it
+  using propagate_on_container_copy_assignment = std::true_type;
+  using propagate_on_container_swap = std::true_type;
+  ColumnAllocator() = default; explicit ColumnAllocator(bool p) : pinned(p) {}
+  template <class U> ColumnAllocator(const ColumnAllocator<U> &o) : pinned(o.pinned) {}
+  T *allocate(size_t n) {
+    if (!pinned) return static_cast<T *>(::operator new(n * sizeof(T)));
+    void *p = nullptr; check(mi355_host_alloc(n * sizeof(T), &p)); return static_cast<T *>(p);
+  }
+  // a block that outlives mi355_shutdown cannot be returned to the library any more: the error is dropped, the pages go back with the process
+  void deallocate(T *p, size_t) noexcept { if (pinned) (void)mi355_host_free(p); else ::operator delete(p); }
+  template <class U> bool operator==(const ColumnAllocator<U> &o) const { return pinned == o.pinned; }
+  template <class U> bool operator!=(const ColumnAllocator<U> &o) const { return pinned != o.pinned; }
+};
+using Column = std::vector<Fr, ColumnAllocator<Fr>>;
 
 // ------------------------------------------------------------------------------------------------ poly/domain.rs
 class EvaluationDomain {
@@ -279,5 +302,4 @@ class ParamsKZG {
 }  // namespace halo2
 }  // namespace mi355zk
 
-// create_proof_gpu_side(...): steps 1-10 of plonk::create_proof over resident polynomials, with the proving key's cosets in HBM
-#include "mi355zk_create_proof.hpp"
+// plonk::create_proof for a PlonkProtocol over resident polynomials: include "mi355zk_plonk.hpp"

@@ -45,7 +45,7 @@ struct Atom { AtomKind kind; uint32_t idx; int32_t rot; bool operator<(const Ato
 struct Term { Fr coeff; std::vector<Atom> f; };
 using SoP = std::vector<Term>;
 struct Launch { int dst; bool accumulate; std::vector<Term> terms; };     // dst >= 0: TMP[dst]; dst == -1: the quotient accumulator of the part
-constexpr uint32_t PLAN_MAX_TERMS = 16, PLAN_MAX_FACTORS = 48, PLAN_MAX_POLYS = 24, PLAN_MAX_TERM_LEN = 8;   // per launch (mi355_fr_gate_eval_dev)
+constexpr uint32_t PLAN_MAX_TERMS = 16, PLAN_MAX_FACTORS = 48, PLAN_MAX_POLYS = 24, PLAN_MAX_TERM_LEN = 16;   // per launch (mi355_fr_gate_eval_dev)
 
 struct CommonRegistry {   // the fixed polynomials the numerator names through CommonPolynomial leaves, deduplicated by subtree
   std::vector<CommonLinear> defs; std::map<std::string, uint32_t> by_key;
@@ -81,7 +81,7 @@ struct Compiler {
     Launch cur{dst, accumulate_first, {}}; std::set<Atom> polys; uint32_t nf = 0; bool any = false;
     auto key = [](const Atom &a) { return Atom{a.kind, a.idx, 0}; };
     for (const auto &t : S) {
-      if (t.f.size() > PLAN_MAX_TERM_LEN) throw std::invalid_argument("plan compiler: a term exceeds 8 factors");
+      if (t.f.size() > PLAN_MAX_TERM_LEN) throw std::invalid_argument("plan compiler: a term exceeds 16 factors");
       std::set<Atom> np = polys; for (const auto &a : t.f) np.insert(key(a));
       if (cur.terms.size() + 1 > PLAN_MAX_TERMS || nf + t.f.size() > PLAN_MAX_FACTORS || np.size() > PLAN_MAX_POLYS) {
         out.push_back(cur); any = true; cur = Launch{dst, true, {}}; polys.clear(); nf = 0; np.clear(); for (const auto &a : t.f) np.insert(key(a));
@@ -136,16 +136,28 @@ struct Compiler {
   }
   // the whole numerator: constraint i of DistributePowers(constraints, y) carries y^(m - 1 - i); constraints that needed temporaries are flushed at once so that the
   // next one may reuse them
+  // Constraints that needed temporaries share an accumulate launch while their temporaries fit TMP_GROUP blocks: each constraint is compiled with ids from 0 and
+  // RELOCATED behind the ids of the constraints already waiting in the group; the group is flushed (its terms emitted) before ids are reused.
+  static constexpr uint32_t TMP_GROUP = 12;
   void compile_numerator(const Expr &num) {
     const size_t m = num.kids.size() - 1; const Fr y = scalar_of(compile(num.kids.back()));
     std::vector<Fr> ypow(m, fr_one()); for (size_t i = 1; i < m; i++) ypow[i] = fr_mul(ypow[i - 1], y);
-    SoP pending;
+    SoP pending; uint32_t group_tmps = 0;
+    auto relocate = [](std::vector<Term> &ts, uint32_t off) { for (auto &t : ts) for (auto &a : t.f) if (a.kind == A_TMP) a.idx += off; };
     for (size_t i = 0; i < m; i++) {
-      tmp_next = 0;
+      const size_t first_launch = out.size();
+      tmp_base = 0; tmp_next = 0;
       SoP s = scaled(compile(num.kids[i]), ypow[m - 1 - i]);
       constraints++; terms_total += (uint32_t)s.size();
+      const uint32_t used = tmp_next;
+      std::vector<Launch> mine(out.begin() + (long)first_launch, out.end()); out.resize(first_launch);   // this constraint's temporaries
+      if (used > 0 && group_tmps > 0 && group_tmps + used > TMP_GROUP) { emit(-1, pending, true); pending.clear(); group_tmps = 0; }
+      if (used > 0) {
+        if (group_tmps > 0) { for (auto &L : mine) { L.dst += (int)group_tmps; relocate(L.terms, group_tmps); } relocate(s, group_tmps); }
+        group_tmps += used; tmp_max = std::max(tmp_max, group_tmps);
+      }
+      out.insert(out.end(), mine.begin(), mine.end());
       pending.insert(pending.end(), s.begin(), s.end());
-      if (tmp_next > 0) { emit(-1, pending, true); pending.clear(); }
     }
     if (!pending.empty()) emit(-1, pending, true);
   }
@@ -206,6 +218,41 @@ inline PkSizes pk_sizes(const Protocol &P) {
   const double step7 = per * (2.0 * NW - 1 + s.plan_tmps + 2.0 * P.Q), step4 = per * (NW + (P.num_advice() >= 8 ? P.num_advice() : 0) + 3.0 + 2.0 * max_chunk), step10 = per * (NW + P.Q + 10.0);
   s.working_bytes = std::max(step7, std::max(step4, step10)) + per * P.Q + (double)P.n * 13 * 22 + 0.5 * 1024.0 * 1024 * 1024;
   return s;
+}
+
+
+// ------------------------------------------------------------------------------------------------ what stays resident
+// A prover process holds several layers at once (a chunk prover the degrees {20, 24, 25}, a batch prover {21, 26} [REF bin/src/trace_prover.rs:35-36]): the
+// SRS of every degree, every layer's proving key, and the working set of the ONE proof that runs.  Everything resident does not fit 288 GiB; this is the
+// rule of section 7c as code.  What each optional resident buys per proof: window tables of a basis ~8 % of every commitment on it (W x the basis of HBM);
+// the Q coset parts of a proving key one coset transform per polynomial and part.  So cosets are kept before tables, smaller keys first (more layers stay
+// fully resident), then tables go to the Lagrange bases (they carry most commitments), the largest degree first.
+struct LayerResidency { const Protocol *P; PkSizes sz; bool cosets_resident = false, table_lagrange = false, table_coeff = false; };
+struct ResidencyPlan { std::vector<LayerResidency> layers; double srs_gib = 0, keys_gib = 0, tables_gib = 0, working_gib = 0, total_gib = 0, budget_gib = 0; bool fits = false; };
+inline ResidencyPlan plan_residency(const std::vector<const Protocol *> &protos, double hbm_gib, double reserve_fraction = 0.08) {
+  const double GiB = 1024.0 * 1024 * 1024;
+  ResidencyPlan R; R.budget_gib = hbm_gib * (1.0 - reserve_fraction);
+  std::set<uint32_t> degrees;
+  for (const Protocol *p : protos) { LayerResidency L{p, pk_sizes(*p)}; R.working_gib = std::max(R.working_gib, L.sz.working_bytes / GiB); degrees.insert(p->k); R.keys_gib += L.sz.base_bytes / GiB; R.layers.push_back(L); }
+  for (uint32_t k : degrees) R.srs_gib += 2.0 * (double)(uint64_t(64) << k) / GiB;                       // two bases of 64-byte points
+  double used = R.srs_gib + R.keys_gib + R.working_gib, lean_tmp = 0;                                     // lean_tmp: one part's cosets of the largest key that recomputes them
+  std::vector<size_t> order(R.layers.size()); for (size_t i = 0; i < order.size(); i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return R.layers[a].sz.coset_bytes < R.layers[b].sz.coset_bytes; });
+  for (size_t i : order) {
+    const double c = R.layers[i].sz.coset_bytes / GiB;
+    if (used + c + lean_tmp <= R.budget_gib) { R.layers[i].cosets_resident = true; used += c; R.keys_gib += c; }
+    else lean_tmp = std::max(lean_tmp, R.layers[i].sz.lean_tmp_bytes / GiB);
+  }
+  used += lean_tmp;
+  std::vector<uint32_t> ks(degrees.rbegin(), degrees.rend());
+  for (int pass = 0; pass < 2; pass++) for (uint32_t k : ks) {
+    const double t = (double)(uint64_t(64) << k) * (k >= 24 ? 12 : 15) / GiB;                               // W x 64 bytes per point
+    if (used + t > R.budget_gib) continue;
+    used += t; R.tables_gib += t;
+    for (auto &L : R.layers) if (L.P->k == k) (pass == 0 ? L.table_lagrange : L.table_coeff) = true;
+  }
+  R.total_gib = used; R.fits = used <= R.budget_gib;
+  return R;
 }
 
 inline std::unique_ptr<ProvingKey> keygen(const Protocol &P, const Circuit &C, uint64_t h_g_lagrange, bool resident_cosets, int devices) {

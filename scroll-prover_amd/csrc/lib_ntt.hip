@@ -612,7 +612,7 @@ int mi355_fr_gate_eval_dev(void *dst_dev, const void *const *polys_dev, uint32_t
   G.n_terms = n_terms; G.accumulate = accumulate ? 1u : 0u;
   uint32_t nf = 0;
   for (uint32_t j = 0; j < n_terms; j++) {
-    if (term_len[j] > 8 || nf + term_len[j] > GATE_MAX_FACTORS) return fail(MI355_EBADARG, "fr_gate_eval: at most 8 factors per term and 48 per launch");
+    if (term_len[j] > GATE_MAX_TERM_LEN || nf + term_len[j] > GATE_MAX_FACTORS) return fail(MI355_EBADARG, "fr_gate_eval: at most 16 factors per term and 48 per launch");
     G.term_len[j] = (uint8_t)term_len[j]; nf += term_len[j];
     memcpy(&G.coeff[j], (const char *)coeffs + 32 * (size_t)j, 32);
     G.coeff29[j] = Fr29::from_sat(G.coeff[j]);

@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256) k_fr_vec_mul_periodic(fe_t *__restrict__ 
 // Arithmetic: the first factor is re-sliced in the ABI domain (x 2^256), the coefficient and every further factor enter as y 2^261, so each
 // Montgomery product (R' = 2^261) lands back in the ABI domain; term values (< 2 r) are summed lazily, carried every fourth term, and reduced
 // once (<= 16 terms + dst: < 34 r, below reduce_small's 64 r).
-constexpr uint32_t GATE_MAX_TERMS = 16, GATE_MAX_FACTORS = 48, GATE_MAX_POLYS = 24;
+constexpr uint32_t GATE_MAX_TERMS = 16, GATE_MAX_FACTORS = 48, GATE_MAX_POLYS = 24, GATE_MAX_TERM_LEN = 16;   // a degree-9 gate of the inner circuit (selector, coefficient, seven cells) is ONE term
 struct GatePlan {
   const fe_t *poly[GATE_MAX_POLYS];
   fe_t coeff[GATE_MAX_TERMS];            // Montgomery (ABI) form (constant terms)

@@ -7,7 +7,7 @@
 #include <random>
 #include <set>
 
-#include "mi355zk_halo2.hpp"
+#include "mi355zk_plonk.hpp"
 
 using namespace mi355zk::halo2;
 
@@ -32,7 +32,8 @@ static int failures = 0;
 static Fr rand_fr(std::mt19937_64 &g) { Fr r{g(), g(), g(), g() & ((uint64_t(1) << 60) - 1)}; return r; }
 
 int main(int argc, char **argv) {
-  const bool host_only = argc > 1 && std::strcmp(argv[1], "--host-only") == 0;
+  bool host_only = false; std::string protocol_dir;
+  for (int i = 1; i < argc; i++) { if (std::strcmp(argv[i], "--host-only") == 0) host_only = true; else if (std::strcmp(argv[i], "--protocols") == 0 && i + 1 < argc) protocol_dir = argv[++i]; }
   // --- EvaluationDomain::new against [REF release-v0.13.1/chunk.protocol] domain {k: 25, gen, gen_inv, n_inv}
   EvaluationDomain d25(2, 25);
   const Fr gen{13338605924273364442ull, 11440449704248451096ull, 16859609365912477452ull, 3421252324365184758ull};
@@ -64,53 +65,53 @@ int main(int argc, char **argv) {
     for (uint8_t v = 1; v < 40; v++) { G1Bytes t{}; t[0] = v; G1Affine o1, o2; const bool a = g1_from_bytes(t, o1); const int b = orc_g1_decompress(o2.data(), t.data()); EXPECT(a == (b == 1)); if (a) EXPECT(o1 == o2); else rejected++; }
     EXPECT(rejected > 5);
   }
-  // --- the expression plans of create_proof_gpu_side (include/mi355zk_create_proof.hpp), host logic only: every launch of every layer's plan stays
-  // inside the limits of mi355_fr_gate_eval_dev, intermediates are written before they are read, the counts follow from the shapes
-  {
-    Challenges ch; ch.theta = detail::fr_from_u64(2); ch.beta = detail::fr_from_u64(3); ch.gamma = detail::fr_from_u64(5); ch.y = detail::fr_from_u64(7);
-    ch.x = detail::fr_from_u64(11); ch.v = detail::fr_from_u64(13); ch.z0 = detail::fr_from_u64(17); ch.z1 = detail::fr_from_u64(19);
-    const uint32_t want_commitments[7] = {955, 37, 11, 163, 14, 17, 12};   // layers 2 and 4: the fixtures' proof word counts
+  // --- the plan compiler of mi355zk::plonk::create_proof (include/mi355zk_plonk.hpp), host logic only, on the protocols of all seven layers at full size
+  // (--protocols DIR: layer0.json ... layer6.json written by scroll-prover_amd/protocols.py; layers 2 / 4 equal the reference's fixtures): every launch stays
+  // inside the limits of mi355_fr_gate_eval_dev, temporaries are written before they are read, the counts are the fixtures'
+  if (!protocol_dir.empty()) {
+    using namespace mi355zk::plonk;
+    const uint32_t want_commitments[7] = {953, 35, 11, 148, 14, 17, 11};   // layers 2, 4 (and 6 = layer 2's system): the released proofs' word counts
+    const uint32_t want_evals[7] = {0, 125, 17, 652, 27, 42, 17};
+    std::vector<std::unique_ptr<Protocol>> protos;
     for (int layer = 0; layer <= 6; layer++) {
-      const CircuitShape sh = layer_shape(layer);
-      EXPECT(sh.commitments() == want_commitments[layer]);
-      EXPECT(sh.chunk_len + 2 <= sh.degree && sh.chunk_len <= 6 && ((sh.Q() & (sh.Q() - 1)) == 0));
-      const ExpressionPlan P = build_plan(sh, ch);
-      EXPECT(P.gates == 1 + (sh.advice > 2 ? sh.advice - 2 : 0) + sh.lookups + 2 * sh.perm_z());
-      EXPECT(P.perm_product.size() == sh.perm_z());
+      auto P = std::make_unique<Protocol>(); P->load(protocol_dir + "/layer" + std::to_string(layer) + ".json");
+      EXPECT(P->commitments() == want_commitments[layer]);
+      if (want_evals[layer]) EXPECT(P->evaluations.size() == want_evals[layer]);
+      EXPECT(P->last_rot == -7 && P->blind == 6 && P->queries.size() == P->evaluations.size() + 1);
+      for (const auto &c : P->perm) EXPECT(c.columns.size() + 2 <= P->Q + 1);                                        // chunks of degree - 2
+      CommonRegistry reg; Compiler cmp(reg, true, {fr_u64(2), fr_u64(3), fr_u64(5), fr_u64(7)});
+      cmp.compile_numerator(P->numerator);
+      EXPECT(reg.defs.size() >= 3 && reg.defs.size() <= 4);                                                            // l_0, l_last, l_active (, X)
       std::set<uint32_t> written; uint32_t quotient_launches = 0;
-      for (const auto &L : P.quotient) {
-        std::set<PolyRef> polys; uint32_t nf = 0;
+      for (const auto &L : cmp.out) {
+        std::set<Atom> polys; uint32_t nf = 0;
         EXPECT(L.terms.size() >= 1 && L.terms.size() <= PLAN_MAX_TERMS);
         for (const auto &t : L.terms) {
-          EXPECT(t.f.size() <= 8); nf += (uint32_t)t.f.size();
-          for (const auto &f : t.f) { polys.insert(f.p); if (f.p.kind == P_TMP) EXPECT(written.count(f.p.idx) == 1); EXPECT(t.f.size() <= sh.degree); }
+          EXPECT(t.f.size() <= PLAN_MAX_TERM_LEN); nf += (uint32_t)t.f.size();
+          for (const auto &f : t.f) { polys.insert(Atom{f.kind, f.idx, 0}); if (f.kind == A_TMP) EXPECT(written.count(f.idx) == 1); }
         }
         EXPECT(nf <= PLAN_MAX_FACTORS && polys.size() <= PLAN_MAX_POLYS);
-        if (L.to_tmp) { EXPECT(L.tmp < 2 * sh.chunk_len); written.insert(L.tmp); } else quotient_launches++;
+        if (L.dst >= 0) { EXPECT((uint32_t)L.dst < cmp.tmp_max); if (!L.accumulate) written.erase((uint32_t)L.dst); written.insert((uint32_t)L.dst); } else quotient_launches++;
       }
-      EXPECT(quotient_launches >= 1);
-      for (size_t q = 1; q < P.queries.size(); q++) EXPECT(P.queries[q - 1] < P.queries[q]);   // sorted, no duplicates
-      for (const auto &qr : P.queries) EXPECT(qr.p.kind != P_TMP && qr.p.kind != P_INSTANCE && qr.p.kind != P_ID);
+      EXPECT(quotient_launches >= 1 && cmp.constraints + 1 == P->numerator.kids.size());
+      if (layer == 2) { EXPECT(cmp.constraints == 7); const auto sets = rotation_sets(P->queries); EXPECT(sets.size() == 3 && sets[0].rots.size() == 4 && sets[2].polys.size() == 10); }
+      if (layer == 4) { EXPECT(cmp.constraints == 10); const auto sets = rotation_sets(P->queries); EXPECT(sets.size() == 4 && sets[2].rots.size() == 3 && sets[2].polys.size() == 1); }   // z_0 is opened at x, w x and w^-7 x
+      protos.push_back(std::move(P));
     }
-    // the 16-term limit really cuts: layer 0's 798 custom gates of 3 terms cannot share fewer than 160 launches
-    const ExpressionPlan P0 = build_plan(layer_shape(0), ch);
-    uint32_t non_tmp = 0; for (const auto &L : P0.quotient) if (!L.to_tmp) non_tmp++;
-    EXPECT(non_tmp >= 160 && P0.terms > 2500);
-  }
-  // --- the residency rule of DESIGN.md 7c as code: one layer alone keeps its cosets and (below k = 26) both tables; a chunk prover {0, 1, 2} and a batch
-  // prover {3, 4} fit 288 GiB only by giving things up, cosets before tables
-  {
-    auto one = [&](int l) { return plan_residency({layer_shape(l)}, 288.0); };
-    for (int l : {0, 1, 2, 3, 5}) { const ResidencyPlan P = one(l); EXPECT(P.fits && P.layers[0].cosets_resident && P.layers[0].table_lagrange && P.layers[0].table_coeff); }
-    { const ResidencyPlan P = one(4); EXPECT(P.fits && P.layers[0].cosets_resident && !P.layers[0].table_coeff); EXPECT(P.total_gib <= 288.0 * 0.92 + 1e-9); }
-    const ResidencyPlan C = plan_residency({layer_shape(0), layer_shape(1), layer_shape(2)}, 288.0);
+    // --- the residency rule of DESIGN.md 7c as code: one layer alone keeps its cosets (and below k = 26 both tables); a chunk prover {0, 1, 2} and a batch
+    // prover {3, 4} fit 288 GiB only by giving things up, cosets before tables
+    auto one = [&](int l) { return plan_residency({protos[l].get()}, 288.0); };
+    for (int l : {0, 1, 2, 3, 5}) { const ResidencyPlan R = one(l); EXPECT(R.fits && R.layers[0].cosets_resident && R.layers[0].table_lagrange && R.layers[0].table_coeff); }
+    { const ResidencyPlan R = one(4); EXPECT(R.fits && R.layers[0].cosets_resident && !R.layers[0].table_coeff); EXPECT(R.total_gib <= 288.0 * 0.92 + 1e-9); }
+    const ResidencyPlan C = plan_residency({protos[0].get(), protos[1].get(), protos[2].get()}, 288.0);
     EXPECT(C.fits && C.total_gib <= 265.0);
     int resident = 0; for (const auto &L : C.layers) resident += L.cosets_resident;
-    EXPECT(resident >= 2);                                            // not everything (354 GiB) fits, but most keys keep their cosets
-    const ResidencyPlan B = plan_residency({layer_shape(3), layer_shape(4)}, 288.0);
-    EXPECT(B.fits && B.layers[0].cosets_resident && B.layers[1].cosets_resident);   // 38 + 116 GiB of keys resident ...
-    EXPECT(!B.layers[1].table_lagrange && !B.layers[1].table_coeff);               // ... and the k = 26 bases table-free (section 7c: 246 GiB)
-    const ResidencyPlan T = plan_residency({layer_shape(4)}, 80.0);                  // a smaller card: the key's cosets no longer fit
+    EXPECT(resident >= 2);
+    const ResidencyPlan B = plan_residency({protos[3].get(), protos[4].get()}, 288.0);
+    EXPECT(B.fits && B.layers[0].cosets_resident && !B.layers[1].cosets_resident);   // with the reference's real layer-4 system (13 key polynomials: 42 GiB + 104 GiB of cosets) a batch prover
+    EXPECT(!B.layers[1].table_coeff);                                                // keeps layer 3's cosets and recomputes layer 4's per part; the k = 26 bases stay table-free
+    for (const ResidencyPlan *R : {&C, &B}) std::printf("residency plan: srs %.1f keys %.1f tables %.1f working %.1f total %.1f of %.1f GiB\n", R->srs_gib, R->keys_gib, R->tables_gib, R->working_gib, R->total_gib, R->budget_gib);
+    const ResidencyPlan T = plan_residency({protos[4].get()}, 80.0);                  // a smaller card: the key's cosets no longer fit
     EXPECT(!T.layers[0].cosets_resident);
   }
   if (host_only) {
