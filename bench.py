@@ -42,6 +42,30 @@ MADD_CHAIN_PEAK = 15.9e9
 MADS_PER_MADD = 1467   # v_mad_[ui]64 on the common path of one XYZZ mixed addition (tools/isa_block_census.py)
 
 
+def source_hash(kind: str) -> str:
+    """sha256[:16] of the kernel sources a recorded counter figure belongs to (profiles/pmc_latest.json stores it; a figure whose sources changed is not re-emitted)"""
+    import hashlib
+    files = {"msm": ("msm.hpp", "lib_msm.hip", "fp29.hpp", "g1_29.hpp"), "ntt": ("ntt29.hpp", "lib_ntt.hip", "fp29.hpp")}[kind]
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "scroll-prover_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(key: str, kind: str):
+    """HBM bytes from the separate rocprofv3 --pmc passes (tools/collect_profiles.sh + tools/pmc_report.py): counter collection cannot share a run with the timing, so the
+    figure is RECORDED -- and only re-emitted while the kernel sources it was measured on are the ones that just ran"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    except Exception:
+        return None, None
+    want = (rec.get("source_sha16") or {}).get(kind)
+    if want != source_hash(kind):
+        return None, f"stale: {rec.get('source')} was measured on other {kind} sources (recorded {want}, now {source_hash(kind)}); re-run tools/collect_profiles.sh"
+    return rec.get(key), rec.get("source")
+
+
 def rand_scalars(n: int, seed: int, device) -> torch.Tensor:
     """n field elements as [n,4] int64 limbs (Montgomery form of uniformly random elements), generated on the device."""
     gen = torch.Generator(device=device)
@@ -222,15 +246,25 @@ def main() -> None:
     assert n_total % world == 0
     n = n_total // world                      # pairs owned by this rank (point-range shard)
 
-    # ---- synthetic inputs, resident in HBM
-    tau = 0x5343524F4C4C0001 + 7919 * rank    # seed ("SCROLL", 1), distinct per shard
+    # ---- synthetic inputs, resident in HBM.  ONE tau for the whole job: rank r owns the points g[r n .. (r + 1) n) = tau^(r n + i) G of the SAME SRS, so that the
+    # N > 1 result is the one identity a sharded commitment must satisfy, commit(p) = p(tau) G over the whole 2^k-point basis
+    tau = 0x5343524F4C4C0001                  # seed ("SCROLL", 1)
     shard_k = (n - 1).bit_length()
     g = torch.empty(n * 64, dtype=torch.uint8, device=dev)
-    gl_scratch = torch.empty(n * 64, dtype=torch.uint8, device=dev)
-    w_shard = pow(h2.FR_ROOT_OF_UNITY, 1 << (h2.FR_S - shard_k), h2.R_MOD)
-    tau_m, w_m = h2.fr(tau), h2.fr(w_shard)
-    check(lib.mi355_srs_setup_dev(ptr(g), ptr(gl_scratch), shard_k, ptr(tau_m), ptr(w_m)))
-    del gl_scratch
+    tau_m = h2.fr(tau)
+    if world == 1:
+        gl_scratch = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        w_shard = pow(h2.FR_ROOT_OF_UNITY, 1 << (h2.FR_S - shard_k), h2.R_MOD)
+        check(lib.mi355_srs_setup_dev(ptr(g), ptr(gl_scratch), shard_k, ptr(tau_m), ptr(h2.fr(w_shard))))
+        del gl_scratch
+    else:
+        # this rank's slice only: scalars tau^(r n) * tau^i by a constant fill and distribute_powers, then the fixed-base multiples (what mi355_srs_setup_dev does for i < n)
+        pw = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        h2.gate_eval(pw, [], [(h2.fr(pow(tau, rank * n, h2.R_MOD)), [])], n)
+        check(lib.mi355_distribute_powers_fr_dev(ptr(pw), n, ptr(tau_m)))
+        check(lib.mi355_g1_fixed_base_mul_dev(ptr(g), ptr(pw), n))
+        check(lib.mi355_synchronize())
+        del pw
     handle = C.c_uint64()
     check(lib.mi355_srs_register_dev(ptr(g), n, 0, C.byref(handle)))
     pre_ms = None
@@ -316,11 +350,11 @@ def main() -> None:
         want = cref.g1_to_affine(cref.g1_mul(cref.g1_generator(), p_tau))
         verified = bool((np.asarray(result)[:8] == want).all())
 
-    # N > 1: every rank evaluates its shard polynomial at its own tau in the field (oracle = checker only, outside the timed
-    # region), the 32-byte evaluations are gathered, and rank 0 checks  result == (sum_r p_r(tau_r)) * G
+    # N > 1: every rank evaluates its slice of the polynomial in the field, p_r(tau) tau^(r n) (oracle = checker only, outside the timed region), the 32-byte
+    # values are gathered, and rank 0 checks  result == (sum_r tau^(r n) p_r(tau)) G = p(tau) G  for the ONE polynomial p the ranks hold together
     if world > 1 and k <= 26:
         from oracle import cref
-        e_r = cref.eval_polynomial(scalars.cpu().numpy().view(np.uint64), tau_m)
+        e_r = cref.f_mul(cref.FR, cref.eval_polynomial(scalars.cpu().numpy().view(np.uint64), tau_m), h2.fr(pow(tau, rank * n, h2.R_MOD)))
         mine = torch.from_numpy(e_r.view(np.uint8).copy()).to("cpu" if share else dev)
         allv = torch.empty(world * 32, dtype=torch.uint8, device=mine.device)
         dist.all_gather_into_tensor(allv, mine)
@@ -360,12 +394,7 @@ def main() -> None:
         check(lib.mi355_profile_enable(0))
         pass_ms, pass_cnt = prof("ntt_pass")
         bf = (1 << k) // 2 * k
-        ntt_traffic, ntt_traffic_src = None, None   # HBM bytes per transform from the separate --pmc passes (recorded, like the MSM's)
-        try:
-            rec_ = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            ntt_traffic, ntt_traffic_src = rec_.get(f"ntt_k{k}_hbm_bytes_per_transform"), rec_.get("source")
-        except Exception:
-            pass
+        ntt_traffic, ntt_traffic_src = recorded_traffic(f"ntt_k{k}_hbm_bytes_per_transform", "ntt")   # HBM bytes per transform from the separate --pmc passes
         ntt = {"log_n": k, "ms_per_transform": dt_ntt * 1e3, "butterflies_per_s": bf / dt_ntt, "roundtrip_ok": rt_ok,
                "passes_per_transform": pass_cnt / (2 * reps),
                "roofline": {"bound": "hbm", "achieved": 64.0 * (1 << k) / dt_ntt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -488,6 +517,15 @@ def main() -> None:
                    "srs_window_tables": bool(shd.value), "verified_against_field_check": ok_s, "msm_phase_ms": ph_s,
                    "msm_roofline_frac_hbm": 96.0 * ns / dt_s / 1e9 / HBM_PEAK_GBS}
             check(lib.mi355_srs_release(hp.value))
+            if not args.no_cpu_baseline:
+                # the reference CPU path beside this size too (north_star: "k = 20 / 24 / 26 ... next to the reference CPU path ... in the same run"): same pairs
+                cores_s = cref.usable_cpus()
+                g_s = g[: ns * 64].cpu().numpy().view(np.uint64).reshape(ns, 8); sc_h = sc_s.cpu().numpy().view(np.uint64)
+                tc = time.perf_counter(); ref_s = cref.best_multiexp(sc_h, g_s, threads=cores_s); dt_c = time.perf_counter() - tc
+                chunk_s = max(1, ns // cores_s); c_s = int(np.ceil(np.log(chunk_s))) if chunk_s >= 32 else 3; seg_s = 256 // c_s + 1
+                rec["cpu_baseline"] = {"msm": {"value": (ns * seg_s + (ns // chunk_s) * seg_s * 2 * ((1 << c_s) - 1)) / dt_c, "unit": "G1-adds/s", "pairs_per_s": ns / dt_c, "cores": cores_s, "kind": "port",
+                                               "sample": f"best_multiexp restatement on the same 2^{ks} pairs, {dt_c:.2f} s wall", "equals_gpu_result": bool((np.asarray(out)[:8] == cref.g1_to_affine(ref_s)).all())}}
+                del g_s, sc_h
             if not args.no_ntt:
                 dom_s = h2.EvaluationDomain(2, ks)
                 poly_s = rand_scalars(ns, 0x5343524F4C4C0003, dev)
@@ -498,6 +536,13 @@ def main() -> None:
                 check(lib.mi355_synchronize()); torch.cuda.synchronize()
                 dt_n = (time.perf_counter() - t10) / (2 * reps_s)
                 rec.update({"ntt_ms_per_transform": dt_n * 1e3, "butterflies_per_s": ns // 2 * ks / dt_n, "ntt_roofline_frac_hbm": 64.0 * ns / dt_n / 1e9 / HBM_PEAK_GBS})
+                if not args.no_cpu_baseline:
+                    src_h = poly_s.cpu().numpy().view(np.uint64).reshape(ns, 4).copy()
+                    tn = time.perf_counter(); want_s = cref.best_fft(src_h, dom_s.omega, ks, threads=cref.usable_cpus()); dt_cn = time.perf_counter() - tn
+                    dom_s.coeff_to_lagrange(poly_s)
+                    rec.setdefault("cpu_baseline", {})["ntt"] = {"value": ns // 2 * ks / dt_cn, "unit": "butterflies/s", "cores": cref.usable_cpus(), "kind": "port", "sample": f"best_fft restatement on the same 2^{ks} coefficients, {dt_cn:.2f} s wall",
+                                                                "equals_gpu_result": bool((poly_s.cpu().numpy().view(np.uint64).reshape(ns, 4) == want_s).all())}
+                    del src_h, want_s
                 del poly_s
             sizes["k%d" % ks] = rec
         extra["sizes"] = sizes
@@ -568,14 +613,7 @@ def main() -> None:
         achieved = 96.0 * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else None
         # HBM bytes of one k_msm_accumulate launch from the PMC counters: RECORDED from a separate rocprofv3 --pmc pass over this same
         # command (profiles/r02b_pmc_msm_k26.md), not measured inside this run (counter collection cannot share a run with the timing)
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc) and not single and world == 1:
-            try:
-                rec = json.load(open(pmc))
-                traffic, traffic_src = rec.get(f"msm_accumulate_k{k}_hbm_bytes_per_launch"), rec.get("source")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = (recorded_traffic(f"msm_accumulate_k{k}_hbm_bytes_per_launch", "msm") if (not single and world == 1) else (None, None))
         line = {
             "metric": "BN254 MSM G1-adds/sec at k=%d" % k, "value": value, "unit": "G1-adds/s", "n_gpus": args.gpus if single else world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

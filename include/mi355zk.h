@@ -89,6 +89,17 @@ int mi355_buf_slot(const void *dev_ptr, int *slot_out);     /* which device slot
  * issued afterwards see it) and the host buffer may be reused.  Takes no device lock.                                                   */
 int mi355_buf_upload(void *dst_dev, const void *src_host, uint64_t bytes);
 int mi355_buf_download(void *dst_host, const void *src_dev, uint64_t bytes);   /* ordered after everything queued on the owner; synchronous */
+/* Narrow uploads for narrow columns (create_proof steps 2-3 are PCIe-bound at the many-column layers while most witness cells are zeros, bytes or 64-bit words: SURVEY 8d's
+ * witness-like distribution; lookup_bits of [REF integration/configs/layer1.config:11]).  dst receives n 32-byte Montgomery words either way.
+ *   packed  src = n little-endian unsigned integers of width_bytes in {1, 2, 4, 8} (CANONICAL values: selectors, byte / range-checked / limb columns, whose kind the caller
+ *           knows statically); W bytes per cell cross the link, the device multiplies by R
+ *   sparse  the non-zero cells as (index, 32-byte Montgomery value) pairs in any order; dst is zero-filled first.  mi355_host_compact_nonzero builds the pairs from a plain
+ *           column with `threads` host threads (zero is zero in Montgomery form: the scan needs no arithmetic), idx_out / vals_out sized for n entries.
+ * The narrow data crosses PCIe like mi355_buf_upload (copy stream, no device lock; the host buffers may be reused on return); the expansion is QUEUED on the owner's compute
+ * stream: calls issued afterwards on that device see the data.                                                                                                          */
+int mi355_buf_upload_packed(void *dst_dev, const void *src_host, uint64_t n, uint32_t width_bytes);
+int mi355_buf_upload_sparse(void *dst_dev, uint64_t n, const uint32_t *idx_host, const void *vals_host, uint64_t count);
+int mi355_host_compact_nonzero(const void *src_host, uint64_t n, uint32_t *idx_out, void *vals_out, uint64_t *count_out, int threads);
 int mi355_buf_copy(void *dst_dev, const void *src_dev, uint64_t bytes);        /* within a device or between two bound devices (xGMI)       */
 int mi355_buf_zero(void *dst_dev, uint64_t bytes);
 /* Page-locked host memory for buffers that cross PCIe more than once, or once but on the critical path (the witness columns of the many-column layers):

@@ -23,6 +23,8 @@
 // The Rust twin of the flow is rust_shim/create_proof_resident.rs.  Host code here is the transcript, the plan compiler and a few field operations per rotation
 // set; everything proportional to 2^k runs on the device.
 #pragma once
+#include <atomic>
+#include <cstdlib>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -137,32 +139,69 @@ struct Compiler {
   // the whole numerator: constraint i of DistributePowers(constraints, y) carries y^(m - 1 - i); constraints that needed temporaries are flushed at once so that the
   // next one may reuse them
   // Constraints that needed temporaries share an accumulate launch while their temporaries fit TMP_GROUP blocks: each constraint is compiled with ids from 0 and
-  // RELOCATED behind the ids of the constraints already waiting in the group; the group is flushed (its terms emitted) before ids are reused.
-  static constexpr uint32_t TMP_GROUP = 12;
+  // RELOCATED behind the ids of the constraints already waiting; everything waiting is flushed (its terms emitted) before ids are reused.
+  // COMMON PREFIXES.  Many constraints are  p * (...)  with the same leading polynomial p -- every assigned gate of the inner circuit carries the one selector, every
+  // permutation chunk and lookup carries l_active.  Distributed, p is loaded, re-sliced and multiplied into every term; instead the bracketed parts of such a group
+  // (>= 16 constraints) accumulate, with their powers of y, into ONE long-lived temporary G_p, and the quotient receives the single term p * G_p at the end:
+  // one factor fewer in every term of the group for one more pass over HBM per group.
+  static constexpr uint32_t TMP_GROUP = 12, GROUP_BASE = 32;   // waiting constraints share up to TMP_GROUP local temporaries (ids < GROUP_BASE); the long-lived G_p live at GROUP_BASE + g
+  static uint32_t prefix_min() { const char *e = std::getenv("MI355_PLAN_PREFIX_MIN"); const long v = e ? std::atol(e) : 16; return v <= 0 ? 0xffffffffu : (uint32_t)v; }   // 0: never group (A/B, profiles/r05_gate_eval.md)
+  uint32_t prefix_groups = 0;
+  uint32_t tmps_used() const { std::set<int> u; for (const auto &L : out) if (L.dst >= 0) u.insert(L.dst); return (uint32_t)u.size(); }
   void compile_numerator(const Expr &num) {
     const size_t m = num.kids.size() - 1; const Fr y = scalar_of(compile(num.kids.back()));
     std::vector<Fr> ypow(m, fr_one()); for (size_t i = 1; i < m; i++) ypow[i] = fr_mul(ypow[i - 1], y);
-    SoP pending; uint32_t group_tmps = 0;
-    auto relocate = [](std::vector<Term> &ts, uint32_t off) { for (auto &t : ts) for (auto &a : t.f) if (a.kind == A_TMP) a.idx += off; };
+    // pass 0: which constraints share a leading polynomial
+    auto prefix_of = [&](const Expr &c, Atom &a) -> bool {
+      if (c.kind != Expr::PROD) return false;
+      const Expr &p = c.kids[0]; bool common = false;
+      if (p.kind == Expr::POLY) { a = Atom{A_POLY, (uint32_t)p.i, p.rot}; return true; }
+      if (is_common_linear(p, &common) && common) { a = Atom{A_COMMON, reg.id_of(p, create_commons), 0}; return true; }
+      return false;
+    };
+    std::map<Atom, uint32_t> count; std::map<Atom, int> group_tmp;
+    for (size_t i = 0; i < m; i++) { Atom a; if (prefix_of(num.kids[i], a)) count[a]++; }
+    for (const auto &kv : count) if (kv.second >= prefix_min()) { group_tmp[kv.first] = (int)(GROUP_BASE + prefix_groups++); tmp_max = std::max(tmp_max, GROUP_BASE + prefix_groups); }
+    // pass 1
+    std::map<int, SoP> pending; std::set<int> started; uint32_t waiting_tmps = 0;
+    auto relocate = [](std::vector<Term> &ts, uint32_t off) { for (auto &t : ts) for (auto &a : t.f) if (a.kind == A_TMP && a.idx < GROUP_BASE) a.idx += off; };
+    auto flush = [&]() {
+      for (auto &kv : pending) { if (kv.second.empty()) continue; emit(kv.first, kv.second, kv.first < 0 || started.count(kv.first) > 0); started.insert(kv.first); kv.second.clear(); }
+      waiting_tmps = 0;
+    };
     for (size_t i = 0; i < m; i++) {
+      Atom pa; const bool grouped = prefix_of(num.kids[i], pa) && group_tmp.count(pa);
       const size_t first_launch = out.size();
       tmp_base = 0; tmp_next = 0;
-      SoP s = scaled(compile(num.kids[i]), ypow[m - 1 - i]);
+      SoP s = scaled(compile(grouped ? num.kids[i].kids[1] : num.kids[i]), ypow[m - 1 - i]);
       constraints++; terms_total += (uint32_t)s.size();
       const uint32_t used = tmp_next;
+      if (used > GROUP_BASE) throw std::invalid_argument("plan compiler: one constraint needs more than 32 temporaries");
       std::vector<Launch> mine(out.begin() + (long)first_launch, out.end()); out.resize(first_launch);   // this constraint's temporaries
-      if (used > 0 && group_tmps > 0 && group_tmps + used > TMP_GROUP) { emit(-1, pending, true); pending.clear(); group_tmps = 0; }
+      if (used > 0 && waiting_tmps > 0 && waiting_tmps + used > TMP_GROUP) flush();
       if (used > 0) {
-        if (group_tmps > 0) { for (auto &L : mine) { L.dst += (int)group_tmps; relocate(L.terms, group_tmps); } relocate(s, group_tmps); }
-        group_tmps += used; tmp_max = std::max(tmp_max, group_tmps);
+        if (waiting_tmps > 0) { for (auto &L : mine) { L.dst += (int)waiting_tmps; relocate(L.terms, waiting_tmps); } relocate(s, waiting_tmps); }
+        waiting_tmps += used; tmp_max = std::max(tmp_max, waiting_tmps);
       }
       out.insert(out.end(), mine.begin(), mine.end());
-      pending.insert(pending.end(), s.begin(), s.end());
+      SoP &dst = pending[grouped ? group_tmp[pa] : -1];
+      dst.insert(dst.end(), s.begin(), s.end());
     }
-    if (!pending.empty()) emit(-1, pending, true);
+    flush();                                                                                                    // every G_p is complete ...
+    for (const auto &kv : group_tmp) pending[-1].push_back(Term{fr_one(), {kv.first, Atom{A_TMP, (uint32_t)kv.second, 0}}});
+    flush();                                                                                                    // ... before the quotient reads p * G_p
   }
 };
 
+// what the fused kernel was asked to do, summed over every launch of this process: the ALGORITHMIC side of its roofline (profiles/r05_gate_eval.md compares it with
+// the FETCH_SIZE / WRITE_SIZE and SQ counters of the same run).  bytes = 32 B x rows x (distinct operand polynomials + dst written + dst read when accumulating)
+struct GateStats { std::atomic<uint64_t> launches{0}, bytes{0}, factor_rows{0}, term_rows{0}; };
+inline GateStats &gate_stats() { static GateStats g; return g; }
+inline void gate_eval(void *dst, const void *const *polys, uint32_t n_polys, const Fr *coeffs, const uint32_t *term_len, uint32_t n_terms, const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate) {
+  check(mi355_fr_gate_eval_dev(dst, polys, n_polys, coeffs, term_len, n_terms, factor_poly, factor_rot, n, accumulate));
+  uint64_t nf = 0; for (uint32_t j = 0; j < n_terms; j++) nf += term_len[j];
+  GateStats &g = gate_stats(); g.launches++; g.bytes += 32 * n * (uint64_t)(n_polys + 1 + (accumulate ? 1 : 0)); g.factor_rows += nf * n; g.term_rows += (uint64_t)n_terms * n;
+}
 // one Launch through mi355_fr_gate_eval_dev; resolve(Atom) -> device pointer of the operand on the domain the launch runs on
 template <class Resolve> inline void run_launch(const Launch &L, void *dst, uint64_t n, const Fr &scale, bool accumulate, Resolve resolve) {
   std::vector<const void *> polys; std::map<Atom, uint32_t> slot;
@@ -177,7 +216,7 @@ template <class Resolve> inline void run_launch(const Launch &L, void *dst, uint
     }
   }
   if (L.terms.empty()) { if (!accumulate) check(mi355_buf_zero(dst, n * 32)); return; }
-  check(mi355_fr_gate_eval_dev(dst, polys.empty() ? nullptr : polys.data(), (uint32_t)polys.size(), coeffs.data(), tl.data(), (uint32_t)tl.size(), fp.empty() ? nullptr : fp.data(), fr.empty() ? nullptr : fr.data(), n, accumulate ? 1 : 0));
+  gate_eval(dst, polys.empty() ? nullptr : polys.data(), (uint32_t)polys.size(), coeffs.data(), tl.data(), (uint32_t)tl.size(), fp.empty() ? nullptr : fp.data(), fr.empty() ? nullptr : fr.data(), n, accumulate ? 1 : 0);
 }
 inline DevicePoly clone(const DevicePoly &s, int slot) { DevicePoly d(s.n, slot); check(mi355_buf_copy(d.p, s.p, s.n * 32)); return d; }
 inline Fr part_factor(const EvaluationDomain &dom, uint32_t q) { return fr_mul(dom.g_coset, fr_pow(dom.extended_omega, q)); }
@@ -206,7 +245,7 @@ inline PkSizes pk_sizes(const Protocol &P) {
   const double per = (double)P.n * 32; PkSizes s;
   CommonRegistry reg; { Expr id; id.kind = Expr::IDENTITY; reg.id_of(id, true); }
   Compiler cmp(reg, true, std::vector<Fr>(4, fr_one())); cmp.compile_numerator(P.numerator);
-  s.commons = (uint32_t)reg.defs.size(); s.plan_tmps = cmp.tmp_max;
+  s.commons = (uint32_t)reg.defs.size(); s.plan_tmps = cmp.tmps_used();
   s.polys = P.num_pre + s.commons; s.lagrange = (uint32_t)lagrange_needed(P).size() + 1;
   s.base_bytes = per * (s.polys + s.lagrange); s.coset_bytes = per * s.polys * P.Q; s.lean_tmp_bytes = per * s.polys;
   uint32_t NW = 1; for (auto w : P.num_witness) NW += w;                     // instance + witness polynomials
@@ -300,7 +339,7 @@ inline std::unique_ptr<ProvingKey> keygen(const Protocol &P, const Circuit &C, u
     if (!fr_is_zero(d.x_coeff)) { check(mi355_synchronize()); check(mi355_buf_upload(lag.at(1), d.x_coeff.data(), 32)); check(mi355_ntt_fr_dev(lag.p, dom.k, dom.omega.data())); }   // x_coeff X -> x_coeff omega^row
     if (!fr_is_zero(d.constant)) {
       const void *pp[1] = {lag.p}; const Fr cs[2] = {one, d.constant}; const uint32_t tl[2] = {1, 0}, fp[1] = {0}; const int32_t fr_[1] = {0};
-      check(mi355_fr_gate_eval_dev(lag.p, pp, 1, cs, tl, 2, fp, fr_, n, 0));
+      gate_eval(lag.p, pp, 1, cs, tl, 2, fp, fr_, n, 0);
     }
     for (const auto &sp : d.lagrange) {
       const uint64_t row = (uint64_t)(((int64_t)sp.first % (int64_t)n + (int64_t)n) % (int64_t)n);
@@ -318,12 +357,14 @@ inline std::unique_ptr<ProvingKey> keygen(const Protocol &P, const Circuit &C, u
 }
 
 // ------------------------------------------------------------------------------------------------ create_proof
-struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 1; int early_intt = -1 /* -1: by column count */; };
+struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 1; int early_intt = -1 /* -1: by column count */;
+                      bool sparse_uploads = false /* columns that are at least half zeros cross PCIe as (index, value) pairs */; };
 struct ProofResult {
   std::vector<uint8_t> proof;
   double step_ms[11] = {0}; double total_ms = 0;
   uint64_t peak_hbm_bytes = 0, hbm_total_bytes = 0;
-  uint32_t msm = 0, intt = 0, coset_ntt = 0, gate_launches = 0, evals = 0, plan_launches = 0, plan_terms = 0, plan_tmps = 0, plan_constraints = 0, rotation_sets = 0;
+  uint64_t sparse_columns = 0, witness_link_bytes = 0;
+  uint32_t msm = 0, intt = 0, coset_ntt = 0, gate_launches = 0, evals = 0, plan_launches = 0, plan_terms = 0, plan_tmps = 0, plan_constraints = 0, plan_prefix_groups = 0, rotation_sets = 0;
 };
 
 namespace detail {
@@ -382,10 +423,20 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   for (const auto &l : P.lookups) poly[l.phi];
   std::mutex mu; std::condition_variable cv; std::vector<char> arrived(uploads.size(), 0); std::string upload_error;
   const size_t UT = (size_t)std::max(1, std::min<int>(opt.upload_threads, (int)uploads.size()));
+  std::atomic<uint64_t> sparse_cols{0}, link_bytes{0};
   auto upload_worker = [&](size_t first) {
     try {
+      std::vector<uint32_t> sidx; std::vector<Fr> svals;   // this worker's scratch for the sparse form
       for (size_t i = first; i < uploads.size(); i += UT) {
-        DevicePoly d(uploads[i].second->size(), 0); check(mi355_buf_upload(d.p, uploads[i].second->data(), uploads[i].second->size() * 32));
+        const uint64_t len = uploads[i].second->size();
+        DevicePoly d(len, 0);
+        uint64_t nz = len;
+        if (opt.sparse_uploads && len >= (1u << 12) && uploads[i].first != P.random_poly) {
+          sidx.resize(len); svals.resize(len);
+          check(mi355_host_compact_nonzero(uploads[i].second->data(), len, sidx.data(), svals.data(), &nz, std::max(1, opt.threads / (int)UT)));
+        }
+        if (2 * nz <= len) { check(mi355_buf_upload_sparse(d.p, len, sidx.data(), svals.data(), nz)); sparse_cols++; link_bytes += nz * 36; }
+        else { check(mi355_buf_upload(d.p, uploads[i].second->data(), len * 32)); link_bytes += len * 32; }
         { std::lock_guard<std::mutex> lk(mu); poly.at(uploads[i].first) = std::move(d); arrived[i] = 1; }
         cv.notify_all();
       }
@@ -508,7 +559,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   {
     Compiler cmp(const_cast<CommonRegistry &>(pk.commons), false, ch);
     cmp.compile_numerator(P.numerator);
-    R.plan_launches = (uint32_t)cmp.out.size(); R.plan_terms = cmp.terms_total; R.plan_tmps = cmp.tmp_max; R.plan_constraints = cmp.constraints;
+    R.plan_launches = (uint32_t)cmp.out.size(); R.plan_terms = cmp.terms_total; R.plan_tmps = cmp.tmps_used(); R.plan_constraints = cmp.constraints; R.plan_prefix_groups = cmp.prefix_groups;
     std::set<uint32_t> wset; std::set<Atom> pkset;
     for (const auto &L : cmp.out) for (const auto &t : L.terms) for (const auto &f : t.f) { if (f.kind == A_POLY && !P.is_pre(f.idx)) wset.insert(f.idx); else if (f.kind != A_TMP) pkset.insert(Atom{f.kind, f.idx, 0}); }
     const std::vector<uint32_t> wrefs(wset.begin(), wset.end()); const uint32_t NP = (uint32_t)wrefs.size();
@@ -517,7 +568,8 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
     std::vector<DevicePoly> hpart; for (uint32_t q = 0; q < Q; q++) hpart.emplace_back(n, 0);
     for (int d = 0; d < D; d++) {
       for (uint32_t r : wrefs) part_on[d][r] = DevicePoly(n, d);
-      for (uint32_t i = 0; i < cmp.tmp_max; i++) tmp_on[d].emplace_back(n, d);
+      tmp_on[d].resize(cmp.tmp_max);
+      for (const auto &L : cmp.out) if (L.dst >= 0 && !tmp_on[d][(size_t)L.dst].p) tmp_on[d][(size_t)L.dst] = DevicePoly(n, d);   // only the ids the plan writes
       if (d > 0) { hq_on[d] = DevicePoly(n, d); for (uint32_t r : wrefs) { coeff_on[d][r] = DevicePoly(n, d); check(mi355_buf_copy(coeff_on[d][r].p, poly.at(r).p, n * 32)); } }
     }
     std::vector<std::string> errs(D); std::vector<uint32_t> launches(D, 0), cosets(D, 0);
@@ -585,7 +637,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
     {
       const Fr xn = fr_pow(x, n); std::vector<const void *> pp(Q); std::vector<Fr> cs(Q); std::vector<uint32_t> tl_(Q, 1), fp(Q); std::vector<int32_t> fr_(Q, 0);
       Fr f = fr_one(); for (uint32_t q = 0; q < Q; q++) { pp[q] = h.at((uint64_t)q * n); cs[q] = f; f = fr_mul(f, xn); fp[q] = q; }
-      check(mi355_fr_gate_eval_dev(hcomb.p, pp.data(), Q, cs.data(), tl_.data(), Q, fp.data(), fr_.data(), n, 0)); R.gate_launches++;
+      gate_eval(hcomb.p, pp.data(), Q, cs.data(), tl_.data(), Q, fp.data(), fr_.data(), n, 0); R.gate_launches++;
     }
     auto opened = [&](uint32_t p) -> const void * { return p == P.quotient_poly ? hcomb.p : coeff_ptr(p); };
     const Fr ys = T.squeeze_challenge(), v = T.squeeze_challenge();
@@ -602,7 +654,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
         const uint32_t cnt = (uint32_t)std::min<size_t>(16, np - base);
         std::vector<const void *> pp(cnt); std::vector<Fr> cs(cnt); std::vector<uint32_t> tl_(cnt, 1), fp(cnt); std::vector<int32_t> fr_(cnt, 0);
         for (uint32_t j = 0; j < cnt; j++) { pp[j] = opened(s.polys[base + j]); cs[j] = ypow[np - 1 - (base + j)]; fp[j] = j; }
-        check(mi355_fr_gate_eval_dev(Ai.p, pp.data(), cnt, cs.data(), tl_.data(), cnt, fp.data(), fr_.data(), n, base ? 1 : 0)); R.gate_launches++;
+        gate_eval(Ai.p, pp.data(), cnt, cs.data(), tl_.data(), cnt, fp.data(), fr_.data(), n, base ? 1 : 0); R.gate_launches++;
       }
       std::vector<Fr> rsum(m, fr_zero());
       for (size_t j = 0; j < np; j++) {
@@ -640,7 +692,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
       std::vector<const void *> pp; std::vector<Fr> cs; for (size_t i = 0; i < M; i++) { pp.push_back(Acomb[i].p); cs.push_back(fr_mul(lc[i], zi)); }
       pp.push_back(H.p); cs.push_back(fr_neg(fr_mul(zt, zi)));
       std::vector<uint32_t> tl_(M + 1, 1), fp(M + 1); std::vector<int32_t> fr_(M + 1, 0); for (size_t i = 0; i <= M; i++) fp[i] = (uint32_t)i;
-      check(mi355_fr_gate_eval_dev(Lx.p, pp.data(), (uint32_t)(M + 1), cs.data(), tl_.data(), (uint32_t)(M + 1), fp.data(), fr_.data(), n, 0)); R.gate_launches++;
+      gate_eval(Lx.p, pp.data(), (uint32_t)(M + 1), cs.data(), tl_.data(), (uint32_t)(M + 1), fp.data(), fr_.data(), n, 0); R.gate_launches++;
       Fr l0; check(mi355_buf_download(l0.data(), Lx.p, 32)); l0 = fr_sub(l0, fr_mul(cst, zi)); check(mi355_buf_upload(Lx.p, l0.data(), 32));
     }
     check(mi355_buf_zero(work.p, n * 32));
@@ -650,7 +702,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   check(mi355_synchronize());
   lap(10);
   R.total_ms = ms_since(t_start);
-  R.proof = std::move(T.proof);
+  R.proof = std::move(T.proof); R.sparse_columns = sparse_cols.load(); R.witness_link_bytes = link_bytes.load();
   { uint64_t fr_ = 0, tot = 0; check(mi355_mem_info(0, &fr_, &tot, nullptr, nullptr, nullptr)); R.peak_hbm_bytes = tot - fr_; R.hbm_total_bytes = tot; }
   return R;
 }

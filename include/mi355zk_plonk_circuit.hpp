@@ -110,7 +110,7 @@ struct RowEval {
 };
 }  // namespace detail
 
-struct CircuitOptions { uint64_t seed = 1; int threads = 8; bool pinned = false; double fill = 0.9; };
+struct CircuitOptions { uint64_t seed = 1; int threads = 8; bool pinned = false; double fill = 0.9; double assign_density = 1.0 /* fraction of the usable rows on which the assigned gates' selector is on: the other cells of every dependent column stay zero */; };
 
 inline std::unique_ptr<Circuit> build_circuit(const Protocol &P, const CircuitOptions &opt) {
   using namespace detail;
@@ -248,13 +248,17 @@ inline std::unique_ptr<Circuit> build_circuit(const Protocol &P, const CircuitOp
   }
   // every advice column's blinding rows are drawn BEFORE the assigned gates run: their P may read rotated cells of earlier columns across the wrap-around
   for (uint32_t a = 0; a < A; a++) { Rng g(top.next()); for (uint64_t r = u + 1; r < n; r++) C->advice[a][r] = g.uniform(); }
+  std::set<uint32_t> assign_selectors;
   for (uint32_t a = 0; a < A; a++) if (role[a].kind == ASSIGN) {
     const Gate &g = *role[a].gate;
     Column &sel = pre_col(g.selector);
-    if (fr_is_zero(sel[0])) C->parallel(u, [&](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) sel[i] = fr_one(); });
+    if (assign_selectors.insert(g.selector).second) {
+      const uint64_t thr = opt.assign_density >= 1.0 ? ~uint64_t(0) : (uint64_t)(opt.assign_density * 18446744073709551615.0);
+      C->parallel(u, [&](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) { Rng h(i * 0x9E3779B97F4A7C15ull + g.selector); if (h.next() <= thr) sel[i] = fr_one(); } });
+    }
     RowEval ev; ev.compile(*g.p, host_column);
     Column &t = C->advice[a];
-    C->parallel(u, [&](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) t[i] = ev.at(i, n); });
+    C->parallel(u, [&](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) if (!fr_is_zero(sel[i])) t[i] = ev.at(i, n); });
   }
   // ---- multiplicities
   for (uint32_t l = 0; l < L; l++) {

@@ -62,6 +62,9 @@ extern "C" {
     pub fn mi355_buf_free(dev_ptr: *mut c_void) -> c_int;
     pub fn mi355_buf_upload(dst_dev: *mut c_void, src_host: *const c_void, bytes: u64) -> c_int;
     pub fn mi355_buf_download(dst_host: *mut c_void, src_dev: *const c_void, bytes: u64) -> c_int;
+    pub fn mi355_buf_upload_packed(dst_dev: *mut c_void, src_host: *const c_void, n: u64, width_bytes: u32) -> c_int;
+    pub fn mi355_buf_upload_sparse(dst_dev: *mut c_void, n: u64, idx_host: *const u32, vals_host: *const c_void, count: u64) -> c_int;
+    pub fn mi355_host_compact_nonzero(src_host: *const c_void, n: u64, idx_out: *mut u32, vals_out: *mut c_void, count_out: *mut u64, threads: c_int) -> c_int;
     pub fn mi355_buf_copy(dst_dev: *mut c_void, src_dev: *const c_void, bytes: u64) -> c_int;
     pub fn mi355_buf_zero(dst_dev: *mut c_void, bytes: u64) -> c_int;
     pub fn mi355_host_alloc(bytes: u64, host_ptr_out: *mut *mut c_void) -> c_int;
@@ -200,6 +203,30 @@ impl DevicePoly {
         if unsafe { mi355_buf_alloc((v.len() * 32) as u64, slot, &mut p) } != MI355_OK { return None; }
         let d = DevicePoly { ptr: p, len: v.len(), slot };
         if unsafe { mi355_buf_upload(d.ptr, v.as_ptr() as *const c_void, (v.len() * 32) as u64) } != MI355_OK { return None; }
+        Some(d)
+    }
+    /// The same upload for a column that is mostly zeros (selectors, padding rows, sparse lookup inputs): only the non-zero cells cross PCIe, as (index, value) pairs.
+    /// `scratch` (idx, vals) is reused across columns; below `min_zero_fraction` of zeros the plain upload is cheaper and is used instead.
+    pub fn from_slice_sparse(v: &[Fr], slot: c_int, scratch: &mut (Vec<u32>, Vec<Fr>), threads: c_int, min_zero_fraction: f64) -> Option<DevicePoly> {
+        if !available() || v.is_empty() || v.len() > (1usize << 32) { return None; }
+        scratch.0.resize(v.len(), 0); scratch.1.resize(v.len(), Fr::zero());
+        let mut count: u64 = 0;
+        if unsafe { mi355_host_compact_nonzero(v.as_ptr() as *const c_void, v.len() as u64, scratch.0.as_mut_ptr(), scratch.1.as_mut_ptr() as *mut c_void, &mut count, threads) } != MI355_OK { return None; }
+        if (count as f64) > (1.0 - min_zero_fraction) * v.len() as f64 { return DevicePoly::from_slice(v, slot); }
+        let mut p: *mut c_void = std::ptr::null_mut();
+        if unsafe { mi355_buf_alloc((v.len() * 32) as u64, slot, &mut p) } != MI355_OK { return None; }
+        let d = DevicePoly { ptr: p, len: v.len(), slot };
+        if unsafe { mi355_buf_upload_sparse(d.ptr, v.len() as u64, scratch.0.as_ptr(), scratch.1.as_ptr() as *const c_void, count) } != MI355_OK { return None; }
+        Some(d)
+    }
+    /// A column whose kind bounds its cells (selector bits, bytes, range-checked limbs below 2^lookup_bits, 64-bit words): the caller hands the CANONICAL values as
+    /// `width`-byte little-endian integers and `width` bytes per cell cross the link.
+    pub fn from_packed(values_le: &[u8], n: usize, width: u32, slot: c_int) -> Option<DevicePoly> {
+        if !available() || n == 0 || values_le.len() != n * width as usize { return None; }
+        let mut p: *mut c_void = std::ptr::null_mut();
+        if unsafe { mi355_buf_alloc((n * 32) as u64, slot, &mut p) } != MI355_OK { return None; }
+        let d = DevicePoly { ptr: p, len: n, slot };
+        if unsafe { mi355_buf_upload_packed(d.ptr, values_le.as_ptr() as *const c_void, n as u64, width) } != MI355_OK { return None; }
         Some(d)
     }
     pub fn len(&self) -> usize { self.len }

@@ -28,6 +28,9 @@ SIGNATURES = {
     "mi355_buf_slot": (_int, [_vp, C.POINTER(_int)]),
     "mi355_buf_upload": (_int, [_vp, _vp, _u64]),
     "mi355_buf_download": (_int, [_vp, _vp, _u64]),
+    "mi355_buf_upload_packed": (_int, [_vp, _vp, _u64, C.c_uint32]),
+    "mi355_buf_upload_sparse": (_int, [_vp, _u64, _vp, _vp, _u64]),
+    "mi355_host_compact_nonzero": (_int, [_vp, _u64, _vp, _vp, C.POINTER(_u64), _int]),
     "mi355_buf_copy": (_int, [_vp, _vp, _u64]),
     "mi355_buf_zero": (_int, [_vp, _u64]),
     "mi355_host_alloc": (_int, [_u64, C.POINTER(_vp)]),

@@ -227,7 +227,21 @@ __global__ void __launch_bounds__(FRSCAN_THREADS) k_g1_batch_normalize(const g1_
   }
   g_store(&out[i].x, r.x); g_store(&out[i].y, r.y);
 }
+// ---- narrow uploads (create_proof steps 2-3: witness columns are mostly zeros / bytes / 64-bit words; 32-byte Montgomery words waste the PCIe link)
+// packed: src = n little-endian unsigned integers of W bytes (canonical values) -> dst[i] = value * R mod r (one Montgomery product with R^2 per element);
+// a lane reads W bytes and writes 32: both sides coalesced
+template <int W> __global__ void __launch_bounds__(256) k_expand_packed(fe_t *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t v;
+    if (W == 1) v = src[i]; else if (W == 2) v = ((const uint16_t *)src)[i]; else if (W == 4) v = ((const uint32_t *)src)[i]; else v = ((const uint64_t *)src)[i];
+    fe_t c = Fr::zero(); c.l[0] = (uint32_t)v; c.l[1] = (uint32_t)(v >> 32);
+    g_store(&dst[i], v ? Fr::from_canonical(c) : c);
+  }
+}
+// sparse: dst is zero-filled by the caller; dst[idx[j]] = vals[j] (32-byte Montgomery words, as they sit in the caller's column)
+__global__ void __launch_bounds__(256) k_scatter_fr(fe_t *__restrict__ dst, const uint32_t *__restrict__ idx, const fe_t *__restrict__ vals, uint64_t count) {
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) g_store(&dst[idx[j]], g_load(&vals[j]));
+}
 #endif  // ZK_FRSCAN_DEVICE_ONLY
-
 #endif  // __HIPCC__
 }  // namespace zk

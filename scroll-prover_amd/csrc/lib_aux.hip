@@ -6,6 +6,7 @@
 #include "frscan.hpp"
 #include "g2.hpp"
 #include "lib_common.hpp"
+#include <thread>
 
 namespace mi355 {
 
@@ -225,6 +226,78 @@ int mi355_g2_mul_host(const void *p_affine_host, const void *scalar, void *out_a
   HIPCHK(hipStreamSynchronize(g.stream));
   if (!ok) return fail(MI355_EBADARG, "g2_mul: the point is not on the twist y^2 = x^3 + 3 / (9 + u)");
   memcpy(out_affine_host, &res, sizeof res);
+  return MI355_OK;
+  });
+}
+
+// ---- narrow uploads: a witness column as W-byte integers or as (index, value) pairs of its non-zero cells instead of n 32-byte words.  The narrow data crosses PCIe through
+// mi355_buf_upload (copy stream, no device lock) into a pooled staging block; the expansion kernel is queued on the owner's compute stream WITHOUT the device lock (it touches
+// no context state; HIP streams accept work from several threads) and the call returns without waiting for it: calls issued afterwards on that device are ordered behind it.
+int mi355_buf_upload_packed(void *dst_dev, const void *src_host, uint64_t n, uint32_t width_bytes) {
+  return guarded([&]() -> int {
+  if (n == 0) return MI355_OK;
+  if (!dst_dev || !src_host) return fail(MI355_EBADARG, "buf_upload_packed: null pointer");
+  if (width_bytes != 1 && width_bytes != 2 && width_bytes != 4 && width_bytes != 8) return fail(MI355_EBADARG, "buf_upload_packed: width must be 1, 2, 4 or 8 bytes");
+  const int slot = slot_of(dst_dev);
+  void *stage = nullptr; CHK(mi355_buf_alloc(n * width_bytes, slot, &stage));
+  int rc = mi355_buf_upload(stage, src_host, n * width_bytes);
+  if (rc == MI355_OK) rc = need_init(slot);
+  if (rc == MI355_OK) {
+    hipStream_t s = g_ctx[slot].stream; const dim3 grid((uint32_t)std::min<uint64_t>(ceil_div(n, 256), 65535u * 4));
+    switch (width_bytes) {
+      case 1: hipLaunchKernelGGL(k_expand_packed<1>, grid, dim3(256), 0, s, (fe_t *)dst_dev, (const uint8_t *)stage, n); break;
+      case 2: hipLaunchKernelGGL(k_expand_packed<2>, grid, dim3(256), 0, s, (fe_t *)dst_dev, (const uint8_t *)stage, n); break;
+      case 4: hipLaunchKernelGGL(k_expand_packed<4>, grid, dim3(256), 0, s, (fe_t *)dst_dev, (const uint8_t *)stage, n); break;
+      default: hipLaunchKernelGGL(k_expand_packed<8>, grid, dim3(256), 0, s, (fe_t *)dst_dev, (const uint8_t *)stage, n); break;
+    }
+    if (hipGetLastError() != hipSuccess) rc = fail(MI355_EHIP, "buf_upload_packed: kernel launch failed");
+  }
+  (void)mi355_buf_free(stage);   // back to the pool; its reuse waits for the kernel queued above
+  return rc;
+  });
+}
+int mi355_buf_upload_sparse(void *dst_dev, uint64_t n, const uint32_t *idx_host, const void *vals_host, uint64_t count) {
+  return guarded([&]() -> int {
+  if (n == 0) return MI355_OK;
+  if (!dst_dev || (count && (!idx_host || !vals_host))) return fail(MI355_EBADARG, "buf_upload_sparse: null pointer");
+  if (count > n || n > (1ull << 32)) return fail(MI355_EBADARG, "buf_upload_sparse: more pairs than cells, or more than 2^32 cells");
+  const int slot = slot_of(dst_dev);
+  CHK(need_init(slot));
+  hipStream_t s = g_ctx[slot].stream;
+  if (count == 0) { HIPCHK(hipMemsetAsync(dst_dev, 0, n * sizeof(fe_t), s)); return MI355_OK; }
+  const uint64_t idx_bytes = (count * 4 + 31) & ~31ull;
+  void *stage = nullptr; CHK(mi355_buf_alloc(idx_bytes + count * sizeof(fe_t), slot, &stage));
+  int rc = mi355_buf_upload(stage, idx_host, count * 4);
+  if (rc == MI355_OK) rc = mi355_buf_upload((char *)stage + idx_bytes, vals_host, count * sizeof(fe_t));
+  if (rc == MI355_OK) rc = need_init(slot);
+  if (rc == MI355_OK) {
+    if (hipMemsetAsync(dst_dev, 0, n * sizeof(fe_t), s) != hipSuccess) rc = fail(MI355_EHIP, "buf_upload_sparse: memset failed");
+    else {
+      hipLaunchKernelGGL(k_scatter_fr, dim3((uint32_t)std::min<uint64_t>(ceil_div(count, 256), 65535u * 4)), dim3(256), 0, s, (fe_t *)dst_dev, (const uint32_t *)stage, (const fe_t *)((char *)stage + idx_bytes), count);
+      if (hipGetLastError() != hipSuccess) rc = fail(MI355_EHIP, "buf_upload_sparse: kernel launch failed");
+    }
+  }
+  (void)mi355_buf_free(stage);
+  return rc;
+  });
+}
+// host helper for the sparse form: the non-zero cells of a column of n 32-byte words as (index, value) pairs, in index order; `threads` workers scan disjoint ranges
+// (zero is zero in Montgomery form too, so the scan needs no arithmetic).  idx_out / vals_out must hold n entries in the worst case; pure host code, no device.
+int mi355_host_compact_nonzero(const void *src_host, uint64_t n, uint32_t *idx_out, void *vals_out, uint64_t *count_out, int threads) {
+  return guarded([&]() -> int {
+  if (!count_out || (n && (!src_host || !idx_out || !vals_out))) return fail(MI355_EBADARG, "host_compact_nonzero: null pointer");
+  if (n > (1ull << 32)) return fail(MI355_EBADARG, "host_compact_nonzero: more than 2^32 cells");
+  const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, threads), std::max<uint64_t>(1, n >> 16)));
+  const uint64_t *w = (const uint64_t *)src_host; uint64_t *vo = (uint64_t *)vals_out;
+  std::vector<uint64_t> cnt(T + 1, 0);
+  auto nz = [&](uint64_t i) { return (w[4 * i] | w[4 * i + 1] | w[4 * i + 2] | w[4 * i + 3]) != 0; };
+  auto range = [&](int t, uint64_t &lo, uint64_t &hi) { lo = n * t / T; hi = n * (t + 1) / T; };
+  auto count_job = [&](int t) { uint64_t lo, hi; range(t, lo, hi); uint64_t c = 0; for (uint64_t i = lo; i < hi; i++) c += nz(i); cnt[t + 1] = c; };
+  { std::vector<std::thread> th; for (int t = 1; t < T; t++) th.emplace_back(count_job, t); count_job(0); for (auto &x : th) x.join(); }
+  for (int t = 0; t < T; t++) cnt[t + 1] += cnt[t];
+  auto write_job = [&](int t) { uint64_t lo, hi; range(t, lo, hi); uint64_t o = cnt[t]; for (uint64_t i = lo; i < hi; i++) if (nz(i)) { idx_out[o] = (uint32_t)i; memcpy(vo + 4 * o, w + 4 * i, 32); o++; } };
+  { std::vector<std::thread> th; for (int t = 1; t < T; t++) th.emplace_back(write_job, t); write_job(0); for (auto &x : th) x.join(); }
+  *count_out = cnt[T];
   return MI355_OK;
   });
 }

@@ -79,7 +79,11 @@ int dev_malloc(void **out, size_t bytes, const char *what) {
 int ws_get(const char *role, size_t bytes, void **out) {
   Buf &b = g.ws[role];
   if (b.cap < bytes) {
-    if (b.p) { HIPCHK(hipStreamSynchronize(g.stream)); for (int i = 0; i < 2; i++) if (g.aux_stream[i]) HIPCHK(hipStreamSynchronize(g.aux_stream[i])); HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    if (b.p) {   // every stream that may still touch the old block: compute, the two auxiliary streams, and the copy stream (host-pointer entry points stage through workspace blocks)
+      HIPCHK(hipStreamSynchronize(g.stream)); for (int i = 0; i < 2; i++) if (g.aux_stream[i]) HIPCHK(hipStreamSynchronize(g.aux_stream[i]));
+      if (g.copy_stream) HIPCHK(hipStreamSynchronize(g.copy_stream));
+      HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0;
+    }
     size_t cap = bytes + bytes / 8 + 256;
     // the head-room is a convenience (fewer regrowths), not a requirement: near the HBM limit the exact size is tried as well
     if (dev_malloc(&b.p, cap, role) != MI355_OK) { cap = bytes; CHK(dev_malloc(&b.p, cap, role)); }
@@ -174,7 +178,10 @@ int pick_replica_slot() {
   for (int i = 0; i < D; i++) { const int s = (start + i) % D; if (g_ctx_mu[s].try_lock()) { g_ctx_mu[s].unlock(); return s; } }
   return start;
 }
-// give the pooled (free) blocks of one device slot back to HIP; the caller holds that slot's lock and is bound to its device.  Returns bytes freed.
+// give the pooled (free) blocks of one device slot back to HIP.  Returns bytes freed.  Callers: dev_malloc on an out-of-memory retry -- reached WITH the slot's lock from the
+// compute entry points and WITHOUT it from mi355_buf_alloc -- and mi355_buf_trim.  The invariant that makes both safe: this function touches only state under g_buf_mu
+// (the pool map) plus thread-safe HIP calls (stream synchronisation, hipFree) on the calling thread's bound device; it must never read or write Ctx members that the
+// slot's lock protects (g.ws, the event rings, the plans).
 static size_t pool_release_slot(int slot) {
   std::vector<BufBlock> drop;
   { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto it = g_pool.begin(); it != g_pool.end();) { if (it->first.first == slot) { drop.push_back(it->second); it = g_pool.erase(it); } else ++it; } }

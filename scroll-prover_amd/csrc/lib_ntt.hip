@@ -251,7 +251,9 @@ int ntt_batch_inplace(const std::vector<fe_t *> &data, uint32_t log_n, const voi
     post3 = c + 3;
     CHK(fold_divisor(p, log_n, nullptr, post_host, &fold_tw, &post3));
   }
-  const size_t chunk = std::min<size_t>(cnt, std::max<size_t>(1, (size_t)((1ull << 30) / (N * sizeof(fe_t)))));   // at most 1 GiB of scratch
+  // in-place transforms of ONE buffer listed twice must run one after the other (the serial loop applied the transform twice; concurrent passes would race)
+  { std::vector<const void *> seen(data.begin(), data.end()); std::sort(seen.begin(), seen.end()); if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return single_loop(); }
+  const size_t chunk = std::min<size_t>(std::min<size_t>(cnt, 65535), std::max<size_t>(1, (size_t)((1ull << 30) / (N * sizeof(fe_t)))));   // at most 1 GiB of scratch, and gridDim.y <= 65535
   fe_t *scratch; CHK(ws_get("ntt.scratch.batch", chunk * N * sizeof(fe_t), (void **)&scratch));
   // pointer tables for the whole list: data[i] and the scratch slot of i (slots repeat chunk by chunk; the stream orders their reuse)
   std::vector<const fe_t *> tab(2 * cnt);
@@ -741,8 +743,10 @@ int mi355_eval_polynomial_batch_dev(const void *const *polys_dev, uint32_t batch
   const uint32_t CH = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(4096, (256ull << 20) / (stride * sizeof(fe_t))));
   const uint32_t chunk = std::min(batch, CH);
   fe_t *partial; CHK(ws_get("eval.partial", stride * chunk * sizeof(fe_t), (void **)&partial));
-  char *tab; CHK(ws_get("eval.batch", (size_t)chunk * (sizeof(void *) + 2 * sizeof(fe_t)), (void **)&tab));
-  const fe_t **ptab = (const fe_t **)tab; fe_t *xtab = (fe_t *)(tab + (size_t)chunk * sizeof(void *)); fe_t *res = xtab + chunk;
+  // [pointer table | points | results]: the pointer table is padded to 32 bytes so that the fe_t arrays behind it keep the 16-byte alignment their dwordx4 accesses assume (an odd `chunk` used to leave them 8-byte aligned)
+  const size_t ptab_bytes = ((size_t)chunk * sizeof(void *) + 31) & ~(size_t)31;
+  char *tab; CHK(ws_get("eval.batch", ptab_bytes + (size_t)chunk * 2 * sizeof(fe_t), (void **)&tab));
+  const fe_t **ptab = (const fe_t **)tab; fe_t *xtab = (fe_t *)(tab + ptab_bytes); fe_t *res = xtab + chunk;
   for (uint32_t base = 0; base < batch; base += CH) {
     const uint32_t cnt = std::min(CH, batch - base);
     Scope sc("eval_poly");

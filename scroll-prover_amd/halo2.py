@@ -96,6 +96,15 @@ def best_fft_many(polys, omega: np.ndarray, log_n: int, divisor=None) -> None:
         check(lib().mi355_ntt_fr_batch_host(arr, len(polys), log_n, ptr(omega), ptr(divisor)))
 
 
+def compact_nonzero(col: np.ndarray, threads: int = 8):
+    """(indices, values) of the non-zero cells of a [n, 4] u64 column, in index order (mi355_host_compact_nonzero: host threads, no device)"""
+    col = np.ascontiguousarray(col, dtype=np.uint64)
+    n = col.shape[0]
+    idx = np.empty(n, dtype=np.uint32); vals = np.empty((n, 4), dtype=np.uint64); cnt = C.c_uint64()
+    check(lib().mi355_host_compact_nonzero(ptr(col), n, ptr(idx), ptr(vals), C.byref(cnt), threads))
+    return idx[: cnt.value].copy(), vals[: cnt.value].copy()
+
+
 class DeviceBuffer:
     """One mi355_buf_alloc block: the Python twin of the Rust shim's DevicePoly (rust_shim/mi355zk.rs).  Quacks like a device tensor for
     the wrappers of this module (data_ptr / numel / element_size); `slot` picks the device of an mi355_init_multi process."""
@@ -110,6 +119,24 @@ class DeviceBuffer:
         arr = np.ascontiguousarray(arr)
         b = cls(arr.nbytes, slot)
         b.upload(arr)
+        return b
+
+    @classmethod
+    def from_packed(cls, values: np.ndarray, slot: int = 0) -> "DeviceBuffer":
+        """a column whose cells are known to fit 1 / 2 / 4 / 8 bytes (values: uint8 / 16 / 32 / 64, CANONICAL integers): that many bytes per cell cross PCIe, the device
+        expands to Montgomery words (mi355_buf_upload_packed)"""
+        values = np.ascontiguousarray(values)
+        assert values.dtype in (np.uint8, np.uint16, np.uint32, np.uint64) and values.ndim == 1
+        b = cls(32 * values.shape[0], slot)
+        check(lib().mi355_buf_upload_packed(C.c_void_p(b._ptr), ptr(values), values.shape[0], values.dtype.itemsize))
+        return b
+
+    @classmethod
+    def from_sparse(cls, col: np.ndarray, slot: int = 0, threads: int = 8) -> "DeviceBuffer":
+        """a mostly-zero column ([n, 4] u64 Montgomery words): only its non-zero cells cross PCIe (mi355_host_compact_nonzero + mi355_buf_upload_sparse)"""
+        idx, vals = compact_nonzero(col, threads)
+        b = cls(col.nbytes, slot)
+        check(lib().mi355_buf_upload_sparse(C.c_void_p(b._ptr), col.shape[0], ptr(idx), ptr(vals), idx.shape[0]))
         return b
 
     def data_ptr(self) -> int:

@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <random>
 #include <set>
 
@@ -94,6 +96,40 @@ int main(int argc, char **argv) {
         if (L.dst >= 0) { EXPECT((uint32_t)L.dst < cmp.tmp_max); if (!L.accumulate) written.erase((uint32_t)L.dst); written.insert((uint32_t)L.dst); } else quotient_launches++;
       }
       EXPECT(quotient_launches >= 1 && cmp.constraints + 1 == P->numerator.kids.size());
+      // the plan computes the numerator: run it on ONE row of scalars (every (polynomial, rotation) leaf, X and every Lagrange polynomial a random value) and compare with the
+      // tree walked directly -- with and without the common-prefix groups
+      for (const char *pm : {"16", "0", "2"}) {
+        setenv("MI355_PLAN_PREFIX_MIN", pm, 1);
+        std::mt19937_64 rg(1000 + layer);
+        std::map<std::pair<int32_t, int32_t>, Fr> leaf; std::map<int32_t, Fr> lag; const Fr xval = rand_fr(rg);
+        const std::vector<Fr> chv{rand_fr(rg), rand_fr(rg), rand_fr(rg), rand_fr(rg)};
+        std::function<Fr(const Expr &)> walk = [&](const Expr &e) -> Fr {
+          switch (e.kind) {
+            case Expr::CONSTANT: return e.c;
+            case Expr::IDENTITY: return xval;
+            case Expr::LAGRANGE: { auto it = lag.find(e.i); if (it == lag.end()) it = lag.emplace(e.i, rand_fr(rg)).first; return it->second; }
+            case Expr::POLY: { auto it = leaf.find({e.i, e.rot}); if (it == leaf.end()) it = leaf.emplace(std::make_pair(e.i, e.rot), rand_fr(rg)).first; return it->second; }
+            case Expr::CHALLENGE: return chv[(size_t)e.i];
+            case Expr::NEG: return fr_neg(walk(e.kids[0]));
+            case Expr::SUM: return fr_add(walk(e.kids[0]), walk(e.kids[1]));
+            case Expr::PROD: return fr_mul(walk(e.kids[0]), walk(e.kids[1]));
+            case Expr::SCALED: return fr_mul(walk(e.kids[0]), e.c);
+            default: { const Fr b = walk(e.kids.back()); Fr acc = walk(e.kids[0]); for (size_t i = 1; i + 1 < e.kids.size(); i++) acc = fr_add(fr_mul(acc, b), walk(e.kids[i])); return acc; }
+          }
+        };
+        const Fr want = walk(P->numerator);
+        CommonRegistry reg2; Compiler c2(reg2, true, chv); c2.compile_numerator(P->numerator);
+        std::vector<Fr> common_val; for (const auto &d : reg2.defs) { Fr v = fr_add(d.constant, fr_mul(d.x_coeff, xval)); for (const auto &sp : d.lagrange) v = fr_add(v, fr_mul(sp.second, lag.at(sp.first))); common_val.push_back(v); }
+        std::vector<Fr> tmpv(c2.tmp_max, fr_zero()); Fr got = fr_zero();
+        for (const auto &L : c2.out) {
+          Fr acc = fr_zero();
+          for (const auto &t : L.terms) { Fr v = t.coeff; for (const auto &f : t.f) v = fr_mul(v, f.kind == A_TMP ? tmpv[f.idx] : f.kind == A_COMMON ? common_val[f.idx] : leaf.at({(int32_t)f.idx, f.rot})); acc = fr_add(acc, v); }
+          if (L.dst < 0) got = fr_add(got, acc); else tmpv[(size_t)L.dst] = L.accumulate ? fr_add(tmpv[(size_t)L.dst], acc) : acc;
+        }
+        if (!(got == want)) std::printf("layer %d, MI355_PLAN_PREFIX_MIN=%s: the compiled plan does not compute the numerator\n", layer, pm);
+        EXPECT(got == want);
+      }
+      unsetenv("MI355_PLAN_PREFIX_MIN");
       if (layer == 2) { EXPECT(cmp.constraints == 7); const auto sets = rotation_sets(P->queries); EXPECT(sets.size() == 3 && sets[0].rots.size() == 4 && sets[2].polys.size() == 10); }
       if (layer == 4) { EXPECT(cmp.constraints == 10); const auto sets = rotation_sets(P->queries); EXPECT(sets.size() == 4 && sets[2].rots.size() == 3 && sets[2].polys.size() == 1); }   // z_0 is opened at x, w x and w^-7 x
       protos.push_back(std::move(P));

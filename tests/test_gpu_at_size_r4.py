@@ -236,11 +236,11 @@ def test_eval_polynomial_batch_equals_single_calls_and_oracle(zk):
     2^18 + a ragged tail check at n = 1000, against single calls and the oracle's Horner"""
     h2 = zk.halo2
     lib, capi = zk._capi.lib(), zk._capi
-    for n in (1 << 18, 1000):
+    for n in (1 << 18, 1000, 4096):
         polys = [dev_scalars(n, 1800 + i) for i in range(7)]
         hosts = [as_host(p, n) for p in polys]
         rng = np.random.default_rng(18)
-        B = 300 if n > 1000 else 9
+        B = 300 if n > 4096 else 9 if n == 1000 else 37   # odd batches (9, 37): the pointer table in front of the point / result arrays is padded to keep them 16-byte aligned (ADVICE r4)
         which = [int(rng.integers(0, 7)) for _ in range(B)]
         pts = np.ascontiguousarray(np.stack([h2.fr(int(rng.integers(1, 1 << 62)) * 0x9E3779B97F4A7C15 % R) for _ in range(B)]))
         out = np.zeros((B, 4), dtype=np.uint64)

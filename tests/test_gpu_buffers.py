@@ -133,6 +133,11 @@ def test_batched_transforms_equal_the_serial_loop_one_device(zk):
     for b, w in zip(bufs, want_f):
         assert (b.fr() == w).all()
     h2.best_fft_many([], dom.omega, k)
+    # the same buffer listed twice: the transform is applied twice, one after the other, as the serial loop did (the batched passes must not race on it)
+    twice = h2.DeviceBuffer.from_host(polys[0])
+    h2.best_fft_many([twice, bufs[1], twice], dom.omega, k)
+    assert (twice.fr() == cref.best_fft(want_f[0], dom.omega, k, threads=4)).all() and (bufs[1].fr() == cref.best_fft(want_f[1], dom.omega, k, threads=4)).all()
+    h2.best_fft_many([bufs[1]], dom.omega_inv, k, divisor=dom.ifft_divisor); twice.free()
     for b in bufs:
         b.free()
 
@@ -355,3 +360,37 @@ def test_uploads_allocations_and_frees_race_the_compute_of_other_threads(zk):
     stop.set(); th[0].join()
     assert not errs, errs[:5]
     params.release()
+
+
+def test_narrow_uploads_equal_the_plain_upload(zk):
+    """mi355_buf_upload_packed (1 / 2 / 4 / 8-byte canonical cells expanded to Montgomery words on the device) and mi355_buf_upload_sparse (non-zero cells only, any order)
+    against the plain 32-byte upload of the same column; SURVEY 8d's witness-like mix through the sparse form; offsets into a block; error paths"""
+    h2 = zk.halo2
+    rng = np.random.default_rng(77)
+    lib, check, capi = zk._capi.lib(), zk._capi.check, zk._capi
+    n = (1 << 16) + 77
+    for dt, hi in ((np.uint8, 1 << 8), (np.uint16, 1 << 16), (np.uint32, 1 << 32), (np.uint64, 1 << 64)):
+        vals = rng.integers(0, hi, size=n, dtype=np.uint64).astype(dt)
+        vals[:5] = [0, 1, hi - 1, 2, 0]
+        want = cref.f_from_canonical_vec(cref.FR, np.stack([vals.astype(np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)], axis=1))
+        b = h2.DeviceBuffer.from_packed(vals)
+        assert (b.fr() == want).all()
+        b.free()
+    col = rand_fr(rng, n)
+    u = rng.random(n)
+    col[u < 0.6] = 0
+    small = u >= 0.8
+    col[small] = cref.f_from_canonical_vec(cref.FR, np.stack([rng.integers(0, 256, size=int(small.sum()), dtype=np.uint64)] + [np.zeros(int(small.sum()), np.uint64)] * 3, axis=1))
+    b = h2.DeviceBuffer.from_sparse(col, threads=5)
+    assert (b.fr() == col).all()
+    # pairs in any order, into the middle of a block, and the all-zero column
+    idx, vals = h2.compact_nonzero(col)
+    perm = rng.permutation(idx.shape[0])
+    big = h2.DeviceBuffer(32 * (n + 64))
+    check(lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr() + 32 * 64), n, capi.ptr(np.ascontiguousarray(idx[perm])), capi.ptr(np.ascontiguousarray(vals[perm])), idx.shape[0]))
+    assert (big.fr()[64:] == col).all()
+    check(lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr()), n, None, None, 0))
+    assert not big.fr()[:n].any()
+    assert lib.mi355_buf_upload_packed(C.c_void_p(big.data_ptr()), capi.ptr(col), n, 3) == capi.EBADARG
+    assert lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr()), n, capi.ptr(idx), capi.ptr(vals), n + 1) == capi.EBADARG
+    b.free(); big.free()

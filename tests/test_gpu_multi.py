@@ -167,6 +167,70 @@ def test_three_slots_ragged_length_and_params_file(tmp_path):
         _reinit(pkg, [0, 0], {"MI355_ALLOW_DUP_DEVICES": "1"})
 
 
+def test_eight_slots_the_target_machines_device_count(tmp_path):
+    """D = 8 is what the target node has (BASELINE configs[4]) and what no one-GPU box can bind distinctly: eight duplicate slots run every D-sized array,
+    the 2^14-points-per-device rule, the replica dealing and the per-slot worker threads with real kernels.  Sharded commitments at 2^20 / 2^22
+    incl. slices that cross ALL seven shard boundaries, ragged ones, a basis just under 8 x 2^14 points (stays on fewer devices), window tables per shard, batched
+    commitments, and 20 transforms dealt over the 8 slots."""
+    pkg = ge.load_package()
+    _reinit(pkg, [0] * 8, {"MI355_ALLOW_DUP_DEVICES": "1"})
+    try:
+        h2 = pkg.halo2
+        lib, check = pkg._capi.lib(), pkg._capi.check
+        cnt = C.c_int(); check(lib.mi355_device_count(C.byref(cnt))); assert cnt.value == 8
+        for k in (20, 22):
+            n = 1 << k
+            params = h2.ParamsKZG.setup(k, TAU + 6)
+            sc = dev_scalars(n, 900 + k)
+            want = field_commit(sc, TAU + 6)
+            assert (affine_of(params.commit(sc)) == want).all()
+            run = last_run(pkg)
+            assert run["devices"] == 8 and run["exchange"] == "device_copy", run
+            sc_host = sc.cpu().numpy().view(np.uint64).reshape(n, 4)
+            assert (affine_of(params.commit(sc_host)) == want).all()                 # host scalars: eight worker threads, eight uploads
+            if k == 20:
+                g = params.read_g()
+                # [n/8 - 5, 7n/8 + 5): touches all eight shards, crosses all seven boundaries; and a ragged slice inside shards 2..5
+                for lo, m in ((n // 8 - 5, 6 * n // 8 + 10), (2 * n // 8 + 3, 3 * n // 8 + 1001)):
+                    w = cref.g1_to_affine(cref.best_multiexp(sc_host[:m], g[lo:lo + m], threads=8))
+                    assert (affine_of(h2.best_multiexp(sc_host[:m].copy(), params.g_slice(lo, m))) == w).all()
+                    assert last_run(pkg)["devices"] >= 4
+                params.precompute(lagrange=False)                                      # eight per-shard window tables
+                assert (affine_of(params.commit(sc)) == want).all() and last_run(pkg)["devices"] == 8
+                polys = [dev_scalars(n, 950 + i) for i in range(3)]
+                outs = params.commit_many(polys)
+                for i in range(3):
+                    assert (affine_of(outs[i]) == field_commit(polys[i], TAU + 6)).all()
+            params.release()
+        # just under 8 x 2^14 points: the per-device minimum keeps the basis on fewer than eight devices, results unchanged
+        k = 17
+        n = (1 << k) - 1
+        src = h2.ParamsKZG.setup(k, TAU + 7)
+        g = src.read_g()
+        sc = dev_scalars(n, 77).cpu().numpy().view(np.uint64).reshape(n, 4)
+        want = cref.g1_to_affine(cref.best_multiexp(sc, g[:n], threads=8))
+        assert (affine_of(h2.best_multiexp(sc.copy(), src.g_slice(0, n))) == want).all()
+        assert 1 <= last_run(pkg)["devices"] <= 8
+        src.release()
+        # replicas: 20 independent transforms dealt over the 8 slots (host pointers round-robin, device pointers on their owners) equal the serial loop
+        dom = h2.EvaluationDomain(2, 14)
+        polys = [dev_scalars(1 << 14, 60 + i).cpu().numpy().view(np.uint64).reshape(1 << 14, 4) for i in range(20)]
+        serial = [p.copy() for p in polys]
+        for p in serial:
+            dom.coeff_to_lagrange(p)
+        h2.best_fft_many(polys, dom.omega, 14)
+        for a, b in zip(polys, serial):
+            assert (a == b).all()
+        bufs = [h2.DeviceBuffer.from_host(serial[i], slot=i % 8) for i in range(20)]    # resident on all eight slots
+        h2.best_fft_many(bufs, dom.omega_inv, 14, divisor=dom.ifft_divisor)
+        for i, b in enumerate(bufs):
+            want_i = serial[i].copy(); dom.lagrange_to_coeff(want_i)
+            assert (b.fr() == want_i).all()
+            b.free()
+    finally:
+        _reinit(pkg, [0, 0], {"MI355_ALLOW_DUP_DEVICES": "1"})
+
+
 def test_prefix_view_gets_private_tables_when_much_smaller(zk2):
     """a 2^12 prefix of a 2^20 basis: the inherited table (built for 2^19-point shards) is far from the best width for 2^12 points, so
     mi355_srs_precompute builds a private one for the view; the parent keeps its own."""

@@ -171,3 +171,18 @@ def test_build_is_content_hashed_per_translation_unit():
     closure = {}
     b._closure(os.path.join(b.CSRC, "lib_ntt.hip"), closure)
     assert "ntt29.hpp" in {os.path.basename(p) for p in closure} and "msm.hpp" not in {os.path.basename(p) for p in closure}
+
+
+def test_host_compact_nonzero_needs_no_device():
+    """the host half of the sparse upload (include/mi355zk.h mi355_host_compact_nonzero): indices and values of the non-zero cells in order, any thread count, ragged sizes"""
+    import numpy as np
+    import __graft_entry__ as ge
+    h2 = ge.load_package().halo2
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 1000, (1 << 17) + 13):
+        col = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+        col[rng.random(n) < 0.7] = 0
+        want = np.nonzero(col.any(axis=1))[0].astype(np.uint32)
+        for threads in (1, 3, 16):
+            idx, vals = h2.compact_nonzero(col, threads)
+            assert (idx == want).all() and (vals == col[want]).all()

@@ -194,7 +194,11 @@ GPU_CASES = [
     (4, 10, ["--pk-cosets", "on-the-fly"], {}, {}), (2, 9, ["--no-tables", "--proofs", "3"], {}, {}), (3, 9, ["--pinned-witness", "--upload-threads", "3", "--early-intt", "1", "--tables", "lagrange"], {}, {}),
     (4, 9, ["--devices", "2"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "6"}, {}),
     (2, 8, ["--devices", "3", "--pk-cosets", "on-the-fly"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "6"}, {}),
+    (3, 9, ["--devices", "8"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "6"}, {}),      # the target node's device count: 8 MSM shards, 4 quotient parts on 4 of the slots
+    (0, 8, ["--devices", "8"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "5"}, dict(advice=40, fixed=8, lookups=3, perm_columns=12, degree=9)),   # Q = 8: one quotient part per slot
     (0, 8, [], {}, dict(advice=40, fixed=8, lookups=3, perm_columns=12, degree=5)),
+    (0, 13, ["--sparse-uploads", "--assign-density", "0.3", "--upload-threads", "2"], {}, dict(advice=40, fixed=8, lookups=3, perm_columns=12, degree=5)),   # mostly-zero columns cross PCIe as (index, value) pairs
+    (3, 12, ["--sparse-uploads"], {"MI355_PLAN_PREFIX_MIN": "0"}, {}),                                                                                         # and the plan without common-prefix groups
     (0, 7, [], {}, dict(advice=70, fixed=9, lookups=10, perm_columns=30, degree=9)),
 ]
 
