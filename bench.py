@@ -227,7 +227,7 @@ def main() -> None:
     if single and args.gpus > 1 and not args.no_proof_mix and args.logn == 26:
         # N devices behind ONE prover process: witness columns live round-robin on the devices, commitments take scalars from whichever device
         # holds them (shards of the basis everywhere), the iNTT batch and the coset parts of the quotient run concurrently on different devices
-        # (per-device locks, one host thread per device) -- the layer-4 mix with the other GPUs given work during the NTT phase (DESIGN.md section 6)
+        # (per-device locks, one host thread per device) -- the layer-4 mix with the other GPUs given work during the NTT phase (DESIGN.md section 7)
         l4m = replay_create_proof(4, host_api=False, devices=args.gpus)
         proof_mix = {"c_abi_resident_ms": l4m.get("resident_ms"), "devices": args.gpus, "layer4": l4m}
     zk = ge.load_package()

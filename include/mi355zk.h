@@ -110,7 +110,7 @@ int mi355_host_free(void *host_ptr);
 /* HBM accounting of one bound device (any pointer may be NULL): what HIP reports free / in total, and what this library holds in live
  * mi355_buf blocks, in pooled (freed, reusable) blocks and in its grow-only workspace arena.  A prover keeps the SRS of its degree set
  * [REF bin/src/trace_prover.rs:35-36] AND the proving key's extended-coset polynomials resident: the caller budgets window tables
- * (mi355_srs_precompute: W x the basis) against this figure and stays on the table-free schedule when they do not fit (DESIGN.md 7c).     */
+ * (mi355_srs_precompute: W x the basis) against this figure and stays on the table-free schedule when they do not fit (DESIGN.md section 9).     */
 int mi355_mem_info(int device_slot, uint64_t *free_bytes, uint64_t *total_bytes, uint64_t *live_buf_bytes, uint64_t *pooled_bytes, uint64_t *workspace_bytes);
 
 /* ---- SRS ownership: ParamsKZG { g, g_lagrange } [halo2_proofs poly/kzg/commitment.rs], held for the process

@@ -239,7 +239,7 @@ inline std::set<uint32_t> lagrange_needed(const Protocol &P) {
   for (const auto &l : P.lookups) { std::vector<std::pair<int32_t, int32_t>> r; collect_polys(*l.table, r); collect_polys(*l.input, r); for (const auto &x : r) if (P.is_pre((uint32_t)x.first)) s.insert((uint32_t)x.first); }
   return s;
 }
-// HBM a layer's prover needs (DESIGN.md 7c), from the protocol alone: a dry compile gives the plan's temporaries and the common polynomials
+// HBM a layer's prover needs (DESIGN.md section 9), from the protocol alone: a dry compile gives the plan's temporaries and the common polynomials
 struct PkSizes { uint32_t polys, lagrange, commons, plan_tmps; double base_bytes, coset_bytes, lean_tmp_bytes, working_bytes; };
 inline PkSizes pk_sizes(const Protocol &P) {
   const double per = (double)P.n * 32; PkSizes s;
@@ -260,7 +260,7 @@ inline PkSizes pk_sizes(const Protocol &P) {
 }
 
 
-// ------------------------------------------------------------------------------------------------ what stays resident (DESIGN.md 7c)
+// ------------------------------------------------------------------------------------------------ what stays resident (DESIGN.md section 9)
 // A prover process holds several layers at once (a chunk prover the degrees {20, 24, 25}, a batch prover {21, 26} [REF bin/src/trace_prover.rs:35-36]): the
 // SRS of every degree, every layer's proving key, and the working set of the ONE proof that runs.  Everything resident does not fit 288 GiB; this is the
 // rule of section 7c as code.  What each optional resident buys per proof: window tables of a basis ~8 % of every commitment on it (W x the basis of HBM);

@@ -288,7 +288,7 @@ pub fn fft_many(polys: &mut [&mut [Fr]], k: u32, omega: &Fr, divisor: Option<&Fr
     unsafe { mi355_ntt_fr_batch_host(ptrs.as_ptr(), ptrs.len() as u32, k, omega as *const Fr as *const c_void, d) == MI355_OK }
 }
 /// One term list of `evaluate_h` on one coset part: `dst[i] (+)= sum_j coeffs[j] * prod polys[p][(i + rot) mod n]` in ONE launch.
-/// `terms[j]` = (coefficient, [(index into polys, rotation in elements)]).  At most 16 terms / 48 factors per call (split and accumulate).
+/// `terms[j]` = (coefficient, [(index into polys, rotation in elements)]).  At most 16 terms / 48 factors / 16 factors per term per call (split and accumulate).
 pub fn gate_eval_dev(dst: &mut DevicePoly, polys: &[&DevicePoly], terms: &[(Fr, Vec<(u32, i32)>)], accumulate: bool) -> bool {
     let ptrs: Vec<*const c_void> = polys.iter().map(|p| p.as_ptr()).collect();
     let coeffs: Vec<Fr> = terms.iter().map(|t| t.0).collect();
@@ -299,6 +299,19 @@ pub fn gate_eval_dev(dst: &mut DevicePoly, polys: &[&DevicePoly], terms: &[(Fr, 
     // the kernel reads polys[p][(i + rot) mod n] for every i < n: n must be a power of two and no operand may be shorter than dst
     if n == 0 || !n.is_power_of_two() || polys.iter().any(|p| (p.len() as u64) < n) { return false; }
     if fp.iter().any(|&p| p as usize >= polys.len()) { return false; }
+    unsafe { mi355_fr_gate_eval_dev(dst.as_mut_ptr(), ptrs.as_ptr(), ptrs.len() as u32, coeffs.as_ptr() as *const c_void, term_len.as_ptr(),
+                                    terms.len() as u32, fp.as_ptr(), fr.as_ptr(), n, accumulate as c_int) == MI355_OK }
+}
+
+/// The same with raw device pointers (operands that are slices of a larger block: the quotient pieces inside `h`, or proving-key polynomials held elsewhere).
+/// The caller guarantees every pointer covers `dst.len()` elements.
+pub fn gate_eval_ptrs(dst: &mut DevicePoly, ptrs: &[*const c_void], terms: &[(Fr, Vec<(u32, i32)>)], accumulate: bool) -> bool {
+    let coeffs: Vec<Fr> = terms.iter().map(|t| t.0).collect();
+    let term_len: Vec<u32> = terms.iter().map(|t| t.1.len() as u32).collect();
+    let fp: Vec<u32> = terms.iter().flat_map(|t| t.1.iter().map(|f| f.0)).collect();
+    let fr: Vec<i32> = terms.iter().flat_map(|t| t.1.iter().map(|f| f.1)).collect();
+    let n = dst.len() as u64;
+    if n == 0 || !n.is_power_of_two() || fp.iter().any(|&p| p as usize >= ptrs.len()) { return false; }
     unsafe { mi355_fr_gate_eval_dev(dst.as_mut_ptr(), ptrs.as_ptr(), ptrs.len() as u32, coeffs.as_ptr() as *const c_void, term_len.as_ptr(),
                                     terms.len() as u32, fp.as_ptr(), fr.as_ptr(), n, accumulate as c_int) == MI355_OK }
 }

@@ -134,7 +134,7 @@ int main(int argc, char **argv) {
       if (layer == 4) { EXPECT(cmp.constraints == 10); const auto sets = rotation_sets(P->queries); EXPECT(sets.size() == 4 && sets[2].rots.size() == 3 && sets[2].polys.size() == 1); }   // z_0 is opened at x, w x and w^-7 x
       protos.push_back(std::move(P));
     }
-    // --- the residency rule of DESIGN.md 7c as code: one layer alone keeps its cosets (and below k = 26 both tables); a chunk prover {0, 1, 2} and a batch
+    // --- the residency rule of DESIGN.md section 9 as code: one layer alone keeps its cosets (and below k = 26 both tables); a chunk prover {0, 1, 2} and a batch
     // prover {3, 4} fit 288 GiB only by giving things up, cosets before tables
     auto one = [&](int l) { return plan_residency({protos[l].get()}, 288.0); };
     for (int l : {0, 1, 2, 3, 5}) { const ResidencyPlan R = one(l); EXPECT(R.fits && R.layers[0].cosets_resident && R.layers[0].table_lagrange && R.layers[0].table_coeff); }

@@ -84,7 +84,7 @@ int main(int argc, char **argv) {
       check(mi355_synchronize());
     }
     check(mi355_buf_trim());
-    // ---- HBM plan (DESIGN.md 7c): what must live in HBM for this layer's prover, and which optional residents fit on top
+    // ---- HBM plan (DESIGN.md section 9): what must live in HBM for this layer's prover, and which optional residents fit on top
     uint64_t hbm_free = 0, hbm_total = 0; check(mi355_mem_info(0, &hbm_free, &hbm_total, nullptr, nullptr, nullptr));
     const double GiB = 1024.0 * 1024 * 1024;
     const PkSizes sz = pk_sizes(P);

@@ -170,7 +170,7 @@ if gf and gw and gs and rec:
          f"| VALU instructions (SQ_INSTS_VALU x 64 lanes) | {insts:.4g} = **{insts / tot['factor_rows']:.0f} per factor-row** |",
          f"| VALU busy (SQ_ACTIVE_INST_VALU x 4 / (time x 1.93 GHz x 1024 SIMDs)) | **{active * 4 / (ms_s * 1e-3 * 1.93e9 * CUS * 4):.2f}** |", ""]
     g += ["Reading: the kernel moves about a third of the HBM roof and keeps the vector ALUs busy for most of its issue slots at ~200 instructions per factor (the operand's 8x32 -> 9x29 "
-          "re-slice plus one 9x29 Montgomery product): it sits between the two roofs, closer to the ALU one, as DESIGN.md section 5c says.  The levers are therefore (i) fewer factor-rows for "
+          "re-slice plus one 9x29 Montgomery product): it sits between the two roofs, closer to the ALU one, as DESIGN.md section 5 says.  The levers are therefore (i) fewer factor-rows for "
           "the same expression and (ii) fewer bytes per launch; see the A/B below.\n"]
     ab = os.path.join(OUT, f"{TAG}_job3_ab.json")
     if os.path.exists(ab):
