@@ -222,7 +222,8 @@ inline std::unique_ptr<Circuit> build_circuit(const Protocol &P, const CircuitOp
       const int ja = pos_of_adv(vert[gi]), jb = pos_of_adv(vert[(gi + 1) % G]);
       if (ja >= 0 && jb >= 0) for (uint64_t b = 0; b < Bact; b += 3) C->pairs.push_back({(uint32_t)ja, 4 * b, (uint32_t)jb, 4 * (Bact - 1 - b) + 2});                  // input 0 of block b <-> input 2 of a block of the next column
     }
-    for (size_t fi = 0; fi < fixed_perm.size(); fi++) { const int jb = pos_of_adv(vert[fi % G]); if (jb >= 0) for (uint64_t r = 0; r < NC && 3 * r + 1 < Bact; r++) C->pairs.push_back({fixed_perm[fi], r, (uint32_t)jb, 4 * (3 * r + 1)}); }   // a constant feeds a gate input
+    const uint64_t FS = (fixed_perm.size() + G - 1) / G;   // fixed columns that share one gate column take interleaved blocks: no gate input is fed twice
+    for (size_t fi = 0; fi < fixed_perm.size(); fi++) { const int jb = pos_of_adv(vert[fi % G]); if (jb >= 0) for (uint64_t r = 0; r < NC && 3 * (r * FS + fi / G) + 1 < Bact; r++) C->pairs.push_back({fixed_perm[fi], r, (uint32_t)jb, 4 * (3 * (r * FS + fi / G) + 1)}); }   // a constant feeds a gate input
     if (inst_pos >= 0) { const int jb = pos_of_adv(vert[G - 1]); if (jb >= 0) for (uint64_t r = 0; r < NI && 3 * r + 2 < Bact; r++) C->pairs.push_back({(uint32_t)inst_pos, r, (uint32_t)jb, 4 * (3 * r + 2)}); }                                  // a public input feeds a gate input
     uint32_t li = 0;
     for (uint32_t a = 0; a < A; a++) if (role[a].kind == LOOKUP_IN && li < G) {   // a range-checked cell is copied into the middle input of a gate
