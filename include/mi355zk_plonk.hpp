@@ -358,12 +358,13 @@ inline std::unique_ptr<ProvingKey> keygen(const Protocol &P, const Circuit &C, u
 
 // ------------------------------------------------------------------------------------------------ create_proof
 struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 1; int early_intt = -1 /* -1: by column count */;
-                      bool sparse_uploads = false /* columns that are at least half zeros cross PCIe as (index, value) pairs */; };
+                      bool sparse_uploads = false /* columns that are at least half zeros cross PCIe as (index, value) pairs */;
+                      bool packed_multiplicities = false /* the lookup multiplicities cross PCIe as the 4-byte counts they are (mi355_buf_upload_packed); their blinding rows follow as 32-byte words */; };
 struct ProofResult {
   std::vector<uint8_t> proof;
   double step_ms[11] = {0}; double total_ms = 0;
   uint64_t peak_hbm_bytes = 0, hbm_total_bytes = 0;
-  uint64_t sparse_columns = 0, witness_link_bytes = 0;
+  uint64_t sparse_columns = 0, packed_columns = 0, witness_link_bytes = 0;
   uint32_t msm = 0, intt = 0, coset_ntt = 0, gate_launches = 0, evals = 0, plan_launches = 0, plan_terms = 0, plan_tmps = 0, plan_constraints = 0, plan_prefix_groups = 0, rotation_sets = 0;
 };
 
@@ -423,7 +424,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   for (const auto &l : P.lookups) poly[l.phi];
   std::mutex mu; std::condition_variable cv; std::vector<char> arrived(uploads.size(), 0); std::string upload_error;
   const size_t UT = (size_t)std::max(1, std::min<int>(opt.upload_threads, (int)uploads.size()));
-  std::atomic<uint64_t> sparse_cols{0}, link_bytes{0};
+  std::atomic<uint64_t> sparse_cols{0}, packed_cols{0}, link_bytes{0};
   auto upload_worker = [&](size_t first) {
     try {
       std::vector<uint32_t> sidx; std::vector<Fr> svals;   // this worker's scratch for the sparse form
@@ -435,7 +436,14 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
           sidx.resize(len); svals.resize(len);
           check(mi355_host_compact_nonzero(uploads[i].second->data(), len, sidx.data(), svals.data(), &nz, std::max(1, opt.threads / (int)UT)));
         }
-        if (2 * nz <= len) { check(mi355_buf_upload_sparse(d.p, len, sidx.data(), svals.data(), nz)); sparse_cols++; link_bytes += nz * 36; }
+        const bool is_m = uploads[i].first >= P.phase0[1] && uploads[i].first < P.phase0[1] + NL;
+        if (opt.packed_multiplicities && is_m && wit.m_counts.size() == NL) {
+          // a column whose KIND bounds its cells: counts below 2^32 on the rows up to l_last, then the prover's blinding values
+          check(mi355_buf_upload_packed(d.p, wit.m_counts[uploads[i].first - P.phase0[1]].data(), len, 4));
+          if (P.blind) check(mi355_buf_upload(d.at(u + 1), uploads[i].second->data() + (u + 1), P.blind * 32));
+          packed_cols++; link_bytes += len * 4 + P.blind * 32;
+        }
+        else if (2 * nz <= len) { check(mi355_buf_upload_sparse(d.p, len, sidx.data(), svals.data(), nz)); sparse_cols++; link_bytes += nz * 36; }
         else { check(mi355_buf_upload(d.p, uploads[i].second->data(), len * 32)); link_bytes += len * 32; }
         { std::lock_guard<std::mutex> lk(mu); poly.at(uploads[i].first) = std::move(d); arrived[i] = 1; }
         cv.notify_all();
@@ -702,7 +710,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   check(mi355_synchronize());
   lap(10);
   R.total_ms = ms_since(t_start);
-  R.proof = std::move(T.proof); R.sparse_columns = sparse_cols.load(); R.witness_link_bytes = link_bytes.load();
+  R.proof = std::move(T.proof); R.sparse_columns = sparse_cols.load(); R.packed_columns = packed_cols.load(); R.witness_link_bytes = link_bytes.load();
   { uint64_t fr_ = 0, tot = 0; check(mi355_mem_info(0, &fr_, &tot, nullptr, nullptr, nullptr)); R.peak_hbm_bytes = tot - fr_; R.hbm_total_bytes = tot; }
   return R;
 }

@@ -35,6 +35,7 @@ struct Circuit {
   std::vector<Column> pre;            // Lagrange values of the preprocessed polynomials; the sigma columns are produced on demand (sigma_column)
   std::vector<Fr> instances;
   std::vector<Column> advice, m;
+  std::vector<std::vector<uint32_t>> m_counts;   // the multiplicities as the integers they are (rows below the l_last row; the blinding rows of `m` are random field elements)
   std::vector<std::vector<Fr>> z_blind, phi_blind;
   Column random_poly;                 // coefficients
   std::vector<CopyPair> pairs; std::vector<PermColumn> pcols; std::vector<Fr> omega_pow;
@@ -268,6 +269,7 @@ inline std::unique_ptr<Circuit> build_circuit(const Protocol &P, const CircuitOp
     for (uint64_t i = 0; i < u; i++) cnt[ix[i]]++;       // rows a selector switches off read the all-zero tuple = table row 0, which idx holds there
     Column &mc = C->m[l];
     C->parallel(table_rows, [&](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) mc[i] = fr_small(cnt[i]); });
+    cnt.resize(n, 0); C->m_counts.push_back(std::move(cnt));
     Rng g(top.next()); for (uint64_t r = u + 1; r < n; r++) mc[r] = g.uniform();
   }
   // ---- whatever preprocessed polynomial nothing assigned stays all-zero (materialised), the permutation's bookkeeping, the prover's randomness

@@ -25,7 +25,7 @@ static void write_file(const std::string &path, const void *p, size_t bytes) { s
 int main(int argc, char **argv) {
   std::string protocol_path, out_dir, tables = "auto", pk_mode = "auto";
   int devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2, upload_threads = 1, early_intt = -1;
-  bool host_api = false, builder_only = false, dump_inputs = false, pinned_witness = false, corrupt = false, sparse_uploads = false; uint64_t seed = 1; double fill = 0.9, assign_density = 1.0;
+  bool host_api = false, builder_only = false, dump_inputs = false, pinned_witness = false, corrupt = false, sparse_uploads = false, packed_m = true; uint64_t seed = 1; double fill = 0.9, assign_density = 1.0;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto next = [&]() -> long { return i + 1 < argc ? std::atol(argv[++i]) : 0; };
@@ -35,7 +35,7 @@ int main(int argc, char **argv) {
     else if (a == "--no-tables") tables = "off"; else if (a == "--tables") tables = nexts(); else if (a == "--pk-cosets") pk_mode = nexts(); else if (a == "--proofs") proofs = (int)next();
     else if (a == "--upload-threads") upload_threads = (int)next(); else if (a == "--early-intt") early_intt = (int)next(); else if (a == "--pinned-witness") pinned_witness = true;
     else if (a == "--seed") seed = (uint64_t)next(); else if (a == "--fill") fill = std::atof(nexts().c_str()); else if (a == "--corrupt-witness") corrupt = true;
-    else if (a == "--sparse-uploads") sparse_uploads = true; else if (a == "--assign-density") assign_density = std::atof(nexts().c_str());
+    else if (a == "--sparse-uploads") sparse_uploads = true; else if (a == "--packed-multiplicities") packed_m = true; else if (a == "--no-packed-multiplicities") packed_m = false; else if (a == "--assign-density") assign_density = std::atof(nexts().c_str());
     else if (a == "--transcript-selftest") {   // host only: a fixed byte stream through the Blake2b transcript (tests compare with hashlib)
       Transcript T; T.common_scalar(fr_u64(5)); const Fr c1 = fr_to_canonical(T.squeeze_challenge());
       G1 g{}; { const Fr one = fr_one(); (void)one; mi355zk::halo2::G1Affine gen{}; zk::fe_t x = zk::Fq::one(), y = zk::Fq::add(zk::Fq::one(), zk::Fq::one()); std::memcpy(gen.data(), &x, 32); std::memcpy(gen.data() + 4, &y, 32); std::memcpy(g.data(), gen.data(), 64); std::memcpy(g.data() + 8, &x, 32); }
@@ -47,7 +47,7 @@ int main(int argc, char **argv) {
       return 0;
     }
     else { std::printf("usage: %s --protocol FILE --out DIR [--builder-only] [--dump-inputs] [--devices D] [--threads T] [--proofs N] [--upload-threads U] [--early-intt 0|1] [--pinned-witness]\n"
-                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--assign-density D] | --transcript-selftest\n", argv[0]); return 1; }
+                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--no-packed-multiplicities] [--assign-density D] | --transcript-selftest\n", argv[0]); return 1; }
   }
   if (protocol_path.empty() || out_dir.empty()) { std::printf("--protocol and --out are required\n"); return 1; }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;
@@ -115,7 +115,7 @@ int main(int argc, char **argv) {
     if (devices > 1 && tables == "auto") n_tables = 2;
     if (n_tables >= 1 && mi355_srs_precompute(hl, 0, 0) != MI355_OK) { std::printf("window tables for g_lagrange did not fit (%s): table-free schedule\n", mi355_last_error()); n_tables = 0; }
     if (n_tables >= 2 && mi355_srs_precompute(hg, 0, 0) != MI355_OK) { std::printf("window tables for g did not fit (%s): Lagrange basis only\n", mi355_last_error()); n_tables = 1; }
-    ProofOptions opt; opt.devices = devices; opt.threads = threads; opt.upload_threads = upload_threads; opt.early_intt = early_intt; opt.sparse_uploads = sparse_uploads;
+    ProofOptions opt; opt.devices = devices; opt.threads = threads; opt.upload_threads = upload_threads; opt.early_intt = early_intt; opt.sparse_uploads = sparse_uploads; opt.packed_multiplicities = packed_m;
     // ---- the proofs: a prover process runs proof after proof; the first one grows the workspace arena and the buffer pool, the last one is reported
     ProofResult R; double first_ms = 0;
     for (int it = 0; it < proofs; it++) { R = create_proof(hg, hl, *pk, *C, opt); if (it == 0) first_ms = R.total_ms; }
@@ -153,7 +153,7 @@ int main(int argc, char **argv) {
       "\"circuit\": {\"copy_pairs\": %zu, \"gates_active\": %llu, \"lookup_rows\": %llu, \"build_ms\": %.1f, \"keygen_ms\": %.1f}, "
       "\"plan\": {\"constraints\": %u, \"launches_per_part\": %u, \"terms\": %u, \"temporaries\": %u, \"prefix_groups\": %u, \"common_polynomials\": %zu}, "
       "\"gate_eval_process_totals\": {\"launches\": %llu, \"algorithmic_bytes\": %llu, \"factor_rows\": %llu, \"term_rows\": %llu}, "
-      "\"window_tables\": %s, \"window_table_bases\": %d, \"pk_cosets\": \"%s\", \"upload_threads\": %d, \"pinned_witness\": %s, \"sparse_uploads\": {\"on\": %s, \"columns\": %llu, \"witness_link_gib\": %.2f, \"assign_density\": %.2f}, "
+      "\"window_tables\": %s, \"window_table_bases\": %d, \"pk_cosets\": \"%s\", \"upload_threads\": %d, \"pinned_witness\": %s, \"sparse_uploads\": {\"on\": %s, \"columns\": %llu, \"packed_columns\": %llu, \"witness_link_gib\": %.2f, \"assign_density\": %.2f}, "
       "\"msm\": %u, \"intt\": %u, \"coset_ntt\": %u, \"gate_launches\": %u, \"evals\": %u, \"rotation_sets\": %u, \"proof_bytes\": %zu, \"resident_ms\": %.3f, \"first_proof_ms\": %.3f, \"proofs\": %d, "
       "\"host_api_ms\": %.3f, \"host_api_fft_ms\": %.3f, \"host_api_fft_batched_ms\": %.3f, "
       "\"step_ms\": {\"1_instance\": %.2f, \"2_3_advice_lookup_commits\": %.2f, \"4_products\": %.2f, \"5_random\": %.2f, \"6_to_coeff\": %.2f, \"7_quotient\": %.2f, \"8_commit_h\": %.2f, \"9_evals\": %.2f, \"10_shplonk\": %.2f}, "
@@ -163,7 +163,7 @@ int main(int argc, char **argv) {
       C->pairs.size(), (unsigned long long)C->gates_active, (unsigned long long)C->lookup_rows, build_ms, keygen_ms,
       R.plan_constraints, R.plan_launches, R.plan_terms, R.plan_tmps, R.plan_prefix_groups, pk->commons.defs.size(),
       (unsigned long long)gate_stats().launches.load(), (unsigned long long)gate_stats().bytes.load(), (unsigned long long)gate_stats().factor_rows.load(), (unsigned long long)gate_stats().term_rows.load(),
-      n_tables ? "true" : "false", n_tables, resident ? "resident" : "on-the-fly", upload_threads, pinned_witness ? "true" : "false", sparse_uploads ? "true" : "false", (unsigned long long)R.sparse_columns, R.witness_link_bytes / GiB, assign_density,
+      n_tables ? "true" : "false", n_tables, resident ? "resident" : "on-the-fly", upload_threads, pinned_witness ? "true" : "false", sparse_uploads ? "true" : "false", (unsigned long long)R.sparse_columns, (unsigned long long)R.packed_columns, R.witness_link_bytes / GiB, assign_density,
       R.msm, R.intt, R.coset_ntt, R.gate_launches, R.evals, R.rotation_sets, R.proof.size(), R.total_ms, first_ms, proofs,
       host_ms, host_fft_ms, host_fft_batched_ms,
       R.step_ms[1], R.step_ms[2], R.step_ms[4], R.step_ms[5], R.step_ms[6], R.step_ms[7], R.step_ms[8], R.step_ms[9], R.step_ms[10],

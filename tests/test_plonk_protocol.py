@@ -198,7 +198,8 @@ GPU_CASES = [
     (0, 8, ["--devices", "8"], {"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "5"}, dict(advice=40, fixed=8, lookups=3, perm_columns=12, degree=9)),   # Q = 8: one quotient part per slot
     (0, 8, [], {}, dict(advice=40, fixed=8, lookups=3, perm_columns=12, degree=5)),
     (0, 13, ["--sparse-uploads", "--assign-density", "0.3", "--upload-threads", "2"], {}, dict(advice=40, fixed=8, lookups=3, perm_columns=12, degree=5)),   # mostly-zero columns cross PCIe as (index, value) pairs
-    (3, 12, ["--sparse-uploads"], {"MI355_PLAN_PREFIX_MIN": "0"}, {}),                                                                                         # and the plan without common-prefix groups
+    (3, 12, ["--sparse-uploads"], {"MI355_PLAN_PREFIX_MIN": "0"}, {}),
+    (4, 11, ["--no-packed-multiplicities"], {}, {}),                                                                                                           # by default the multiplicity columns cross PCIe as 4-byte counts + their blinding rows; here as 32-byte words                                                                                         # and the plan without common-prefix groups
     (0, 7, [], {}, dict(advice=70, fixed=9, lookups=10, perm_columns=30, degree=9)),
 ]
 

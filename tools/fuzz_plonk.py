@@ -38,6 +38,7 @@ for it in range(iters):
     if rng.random() < 0.3: args += ["--pk-cosets", "on-the-fly"]
     if rng.random() < 0.3: args += ["--assign-density", str(rng.choice((0.2, 0.6)))]
     if rng.random() < 0.3 and k >= 9: args += ["--sparse-uploads"]
+    if rng.random() < 0.3: args += ["--no-packed-multiplicities"]
     if rng.random() < 0.3: args += ["--upload-threads", "3", "--early-intt", "1"]
     if rng.random() < 0.25:
         args += ["--devices", str(rng.choice((2, 3, 8)))]; env.update({"MI355_ALLOW_DUP_DEVICES": "1", "MI355_SHARD_MIN_LOG": "5"})
