@@ -183,7 +183,8 @@ struct Protocol {
   bool is_instance(uint32_t p) const { return p >= inst0 && p < wit0; }
 
   void load(const std::string &path) {
-    const json::Value root = json::parse_file(path);
+    const json::Value file = json::parse_file(path);
+    const json::Value &root = file.find("protocol") ? file.at("protocol") : file;   // the golden fixtures wrap the protocol with their provenance
     const json::Value &d = root.at("domain");
     k = (uint32_t)d.at("k").u; n = uint64_t(1) << k;
     omega = fr_from_json(d.at("gen")); omega_inv = fr_from_json(d.at("gen_inv")); n_inv = fr_from_json(d.at("n_inv"));

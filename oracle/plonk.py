@@ -61,6 +61,7 @@ def inv(x):
 # ------------------------------------------------------------------------------------------------ protocol
 class Protocol:
     def __init__(self, d: dict):
+        d = d.get("protocol", d)                    # the golden fixtures wrap the protocol with their provenance
         self.d = d
         self.k = d["domain"]["k"]
         self.n = 1 << self.k

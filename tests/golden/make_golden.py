@@ -63,9 +63,12 @@ l2 = json.loads(rd("release-v0.13.1/chunk.protocol", "r"))
 assert l2 == json.loads(rd("integration/tests/test_data/chunk_chunk_0.protocol", "r")) == json.loads(base64.b64decode(cp["protocol"]))
 l4 = json.loads(base64.b64decode(bp["protocol"]))
 assert l4 == json.loads(base64.b64decode(json.loads(rd("integration/tests/test_data/full_proof_batch_agg_2.json", "r"))["protocol"]))
-for name, pr in (("protocol_layer2.json", l2), ("protocol_layer4.json", l4)):
+for name, pr, src in (("protocol_layer2.json", l2, "release-v0.13.1/chunk.protocol == integration/tests/test_data/chunk_chunk_0.protocol == base64 `protocol` of integration/tests/test_data/full_proof_1.json"),
+                      ("protocol_layer4.json", l4, "base64 `protocol` of integration/tests/test_data/full_proof_batch_agg_1.json (== full_proof_batch_agg_2.json)")):
     with open(os.path.join(HERE, name), "w") as f:
-        json.dump(pr, f, separators=(",", ":"))
+        json.dump({"_generated_by": "tests/golden/make_golden.py", "_source": "scroll-tech/scroll-prover: " + src,
+                   "_what": "GOLDEN VECTOR (data fixture of the reference, not source code): the snark-verifier PlonkProtocol the reference ships with this proof, values untouched",
+                   "protocol": pr}, f, separators=(",", ":"))
     print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
 with open(os.path.join(HERE, "layer_configs.json"), "w") as f:
     json.dump({str(i): json.loads(rd(f"integration/configs/layer{i}.config", "r")) for i in range(1, 7)}, f, indent=1)

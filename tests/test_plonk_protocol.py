@@ -29,7 +29,7 @@ TAU0 = 0x5343524F4C4C0001
 
 
 def fixture(layer):
-    return json.load(open(os.path.join(GOLD, f"protocol_layer{layer}.json")))
+    return json.load(open(os.path.join(GOLD, f"protocol_layer{layer}.json")))["protocol"]
 
 
 def exe():
