@@ -88,6 +88,22 @@ def test_released_proofs_parse_under_their_protocols():
         assert T.pos == len(proof)
 
 
+def test_released_bundle_evm_proof_parses_under_the_generated_layer6_protocol():
+    """layer 6 has no protocol fixture; the halo2-base rule gives it layer 2's system at k = 26.  The released bundle proof [REF release-v0.13.1/proof.data] (EVM layout:
+    32-byte big-endian words, points uncompressed) agrees word for word with that shape: 12 accumulator limbs below 2^88, then exactly num_witness + Q = 9 point pairs ON THE
+    CURVE, 17 canonical scalars, and the two SHPLONK points -- a shape check of the generated protocol against a proof the reference really emitted"""
+    p6 = plonk.Protocol(protocols.layer_protocol(6))
+    b = bytes.fromhex(KAT["bundle_proof_data"])
+    w = [int.from_bytes(b[32 * i:32 * i + 32], "big") for i in range(len(b) // 32)]
+    on_curve = lambda x, y: x < pyref.P_MOD and y < pyref.P_MOD and (y * y - x * x * x - 3) % pyref.P_MOD == 0
+    nc, ne = sum(p6.num_witness) + p6.Q, len(p6.evaluations)
+    assert len(w) == 12 + 2 * nc + ne + 4 and all(v < (1 << 88) for v in w[:12])
+    assert all(on_curve(w[12 + 2 * i], w[13 + 2 * i]) for i in range(nc))
+    assert all(v < pyref.R_MOD for v in w[12 + 2 * nc:12 + 2 * nc + ne])
+    assert not any(on_curve(w[i], w[i + 1]) for i in range(12 + 2 * nc, 12 + 2 * nc + ne - 1))        # no point hides among the evaluations: the split is where the protocol says
+    assert on_curve(w[-4], w[-3]) and on_curve(w[-2], w[-1])
+
+
 def test_recognised_structure_of_the_fixtures():
     p2, p4 = plonk.Protocol(fixture(2)), plonk.Protocol(fixture(4))
     assert (p2.last, p2.blind, p2.Q, len(p2.gates), len(p2.perm), len(p2.lookups)) == (-7, 6, 4, 1, 1, 1)
