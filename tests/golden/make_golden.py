@@ -63,11 +63,37 @@ l2 = json.loads(rd("release-v0.13.1/chunk.protocol", "r"))
 assert l2 == json.loads(rd("integration/tests/test_data/chunk_chunk_0.protocol", "r")) == json.loads(base64.b64decode(cp["protocol"]))
 l4 = json.loads(base64.b64decode(bp["protocol"]))
 assert l4 == json.loads(base64.b64decode(json.loads(rd("integration/tests/test_data/full_proof_batch_agg_2.json", "r"))["protocol"]))
+# every chunk proof the reference stores as an input of its batch tests carries this same constraint system, and reads as 9 points | 17 scalars | 2 points under it
+import glob
+P_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def parses(proof: bytes, n_points: int, n_scalars: int) -> bool:
+    def point(b):
+        v = int.from_bytes(b, "little"); x = v & ((1 << 254) - 1)
+        y2 = (x * x * x + 3) % P_MOD; y = pow(y2, (P_MOD + 1) // 4, P_MOD)
+        return x < P_MOD and y * y % P_MOD == y2
+    words = [proof[32 * i:32 * i + 32] for i in range(len(proof) // 32)]
+    return (len(words) == n_points + n_scalars + 2 and all(point(w) for w in words[:n_points]) and all(int.from_bytes(w, "little") < R_MOD for w in words[n_points:n_points + n_scalars])
+            and all(point(w) for w in words[-2:]))
+
+
+same_system = 0
+for path in ["integration/tests/test_data/full_proof_batch_prove_1.json", "integration/tests/test_data/batch-task-no-encode.json", "integration/tests/test_data/batch-task-with-blob.json",
+             "integration/tests/test_data/batch-task-with-blob-raw.json"] + sorted(os.path.relpath(p, REF) for p in glob.glob(os.path.join(REF, "integration/tests/test_data/batch_tasks/*.json"))):
+    for c in json.loads(rd(path, "r")).get("chunk_proofs", []):
+        pr_ = json.loads(base64.b64decode(c["protocol"]))
+        assert pr_["quotient"] == l2["quotient"] and pr_["queries"] == l2["queries"] and pr_["evaluations"] == l2["evaluations"], path
+        assert parses(base64.b64decode(c["proof"]), 9, 17), path
+        same_system += 1
+print("chunk proofs in the reference's test data with this constraint system, each parsing as 9 points | 17 scalars | 2 points:", same_system)
 for name, pr, src in (("protocol_layer2.json", l2, "release-v0.13.1/chunk.protocol == integration/tests/test_data/chunk_chunk_0.protocol == base64 `protocol` of integration/tests/test_data/full_proof_1.json"),
                       ("protocol_layer4.json", l4, "base64 `protocol` of integration/tests/test_data/full_proof_batch_agg_1.json (== full_proof_batch_agg_2.json)")):
     with open(os.path.join(HERE, name), "w") as f:
         json.dump({"_generated_by": "tests/golden/make_golden.py", "_source": "scroll-tech/scroll-prover: " + src,
                    "_what": "GOLDEN VECTOR (data fixture of the reference, not source code): the snark-verifier PlonkProtocol the reference ships with this proof, values untouched",
+                   "_stored_proofs_with_this_constraint_system": same_system if name == "protocol_layer2.json" else 2,
                    "protocol": pr}, f, separators=(",", ":"))
     print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
 with open(os.path.join(HERE, "layer_configs.json"), "w") as f:
