@@ -126,6 +126,32 @@ def replay_create_proof(layer: int, k: int | None = None, host_api: bool = False
     return out
 
 
+def prover_process(layers, timeout: int = 2400):
+    """ONE process holding the SRS, proving keys and witnesses of several layers under plan_residency (tests/cpp/test_prover_process.cpp), their proofs back to back, each
+    verified here from its bytes: the shape of a ChunkProver / BatchProver process [REF integration/src/prove.rs:11-21,30-43]"""
+    zk = ge.load_package()
+    from oracle import plonk
+    rec = zk.replay.run_process(list(layers), timeout=timeout)
+    if not rec.get("ok"):
+        return {"ok": False, "layers": list(layers), "error": rec.get("error")}
+    ok = True
+    for lay in rec["layers"]:
+        pr = plonk.Protocol(json.load(open(lay["protocol_path"])))
+        inst = plonk.mont_to_ints(np.frombuffer(lay["instances"], dtype=np.uint64).reshape(-1, 4))
+        try:
+            lay["verified"] = bool(plonk.verify(pr, lay["vk"], inst, lay["proof"], int(lay["tau"], 16))["ok"])
+        except AssertionError:
+            lay["verified"] = False
+        ok = ok and lay["verified"]
+        for key in ("proof", "vk", "instances", "protocol_path"):
+            lay.pop(key, None)
+    import shutil
+    shutil.rmtree(rec["out_dir"], ignore_errors=True)
+    out = {k_: v for k_, v in rec.items() if k_ not in ("out_dir", "protocol_paths", "returncode")}
+    out["ok"] = out["every_proof_verified"] = ok
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +167,7 @@ def main() -> None:
     ap.add_argument("--no-precompute", action="store_true", help="skip the registration-time window tables (mi355_srs_precompute)")
     ap.add_argument("--no-proof-mix", action="store_true", help="skip the compiled create_proof replays (all seven layers from their PlonkProtocols, each proof verified from its bytes)")
     ap.add_argument("--proxy-chunk-proof", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--prover-process", action="store_true", help="additionally run layers 0 + 1 + 2 inside ONE process (tests/cpp/test_prover_process.cpp: three SRS degrees, three proving keys under plan_residency, proofs back to back; ~80 s)")
     ap.add_argument("--single-process", action="store_true", help="N GPUs behind ONE process (mi355_init_multi: shards, worker threads, ncclAllGather inside the library) instead of one rank per GPU")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer leg (mi355_msm_g1_host: scalars cross PCIe inside the call; reported next to, never as, the headline value)")
     ap.add_argument("--no-table-free", action="store_true", help="skip the leg without window tables")
@@ -223,6 +250,8 @@ def main() -> None:
                      "batch_proof_proxy": proxy("layer 3 (k = 21, halo2-base rule on layer3.config: 93 advice, 8 lookups, 32 grand products) + layer 4 (k = 26, the reference's batch protocol): gen_batch_proof", (3, 4)),
                      "bundle_proof_proxy": proxy("layer 5 (k = 21) + layer 6 (k = 26, layer 2's constraint system at the bundle's degree): gen_bundle_proof", (5, 6)),
                      "every_proof_verified": ok_all,
+                     # optional (--prover-process): the chunk prover as ONE process -- the three layers' SRS, proving keys and witnesses resident together under the HBM plan
+                     "chunk_prover_process": prover_process((0, 1, 2)) if args.prover_process else None,
                      "excludes": "witness synthesis of the real circuits (the circuit instances are built to satisfy each protocol), the Poseidon / Keccak transcripts (halo2's Blake2b transcript stands in)"}
     if single and args.gpus > 1 and not args.no_proof_mix and args.logn == 26:
         # N devices behind ONE prover process: witness columns live round-robin on the devices, commitments take scalars from whichever device
@@ -659,6 +688,10 @@ def main() -> None:
             cfg["proxies"] = "create_proof per layer from its PlonkProtocol (layers 2 / 4: the reference's own), proof verified from its bytes: [chunk = L0 + L1 + L2, batch = L3 + L4, bundle = L5 + L6]"
             cfg["layer_ms"] = {str(x): (proof_mix[p_][f"layer{x}"].get("resident_ms")) for p_, xs in (("chunk_proof_proxy", (0, 1, 2)), ("batch_proof_proxy", (3, 4)), ("bundle_proof_proxy", (5, 6))) for x in xs}
             checks.append(bool(proof_mix["every_proof_verified"]))
+            cpp_ = proof_mix.get("chunk_prover_process")
+            if cpp_ is not None:
+                cfg["chunk_prover_process_ms"] = cpp_.get("round_ms"); cfg["chunk_prover_process_peak_hbm_gib"] = (cpp_.get("hbm") or {}).get("peak_used_gib")
+                checks.append(bool(cpp_.get("ok")))
         cfg["all_checks"] = all(bool(c) for c in checks)
         print(json.dumps(line), flush=True)
     if world > 1:

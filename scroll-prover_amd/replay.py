@@ -53,3 +53,32 @@ def run(layer: int, k: int | None = None, out_dir: str | None = None, args=(), e
             with open(p, "rb") as f:
                 rec[name] = f.read()
     return rec
+
+
+def run_process(layers, ks=None, out_dir: str | None = None, args=(), env=None, timeout: int = 2400, shapes=None) -> dict:
+    """tests/cpp/test_prover_process.cpp: ONE process holding the SRS, proving keys and witnesses of several layers (a chunk prover {0, 1, 2}, a batch prover {3, 4}), under the HBM
+    plan of plan_residency, proofs back to back.  Returns the program's record with, per layer, the bytes it wrote."""
+    import __graft_entry__ as ge
+    out_dir = out_dir or tempfile.mkdtemp(prefix="mi355_prover_process_")
+    os.makedirs(out_dir, exist_ok=True)
+    protos = []
+    for i, layer in enumerate(layers):
+        fx = os.path.join(ROOT, "tests", "golden", f"protocol_layer{layer}.json")
+        k = (ks or {}).get(layer)
+        protos.append(fx if (os.path.exists(fx) and not k) else write_protocol(layer, out_dir, k, None, **((shapes or {}).get(layer) or {})))
+    cmd = [ge.build_cpp("test_prover_process"), "--out", out_dir] + [x for p in protos for x in ("--protocol", p)] + list(args)
+    e = dict(os.environ); e.update(env or {})
+    t0 = time.perf_counter()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e)
+    line = next((l for l in out.stdout.splitlines() if l.startswith("{")), None)
+    rec = {"ok": False, "returncode": out.returncode, "out_dir": out_dir, "protocol_paths": protos, "process_wall_s": time.perf_counter() - t0}
+    if out.returncode != 0 or line is None:
+        rec["error"] = (out.stdout + out.stderr)[-1200:]
+        return rec
+    rec.update(json.loads(line))
+    for i, lay in enumerate(rec["layers"]):
+        for name in ("proof", "vk", "instances"):
+            with open(os.path.join(out_dir, str(i), name + ".bin"), "rb") as f:
+                lay[name] = f.read()
+        lay["protocol_path"] = protos[i]
+    return rec

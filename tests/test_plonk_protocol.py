@@ -268,3 +268,17 @@ def test_gpu_full_size_many_column_layers_verify(tmp_path, layer):
     """layer 3 (k = 21, 93 advice columns, 32 grand products) and the layer-0 stand-in (k = 20, 800 advice columns, degree 9) at full size"""
     rec = zk.replay.run(layer, out_dir=str(tmp_path), timeout=1500)
     verify_record(rec, layer)
+
+
+@pytest.mark.gpu
+def test_gpu_one_prover_process_holds_three_layers(tmp_path):
+    """a chunk prover's shape [REF integration/src/prove.rs:30-43]: ONE process with the SRS of three degrees, the proving keys and witnesses of layers 0, 1, 2 resident under
+    plan_residency, the three proofs back to back, two rounds; every proof verified from its bytes"""
+    rec = zk.replay.run_process([0, 1, 2], ks={0: 9, 1: 11, 2: 12}, out_dir=str(tmp_path), shapes={0: dict(advice=40, fixed=8, lookups=3, perm_columns=12, degree=9)})
+    assert rec.get("ok"), rec.get("error")
+    assert rec["plan"]["fits"] and len(rec["layers"]) == 3 and rec["rounds"] == 2
+    for lay in rec["layers"]:
+        pr = plonk.Protocol(json.load(open(lay["protocol_path"])))
+        inst = plonk.mont_to_ints(np.frombuffer(lay["instances"], dtype=np.uint64).reshape(-1, 4))
+        assert plonk.verify(pr, lay["vk"], inst, lay["proof"], int(lay["tau"], 16))["ok"], lay["layer"]
+        assert lay["cosets_resident"] and lay["proof_bytes"] == len(lay["proof"])
