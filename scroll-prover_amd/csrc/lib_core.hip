@@ -135,11 +135,59 @@ static int rccl_load() {
 // A block handed out by mi355_buf_alloc.  free_ev: recorded on the owner's compute stream when the block was last returned to the pool --
 // the only work an upload into the recycled block has to wait for.  used: the block has been passed to a library call since it was
 // allocated (an upload into it must then wait for the whole compute stream).
-struct BufBlock { void *p = nullptr; size_t bytes = 0; int slot = 0; hipEvent_t free_ev = nullptr; bool used = false; };
+struct BufBlock { void *p = nullptr; size_t bytes = 0; int slot = 0; hipEvent_t free_ev = nullptr; bool used = false; bool arena = false; };
 static std::mutex g_buf_mu;
 static std::map<uintptr_t, BufBlock> &g_bufs = *new std::map<uintptr_t, BufBlock>();                         // live blocks by base address
 static std::multimap<std::pair<int, size_t>, BufBlock> &g_pool = *new std::multimap<std::pair<int, size_t>, BufBlock>();   // free blocks by (slot, size)
 static std::atomic<uint32_t> g_rr{0};
+// Slabs (round 5).  The pool above keeps freed blocks by EXACT size: right for one layer's proofs in a row (the second proof allocates nothing), wrong for a prover process that
+// holds several layers -- a chunk prover runs 2^20-, 2^24- and 2^25-row proofs back to back [REF integration/src/prove.rs:30-43], every layer's blocks have another size, the working
+// sets do not fit HBM together, and each proof used to give the previous layer's blocks back to HIP and hipMalloc its own (measured: 8.4 s per chunk round against 4.3 s for the three
+// layers alone, profiles/r05_prover_process_*.json).  Now blocks are CARVED out of slabs (hipMalloc'd once, >= MI355_BUF_SLAB_MB each, default 1 GiB; a larger request gets a slab of its
+// own size).  Order on a pool miss: carve from the free ranges; else move this device's pooled blocks into the free ranges (adjacent ranges of one slab coalesce) and carve; else a new
+// slab.  A range only enters the free list after the last use of the block it came from has COMPLETED (its free event is synchronised first -- the events of a previous layer's proof are
+// long done), so a carved block is fresh: an upload into it waits for nothing, exactly like a block straight from hipMalloc.  Slabs go back to HIP when they are entirely free and
+// somebody needs the memory (mi355_buf_trim, an out-of-memory retry, shutdown).  MI355_BUF_ARENA=0 restores one hipMalloc per block.
+struct Slab { uintptr_t base; size_t bytes; int slot; };
+static std::vector<Slab> &g_slabs = *new std::vector<Slab>();
+static std::map<uintptr_t, size_t> *g_free = new std::map<uintptr_t, size_t>[MAX_DEV];   // quiescent free ranges per slot, by address, coalesced within a slab
+static bool arena_on() { static const bool on = [] { const char *e = getenv("MI355_BUF_ARENA"); return !(e && e[0] == '0'); }(); return on; }
+static size_t slab_min_bytes() { static const size_t v = [] { const char *e = getenv("MI355_BUF_SLAB_MB"); const long mb = e ? atol(e) : 1024; return (size_t)std::max<long>(1, mb) << 20; }(); return v; }
+static const Slab *slab_of_locked(uintptr_t p) { for (const auto &sl : g_slabs) if (p >= sl.base && p < sl.base + sl.bytes) return &sl; return nullptr; }
+static void arena_insert_locked(int slot, uintptr_t p, size_t len) {
+  auto &F = g_free[slot]; const Slab *sl = slab_of_locked(p);
+  auto nx = F.lower_bound(p);
+  if (sl && nx != F.end() && p + len == nx->first && nx->first < sl->base + sl->bytes) { len += nx->second; nx = F.erase(nx); }
+  if (sl && nx != F.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == p && pv->first >= sl->base) { pv->second += len; return; } }
+  F[p] = len;
+}
+static void *arena_carve_locked(int slot, size_t want) {   // best fit: the smallest free range that holds the request
+  auto &F = g_free[slot]; auto best = F.end();
+  for (auto it = F.begin(); it != F.end(); ++it) if (it->second >= want && (best == F.end() || it->second < best->second)) best = it;
+  if (best == F.end()) return nullptr;
+  const uintptr_t p = best->first; const size_t len = best->second; F.erase(best);
+  if (len > want) F[p + want] = len - want;
+  return (void *)p;
+}
+// this device's pooled blocks -> free ranges (the calling thread is bound to the device: events are synchronised outside the registry mutex)
+static void arena_recycle_pool(int slot) {
+  std::vector<BufBlock> take;
+  { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto it = g_pool.begin(); it != g_pool.end();) { if (it->first.first == slot && it->second.arena) { take.push_back(it->second); it = g_pool.erase(it); } else ++it; } }
+  for (auto &b : take) if (b.free_ev) { (void)hipEventSynchronize(b.free_ev); (void)hipEventDestroy(b.free_ev); }
+  std::lock_guard<std::mutex> bl(g_buf_mu);
+  for (auto &b : take) arena_insert_locked(slot, (uintptr_t)b.p, b.bytes);
+}
+// slabs of this device that are entirely free go back to HIP; returns the bytes freed
+static size_t arena_release_free_slabs(int slot) {
+  std::vector<void *> drop; size_t freed = 0;
+  { std::lock_guard<std::mutex> bl(g_buf_mu);
+    for (auto it = g_slabs.begin(); it != g_slabs.end();) {
+      auto f = it->slot == slot ? g_free[slot].find(it->base) : g_free[slot].end();
+      if (it->slot == slot && f != g_free[slot].end() && f->second == it->bytes) { g_free[slot].erase(f); drop.push_back((void *)it->base); freed += it->bytes; it = g_slabs.erase(it); } else ++it;
+    } }
+  for (void *q : drop) (void)hipFree(q);
+  return freed;
+}
 
 static BufBlock *buf_find_locked(const void *p) {
   auto it = g_bufs.upper_bound((uintptr_t)p);
@@ -183,23 +231,28 @@ int pick_replica_slot() {
 // (the pool map) plus thread-safe HIP calls (stream synchronisation, hipFree) on the calling thread's bound device; it must never read or write Ctx members that the
 // slot's lock protects (g.ws, the event rings, the plans).
 static size_t pool_release_slot(int slot) {
-  std::vector<BufBlock> drop;
-  { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto it = g_pool.begin(); it != g_pool.end();) { if (it->first.first == slot) { drop.push_back(it->second); it = g_pool.erase(it); } else ++it; } }
-  if (drop.empty()) return 0;
+  std::vector<BufBlock> drop; bool any_arena = false;
+  { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto it = g_pool.begin(); it != g_pool.end();) { if (it->first.first == slot && !it->second.arena) { drop.push_back(it->second); it = g_pool.erase(it); } else { any_arena = any_arena || (it->first.first == slot); ++it; } }
+    any_arena = any_arena || !g_free[slot].empty(); }
+  if (drop.empty() && !any_arena) return 0;
   (void)hipStreamSynchronize(g_ctx[slot].stream);   // work queued on a block before its mi355_buf_free
   if (g_ctx[slot].copy_stream) (void)hipStreamSynchronize(g_ctx[slot].copy_stream);
   size_t freed = 0;
   for (auto &b : drop) { if (b.free_ev) (void)hipEventDestroy(b.free_ev); (void)hipFree(b.p); freed += b.bytes; }
+  arena_recycle_pool(slot);                         // carved blocks return to their slabs; slabs that are whole again go back to HIP
+  freed += arena_release_free_slabs(slot);
   return freed;
 }
 static void buf_release_all_locked() {   // shutdown: every slot's lock is held, the devices are still bound
   auto drop = [](BufBlock &b) {
     if (b.slot < g_ndev && g_ctx[b.slot].inited) (void)hipSetDevice(g_ctx[b.slot].device);
     if (b.free_ev) (void)hipEventDestroy(b.free_ev);
-    if (b.p) (void)hipFree(b.p);
+    if (b.p && !b.arena) (void)hipFree(b.p);        // carved blocks are freed with their slabs below
   };
   for (auto &kv : g_bufs) drop(kv.second);
   for (auto &kv : g_pool) drop(kv.second);
+  for (auto &sl : g_slabs) { if (sl.slot < g_ndev && g_ctx[sl.slot].inited) (void)hipSetDevice(g_ctx[sl.slot].device); (void)hipFree((void *)sl.base); }
+  g_slabs.clear(); for (int d = 0; d < MAX_DEV; d++) g_free[d].clear();
   g_bufs.clear(); g_pool.clear();
 }
 
@@ -581,8 +634,25 @@ int mi355_buf_alloc(uint64_t bytes, int device_slot, void **dev_ptr_out) {
     if (it != g_pool.end()) { BufBlock b = it->second; g_pool.erase(it); b.used = false; g_bufs[(uintptr_t)b.p] = b; *dev_ptr_out = b.p; return MI355_OK; }
   }
   void *p = nullptr;
-  CHK(dev_malloc(&p, want, "buf_alloc"));   // the pool of this device is given back to the allocator before giving up
-  BufBlock b; b.p = p; b.bytes = want; b.slot = device_slot;
+  BufBlock b; b.bytes = want; b.slot = device_slot;
+  if (arena_on()) {
+    { std::lock_guard<std::mutex> bl(g_buf_mu); p = arena_carve_locked(device_slot, want); }
+    if (!p) { arena_recycle_pool(device_slot); std::lock_guard<std::mutex> bl(g_buf_mu); p = arena_carve_locked(device_slot, want); }
+    if (!p) {
+      size_t sbytes = std::max(want, slab_min_bytes()); void *base = nullptr;
+      // a new slab; near the HBM limit the head-room of a shared slab is given up and the request gets exactly its size (dev_malloc frees whole slabs and retries before failing)
+      if (sbytes > want && dev_malloc(&base, sbytes, "buf_alloc (slab)") != MI355_OK) { base = nullptr; sbytes = want; }
+      if (!base) CHK(dev_malloc(&base, sbytes, "buf_alloc"));
+      std::lock_guard<std::mutex> bl(g_buf_mu);
+      g_slabs.push_back({(uintptr_t)base, sbytes, device_slot}); arena_insert_locked(device_slot, (uintptr_t)base, sbytes);
+      p = arena_carve_locked(device_slot, want);
+      if (!p) return fail(MI355_EHIP, "buf_alloc: slab bookkeeping");   // another thread took the new range: cannot happen with best fit on a range >= want, kept as a guard
+    }
+    b.arena = true;
+  } else {
+    CHK(dev_malloc(&p, want, "buf_alloc"));   // the pool of this device is given back to the allocator before giving up
+  }
+  b.p = p;
   { std::lock_guard<std::mutex> bl(g_buf_mu); g_bufs[(uintptr_t)p] = b; }
   *dev_ptr_out = p; return MI355_OK;
   });
@@ -611,9 +681,10 @@ int mi355_buf_trim(void) {
   AllGuard lk;
   if (!g_ndev) return MI355_OK;
   std::vector<BufBlock> drop;
-  { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto &kv : g_pool) drop.push_back(kv.second); g_pool.clear(); }
+  { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto it = g_pool.begin(); it != g_pool.end();) { if (!it->second.arena) { drop.push_back(it->second); it = g_pool.erase(it); } else ++it; } }
   for (int s = 0; s < g_ndev; s++) { CHK(bind_ctx(s)); HIPCHK(hipStreamSynchronize(g.stream)); }
   for (auto &b : drop) { CHK(bind_ctx(b.slot)); if (b.free_ev) (void)hipEventDestroy(b.free_ev); (void)hipFree(b.p); }
+  for (int s = 0; s < g_ndev; s++) { CHK(bind_ctx(s)); arena_recycle_pool(s); (void)arena_release_free_slabs(s); }   // carved blocks back to their slabs; whole slabs back to HIP
   return bind_ctx(0);
   });
 }
@@ -740,7 +811,8 @@ int mi355_mem_info(int device_slot, uint64_t *free_bytes, uint64_t *total_bytes,
   uint64_t live = 0, pooled = 0, ws = 0;
   { std::lock_guard<std::mutex> bl(g_buf_mu);
     for (const auto &kv : g_bufs) if (kv.second.slot == device_slot) live += kv.second.bytes;
-    for (const auto &kv : g_pool) if (kv.first.first == device_slot) pooled += kv.second.bytes; }
+    for (const auto &kv : g_pool) if (kv.first.first == device_slot) pooled += kv.second.bytes;
+    for (const auto &kv : g_free[device_slot]) pooled += kv.second; }   // free ranges of the slabs: held by the library, reusable, not live
   for (const auto &kv : g.ws) ws += kv.second.cap;
   if (free_bytes) *free_bytes = fr; if (total_bytes) *total_bytes = tot; if (live_buf_bytes) *live_buf_bytes = live;
   if (pooled_bytes) *pooled_bytes = pooled; if (workspace_bytes) *workspace_bytes = ws;

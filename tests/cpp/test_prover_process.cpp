@@ -19,13 +19,13 @@ static double ms_since(Clock::time_point t0) { return std::chrono::duration<doub
 static void write_file(const std::string &path, const void *p, size_t bytes) { std::ofstream f(path, std::ios::binary); if (!f) throw std::invalid_argument("cannot write " + path); f.write(static_cast<const char *>(p), (std::streamsize)bytes); }
 
 int main(int argc, char **argv) {
-  std::vector<std::string> paths; std::string out_dir; int threads = (int)std::thread::hardware_concurrency(), proofs = 2; uint64_t seed = 1; bool trim_between = true;
+  std::vector<std::string> paths; std::string out_dir; int threads = (int)std::thread::hardware_concurrency(), proofs = 2; uint64_t seed = 1; bool trim_between = false;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "--protocol" && i + 1 < argc) paths.push_back(argv[++i]); else if (a == "--out" && i + 1 < argc) out_dir = argv[++i];
     else if (a == "--proofs" && i + 1 < argc) proofs = std::atoi(argv[++i]); else if (a == "--threads" && i + 1 < argc) threads = std::atoi(argv[++i]);
-    else if (a == "--seed" && i + 1 < argc) seed = (uint64_t)std::atol(argv[++i]); else if (a == "--no-trim") trim_between = false;
-    else { std::printf("usage: %s --protocol FILE [--protocol FILE ...] --out DIR [--proofs N] [--threads T] [--seed S] [--no-trim]\n", argv[0]); return 1; }
+    else if (a == "--seed" && i + 1 < argc) seed = (uint64_t)std::atol(argv[++i]); else if (a == "--trim") trim_between = true;
+    else { std::printf("usage: %s --protocol FILE [--protocol FILE ...] --out DIR [--proofs N] [--threads T] [--seed S] [--trim]\n", argv[0]); return 1; }
   }
   if (paths.empty() || out_dir.empty()) { std::printf("--protocol (one or more) and --out are required\n"); return 1; }
   threads = std::max(1, std::min(threads, 16)); proofs = std::max(1, proofs);
@@ -75,8 +75,8 @@ int main(int argc, char **argv) {
     for (int it = 0; it < proofs; it++) {
       const auto t0 = Clock::now();
       for (size_t i = 0; i < NLY; i++) {
-        // the buffer pool keeps freed blocks by exact size: the previous layer's blocks (another 2^k) are of no use to this one, and left in the pool they push this proof into
-        // out-of-memory retries in the middle of its pipeline.  Between layers they go back to HIP (mi355_buf_trim: one synchronisation at a layer boundary).
+        // the previous layer's blocks have another size: the library carves this layer's blocks out of the same slabs (lib_core.hip "Slabs"), nothing goes back to HIP in between.
+        // --trim forces mi355_buf_trim at every layer boundary (the behaviour a caller had to choose before the slabs existed; kept for A/B)
         if (NLY > 1 && trim_between) check(mi355_buf_trim());
         R[i] = create_proof(srs[P[i]->k].g, srs[P[i]->k].gl, *pk[i], *C[i], opt);
       }
