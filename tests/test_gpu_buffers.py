@@ -394,3 +394,31 @@ def test_narrow_uploads_equal_the_plain_upload(zk):
     assert lib.mi355_buf_upload_packed(C.c_void_p(big.data_ptr()), capi.ptr(col), n, 3) == capi.EBADARG
     assert lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr()), n, capi.ptr(idx), capi.ptr(vals), n + 1) == capi.EBADARG
     b.free(); big.free()
+
+
+def test_slabs_serve_another_block_size_without_going_back_to_hip(zk):
+    """blocks of one size, freed, then blocks of ANOTHER size: the library carves them out of the same slabs (lib_core.hip "Slabs") -- HIP's free memory does not move, the new
+    blocks lie inside the address ranges of the old ones, their contents are what was uploaded; mi355_buf_trim gives whole slabs back"""
+    h2 = zk.halo2
+    lib, check = zk._capi.lib(), zk._capi.check
+    check(lib.mi355_buf_trim())
+    rng = np.random.default_rng(5)
+    small, big = 32 << 20, 96 << 20
+    a = [h2.DeviceBuffer(small) for _ in range(48)]                     # 1.5 GiB in 32 MiB blocks: two 1 GiB slabs
+    lo, hi = min(b.data_ptr() for b in a), max(b.data_ptr() + small for b in a)
+    for b in a:
+        b.free()
+    before = h2.mem_info()
+    assert before["pooled"] >= 48 * small
+    data = [rng.integers(0, 1 << 63, size=(big // 32, 4), dtype=np.uint64) for _ in range(3)]
+    c = [h2.DeviceBuffer.from_host(d) for d in data]                    # 96 MiB blocks: no pooled block has this size
+    after = h2.mem_info()
+    assert abs(int(after["free"]) - int(before["free"])) < (8 << 20), (before, after)      # nothing was hipMalloc'd or hipFree'd
+    assert all(lo <= b.data_ptr() and b.data_ptr() + big <= hi for b in c)
+    assert len({b.data_ptr() for b in c}) == 3 and all((b.fr() == d).all() for b, d in zip(c, data))
+    small_again = h2.DeviceBuffer.from_host(data[0][: small // 32])
+    assert (small_again.fr() == data[0][: small // 32]).all() and lo <= small_again.data_ptr() < hi
+    for b in c + [small_again]:
+        b.free()
+    check(lib.mi355_buf_trim())
+    assert int(h2.mem_info()["free"]) >= int(after["free"]) + (1 << 30)                        # the slabs went back to HIP
