@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include "lib_common.hpp"
+#include "slab_ranges.hpp"
 
 namespace mi355 {
 
@@ -148,44 +149,25 @@ static std::atomic<uint32_t> g_rr{0};
 // slab.  A range only enters the free list after the last use of the block it came from has COMPLETED (its free event is synchronised first -- the events of a previous layer's proof are
 // long done), so a carved block is fresh: an upload into it waits for nothing, exactly like a block straight from hipMalloc.  Slabs go back to HIP when they are entirely free and
 // somebody needs the memory (mi355_buf_trim, an out-of-memory retry, shutdown).  MI355_BUF_ARENA=0 restores one hipMalloc per block.
-struct Slab { uintptr_t base; size_t bytes; int slot; };
-static std::vector<Slab> &g_slabs = *new std::vector<Slab>();
-static std::map<uintptr_t, size_t> *g_free = new std::map<uintptr_t, size_t>[MAX_DEV];   // quiescent free ranges per slot, by address, coalesced within a slab
+static mi355zk::SlabRanges *g_arena = new mi355zk::SlabRanges[MAX_DEV];   // per device slot: its slabs and their quiescent free ranges (csrc/slab_ranges.hpp, model-checked on the host)
 static bool arena_on() { static const bool on = [] { const char *e = getenv("MI355_BUF_ARENA"); return !(e && e[0] == '0'); }(); return on; }
 static size_t slab_min_bytes() { static const size_t v = [] { const char *e = getenv("MI355_BUF_SLAB_MB"); const long mb = e ? atol(e) : 1024; return (size_t)std::max<long>(1, mb) << 20; }(); return v; }
-static const Slab *slab_of_locked(uintptr_t p) { for (const auto &sl : g_slabs) if (p >= sl.base && p < sl.base + sl.bytes) return &sl; return nullptr; }
-static void arena_insert_locked(int slot, uintptr_t p, size_t len) {
-  auto &F = g_free[slot]; const Slab *sl = slab_of_locked(p);
-  auto nx = F.lower_bound(p);
-  if (sl && nx != F.end() && p + len == nx->first && nx->first < sl->base + sl->bytes) { len += nx->second; nx = F.erase(nx); }
-  if (sl && nx != F.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == p && pv->first >= sl->base) { pv->second += len; return; } }
-  F[p] = len;
-}
-static void *arena_carve_locked(int slot, size_t want) {   // best fit: the smallest free range that holds the request
-  auto &F = g_free[slot]; auto best = F.end();
-  for (auto it = F.begin(); it != F.end(); ++it) if (it->second >= want && (best == F.end() || it->second < best->second)) best = it;
-  if (best == F.end()) return nullptr;
-  const uintptr_t p = best->first; const size_t len = best->second; F.erase(best);
-  if (len > want) F[p + want] = len - want;
-  return (void *)p;
-}
-// this device's pooled blocks -> free ranges (the calling thread is bound to the device: events are synchronised outside the registry mutex)
+// this device's pooled blocks -> free ranges (the calling thread is bound to the device: events are synchronised outside the registry mutex).  The copy stream is drained as well: a
+// block's free event only covers the compute stream, and an upload that was queued into a block and never consumed before its mi355_buf_free must not land in whatever is carved there next
 static void arena_recycle_pool(int slot) {
   std::vector<BufBlock> take;
   { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto it = g_pool.begin(); it != g_pool.end();) { if (it->first.first == slot && it->second.arena) { take.push_back(it->second); it = g_pool.erase(it); } else ++it; } }
+  if (take.empty()) return;
   for (auto &b : take) if (b.free_ev) { (void)hipEventSynchronize(b.free_ev); (void)hipEventDestroy(b.free_ev); }
+  if (g_ctx[slot].copy_stream) (void)hipStreamSynchronize(g_ctx[slot].copy_stream);
   std::lock_guard<std::mutex> bl(g_buf_mu);
-  for (auto &b : take) arena_insert_locked(slot, (uintptr_t)b.p, b.bytes);
+  for (auto &b : take) g_arena[slot].insert((uintptr_t)b.p, b.bytes);
 }
 // slabs of this device that are entirely free go back to HIP; returns the bytes freed
 static size_t arena_release_free_slabs(int slot) {
-  std::vector<void *> drop; size_t freed = 0;
-  { std::lock_guard<std::mutex> bl(g_buf_mu);
-    for (auto it = g_slabs.begin(); it != g_slabs.end();) {
-      auto f = it->slot == slot ? g_free[slot].find(it->base) : g_free[slot].end();
-      if (it->slot == slot && f != g_free[slot].end() && f->second == it->bytes) { g_free[slot].erase(f); drop.push_back((void *)it->base); freed += it->bytes; it = g_slabs.erase(it); } else ++it;
-    } }
-  for (void *q : drop) (void)hipFree(q);
+  std::vector<uintptr_t> drop; size_t freed = 0;
+  { std::lock_guard<std::mutex> bl(g_buf_mu); freed = g_arena[slot].take_whole_slabs(drop); }
+  for (uintptr_t q : drop) (void)hipFree((void *)q);
   return freed;
 }
 
@@ -233,7 +215,7 @@ int pick_replica_slot() {
 static size_t pool_release_slot(int slot) {
   std::vector<BufBlock> drop; bool any_arena = false;
   { std::lock_guard<std::mutex> bl(g_buf_mu); for (auto it = g_pool.begin(); it != g_pool.end();) { if (it->first.first == slot && !it->second.arena) { drop.push_back(it->second); it = g_pool.erase(it); } else { any_arena = any_arena || (it->first.first == slot); ++it; } }
-    any_arena = any_arena || !g_free[slot].empty(); }
+    any_arena = any_arena || !g_arena[slot].free_ranges.empty(); }
   if (drop.empty() && !any_arena) return 0;
   (void)hipStreamSynchronize(g_ctx[slot].stream);   // work queued on a block before its mi355_buf_free
   if (g_ctx[slot].copy_stream) (void)hipStreamSynchronize(g_ctx[slot].copy_stream);
@@ -251,8 +233,11 @@ static void buf_release_all_locked() {   // shutdown: every slot's lock is held,
   };
   for (auto &kv : g_bufs) drop(kv.second);
   for (auto &kv : g_pool) drop(kv.second);
-  for (auto &sl : g_slabs) { if (sl.slot < g_ndev && g_ctx[sl.slot].inited) (void)hipSetDevice(g_ctx[sl.slot].device); (void)hipFree((void *)sl.base); }
-  g_slabs.clear(); for (int d = 0; d < MAX_DEV; d++) g_free[d].clear();
+  for (int d = 0; d < MAX_DEV; d++) {
+    if (!g_arena[d].slabs.empty() && d < g_ndev && g_ctx[d].inited) (void)hipSetDevice(g_ctx[d].device);
+    for (auto &sl : g_arena[d].slabs) (void)hipFree((void *)sl.base);
+    g_arena[d].clear();
+  }
   g_bufs.clear(); g_pool.clear();
 }
 
@@ -636,16 +621,16 @@ int mi355_buf_alloc(uint64_t bytes, int device_slot, void **dev_ptr_out) {
   void *p = nullptr;
   BufBlock b; b.bytes = want; b.slot = device_slot;
   if (arena_on()) {
-    { std::lock_guard<std::mutex> bl(g_buf_mu); p = arena_carve_locked(device_slot, want); }
-    if (!p) { arena_recycle_pool(device_slot); std::lock_guard<std::mutex> bl(g_buf_mu); p = arena_carve_locked(device_slot, want); }
+    { std::lock_guard<std::mutex> bl(g_buf_mu); p = (void *)g_arena[device_slot].carve(want); }
+    if (!p) { arena_recycle_pool(device_slot); std::lock_guard<std::mutex> bl(g_buf_mu); p = (void *)g_arena[device_slot].carve(want); }
     if (!p) {
       size_t sbytes = std::max(want, slab_min_bytes()); void *base = nullptr;
       // a new slab; near the HBM limit the head-room of a shared slab is given up and the request gets exactly its size (dev_malloc frees whole slabs and retries before failing)
       if (sbytes > want && dev_malloc(&base, sbytes, "buf_alloc (slab)") != MI355_OK) { base = nullptr; sbytes = want; }
       if (!base) CHK(dev_malloc(&base, sbytes, "buf_alloc"));
       std::lock_guard<std::mutex> bl(g_buf_mu);
-      g_slabs.push_back({(uintptr_t)base, sbytes, device_slot}); arena_insert_locked(device_slot, (uintptr_t)base, sbytes);
-      p = arena_carve_locked(device_slot, want);
+      g_arena[device_slot].add_slab((uintptr_t)base, sbytes);
+      p = (void *)g_arena[device_slot].carve(want);
       if (!p) return fail(MI355_EHIP, "buf_alloc: slab bookkeeping");   // another thread took the new range: cannot happen with best fit on a range >= want, kept as a guard
     }
     b.arena = true;
@@ -812,7 +797,7 @@ int mi355_mem_info(int device_slot, uint64_t *free_bytes, uint64_t *total_bytes,
   { std::lock_guard<std::mutex> bl(g_buf_mu);
     for (const auto &kv : g_bufs) if (kv.second.slot == device_slot) live += kv.second.bytes;
     for (const auto &kv : g_pool) if (kv.first.first == device_slot) pooled += kv.second.bytes;
-    for (const auto &kv : g_free[device_slot]) pooled += kv.second; }   // free ranges of the slabs: held by the library, reusable, not live
+    pooled += g_arena[device_slot].free_bytes(); }   // free ranges of the slabs: held by the library, reusable, not live
   for (const auto &kv : g.ws) ws += kv.second.cap;
   if (free_bytes) *free_bytes = fr; if (total_bytes) *total_bytes = tot; if (live_buf_bytes) *live_buf_bytes = live;
   if (pooled_bytes) *pooled_bytes = pooled; if (workspace_bytes) *workspace_bytes = ws;

@@ -10,6 +10,7 @@
 #include <set>
 
 #include "mi355zk_plonk.hpp"
+#include "../../scroll-prover_amd/csrc/slab_ranges.hpp"   // the bookkeeping behind mi355_buf_alloc's slabs (host-only code, model-checked below)
 
 using namespace mi355zk::halo2;
 
@@ -149,6 +150,67 @@ int main(int argc, char **argv) {
     for (const ResidencyPlan *R : {&C, &B}) std::printf("residency plan: srs %.1f keys %.1f tables %.1f working %.1f total %.1f of %.1f GiB\n", R->srs_gib, R->keys_gib, R->tables_gib, R->working_gib, R->total_gib, R->budget_gib);
     const ResidencyPlan T = plan_residency({protos[4].get()}, 80.0);                  // a smaller card: the key's cosets no longer fit
     EXPECT(!T.layers[0].cosets_resident);
+  }
+  // --- the slab bookkeeping of mi355_buf_alloc (csrc/slab_ranges.hpp) against a byte map: random carve / give-back sequences with the block sizes of a prover process (2^20-,
+  // 2^24-, 2^25-row layers scaled down by 2^12), slabs added on a miss exactly as lib_core.hip does.  Invariants after every step: live blocks never overlap each other or a free
+  // range, every byte of every slab is either live or free, adjacent free ranges of one slab are merged, no range spans two slabs -- and once everything is back, every slab is one
+  // range and take_whole_slabs returns all of them
+  {
+    std::mt19937_64 rs(99);
+    for (int round = 0; round < 3; round++) {
+      mi355zk::SlabRanges A; const size_t SLAB = 1 << 18; uintptr_t next_base = 1 << 20;
+      const size_t sizes[] = {256, 256 * 3, 8192, 8192 * 3, 131072, 262144, 262144 * 2, 768};
+      std::map<uintptr_t, size_t> live; size_t carved_total = 0;
+      auto check_state = [&]() {
+        size_t covered = 0, slab_total = 0; uintptr_t prev_end = 0; bool prev_free = false; const mi355zk::SlabRanges::Slab *prev_slab = nullptr;
+        std::map<uintptr_t, std::pair<size_t, bool>> all;
+        for (auto &kv : live) all[kv.first] = {kv.second, false};
+        for (auto &kv : A.free_ranges) { EXPECT(!all.count(kv.first)); all[kv.first] = {kv.second, true}; }
+        for (auto &kv : all) {
+          const auto *s = A.slab_of(kv.first);
+          EXPECT(s != nullptr); if (!s) continue;
+          EXPECT(kv.first + kv.second.first <= s->base + s->bytes);                                   // no block or range leaves its slab
+          EXPECT(kv.first >= prev_end);                                                                // no overlap
+          if (kv.second.second && prev_free && prev_slab == s) EXPECT(kv.first != prev_end);           // adjacent free ranges of one slab are merged
+          prev_end = kv.first + kv.second.first; prev_free = kv.second.second; prev_slab = s; covered += kv.second.first;
+        }
+        for (auto &s : A.slabs) slab_total += s.bytes;
+        EXPECT(covered == slab_total);                                                                 // every byte is live or free
+      };
+      for (int step = 0; step < 4000; step++) {
+        const bool alloc = live.empty() || (rs() % 100) < (step < 2500 ? 58 : 35);
+        if (alloc) {
+          const size_t want = sizes[rs() % (round == 0 ? 4 : 8)];
+          uintptr_t p = A.carve(want);
+          if (!p) { const size_t sb = std::max(want, SLAB); A.add_slab(next_base, sb); next_base += sb + ((rs() & 1) ? 0 : 4096); p = A.carve(want); }   // some slabs touch the previous one, some do not
+          EXPECT(p != 0); if (!p) break;
+          EXPECT(!live.count(p)); live[p] = want; carved_total += want;
+        } else {
+          auto it = live.begin(); std::advance(it, (long)(rs() % live.size()));
+          A.insert(it->first, it->second); live.erase(it);
+        }
+        if (step % 16 == 0) check_state();
+      }
+      check_state();
+      std::vector<uintptr_t> gone; const size_t before = A.slabs.size(); size_t expect_bytes = 0;
+      { std::set<const void *> busy; for (auto &kv : live) busy.insert(A.slab_of(kv.first)); for (auto &s : A.slabs) if (!busy.count(&s)) expect_bytes += s.bytes; }
+      EXPECT(A.take_whole_slabs(gone) == expect_bytes);                                                // exactly the slabs without a live block
+      for (auto &kv : live) EXPECT(A.slab_of(kv.first) != nullptr);
+      while (!live.empty()) { A.insert(live.begin()->first, live.begin()->second); live.erase(live.begin()); }
+      check_state();
+      gone.clear(); A.take_whole_slabs(gone);
+      EXPECT(A.slabs.empty() && A.free_ranges.empty() && A.free_bytes() == 0);
+      EXPECT(before > 0 && carved_total > 0);
+    }
+    // best fit takes the smallest range that holds the request, from its front; a request no range holds returns 0 and changes nothing
+    mi355zk::SlabRanges B; B.add_slab(0x100000, 0x10000); B.add_slab(0x200000, 0x4000);
+    EXPECT(B.carve(0x3000) == 0x200000); EXPECT(B.carve(0x1000) == 0x203000); EXPECT(B.carve(0x1000) == 0x100000);
+    EXPECT(B.carve(0x20000) == 0 && B.free_bytes() == 0xF000);
+    B.insert(0x203000, 0x1000); B.insert(0x200000, 0x3000); EXPECT(B.free_ranges.at(0x200000) == 0x4000);
+    // two slabs whose addresses touch stay two ranges
+    mi355zk::SlabRanges T; T.add_slab(0x1000, 0x1000); T.add_slab(0x2000, 0x1000);
+    const uintptr_t t0 = T.carve(0x1000), t1 = T.carve(0x1000); T.insert(t0, 0x1000); T.insert(t1, 0x1000);
+    EXPECT(T.free_ranges.size() == 2 && T.carve(0x2000) == 0);
   }
   if (host_only) {
     // without a GPU every compute entry point must fail loudly (no CPU fallback)
