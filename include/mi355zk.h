@@ -93,7 +93,7 @@ int mi355_buf_download(void *dst_host, const void *src_dev, uint64_t bytes);   /
  * witness-like distribution; lookup_bits of [REF integration/configs/layer1.config:11]).  dst receives n 32-byte Montgomery words either way.
  *   packed  src = n little-endian unsigned integers of width_bytes in {1, 2, 4, 8} (CANONICAL values: selectors, byte / range-checked / limb columns, whose kind the caller
  *           knows statically); W bytes per cell cross the link, the device multiplies by R
- *   sparse  the non-zero cells as (index, 32-byte Montgomery value) pairs in any order; dst is zero-filled first.  mi355_host_compact_nonzero builds the pairs from a plain
+ *   sparse  the non-zero cells as (index, 32-byte Montgomery value) pairs in any order; dst is zero-filled first; a pair whose index is >= n is dropped on the device (it never reaches memory).  mi355_host_compact_nonzero builds the pairs from a plain
  *           column with `threads` host threads (zero is zero in Montgomery form: the scan needs no arithmetic), idx_out / vals_out sized for n entries.
  * The narrow data crosses PCIe like mi355_buf_upload (copy stream, no device lock; the host buffers may be reused on return); the expansion is QUEUED on the owner's compute
  * stream: calls issued afterwards on that device see the data.                                                                                                          */

@@ -238,9 +238,10 @@ template <int W> __global__ void __launch_bounds__(256) k_expand_packed(fe_t *__
     g_store(&dst[i], v ? Fr::from_canonical(c) : c);
   }
 }
-// sparse: dst is zero-filled by the caller; dst[idx[j]] = vals[j] (32-byte Montgomery words, as they sit in the caller's column)
-__global__ void __launch_bounds__(256) k_scatter_fr(fe_t *__restrict__ dst, const uint32_t *__restrict__ idx, const fe_t *__restrict__ vals, uint64_t count) {
-  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) g_store(&dst[idx[j]], g_load(&vals[j]));
+// sparse: dst (n cells) is zero-filled by the caller; dst[idx[j]] = vals[j] (32-byte Montgomery words, as they sit in the caller's column).  An index >= n never reaches memory
+// (the pairs come from the caller's host code; the C-ABI documents that such a pair is dropped)
+__global__ void __launch_bounds__(256) k_scatter_fr(fe_t *__restrict__ dst, uint64_t n, const uint32_t *__restrict__ idx, const fe_t *__restrict__ vals, uint64_t count) {
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) { const uint32_t i = idx[j]; if (i < n) g_store(&dst[i], g_load(&vals[j])); }
 }
 #endif  // ZK_FRSCAN_DEVICE_ONLY
 #endif  // __HIPCC__

@@ -273,7 +273,7 @@ int mi355_buf_upload_sparse(void *dst_dev, uint64_t n, const uint32_t *idx_host,
   if (rc == MI355_OK) {
     if (hipMemsetAsync(dst_dev, 0, n * sizeof(fe_t), s) != hipSuccess) rc = fail(MI355_EHIP, "buf_upload_sparse: memset failed");
     else {
-      hipLaunchKernelGGL(k_scatter_fr, dim3((uint32_t)std::min<uint64_t>(ceil_div(count, 256), 65535u * 4)), dim3(256), 0, s, (fe_t *)dst_dev, (const uint32_t *)stage, (const fe_t *)((char *)stage + idx_bytes), count);
+      hipLaunchKernelGGL(k_scatter_fr, dim3((uint32_t)std::min<uint64_t>(ceil_div(count, 256), 65535u * 4)), dim3(256), 0, s, (fe_t *)dst_dev, n, (const uint32_t *)stage, (const fe_t *)((char *)stage + idx_bytes), count);
       if (hipGetLastError() != hipSuccess) rc = fail(MI355_EHIP, "buf_upload_sparse: kernel launch failed");
     }
   }

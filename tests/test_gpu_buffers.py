@@ -391,6 +391,14 @@ def test_narrow_uploads_equal_the_plain_upload(zk):
     assert (big.fr()[64:] == col).all()
     check(lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr()), n, None, None, 0))
     assert not big.fr()[:n].any()
+    # a pair whose index lies outside the column is dropped on the device: the 64 cells after the column keep their contents
+    guard = rand_fr(rng, 64)
+    big.upload(np.concatenate([np.zeros((n, 4), np.uint64), guard]))
+    bad_idx = np.array([3, n, n + 5, 0xFFFFFFFF, 7], np.uint32)
+    bad_vals = rand_fr(rng, 5)
+    check(lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr()), n, capi.ptr(bad_idx), capi.ptr(bad_vals), 5))
+    got = big.fr()
+    assert (got[n:] == guard).all() and (got[3] == bad_vals[0]).all() and (got[7] == bad_vals[4]).all() and np.count_nonzero(got[:n].any(axis=1)) == 2
     assert lib.mi355_buf_upload_packed(C.c_void_p(big.data_ptr()), capi.ptr(col), n, 3) == capi.EBADARG
     assert lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr()), n, capi.ptr(idx), capi.ptr(vals), n + 1) == capi.EBADARG
     b.free(); big.free()
