@@ -28,7 +28,7 @@ import json
 
 import numpy as np
 
-from . import cref, pyref
+from . import cref, pairing, poseidon, pyref
 
 R = pyref.R_MOD
 FR = cref.FR
@@ -247,6 +247,31 @@ class Transcript:
         return v
 
 
+class PoseidonTranscript(Transcript):
+    """snark-verifier's `PoseidonTranscript<NativeLoader, _>` [EXT-recalled snark-verifier system/halo2/transcript/halo2.rs], the transcript the reference's layers 0-5 are
+    proved with: a scalar is absorbed as itself, a point as (x mod r, y mod r), a challenge is one squeeze of the sponge (a full field element, no 128-bit truncation); the proof
+    bytes are the same as Blake2bWrite's (compressed points, little-endian scalars).  Sponge: oracle/poseidon.py (T = 5, RATE = 4, R_F = 8, R_P = 60)."""
+
+    def __init__(self, proof: bytes | None = None):
+        self.h = poseidon.Sponge(5, 8, 60)
+        self.out = bytearray()
+        self.inp = proof
+        self.pos = 0
+
+    def squeeze(self) -> int:
+        return self.h.squeeze()
+
+    def common_point(self, p_affine_int):
+        assert p_affine_int is not None, "the transcript refuses the identity (coordinates() is None)"
+        self.h.update([p_affine_int[0] % R, p_affine_int[1] % R])
+
+    def common_scalar(self, s: int):
+        self.h.update([s % R])
+
+
+TRANSCRIPTS = {"blake2b": Transcript, "poseidon": PoseidonTranscript}
+
+
 def vk_transcript_repr(vk_bytes: bytes) -> int:
     """halo2 hashes the Debug rendering of the pinned verifying key (Blake2b-512, personalisation "Halo2-Verify-Key") into one scalar; that string is
     not reproducible outside Rust, so the bytes hashed here are the .vkey serialisation (u32 BE k | u32 BE fixed columns | compressed commitments,
@@ -397,11 +422,11 @@ def keygen_vk(pr: Protocol, pre, tau: int) -> bytes:
     return out
 
 
-def prove(inp: ProofInputs, vk_bytes: bytes) -> bytes:
+def prove(inp: ProofInputs, vk_bytes: bytes, transcript: str = "blake2b") -> bytes:
     pr = inp.pr
     n, w, u, tau = pr.n, pr.omega, pr.usable, inp.tau
     dom = _Domain(pr)
-    T = Transcript()
+    T = TRANSCRIPTS[transcript]()
     T.common_scalar(vk_transcript_repr(vk_bytes))
     for v in inp.instances:
         T.common_scalar(v)
@@ -510,19 +535,21 @@ def prove(inp: ProofInputs, vk_bytes: bytes) -> bytes:
     ys, v = T.squeeze(), T.squeeze()
     sets = rotation_sets(pr.queries)
     H = [0] * n
+    vp = 1
     for s in sets:
         points = [rot_pt(r) for r in s["rots"]]
         N = [0] * n
-        for p_ in s["polys"]:
+        for p_ in reversed(s["polys"]):                                      # N_i = sum_j y^j (P_ij - R_ij): the j-th polynomial of a set carries y^j
             rcoef = interpolate(points, [evals[(p_, r)] for r in s["rots"]])
             npoly = list(coeff[p_])
             for t, c_ in enumerate(rcoef):
                 npoly[t] = (npoly[t] - c_) % R
-            N = [(a * ys + b) % R for a, b in zip(N, npoly)]                # fold(acc * y + poly)
+            N = [(a * ys + b) % R for a, b in zip(N, npoly)]
         for pt in points:
             N = kate_division(N, pt)
         N = N + [0] * (n - len(N))
-        H = [(a * v + b) % R for a, b in zip(H, N)]                          # fold(acc * v + quotient)
+        H = [(a + vp * b) % R for a, b in zip(H, N)]                         # H = sum_i v^i N_i / Z_i: the i-th rotation set carries v^i
+        vp = vp * v % R
     T.write_point(commit(H))
     uu = T.squeeze()
     super_pts = []
@@ -535,6 +562,7 @@ def prove(inp: ProofInputs, vk_bytes: bytes) -> bytes:
         zt = zt * (uu - pt) % R
     L = [0] * n
     zd0 = None
+    vp = 1
     for s in sets:
         points = [rot_pt(r) for r in s["rots"]]
         zd = 1
@@ -544,12 +572,13 @@ def prove(inp: ProofInputs, vk_bytes: bytes) -> bytes:
         if zd0 is None:
             zd0 = zd
         inner = [0] * n
-        for p_ in s["polys"]:
+        for p_ in reversed(s["polys"]):
             r_u = horner(interpolate(points, [evals[(p_, r)] for r in s["rots"]]), uu)
             lp = list(coeff[p_])
             lp[0] = (lp[0] - r_u) % R
             inner = [(a * ys + b) % R for a, b in zip(inner, lp)]
-        L = [(a * v + zd * b) % R for a, b in zip(L, inner)]
+        L = [(a + vp * zd % R * b) % R for a, b in zip(L, inner)]
+        vp = vp * v % R
     L = [(a - zt * b) % R for a, b in zip(L, H)]
     assert horner(L, uu) == 0
     zi = inv(zd0)
@@ -560,14 +589,32 @@ def prove(inp: ProofInputs, vk_bytes: bytes) -> bytes:
 
 
 # ------------------------------------------------------------------------------------------------ the verifier
-def verify(pr: Protocol, vk_bytes: bytes, instances, proof: bytes, tau: int) -> dict:
-    """returns {"ok": bool, ...}; every failed check is named"""
+def fq_limbs_mont_to_int(l) -> int:
+    """a base-field element as the protocol files serialise it (four u64 limbs of the Montgomery form)"""
+    return sum(int(x) << (64 * i) for i, x in enumerate(l)) * pow(1 << 256, -1, pyref.P_MOD) % pyref.P_MOD
+
+
+def verify(pr: Protocol, vk_bytes: bytes | None, instances, proof: bytes, tau: int | None = None, transcript: str = "blake2b", neg_s_g2=None) -> dict:
+    """The verifier of a SHPLONK halo2 proof, read off the protocol file the way snark-verifier's PlonkVerifier does [EXT-recalled snark-verifier verifier/plonk.rs, pcs/kzg/multiopen/
+    bdfg21.rs]; returns {"ok": bool, ...}, every failed check is named.
+
+    Two ways to call it:
+      * our own proofs (synthetic SRS with a known trapdoor): `vk_bytes` = the .vkey of the proving key, `tau` = the trapdoor; the final check is  lhs == tau * W'.
+      * the REFERENCE'S RELEASED PROOFS: `vk_bytes` = None -- the preprocessed commitments and the transcript's initial scalar come from the protocol file itself --,
+        `transcript` = "poseidon", `neg_s_g2` = the -[s]G2 of the reference's SRS (the second G2 point of [REF release-v0.13.1/evm_verifier.yul:1235-1238]); the final check is the
+        pairing  e(lhs, G2) e(W', -[s]G2) == 1.  tests/test_plonk_protocol.py runs this on the released chunk and batch proofs: it is what pins this file (transcript order,
+        challenge derivation, the evaluation of the numerator tree, the rotation sets, the order of the powers of y and v) to the reference's real prover."""
     n, w = pr.n, pr.omega
     res = {"ok": False}
-    assert int.from_bytes(vk_bytes[:4], "big") == pr.k and len(vk_bytes) == 8 + 32 * pr.num_pre
-    pre_c = [pyref.g1_decompress(vk_bytes[8 + 32 * i:8 + 32 * i + 32]) for i in range(pr.num_pre)]
-    T = Transcript(proof)
-    T.common_scalar(vk_transcript_repr(vk_bytes))
+    T = TRANSCRIPTS[transcript](proof)
+    if vk_bytes is None:
+        pre_c = [(fq_limbs_mont_to_int(p_["x"]), fq_limbs_mont_to_int(p_["y"])) for p_ in pr.d["preprocessed"]]
+        assert all(pyref.g1_is_on_curve(p_) for p_ in pre_c)
+        T.common_scalar(limbs_mont_to_int(pr.d["transcript_initial_state"]))
+    else:
+        assert int.from_bytes(vk_bytes[:4], "big") == pr.k and len(vk_bytes) == 8 + 32 * pr.num_pre
+        pre_c = [pyref.g1_decompress(vk_bytes[8 + 32 * i:8 + 32 * i + 32]) for i in range(pr.num_pre)]
+        T.common_scalar(vk_transcript_repr(vk_bytes))
     for v_ in instances:
         T.common_scalar(v_)
     com = {i: c for i, c in enumerate(pre_c)}
@@ -616,7 +663,8 @@ def verify(pr: Protocol, vk_bytes: bytes, instances, proof: bytes, tau: int) -> 
     E = None
     r_acc = 0
     zd0 = None
-    for s in sets:
+    vp = 1
+    for s in sets:                                                          # the i-th set carries v^i, its j-th polynomial y^j (snark-verifier: powers_of_mu, gamma.powers)
         points = [rot_pt(r) for r in s["rots"]]
         zd = 1
         for pt in super_pts:
@@ -625,18 +673,23 @@ def verify(pr: Protocol, vk_bytes: bytes, instances, proof: bytes, tau: int) -> 
         if zd0 is None:
             zd0 = zd
         inner_c, inner_r = None, 0
-        for p_ in s["polys"]:
+        for p_ in reversed(s["polys"]):
             r_u = horner(interpolate(points, [evals[(p_, r)] for r in s["rots"]]), uu)
             inner_c = g1_add(g1_mul(inner_c, ys), com[p_])
             inner_r = (inner_r * ys + r_u) % R
-        E = g1_add(g1_mul(E, v), g1_mul(inner_c, zd))
-        r_acc = (r_acc * v + zd * inner_r) % R
+        E = g1_add(E, g1_mul(inner_c, vp * zd % R))
+        r_acc = (r_acc + vp * zd % R * inner_r) % R
+        vp = vp * v % R
     zi = inv(zd0)
     E = g1_add(g1_mul(E, zi), g1_of_scalar((-r_acc * zi) % R))
     E = g1_add(E, g1_mul(c_h, (-zt * zi) % R))
     lhs = g1_add(E, g1_mul(c_w, uu))
-    rhs = g1_mul(c_w, tau)
-    res["pairing_with_trapdoor"] = lhs == rhs
-    res["ok"] = lhs == rhs
+    if tau is not None:
+        res["pairing_with_trapdoor"] = lhs == g1_mul(c_w, tau)
+        res["ok"] = res["pairing_with_trapdoor"]
+    else:
+        assert neg_s_g2 is not None, "verify: give the trapdoor of a synthetic SRS or the -[s]G2 of a real one"
+        res["pairing"] = pairing.pairing_product_is_one([(lhs, pyref.G2_GEN), (c_w, neg_s_g2)])
+        res["ok"] = res["pairing"]
     res["challenges"] = {"theta": ch[0], "beta": ch[1], "gamma": ch[2], "y": ch[3], "x": x}
     return res

@@ -75,8 +75,8 @@ def test_proof_word_counts_match_the_released_proofs():
 
 
 def test_released_proofs_parse_under_their_protocols():
-    """the released proofs, read with THEIR protocols by the verifier's reader: every commitment word decompresses on the curve, every evaluation is canonical, nothing is left over.
-    (They cannot verify here: their transcript is Poseidon and their SRS is the production one.)"""
+    """the released proofs, read with THEIR protocols by the verifier's reader: every commitment word decompresses on the curve, every evaluation is canonical, nothing is left over
+    (test_reference_released_proofs_verify below goes all the way)"""
     for layer, blob in ((2, KAT["chunk_proof"]["proof"]), (4, KAT["batch_proof"]["proof"])):
         pr = plonk.Protocol(fixture(layer)); proof = bytes.fromhex(blob)
         T = plonk.Transcript(proof)
@@ -86,6 +86,62 @@ def test_released_proofs_parse_under_their_protocols():
             T.read_scalar()
         T.read_point(); T.read_point()
         assert T.pos == len(proof)
+
+
+def released(name):
+    blob = bytes.fromhex(KAT[name]["instances"])
+    return [int.from_bytes(blob[i:i + 32], "big") for i in range(0, len(blob), 32)], bytes.fromhex(KAT[name]["proof"])
+
+
+NEG_S_G2 = pyref.g2_from_evm_words([int(w, 16) for w in KAT["yul"]["s_g2_words"]])      # the second G2 point of the released EVM verifier's pairing call: -[s]G2 of the reference's SRS
+
+
+def test_poseidon_constants_reproduce_a_published_vector():
+    """the Grain LFSR, the rejection sampling, the Cauchy matrix and the round schedule of oracle/poseidon.py at T = 3, R_F = 8, R_P = 57: circomlib's poseidon([1, 2])"""
+    from oracle import poseidon
+    assert poseidon.hash_circomlib([1, 2]) == 0x115CC0F5E7D690413DF64C6B9662E9CF2A3617F2743245519E19607A4417189A
+    rc, mds = poseidon.parameters(5, 8, 60)
+    assert len(rc) == 68 * 5 and len(set(rc)) == len(rc) and all(len(row) == 5 for row in mds)
+
+
+@pytest.mark.parametrize("name", ["chunk_proof", "batch_proof"])
+def test_released_accumulators_satisfy_the_pairing(name):
+    """the first 12 instances of a released proof are the KZG accumulator the proof carries forward (two G1 points, 3 limbs of 88 bits per coordinate); with the G2 words of the
+    released EVM verifier, e(lhs, G2) e(rhs, -[s]G2) == 1: pins oracle/pairing.py and the reading of those words on the reference's data"""
+    from oracle import pairing
+    inst, _ = released(name)
+    c = [inst[3 * i] + (inst[3 * i + 1] << 88) + (inst[3 * i + 2] << 176) for i in range(4)]
+    lhs, rhs = (c[0], c[1]), (c[2], c[3])
+    assert all(v < (1 << 88) for v in inst[:12]) and pyref.g1_is_on_curve(lhs) and pyref.g1_is_on_curve(rhs)
+    assert pyref.g2_is_on_curve(NEG_S_G2)
+    assert pairing.pairing_product_is_one([(lhs, pyref.G2_GEN), (rhs, NEG_S_G2)])
+    assert not pairing.pairing_product_is_one([(lhs, pyref.G2_GEN), (pyref.g1_neg(rhs), NEG_S_G2)])
+    assert not pairing.pairing_product_is_one([(pyref.g1_add(lhs, pyref.G1_GEN), pyref.G2_GEN), (rhs, NEG_S_G2)])
+
+
+@pytest.mark.parametrize("name,layer", [("chunk_proof", 2), ("batch_proof", 4)])
+def test_reference_released_proofs_verify(name, layer):
+    """THE PIN OF THE RESTATEMENT: the proofs the reference released [REF integration/tests/test_data/full_proof_1.json chunk_proofs[0]; full_proof_batch_agg_1.json], made by the
+    real prover on the production SRS, are ACCEPTED by oracle/plonk.py's verifier -- Poseidon transcript (oracle/poseidon.py), the protocol file's own preprocessed commitments and
+    initial transcript scalar, the numerator tree evaluated at x, instance polynomial from the public values, SHPLONK over the rotation sets with the i-th set at v^i and its j-th
+    polynomial at y^j, and the pairing against the released verifier's -[s]G2.  One wrong constant, word order, rotation set or power breaks the pairing equation; so do a
+    flipped proof word and a changed instance."""
+    pr = plonk.Protocol(fixture(layer))
+    inst, proof = released(name)
+    res = plonk.verify(pr, None, inst, proof, transcript="poseidon", neg_s_g2=NEG_S_G2)
+    assert res["ok"] and res["pairing"], res
+    nc, ne = sum(pr.num_witness) + pr.Q, len(pr.evaluations)
+    for word in (1, nc - 1, nc, nc + ne - 1, nc + ne, nc + ne + 1):
+        bad = bytearray(proof); bad[32 * word + 2] ^= 1
+        try:
+            ok = plonk.verify(pr, None, inst, bytes(bad), transcript="poseidon", neg_s_g2=NEG_S_G2)["ok"]
+        except AssertionError:
+            ok = False
+        assert not ok, f"the released proof with word {word} altered was accepted"
+    for i in (0, 12, len(inst) - 1):
+        bad_inst = list(inst); bad_inst[i] ^= 1
+        assert not plonk.verify(pr, None, bad_inst, proof, transcript="poseidon", neg_s_g2=NEG_S_G2)["ok"]
+    assert not plonk.verify(pr, None, inst, proof, transcript="blake2b", neg_s_g2=NEG_S_G2)["ok"]          # and it is the Poseidon transcript that makes it so
 
 
 def test_released_bundle_evm_proof_parses_under_the_generated_layer6_protocol():
@@ -168,6 +224,10 @@ def test_cpu_prove_and_verify(tmp_path, layer, k, shape):
         assert not ok, f"a proof with word {word} altered was accepted"
     wrong_inst = list(inp.instances); wrong_inst[0] = (wrong_inst[0] + 1) % pyref.R_MOD
     assert not plonk.verify(pr, vk, wrong_inst, proof, inp.tau)["ok"]
+    if layer in (2, 4):       # the same circuit under the transcript the reference proves these layers with
+        pp = plonk.prove(inp, vk, transcript="poseidon")
+        assert len(pp) == len(proof) and pp != proof and pp[:32 * pr.num_witness[0]] == proof[:32 * pr.num_witness[0]]
+        assert plonk.verify(pr, vk, inp.instances, pp, inp.tau, transcript="poseidon")["ok"] and not plonk.verify(pr, vk, inp.instances, pp, inp.tau)["ok"]
 
 
 def test_a_witness_that_breaks_a_gate_yields_a_rejected_proof(tmp_path):
