@@ -115,7 +115,7 @@ def replay_create_proof(layer: int, k: int | None = None, host_api: bool = False
     pr = plonk.Protocol(json.load(open(rec["protocol_path"])))
     inst = plonk.mont_to_ints(np.frombuffer(rec["instances"], dtype=np.uint64).reshape(-1, 4))
     try:
-        ver = plonk.verify(pr, rec["vk"], inst, rec["proof"], 0x5343524F4C4C0001 + (rec["layer"] if rec["layer"] >= 0 else 0))
+        ver = plonk.verify(pr, rec["vk"], inst, rec["proof"], 0x5343524F4C4C0001 + (rec["layer"] if rec["layer"] >= 0 else 0), transcript=rec["transcript"])
     except AssertionError as e:
         ver = {"ok": False, "error": str(e)}
     out = {k_: v for k_, v in rec.items() if k_ not in ("proof", "vk", "instances", "out_dir", "protocol_path", "returncode")}
@@ -139,7 +139,7 @@ def prover_process(layers, timeout: int = 2400):
         pr = plonk.Protocol(json.load(open(lay["protocol_path"])))
         inst = plonk.mont_to_ints(np.frombuffer(lay["instances"], dtype=np.uint64).reshape(-1, 4))
         try:
-            lay["verified"] = bool(plonk.verify(pr, lay["vk"], inst, lay["proof"], int(lay["tau"], 16))["ok"])
+            lay["verified"] = bool(plonk.verify(pr, lay["vk"], inst, lay["proof"], int(lay["tau"], 16), transcript=lay["transcript"])["ok"])
         except AssertionError:
             lay["verified"] = False
         ok = ok and lay["verified"]
@@ -252,7 +252,7 @@ def main() -> None:
                      "every_proof_verified": ok_all,
                      # optional (--prover-process): the chunk prover as ONE process -- the three layers' SRS, proving keys and witnesses resident together under the HBM plan
                      "chunk_prover_process": prover_process((0, 1, 2)) if args.prover_process else None,
-                     "excludes": "witness synthesis of the real circuits (the circuit instances are built to satisfy each protocol), the Poseidon / Keccak transcripts (halo2's Blake2b transcript stands in)"}
+                     "excludes": "witness synthesis of the real circuits (the circuit instances are built to satisfy each protocol), layer 6's Keccak transcript and EVM proof layout (halo2's Blake2b transcript stands in there; layers 0-5 run the reference's Poseidon transcript)"}
     if single and args.gpus > 1 and not args.no_proof_mix and args.logn == 26:
         # N devices behind ONE prover process: witness columns live round-robin on the devices, commitments take scalars from whichever device
         # holds them (shards of the basis everywhere), the iNTT batch and the coset parts of the quotient run concurrently on different devices

@@ -359,7 +359,12 @@ inline std::unique_ptr<ProvingKey> keygen(const Protocol &P, const Circuit &C, u
 // ------------------------------------------------------------------------------------------------ create_proof
 struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 1; int early_intt = -1 /* -1: by column count */;
                       bool sparse_uploads = false /* columns that are at least half zeros cross PCIe as (index, value) pairs */;
-                      bool packed_multiplicities = false /* the lookup multiplicities cross PCIe as the 4-byte counts they are (mi355_buf_upload_packed); their blinding rows follow as 32-byte words */; };
+                      bool packed_multiplicities = false /* the lookup multiplicities cross PCIe as the 4-byte counts they are (mi355_buf_upload_packed); their blinding rows follow as 32-byte words */;
+                      TranscriptKind transcript = TranscriptKind::Blake2b /* Poseidon: what the reference proves layers 0-5 with (mi355zk_transcript.hpp) */; };
+// the transcript the reference proves a layer with: Poseidon for every proof the next layer verifies in-circuit (layers 0-5, [REF integration/src/prove.rs:30-43,67,95-97] -> snark-verifier-sdk
+// gen_snark_shplonk), Keccak in the EVM layout for layer 6 (not built: the stock Blake2b transcript stands in there).  Files without a layer number are the reference's fixtures (layers 2, 4).
+inline TranscriptKind reference_transcript(const Protocol &P) { return P.layer == 6 ? TranscriptKind::Blake2b : TranscriptKind::Poseidon; }
+inline const char *transcript_name(TranscriptKind k) { return k == TranscriptKind::Poseidon ? "poseidon" : "blake2b"; }
 struct ProofResult {
   std::vector<uint8_t> proof;
   double step_ms[11] = {0}; double total_ms = 0;
@@ -398,7 +403,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   auto ms_since = [](Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); };
   const auto t_start = Clock::now(); auto tl = t_start;
   auto lap = [&](int step) { R.step_ms[step] += ms_since(tl); tl = Clock::now(); };
-  Transcript T;
+  Transcript T(opt.transcript);
   T.common_scalar(vk_transcript_repr(pk.vk));
   for (const auto &v : wit.instances) T.common_scalar(v);
   std::map<uint32_t, DevicePoly> poly;   // protocol index -> Lagrange values until step 6, coefficients afterwards
@@ -652,46 +657,48 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
     const std::vector<RotationSet> sets = rotation_sets(P.queries); const size_t M = sets.size(); R.rotation_sets = (uint32_t)M;
     std::vector<DevicePoly> Acomb; std::vector<std::vector<Fr>> points(M); std::vector<std::vector<std::vector<Fr>>> rcoef(M);
     DevicePoly H(n, 0), work(n, 0); check(mi355_buf_zero(H.p, n * 32));
+    Fr vpow_i = fr_one();
     for (size_t i = 0; i < M; i++) {
       const RotationSet &s = sets[i]; const size_t np = s.polys.size(), m = s.rots.size();
       for (int32_t r : s.rots) points[i].push_back(rot_point(r));
-      // A_i = sum_j y^(len-1-j) P_ij  (halo2 folds acc * y + poly), and the same combination of the interpolated remainders (m coefficients, on the host)
+      // A_i = sum_j y^j P_ij (the j-th polynomial of a set carries y^j: what the reference's released proofs satisfy, tests/test_plonk_protocol.py::test_reference_released_proofs_verify),
+      // and the same combination of the interpolated remainders (m coefficients, on the host)
       std::vector<Fr> ypow(np, fr_one()); for (size_t j = 1; j < np; j++) ypow[j] = fr_mul(ypow[j - 1], ys);
       DevicePoly Ai(n, 0);
       for (size_t base = 0; base < np; base += 16) {
         const uint32_t cnt = (uint32_t)std::min<size_t>(16, np - base);
         std::vector<const void *> pp(cnt); std::vector<Fr> cs(cnt); std::vector<uint32_t> tl_(cnt, 1), fp(cnt); std::vector<int32_t> fr_(cnt, 0);
-        for (uint32_t j = 0; j < cnt; j++) { pp[j] = opened(s.polys[base + j]); cs[j] = ypow[np - 1 - (base + j)]; fp[j] = j; }
+        for (uint32_t j = 0; j < cnt; j++) { pp[j] = opened(s.polys[base + j]); cs[j] = ypow[base + j]; fp[j] = j; }
         gate_eval(Ai.p, pp.data(), cnt, cs.data(), tl_.data(), cnt, fp.data(), fr_.data(), n, base ? 1 : 0); R.gate_launches++;
       }
       std::vector<Fr> rsum(m, fr_zero());
       for (size_t j = 0; j < np; j++) {
         std::vector<Fr> vals; for (int32_t r : s.rots) vals.push_back(evals.at({s.polys[j], r}));
         rcoef[i].push_back(detail::interpolate(points[i], vals));
-        for (size_t t = 0; t < m; t++) rsum[t] = fr_add(rsum[t], fr_mul(ypow[np - 1 - j], rcoef[i][j][t]));
+        for (size_t t = 0; t < m; t++) rsum[t] = fr_add(rsum[t], fr_mul(ypow[j], rcoef[i][j][t]));
       }
       // N_i = A_i - R_i: only the lowest m coefficients change; then N_i / prod (X - point), one kate_division per point, in place (shifting up by one each time)
       check(mi355_buf_copy(work.p, Ai.p, n * 32));
       { std::vector<Fr> low(m); check(mi355_buf_download(low.data(), work.p, m * 32)); for (size_t t = 0; t < m; t++) low[t] = fr_sub(low[t], rsum[t]); check(mi355_buf_upload(work.p, low.data(), m * 32)); }
       for (size_t t = 0; t < m; t++) check(mi355_fr_kate_division_dev(work.at(t + 1), work.at(t), n - t, points[i][t].data()));
-      // H = H v + Q_i  (fold acc * v + quotient); Q_i has n - m coefficients at work[m ..]
-      if (i > 0) check(mi355_fr_vec_axpy_dev(H.p, nullptr, H.p, v.data(), n));
-      check(mi355_fr_vec_op_dev(0, H.p, H.p, work.at(m), n - m));
+      // H += v^i Q_i (the i-th rotation set carries v^i); Q_i has n - m coefficients at work[m ..]
+      check(mi355_fr_vec_axpy_dev(H.p, H.p, work.at(m), vpow_i.data(), n - m));
+      vpow_i = fr_mul(vpow_i, v);
       Acomb.push_back(std::move(Ai));
     }
     commit_one(h_g, H.p);
     const Fr uu = T.squeeze_challenge();
     std::vector<Fr> super; for (size_t i = 0; i < M; i++) for (const auto &pt : points[i]) if (std::find(super.begin(), super.end(), pt) == super.end()) super.push_back(pt);
     Fr zt = fr_one(); for (const auto &pt : super) zt = fr_mul(zt, fr_sub(uu, pt));
-    // L = sum_i v^(M-1-i) zd_i (A_i - r_i(u)) - Z_T(u) H, scaled by 1 / zd_0;  L(u) = 0
+    // L = sum_i v^i zd_i (A_i - r_i(u)) - Z_T(u) H, scaled by 1 / zd_0;  L(u) = 0
     std::vector<Fr> vpow(M, fr_one()); for (size_t i = 1; i < M; i++) vpow[i] = fr_mul(vpow[i - 1], v);
     std::vector<Fr> lc(M); Fr zd0 = fr_one(), cst = fr_zero();
     for (size_t i = 0; i < M; i++) {
       Fr zd = fr_one(); for (const auto &pt : super) if (std::find(points[i].begin(), points[i].end(), pt) == points[i].end()) zd = fr_mul(zd, fr_sub(uu, pt));
       if (i == 0) zd0 = zd;
       const size_t np = sets[i].polys.size(); Fr ri = fr_zero();
-      for (size_t j = 0; j < np; j++) ri = fr_add(fr_mul(ri, ys), detail::horner(rcoef[i][j], uu));
-      lc[i] = fr_mul(vpow[M - 1 - i], zd); cst = fr_add(cst, fr_mul(lc[i], ri));
+      Fr yp = fr_one(); for (size_t j = 0; j < np; j++) { ri = fr_add(ri, fr_mul(yp, detail::horner(rcoef[i][j], uu))); yp = fr_mul(yp, ys); }
+      lc[i] = fr_mul(vpow[i], zd); cst = fr_add(cst, fr_mul(lc[i], ri));
     }
     const Fr zi = fr_inv(zd0);
     DevicePoly Lx(n, 0);

@@ -1,15 +1,22 @@
-// mi355zk_transcript.hpp -- halo2's Blake2b transcript on the host side of create_proof.
+// mi355zk_transcript.hpp -- the Fiat-Shamir transcripts of create_proof on the host side: halo2's stock Blake2b one and the Poseidon one the reference proves its layers 0-5 with.
 //
-// create_proof owns the transcript: commitments and evaluations go in, challenges come out [EXT-recalled halo2_proofs src/transcript/blake2b.rs:
-// Blake2bWrite<_, _, Challenge255<_>>]: Blake2b-512 with the personalisation "Halo2-Transcript"; a point is absorbed as 0x01 | x | y (canonical 32-byte
-// little-endian coordinates; the identity is refused) and WRITTEN to the proof in its 32-byte compressed form; a scalar as 0x02 | canonical bytes, written
-// the same way; a challenge = the 64-byte digest of (state | 0x00), read as a 512-bit little-endian integer and reduced mod r (Fr::from_uniform_bytes).
-// The reference's inner layers hash with Poseidon and layer 6 with Keccak [EXT-recalled snark-verifier-sdk]: their parameters are not in the checkout,
-// so this stock halo2 transcript stands in; the proof's BYTE LAYOUT is the reference's either way.
+// create_proof owns the transcript: commitments and evaluations go in, challenges come out.  Both kinds WRITE the same proof bytes (a point in its 32-byte compressed form, a scalar
+// as 32 canonical little-endian bytes: the reference's layout); they differ in what they hash:
+//   Blake2b  [EXT-recalled halo2_proofs src/transcript/blake2b.rs: Blake2bWrite<_, _, Challenge255<_>>]: Blake2b-512, personalisation "Halo2-Transcript"; a point is absorbed as
+//            0x01 | x | y (canonical little-endian coordinates), a scalar as 0x02 | bytes; a challenge = the 64-byte digest of (state | 0x00) reduced mod r.
+//   Poseidon [EXT-recalled snark-verifier system/halo2/transcript/halo2.rs PoseidonTranscript<NativeLoader>, util/hash/poseidon.rs; snark-verifier-sdk: T = 5, RATE = 4, R_F = 8,
+//            R_P = 60; constants from the Grain LFSR of the Poseidon paper's reference script, as the `poseidon` crate [REF Cargo.lock:2927-2929] generates them]: a scalar is absorbed
+//            as itself, a point as (x mod r, y mod r); `update` only buffers; a challenge = one squeeze: the buffer is absorbed RATE words at a time into state words 1.., a short
+//            chunk is followed by a 1, an exact multiple of RATE by one more permutation of an empty chunk, and state word 1 is the answer (a full field element).
+//            The Python restatement of the same sponge (oracle/poseidon.py) makes the reference's RELEASED chunk and batch proofs verify
+//            (tests/test_plonk_protocol.py::test_reference_released_proofs_verify); this C++ one is compared with it word for word (--transcript-selftest).
+//            Layer 6's Keccak transcript (EVM layout, uncompressed points) is not built: it is the last 1.3 s of a bundle and its proof format differs.
+// Both refuse the identity (halo2's common_point fails on it).
 // The GPU library sees none of this: 96-byte commitments and 32-byte evaluations arrive from the C-ABI and are hashed here, on the calling thread.
-// Cross-checked against Python's hashlib.blake2b in tests/test_plonk_host.py (same personalisation, same byte stream).
 #pragma once
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "mi355zk_halo2.hpp"
 
@@ -78,11 +85,84 @@ inline halo2::Fr fr_from_uniform_bytes(const std::array<uint8_t, 64> &b) {
   return halo2::detail::from_fe(zk::Fr::add(lo, zk::Fr::mul(hi, r2)));
 }
 
+// ---- Poseidon: parameters from the Grain LFSR (80-bit state: field type 1 (2 bits) | s-box 0 (4) | field bits 254 (12) | t (12) | R_F (10) | R_P (10) | thirty 1s; 160 warm-up
+// clocks; self-shrinking output), round constants by rejection sampling of 254-bit draws, the Cauchy matrix 1 / (x_i + y_j) from 2 t draws reduced mod r
+struct PoseidonSpec {
+  static constexpr int T = 5, RATE = 4, RF = 8, RP = 60;
+  std::vector<halo2::Fr> rc; halo2::Fr mds[T][T];
+  static const PoseidonSpec &get() { static const PoseidonSpec s; return s; }
+ private:
+  PoseidonSpec() {
+    std::vector<uint8_t> st;
+    auto push_bits = [&](uint32_t v, int nb) { for (int i = nb - 1; i >= 0; i--) st.push_back((v >> i) & 1); };
+    push_bits(1, 2); push_bits(0, 4); push_bits(254, 12); push_bits(T, 12); push_bits(RF, 10); push_bits(RP, 10); for (int i = 0; i < 30; i++) st.push_back(1);
+    size_t head = 0;   // st[head .. head + 80) is the register; clocking appends and advances
+    auto clock = [&]() { const uint8_t nb = st[head + 62] ^ st[head + 51] ^ st[head + 38] ^ st[head + 23] ^ st[head + 13] ^ st[head]; st.push_back(nb); head++; return nb; };
+    for (int i = 0; i < 160; i++) clock();
+    auto next_bit = [&]() { uint8_t nb = clock(); while (nb == 0) { clock(); nb = clock(); } return clock(); };
+    uint32_t modw[8]; for (int i = 0; i < 8; i++) modw[i] = zk::FrP::mod(i);
+    auto draw = [&](bool reject, bool &ok) {   // 254 bits, most significant first
+      zk::fe_t a = zk::Fr::zero();
+      for (int b = 253; b >= 0; b--) if (next_bit()) a.l[b / 32] |= 1u << (b % 32);
+      ok = !zk::Fr::w_geq(a.l, modw);
+      if (!ok && !reject) { while (zk::Fr::w_geq(a.l, modw)) zk::Fr::w_sub(a.l, modw); ok = true; }
+      return halo2::detail::from_fe(zk::Fr::from_canonical(a));
+    };
+    while (rc.size() < (size_t)(RF + RP) * T) { bool ok; const halo2::Fr v = draw(true, ok); if (ok) rc.push_back(v); }
+    halo2::Fr xs[T], ys[T]; bool ok;
+    for (auto &x : xs) x = draw(false, ok);
+    for (auto &y : ys) y = draw(false, ok);
+    for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) mds[i][j] = halo2::detail::fr_inv(halo2::detail::from_fe(zk::Fr::add(halo2::detail::to_fe(xs[i]), halo2::detail::to_fe(ys[j]))));
+  }
+};
+struct PoseidonSponge {
+  static constexpr int T = PoseidonSpec::T, RATE = PoseidonSpec::RATE;
+  zk::fe_t state[T]; std::vector<zk::fe_t> buf;
+  PoseidonSponge() { for (auto &w : state) w = zk::Fr::zero(); zk::fe_t c = zk::Fr::zero(); c.l[2] = 1; state[0] = zk::Fr::from_canonical(c); }   // [2^64, 0, 0, 0, 0]
+  void update(const halo2::Fr &w) { buf.push_back(halo2::detail::to_fe(w)); }
+  static zk::fe_t pow5(const zk::fe_t &a) { const zk::fe_t a2 = zk::Fr::mul(a, a); return zk::Fr::mul(zk::Fr::mul(a2, a2), a); }
+  void permute() {
+    const PoseidonSpec &S = PoseidonSpec::get();
+    for (int r = 0; r < PoseidonSpec::RF + PoseidonSpec::RP; r++) {
+      for (int i = 0; i < T; i++) state[i] = zk::Fr::add(state[i], halo2::detail::to_fe(S.rc[(size_t)r * T + i]));
+      if (r < PoseidonSpec::RF / 2 || r >= PoseidonSpec::RF / 2 + PoseidonSpec::RP) { for (auto &w : state) w = pow5(w); } else state[0] = pow5(state[0]);
+      zk::fe_t nx[T];
+      for (int i = 0; i < T; i++) { zk::fe_t acc = zk::Fr::zero(); for (int j = 0; j < T; j++) acc = zk::Fr::add(acc, zk::Fr::mul(halo2::detail::to_fe(S.mds[i][j]), state[j])); nx[i] = acc; }
+      for (int i = 0; i < T; i++) state[i] = nx[i];
+    }
+  }
+  void absorb_and_permute(const zk::fe_t *chunk, size_t len) {
+    for (size_t i = 0; i < len; i++) state[1 + i] = zk::Fr::add(state[1 + i], chunk[i]);
+    if (len < (size_t)RATE) state[len + 1] = zk::Fr::add(state[len + 1], zk::Fr::one());
+    permute();
+  }
+  halo2::Fr squeeze() {
+    std::vector<zk::fe_t> b; b.swap(buf);
+    for (size_t i = 0; i < b.size(); i += RATE) absorb_and_permute(b.data() + i, std::min<size_t>(RATE, b.size() - i));
+    if (b.size() % RATE == 0) absorb_and_permute(nullptr, 0);
+    return halo2::detail::from_fe(state[1]);
+  }
+};
+
+enum class TranscriptKind { Blake2b, Poseidon };
+inline TranscriptKind transcript_kind_from_name(const std::string &s) {
+  if (s == "blake2b") return TranscriptKind::Blake2b;
+  if (s == "poseidon") return TranscriptKind::Poseidon;
+  throw std::invalid_argument("transcript: blake2b or poseidon expected, got " + s);
+}
+
 struct Transcript {
+  TranscriptKind kind;
   Blake2b state{"Halo2-Transcript"};
-  std::vector<uint8_t> proof;                                   // what Blake2bWrite's writer receives: the proof, in the reference's layout
-  halo2::Fr squeeze_challenge() { const uint8_t z = 0; state.update(&z, 1); return fr_from_uniform_bytes(state.digest()); }
+  PoseidonSponge sponge;
+  std::vector<uint8_t> proof;                                   // what the transcript's writer receives: the proof, in the reference's layout
+  explicit Transcript(TranscriptKind k = TranscriptKind::Blake2b) : kind(k) {}
+  halo2::Fr squeeze_challenge() {
+    if (kind == TranscriptKind::Poseidon) return sponge.squeeze();
+    const uint8_t z = 0; state.update(&z, 1); return fr_from_uniform_bytes(state.digest());
+  }
   void common_scalar(const halo2::Fr &s) {
+    if (kind == TranscriptKind::Poseidon) { sponge.update(s); return; }
     const uint8_t tag = 2; state.update(&tag, 1);
     const zk::fe_t c = zk::Fr::to_canonical(halo2::detail::to_fe(s)); state.update(&c, 32);
   }
@@ -97,7 +177,16 @@ struct Transcript {
     if (ident) throw std::invalid_argument("transcript: the identity has no coordinates (halo2's common_point fails on it)");
     zk::fe_t x, y; std::memcpy(&x, a.data(), 32); std::memcpy(&y, a.data() + 4, 32);
     const zk::fe_t xc = zk::Fq::to_canonical(x), yc = zk::Fq::to_canonical(y);
-    const uint8_t tag = 1; state.update(&tag, 1); state.update(&xc, 32); state.update(&yc, 32);
+    if (kind == TranscriptKind::Poseidon) {
+      auto base_to_scalar = [](zk::fe_t c) {   // a base-field coordinate as a scalar: its value mod r (q < 2 r: one subtraction at most)
+        uint32_t m[8]; for (int i = 0; i < 8; i++) m[i] = zk::FrP::mod(i);
+        while (zk::Fr::w_geq(c.l, m)) zk::Fr::w_sub(c.l, m);
+        return halo2::detail::from_fe(zk::Fr::from_canonical(c));
+      };
+      sponge.update(base_to_scalar(xc)); sponge.update(base_to_scalar(yc));
+    } else {
+      const uint8_t tag = 1; state.update(&tag, 1); state.update(&xc, 32); state.update(&yc, 32);
+    }
     const halo2::G1Bytes b = halo2::g1_to_bytes(a); proof.insert(proof.end(), b.begin(), b.end());
   }
 };

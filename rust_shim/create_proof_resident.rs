@@ -148,12 +148,14 @@ pub fn evaluate_all(polys: &[*const c_void], points: &[Fr], n: usize) -> Option<
 
 /// R8 (hpp: step 10): SHPLONK as halo2's ProverSHPLONK runs it.  `sets[i]` = one rotation set: its points x omega^rot, its polynomials (coefficient
 /// pointers, first-appearance order of the queries) and, per polynomial, the interpolated remainder's coefficients (host, <= 4).  Per set: A_i = sum_j
-/// y^(len-1-j) P_ij (fused launches of 16), N_i = A_i - R_i (only the lowest |points| coefficients change), N_i / prod (X - point) by one in-place
-/// `kate_division` per point; H = fold(acc v + Q_i).  The caller commits H, squeezes u, then `linearised` builds L = sum_i v^(M-1-i) zd_i (A_i - r_i(u))
-/// - Z_T(u) H scaled by 1 / zd_0 and returns L / (X - u) for the second commitment.
+/// y^j P_ij (fused launches of 16; `y_pows[i][j]` = y^j), N_i = A_i - R_i (only the lowest |points| coefficients change), N_i / prod (X - point) by one in-place
+/// `kate_division` per point; H = sum_i v^i Q_i.  The caller commits H, squeezes u, then `linearised` builds L = sum_i v^i zd_i (A_i - r_i(u))
+/// - Z_T(u) H scaled by 1 / zd_0 and returns L / (X - u) for the second commitment.  (Ascending powers: the order the reference's released proofs satisfy,
+/// tests/test_plonk_protocol.py::test_reference_released_proofs_verify.)
 pub struct RotationSet { pub points: Vec<Fr>, pub polys: Vec<*const c_void>, pub remainder_sum: Vec<Fr> }
 pub fn shplonk_quotient(sets: &[RotationSet], y_pows: &[Vec<Fr>], v: Fr, n: usize) -> Option<(Vec<DevicePoly>, DevicePoly)> {
     let (mut combos, mut h, mut work) = (Vec::new(), DevicePoly::zeroed(n, 0)?, DevicePoly::zeroed(n, 0)?);
+    let mut v_pow = Fr::one();
     for (i, s) in sets.iter().enumerate() {
         let mut a = DevicePoly::zeroed(n, 0)?;
         for (c, chunk) in s.polys.chunks(16).enumerate() {
@@ -171,9 +173,9 @@ pub fn shplonk_quotient(sets: &[RotationSet], y_pows: &[Vec<Fr>], v: Fr, n: usiz
                 let base = work.as_mut_ptr() as *mut u8;
                 if mi355zk::mi355_fr_kate_division_dev(base.add(32 * (t + 1)) as *mut c_void, base.add(32 * t) as *const c_void, (n - t) as u64, p(&s.points[t])) != 0 { return None; }
             }
-            if i > 0 && mi355_fr_vec_axpy_dev(h.as_mut_ptr(), std::ptr::null(), h.as_ptr(), p(&v), n as u64) != 0 { return None; }
-            if mi355_fr_vec_op_dev(0, h.as_mut_ptr(), h.as_ptr(), (work.as_ptr() as *const u8).add(32 * m) as *const c_void, (n - m) as u64) != 0 { return None; }
+            if mi355_fr_vec_axpy_dev(h.as_mut_ptr(), h.as_ptr(), (work.as_ptr() as *const u8).add(32 * m) as *const c_void, p(&v_pow), (n - m) as u64) != 0 { return None; }
         }
+        v_pow *= v;
         combos.push(a);
     }
     Some((combos, h))

@@ -25,7 +25,7 @@ static void write_file(const std::string &path, const void *p, size_t bytes) { s
 int main(int argc, char **argv) {
   std::string protocol_path, out_dir, tables = "auto", pk_mode = "auto";
   int devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2, upload_threads = 1, early_intt = -1;
-  bool host_api = false, builder_only = false, dump_inputs = false, pinned_witness = false, corrupt = false, sparse_uploads = false, packed_m = true; uint64_t seed = 1; double fill = 0.9, assign_density = 1.0;
+  bool host_api = false, builder_only = false, dump_inputs = false, pinned_witness = false, corrupt = false, sparse_uploads = false, packed_m = true; uint64_t seed = 1; double fill = 0.9, assign_density = 1.0; TranscriptKind transcript = TranscriptKind::Blake2b; bool transcript_auto = true;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto next = [&]() -> long { return i + 1 < argc ? std::atol(argv[++i]) : 0; };
@@ -36,6 +36,7 @@ int main(int argc, char **argv) {
     else if (a == "--upload-threads") upload_threads = (int)next(); else if (a == "--early-intt") early_intt = (int)next(); else if (a == "--pinned-witness") pinned_witness = true;
     else if (a == "--seed") seed = (uint64_t)next(); else if (a == "--fill") fill = std::atof(nexts().c_str()); else if (a == "--corrupt-witness") corrupt = true;
     else if (a == "--sparse-uploads") sparse_uploads = true; else if (a == "--packed-multiplicities") packed_m = true; else if (a == "--no-packed-multiplicities") packed_m = false; else if (a == "--assign-density") assign_density = std::atof(nexts().c_str());
+    else if (a == "--transcript") { const std::string tn = nexts(); if (tn == "auto") continue; transcript_auto = false; try { transcript = transcript_kind_from_name(tn); } catch (const std::exception &e) { std::printf("%s\n", e.what()); return 1; } }
     else if (a == "--transcript-selftest") {   // host only: a fixed byte stream through the Blake2b transcript (tests compare with hashlib)
       Transcript T; T.common_scalar(fr_u64(5)); const Fr c1 = fr_to_canonical(T.squeeze_challenge());
       G1 g{}; { const Fr one = fr_one(); (void)one; mi355zk::halo2::G1Affine gen{}; zk::fe_t x = zk::Fq::one(), y = zk::Fq::add(zk::Fq::one(), zk::Fq::one()); std::memcpy(gen.data(), &x, 32); std::memcpy(gen.data() + 4, &y, 32); std::memcpy(g.data(), gen.data(), 64); std::memcpy(g.data() + 8, &x, 32); }
@@ -43,11 +44,19 @@ int main(int argc, char **argv) {
       std::vector<uint8_t> vkb(40, 7); const Fr c3 = fr_to_canonical(vk_transcript_repr(vkb));
       auto hex = [](const Fr &c) { char b[65]; std::snprintf(b, sizeof b, "%016llx%016llx%016llx%016llx", (unsigned long long)c[3], (unsigned long long)c[2], (unsigned long long)c[1], (unsigned long long)c[0]); return std::string(b); };
       std::string ph; for (uint8_t b : T.proof) { char t[3]; std::snprintf(t, sizeof t, "%02x", b); ph += t; }
-      std::printf("{\"c1\": \"%s\", \"c2\": \"%s\", \"vk_repr\": \"%s\", \"proof\": \"%s\"}\n", hex(c1).c_str(), hex(c2).c_str(), hex(c3).c_str(), ph.c_str());
+      // the same stream through the Poseidon transcript, plus squeezes on every buffer length 0 .. 9 (short chunk, exact multiple of RATE, empty) and the first constants
+      Transcript S(TranscriptKind::Poseidon); S.common_scalar(fr_u64(5)); const Fr p1 = fr_to_canonical(S.squeeze_challenge());
+      S.write_point(g); S.write_scalar(fr_u64(0xDEADBEEFull)); const Fr p2 = fr_to_canonical(S.squeeze_challenge());
+      std::string lens; Transcript L(TranscriptKind::Poseidon);
+      for (int len = 0; len < 10; len++) { for (int i = 0; i < len; i++) L.common_scalar(fr_u64(1000 * len + i)); lens += (len ? ", \"" : "\"") + hex(fr_to_canonical(L.squeeze_challenge())) + "\""; }
+      const PoseidonSpec &PS = PoseidonSpec::get();
+      std::printf("{\"c1\": \"%s\", \"c2\": \"%s\", \"vk_repr\": \"%s\", \"proof\": \"%s\", \"poseidon\": {\"c1\": \"%s\", \"c2\": \"%s\", \"by_length\": [%s], \"rc0\": \"%s\", \"rc_last\": \"%s\", \"mds00\": \"%s\", \"mds44\": \"%s\", \"proof_equal\": %s}}\n",
+                  hex(c1).c_str(), hex(c2).c_str(), hex(c3).c_str(), ph.c_str(), hex(p1).c_str(), hex(p2).c_str(), lens.c_str(), hex(fr_to_canonical(PS.rc.front())).c_str(), hex(fr_to_canonical(PS.rc.back())).c_str(),
+                  hex(fr_to_canonical(PS.mds[0][0])).c_str(), hex(fr_to_canonical(PS.mds[4][4])).c_str(), S.proof == T.proof ? "true" : "false");
       return 0;
     }
     else { std::printf("usage: %s --protocol FILE --out DIR [--builder-only] [--dump-inputs] [--devices D] [--threads T] [--proofs N] [--upload-threads U] [--early-intt 0|1] [--pinned-witness]\n"
-                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--no-packed-multiplicities] [--assign-density D] | --transcript-selftest\n", argv[0]); return 1; }
+                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--no-packed-multiplicities] [--transcript auto|blake2b|poseidon] [--assign-density D] | --transcript-selftest\n", argv[0]); return 1; }
   }
   if (protocol_path.empty() || out_dir.empty()) { std::printf("--protocol and --out are required\n"); return 1; }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;
@@ -56,6 +65,7 @@ int main(int argc, char **argv) {
   Protocol P;
   try { P.load(protocol_path); } catch (const std::exception &e) { std::printf("cannot load the protocol: %s\n", e.what()); return 1; }
   const uint32_t k = P.k, Q = P.Q; const uint64_t n = P.n;
+  if (transcript_auto) transcript = reference_transcript(P);   // what the reference proves this layer with
   const Fr tau = fr_u64(0x5343524F4C4C0001ull + (uint64_t)(P.layer < 0 ? 0 : P.layer));
   if (builder_only) {
     try {
@@ -115,7 +125,7 @@ int main(int argc, char **argv) {
     if (devices > 1 && tables == "auto") n_tables = 2;
     if (n_tables >= 1 && mi355_srs_precompute(hl, 0, 0) != MI355_OK) { std::printf("window tables for g_lagrange did not fit (%s): table-free schedule\n", mi355_last_error()); n_tables = 0; }
     if (n_tables >= 2 && mi355_srs_precompute(hg, 0, 0) != MI355_OK) { std::printf("window tables for g did not fit (%s): Lagrange basis only\n", mi355_last_error()); n_tables = 1; }
-    ProofOptions opt; opt.devices = devices; opt.threads = threads; opt.upload_threads = upload_threads; opt.early_intt = early_intt; opt.sparse_uploads = sparse_uploads; opt.packed_multiplicities = packed_m;
+    ProofOptions opt; opt.devices = devices; opt.threads = threads; opt.upload_threads = upload_threads; opt.early_intt = early_intt; opt.sparse_uploads = sparse_uploads; opt.packed_multiplicities = packed_m; opt.transcript = transcript;
     // ---- the proofs: a prover process runs proof after proof; the first one grows the workspace arena and the buffer pool, the last one is reported
     ProofResult R; double first_ms = 0;
     for (int it = 0; it < proofs; it++) { R = create_proof(hg, hl, *pk, *C, opt); if (it == 0) first_ms = R.total_ms; }
@@ -158,7 +168,7 @@ int main(int argc, char **argv) {
       "\"host_api_ms\": %.3f, \"host_api_fft_ms\": %.3f, \"host_api_fft_batched_ms\": %.3f, "
       "\"step_ms\": {\"1_instance\": %.2f, \"2_3_advice_lookup_commits\": %.2f, \"4_products\": %.2f, \"5_random\": %.2f, \"6_to_coeff\": %.2f, \"7_quotient\": %.2f, \"8_commit_h\": %.2f, \"9_evals\": %.2f, \"10_shplonk\": %.2f}, "
       "\"hbm\": {\"total_gib\": %.1f, \"peak_used_gib\": %.1f, \"proving_key_gib\": %.1f, \"live_buffers_gib\": %.1f, \"pooled_gib\": %.1f, \"workspace_gib\": %.1f, \"planned\": {\"pk_base_gib\": %.1f, \"pk_cosets_gib\": %.1f, \"working_set_gib\": %.1f, \"one_table_gib\": %.1f, \"usable_gib\": %.1f}}, "
-      "\"ok\": true}",
+      "\"transcript\": \"%s\", \"ok\": true}",
       P.layer, k, devices, P.num_pre, P.num_witness[0], P.num_witness[1], P.num_witness[2], Q, P.evaluations.size(), P.queries.size(), P.perm.size(), P.lookups.size(), P.gates.size(), P.last_rot,
       C->pairs.size(), (unsigned long long)C->gates_active, (unsigned long long)C->lookup_rows, build_ms, keygen_ms,
       R.plan_constraints, R.plan_launches, R.plan_terms, R.plan_tmps, R.plan_prefix_groups, pk->commons.defs.size(),
@@ -167,7 +177,7 @@ int main(int argc, char **argv) {
       R.msm, R.intt, R.coset_ntt, R.gate_launches, R.evals, R.rotation_sets, R.proof.size(), R.total_ms, first_ms, proofs,
       host_ms, host_fft_ms, host_fft_batched_ms,
       R.step_ms[1], R.step_ms[2], R.step_ms[4], R.step_ms[5], R.step_ms[6], R.step_ms[7], R.step_ms[8], R.step_ms[9], R.step_ms[10],
-      hbm_total / GiB, (hbm_total - fr_end) / GiB, pk->bytes / GiB, live / GiB, pooled / GiB, ws / GiB, sz.base_bytes / GiB, sz.coset_bytes / GiB, working / GiB, table_one / GiB, usable / GiB);
+      hbm_total / GiB, (hbm_total - fr_end) / GiB, pk->bytes / GiB, live / GiB, pooled / GiB, ws / GiB, sz.base_bytes / GiB, sz.coset_bytes / GiB, working / GiB, table_one / GiB, usable / GiB, transcript_name(transcript));
     std::printf("%s\n", line);
     write_file(out_dir + "/result.json", line, std::strlen(line));
     pk.reset();

@@ -78,6 +78,7 @@ int main(int argc, char **argv) {
         // the previous layer's blocks have another size: the library carves this layer's blocks out of the same slabs (lib_core.hip "Slabs"), nothing goes back to HIP in between.
         // --trim forces mi355_buf_trim at every layer boundary (the behaviour a caller had to choose before the slabs existed; kept for A/B)
         if (NLY > 1 && trim_between) check(mi355_buf_trim());
+        opt.transcript = reference_transcript(*P[i]);   // Poseidon for the layers the next one verifies in-circuit
         R[i] = create_proof(srs[P[i]->k].g, srs[P[i]->k].gl, *pk[i], *C[i], opt);
       }
       round_ms.push_back(ms_since(t0));
@@ -91,8 +92,8 @@ int main(int argc, char **argv) {
       const Fr tc = fr_to_canonical(srs[P[i]->k].tau); char hex[65];
       std::snprintf(hex, sizeof hex, "%016llx%016llx%016llx%016llx", (unsigned long long)tc[3], (unsigned long long)tc[2], (unsigned long long)tc[1], (unsigned long long)tc[0]);
       char b[1024];
-      std::snprintf(b, sizeof b, "%s{\"index\": %zu, \"layer\": %d, \"k\": %u, \"tau\": \"%s\", \"ms\": %.3f, \"msm\": %u, \"coset_ntt\": %u, \"proof_bytes\": %zu, \"cosets_resident\": %s, \"table_lagrange\": %s, \"table_coeff\": %s, \"proving_key_gib\": %.1f}",
-                    i ? ", " : "", i, P[i]->layer, P[i]->k, hex, R[i].total_ms, R[i].msm, R[i].coset_ntt, R[i].proof.size(), plan.layers[i].cosets_resident ? "true" : "false",
+      std::snprintf(b, sizeof b, "%s{\"index\": %zu, \"layer\": %d, \"k\": %u, \"tau\": \"%s\", \"transcript\": \"%s\", \"ms\": %.3f, \"msm\": %u, \"coset_ntt\": %u, \"proof_bytes\": %zu, \"cosets_resident\": %s, \"table_lagrange\": %s, \"table_coeff\": %s, \"proving_key_gib\": %.1f}",
+                    i ? ", " : "", i, P[i]->layer, P[i]->k, hex, transcript_name(reference_transcript(*P[i])), R[i].total_ms, R[i].msm, R[i].coset_ntt, R[i].proof.size(), plan.layers[i].cosets_resident ? "true" : "false",
                     plan.layers[i].table_lagrange ? "true" : "false", plan.layers[i].table_coeff ? "true" : "false", pk[i]->bytes / GiB);
       layers_json += b;
     }

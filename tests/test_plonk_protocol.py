@@ -189,6 +189,28 @@ def test_cpp_transcript_equals_hashlib_blake2b():
     assert "%064x" % plonk.vk_transcript_repr(bytes([7] * 40)) == got["vk_repr"]
 
 
+def test_cpp_poseidon_transcript_equals_the_restatement_that_verifies_the_released_proofs():
+    """the product's Poseidon transcript (include/mi355zk_transcript.hpp: Grain constants generated in C++, the sponge, points as (x mod r, y mod r)) against oracle/poseidon.py,
+    which the reference's released proofs pin: first / last round constant, two matrix entries, the same stream as the Blake2b test, and a squeeze after every buffer length 0 .. 9
+    on one running sponge (short chunk + 1, exact multiple of RATE + empty permutation, nothing buffered)"""
+    from oracle import poseidon
+    got = json.loads(subprocess.run([exe(), "--transcript-selftest"], capture_output=True, text=True, timeout=60).stdout)["poseidon"]
+    rc, mds = poseidon.parameters(5, 8, 60)
+    assert ["%064x" % v for v in (rc[0], rc[-1], mds[0][0], mds[4][4])] == [got["rc0"], got["rc_last"], got["mds00"], got["mds44"]]
+    T = plonk.PoseidonTranscript(); T.common_scalar(5)
+    assert "%064x" % T.squeeze() == got["c1"]
+    T.write_point((1, 2)); T.write_scalar(0xDEADBEEF)
+    assert "%064x" % T.squeeze() == got["c2"] and got["proof_equal"] is True
+    L = plonk.PoseidonTranscript()
+    for ln in range(10):
+        for i in range(ln):
+            L.common_scalar(1000 * ln + i)
+        assert "%064x" % L.squeeze() == got["by_length"][ln], ln
+    # a coordinate above r is absorbed reduced: (x mod r, y mod r)
+    big = plonk.PoseidonTranscript(); big.common_point((pyref.R_MOD + 5, 7)); ref = plonk.PoseidonTranscript(); ref.common_scalar(5); ref.common_scalar(7)
+    assert big.squeeze() == ref.squeeze()
+
+
 def build_instance(tmp_path, layer, k, **shape):
     d = str(tmp_path / f"l{layer}"); os.makedirs(d, exist_ok=True)
     proto = protocols.write(layer, os.path.join(d, "p.json"), k, **shape)
@@ -254,11 +276,12 @@ def check_against_restatement(rec):
     inp, man = plonk.ProofInputs.load(rec["out_dir"])
     vk = plonk.keygen_vk(inp.pr, inp.pre, inp.tau)
     assert rec["vk"] == vk, "verifying key (commit_lagrange of the fixed / sigma columns) differs"
-    want = plonk.prove(inp, vk)
+    assert rec["transcript"] == ("blake2b" if inp.pr.d.get("layer") == 6 else "poseidon")       # the reference's choice per layer (Keccak at layer 6: Blake2b stands in)
+    want = plonk.prove(inp, vk, transcript=rec["transcript"])
     got = rec["proof"]
     first = next((i // 32 for i in range(0, min(len(got), len(want)), 32) if got[i:i + 32] != want[i:i + 32]), None)
     assert got == want, f"proof bytes differ from the CPU restatement from word {first} on ({len(got)} vs {len(want)} bytes)"
-    assert plonk.verify(inp.pr, rec["vk"], inp.instances, got, inp.tau)["ok"]
+    assert plonk.verify(inp.pr, rec["vk"], inp.instances, got, inp.tau, transcript=rec["transcript"])["ok"]
     pr = inp.pr
     nw = sum(pr.num_witness)
     assert rec["msm"] == nw + pr.Q + 2 and rec["intt"] == nw and rec["evals"] == len(pr.evaluations) and rec["proof_bytes"] == len(want)   # nw - 1 witness polynomials + the instance column
@@ -297,7 +320,7 @@ def test_gpu_proof_of_a_broken_witness_is_rejected(tmp_path):
     assert rec.get("ok"), rec.get("error")
     pr = plonk.Protocol(json.load(open(rec["protocol_path"])))
     inst = plonk.mont_to_ints(np.frombuffer(rec["instances"], dtype=np.uint64).reshape(-1, 4))
-    assert len(rec["proof"]) == 1312 and not plonk.verify(pr, rec["vk"], inst, rec["proof"], TAU0 + 4)["ok"]
+    assert len(rec["proof"]) == 1312 and not plonk.verify(pr, rec["vk"], inst, rec["proof"], TAU0 + 4, transcript=rec["transcript"])["ok"]
 
 
 def verify_record(rec, layer):
@@ -305,7 +328,7 @@ def verify_record(rec, layer):
     pr = plonk.Protocol(json.load(open(rec["protocol_path"])))
     inst = plonk.mont_to_ints(np.frombuffer(rec["instances"], dtype=np.uint64).reshape(-1, 4))
     tau = TAU0 + (rec["layer"] if rec["layer"] >= 0 else 0)
-    res = plonk.verify(pr, rec["vk"], inst, rec["proof"], tau)
+    res = plonk.verify(pr, rec["vk"], inst, rec["proof"], tau, transcript=rec["transcript"])
     assert res["ok"], res
     return pr
 
@@ -340,5 +363,5 @@ def test_gpu_one_prover_process_holds_three_layers(tmp_path):
     for lay in rec["layers"]:
         pr = plonk.Protocol(json.load(open(lay["protocol_path"])))
         inst = plonk.mont_to_ints(np.frombuffer(lay["instances"], dtype=np.uint64).reshape(-1, 4))
-        assert plonk.verify(pr, lay["vk"], inst, lay["proof"], int(lay["tau"], 16))["ok"], lay["layer"]
+        assert plonk.verify(pr, lay["vk"], inst, lay["proof"], int(lay["tau"], 16), transcript=lay["transcript"])["ok"], lay["layer"]
         assert lay["cosets_resident"] and lay["proof_bytes"] == len(lay["proof"])

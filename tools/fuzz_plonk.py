@@ -50,9 +50,9 @@ for it in range(iters):
         try:
             inp, man = plonk.ProofInputs.load(d)
             vk = plonk.keygen_vk(inp.pr, inp.pre, inp.tau)
-            want = plonk.prove(inp, vk)
+            want = plonk.prove(inp, vk, transcript=rec["transcript"])
             same = rec["proof"] == want and rec["vk"] == vk
-            ver = plonk.verify(inp.pr, rec["vk"], inp.instances, rec["proof"], inp.tau)["ok"]
+            ver = plonk.verify(inp.pr, rec["vk"], inp.instances, rec["proof"], inp.tau, transcript=rec["transcript"])["ok"]
             ok = same and ver
             if not ok:
                 first = next((i // 32 for i in range(0, min(len(want), len(rec["proof"])), 32) if want[i:i + 32] != rec["proof"][i:i + 32]), None)
