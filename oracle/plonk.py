@@ -28,7 +28,7 @@ import json
 
 import numpy as np
 
-from . import cref, pairing, poseidon, pyref
+from . import cref, keccak, pairing, poseidon, pyref
 
 R = pyref.R_MOD
 FR = cref.FR
@@ -269,7 +269,51 @@ class PoseidonTranscript(Transcript):
         self.h.update([s % R])
 
 
-TRANSCRIPTS = {"blake2b": Transcript, "poseidon": PoseidonTranscript}
+class EvmTranscript(Transcript):
+    """snark-verifier's `EvmTranscript` [EXT-recalled snark-verifier system/halo2/transcript/evm.rs; spelled out by REF release-v0.13.1/evm_verifier.yul:66-100], the transcript of
+    layer 6: everything is 32-byte BIG-endian words -- a scalar one word, a point two (x, y; the proof carries points uncompressed) --, appended to a buffer; a challenge =
+    Keccak-256 of the buffer (plus one byte 0x01 when the buffer is exactly one word, i.e. a squeeze right after a squeeze) reduced mod r, and the 32-byte hash becomes the new buffer."""
+
+    def __init__(self, proof: bytes | None = None):
+        self.buf = b""
+        self.out = bytearray()
+        self.inp = proof
+        self.pos = 0
+
+    def squeeze(self) -> int:
+        h = keccak.keccak256(self.buf + (b"\x01" if len(self.buf) == 32 else b""))
+        self.buf = h
+        return int.from_bytes(h, "big") % R
+
+    def common_point(self, p_affine_int):
+        assert p_affine_int is not None, "the transcript refuses the identity"
+        self.buf += int(p_affine_int[0]).to_bytes(32, "big") + int(p_affine_int[1]).to_bytes(32, "big")
+
+    def common_scalar(self, s: int):
+        self.buf += int(s % R).to_bytes(32, "big")
+
+    def write_point(self, p_affine_int):
+        self.common_point(p_affine_int)
+        self.out += int(p_affine_int[0]).to_bytes(32, "big") + int(p_affine_int[1]).to_bytes(32, "big")
+
+    def write_scalar(self, s: int):
+        self.common_scalar(s)
+        self.out += int(s % R).to_bytes(32, "big")
+
+    def read_point(self):
+        x = int.from_bytes(self.inp[self.pos:self.pos + 32], "big"); y = int.from_bytes(self.inp[self.pos + 32:self.pos + 64], "big"); self.pos += 64
+        assert x < pyref.P_MOD and y < pyref.P_MOD and pyref.g1_is_on_curve((x, y)), "proof holds an invalid point"
+        self.common_point((x, y))
+        return (x, y)
+
+    def read_scalar(self):
+        v = int.from_bytes(self.inp[self.pos:self.pos + 32], "big"); self.pos += 32
+        assert v < R, "proof holds a non-canonical scalar"
+        self.common_scalar(v)
+        return v
+
+
+TRANSCRIPTS = {"blake2b": Transcript, "poseidon": PoseidonTranscript, "evm": EvmTranscript}
 
 
 def vk_transcript_repr(vk_bytes: bytes) -> int:
@@ -594,7 +638,7 @@ def fq_limbs_mont_to_int(l) -> int:
     return sum(int(x) << (64 * i) for i, x in enumerate(l)) * pow(1 << 256, -1, pyref.P_MOD) % pyref.P_MOD
 
 
-def verify(pr: Protocol, vk_bytes: bytes | None, instances, proof: bytes, tau: int | None = None, transcript: str = "blake2b", neg_s_g2=None) -> dict:
+def verify(pr: Protocol, vk_bytes: bytes | None, instances, proof: bytes, tau: int | None = None, transcript: str = "blake2b", neg_s_g2=None, preprocessed=None, initial_state=None) -> dict:
     """The verifier of a SHPLONK halo2 proof, read off the protocol file the way snark-verifier's PlonkVerifier does [EXT-recalled snark-verifier verifier/plonk.rs, pcs/kzg/multiopen/
     bdfg21.rs]; returns {"ok": bool, ...}, every failed check is named.
 
@@ -608,9 +652,9 @@ def verify(pr: Protocol, vk_bytes: bytes | None, instances, proof: bytes, tau: i
     res = {"ok": False}
     T = TRANSCRIPTS[transcript](proof)
     if vk_bytes is None:
-        pre_c = [(fq_limbs_mont_to_int(p_["x"]), fq_limbs_mont_to_int(p_["y"])) for p_ in pr.d["preprocessed"]]
-        assert all(pyref.g1_is_on_curve(p_) for p_ in pre_c)
-        T.common_scalar(limbs_mont_to_int(pr.d["transcript_initial_state"]))
+        pre_c = list(preprocessed) if preprocessed is not None else [(fq_limbs_mont_to_int(p_["x"]), fq_limbs_mont_to_int(p_["y"])) for p_ in pr.d["preprocessed"]]
+        assert len(pre_c) == pr.num_pre and all(pyref.g1_is_on_curve(p_) for p_ in pre_c)
+        T.common_scalar(initial_state if initial_state is not None else limbs_mont_to_int(pr.d["transcript_initial_state"]))
     else:
         assert int.from_bytes(vk_bytes[:4], "big") == pr.k and len(vk_bytes) == 8 + 32 * pr.num_pre
         pre_c = [pyref.g1_decompress(vk_bytes[8 + 32 * i:8 + 32 * i + 32]) for i in range(pr.num_pre)]

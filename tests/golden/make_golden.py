@@ -56,7 +56,10 @@ out["batch_proof"] = {"protocol": proto_digest(json.loads(base64.b64decode(bp["p
 yul = rd("release-v0.13.1/evm_verifier.yul", "r").splitlines()
 out["yul"] = {"f_p": re.search(r"0x[0-9a-f]+", yul[16]).group(0), "f_q": re.search(r"0x[0-9a-f]+", yul[17]).group(0),
               "g2_words": [re.search(r", (0x[0-9a-f]+)\)", yul[i]).group(1) for i in range(1229, 1233)],
-              "s_g2_words": [re.search(r", (0x[0-9a-f]+)\)", yul[i]).group(1) for i in range(1235, 1239)]}
+              "s_g2_words": [re.search(r", (0x[0-9a-f]+)\)", yul[i]).group(1) for i in range(1235, 1239)],
+              # the transcript's first word (the verifying key's scalar of layer 6) [REF release-v0.13.1/evm_verifier.yul:66]; NOTE the second G2 point above is -[s]G2: the
+              # verifier's pairing call is e(lhs, G2) e(rhs, -[s]G2) == 1 (tests/test_plonk_protocol.py::test_released_accumulators_satisfy_the_pairing)
+              "transcript_initial_state": re.search(r"mstore\(0x0, (\d+)\)", yul[65]).group(1)}
 out["bundle_proof_data"] = rd("release-v0.13.1/proof.data").hex()
 out["bundle_pi_data"] = rd("release-v0.13.1/pi.data").hex()
 l2 = json.loads(rd("release-v0.13.1/chunk.protocol", "r"))
@@ -80,14 +83,37 @@ def parses(proof: bytes, n_points: int, n_scalars: int) -> bool:
 
 
 same_system = 0
+more = []          # a few more stored chunk proofs (one per source file, the first of each), for the verifier test: same protocol, other witnesses
+verify_all = "--verify-all" in sys.argv
+if verify_all:     # every stored chunk proof through the CPU restatement of the verifier (about 0.7 s each)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import plonk as _plonk, pyref as _pyref
+    _neg = _pyref.g2_from_evm_words([int(w, 16) for w in out["yul"]["s_g2_words"]])
+    _l2p = _plonk.Protocol(l2)
+verified = 0
 for path in ["integration/tests/test_data/full_proof_batch_prove_1.json", "integration/tests/test_data/batch-task-no-encode.json", "integration/tests/test_data/batch-task-with-blob.json",
              "integration/tests/test_data/batch-task-with-blob-raw.json"] + sorted(os.path.relpath(p, REF) for p in glob.glob(os.path.join(REF, "integration/tests/test_data/batch_tasks/*.json"))):
     for c in json.loads(rd(path, "r")).get("chunk_proofs", []):
         pr_ = json.loads(base64.b64decode(c["protocol"]))
         assert pr_["quotient"] == l2["quotient"] and pr_["queries"] == l2["queries"] and pr_["evaluations"] == l2["evaluations"], path
         assert parses(base64.b64decode(c["proof"]), 9, 17), path
+        assert pr_["preprocessed"] == l2["preprocessed"] and pr_["transcript_initial_state"] == l2["transcript_initial_state"], path     # one verifying key throughout
+        if same_system == 0 or (len(more) < 6 and all(m["source"] != path for m in more) and base64.b64decode(c["proof"]).hex() != out["chunk_proof"]["proof"]):
+            more.append({"source": path, "proof": base64.b64decode(c["proof"]).hex(), "instances": base64.b64decode(c["instances"]).hex()})
+        if verify_all:
+            ib = base64.b64decode(c["instances"])
+            ok = _plonk.verify(_l2p, None, [int.from_bytes(ib[i:i + 32], "big") for i in range(0, len(ib), 32)], base64.b64decode(c["proof"]), transcript="poseidon", neg_s_g2=_neg)["ok"]
+            assert ok, (path, same_system)
+            verified += 1
         same_system += 1
 print("chunk proofs in the reference's test data with this constraint system, each parsing as 9 points | 17 scalars | 2 points:", same_system)
+out["more_chunk_proofs"] = more
+bp2 = json.loads(rd("integration/tests/test_data/full_proof_batch_agg_2.json", "r"))
+out["batch_proof_2"] = {"proof": base64.b64decode(bp2["proof"]).hex(), "instances": base64.b64decode(bp2["instances"]).hex()}
+if verify_all:
+    print("stored chunk proofs ACCEPTED by oracle/plonk.py's verifier (Poseidon transcript, pairing against the released verifier's -[s]G2):", verified, "of", same_system)
+    with open(os.path.join(HERE, "released_proofs_verified.json"), "w") as f:
+        json.dump({"_generated_by": "tests/golden/make_golden.py --verify-all", "stored_chunk_proofs": same_system, "accepted_by_oracle_plonk_verify": verified}, f, indent=1)
 for name, pr, src in (("protocol_layer2.json", l2, "release-v0.13.1/chunk.protocol == integration/tests/test_data/chunk_chunk_0.protocol == base64 `protocol` of integration/tests/test_data/full_proof_1.json"),
                       ("protocol_layer4.json", l4, "base64 `protocol` of integration/tests/test_data/full_proof_batch_agg_1.json (== full_proof_batch_agg_2.json)")):
     with open(os.path.join(HERE, name), "w") as f:

@@ -144,6 +144,65 @@ def test_reference_released_proofs_verify(name, layer):
     assert not plonk.verify(pr, None, inst, proof, transcript="blake2b", neg_s_g2=NEG_S_G2)["ok"]          # and it is the Poseidon transcript that makes it so
 
 
+def test_more_stored_proofs_verify():
+    """six more of the 318 chunk proofs the reference stores as inputs of its batch tests (the first of six different files; tests/golden/make_golden.py --verify-all ran ALL 318
+    through the same verifier when the fixtures were made: tests/golden/released_proofs_verified.json), and the second stored batch proof"""
+    pr = plonk.Protocol(fixture(2))
+    assert len(KAT["more_chunk_proofs"]) == 6
+    for m in KAT["more_chunk_proofs"]:
+        ib, proof = bytes.fromhex(m["instances"]), bytes.fromhex(m["proof"])
+        assert proof != bytes.fromhex(KAT["chunk_proof"]["proof"])
+        assert plonk.verify(pr, None, [int.from_bytes(ib[i:i + 32], "big") for i in range(0, len(ib), 32)], proof, transcript="poseidon", neg_s_g2=NEG_S_G2)["ok"], m["source"]
+    ib, proof = bytes.fromhex(KAT["batch_proof_2"]["instances"]), bytes.fromhex(KAT["batch_proof_2"]["proof"])
+    assert plonk.verify(plonk.Protocol(fixture(4)), None, [int.from_bytes(ib[i:i + 32], "big") for i in range(0, len(ib), 32)], proof, transcript="poseidon", neg_s_g2=NEG_S_G2)["ok"]
+    rec = json.load(open(os.path.join(GOLD, "released_proofs_verified.json")))
+    assert rec["stored_chunk_proofs"] == rec["accepted_by_oracle_plonk_verify"] == 318
+
+
+def test_vkey_files_hold_the_protocols_preprocessed_commitments_in_order():
+    """[REF release-v0.13.1/vk_chunk.vkey] = u32 k | u32 fixed columns | the SAME seven commitments, in the same order, as `preprocessed` of [REF release-v0.13.1/chunk.protocol]:
+    the .vkey layout our keygen writes (fixed columns, then the permutation's sigma columns) is the reference's"""
+    vk = bytes.fromhex(KAT["vk_chunk"])
+    pts = [pyref.g1_decompress(vk[8 + 32 * i:8 + 32 * i + 32]) for i in range(7)]
+    assert pts == [(plonk.fq_limbs_mont_to_int(p["x"]), plonk.fq_limbs_mont_to_int(p["y"])) for p in fixture(2)["preprocessed"]]
+    assert int.from_bytes(vk[:4], "big") == 25 and len(vk) == 8 + 7 * 32
+
+
+def bundle_inputs():
+    pd, pi = bytes.fromhex(KAT["bundle_proof_data"]), bytes.fromhex(KAT["bundle_pi_data"])
+    words = lambda b: [int.from_bytes(b[i:i + 32], "big") for i in range(0, len(b), 32)]
+    vk = bytes.fromhex(KAT["vk_bundle"])
+    return words(pd[:384]) + words(pi), pd[384:], [pyref.g1_decompress(vk[8 + 32 * i:8 + 32 * i + 32]) for i in range(7)]
+
+
+def test_released_bundle_evm_proof_verifies():
+    """Layer 6 has NO protocol fixture: its constraint system here is GENERATED by the halo2-base rule from [REF integration/configs/layer6.config] (scroll-prover_amd/protocols.py).
+    The released bundle proof [REF release-v0.13.1/proof.data, pi.data] verifies under it: calldata = 12 accumulator limbs | 13 public-input words | the proof proper (points
+    uncompressed), Keccak transcript (oracle/keccak.py, EvmTranscript) started from the released verifier's own first word [REF release-v0.13.1/evm_verifier.yul:66], preprocessed
+    commitments = [REF release-v0.13.1/vk_bundle.vkey] in file order, pairing against the verifier's -[s]G2.  Pins the generator on a layer it was not fitted to, the Keccak
+    transcript, and the .vkey layout."""
+    inst, proof, pre = bundle_inputs()
+    assert len(inst) == protocols.LAYER_NUM_INSTANCE[6] == 25 and len(proof) == 11 * 64 + 17 * 32
+    pr = plonk.Protocol(protocols.layer_protocol(6))
+    kw = dict(transcript="evm", neg_s_g2=NEG_S_G2, preprocessed=pre, initial_state=int(KAT["yul"]["transcript_initial_state"]))
+    assert plonk.verify(pr, None, inst, proof, **kw)["ok"]
+    bad = bytearray(proof); bad[64 * 9 + 5] ^= 1                                  # an evaluation word
+    assert not plonk.verify(pr, None, inst, bytes(bad), **kw)["ok"]
+    assert not plonk.verify(pr, None, inst[:12] + [inst[12] ^ 1] + inst[13:], proof, **kw)["ok"]
+    assert not plonk.verify(pr, None, inst, proof, **dict(kw, preprocessed=pre[1:] + pre[:1]))["ok"]
+    # its accumulator obeys the pairing too, and the first public-input word is the digest the release publishes
+    from oracle import pairing
+    c = [inst[3 * i] + (inst[3 * i + 1] << 88) + (inst[3 * i + 2] << 176) for i in range(4)]
+    assert pairing.pairing_product_is_one([((c[0], c[1]), pyref.G2_GEN), ((c[2], c[3]), NEG_S_G2)])
+
+
+def test_keccak256_vectors():
+    from oracle import keccak
+    assert keccak.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert keccak.keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    assert keccak.keccak256(bytes(136)).hex() != keccak.keccak256(bytes(135)).hex()
+
+
 def test_released_bundle_evm_proof_parses_under_the_generated_layer6_protocol():
     """layer 6 has no protocol fixture; the halo2-base rule gives it layer 2's system at k = 26.  The released bundle proof [REF release-v0.13.1/proof.data] (EVM layout:
     32-byte big-endian words, points uncompressed) agrees word for word with that shape: 12 accumulator limbs below 2^88, then exactly num_witness + Q = 9 point pairs ON THE
@@ -246,6 +305,11 @@ def test_cpu_prove_and_verify(tmp_path, layer, k, shape):
         assert not ok, f"a proof with word {word} altered was accepted"
     wrong_inst = list(inp.instances); wrong_inst[0] = (wrong_inst[0] + 1) % pyref.R_MOD
     assert not plonk.verify(pr, vk, wrong_inst, proof, inp.tau)["ok"]
+    if layer == 6:            # layer 6 in the EVM layout: points uncompressed, big-endian words, Keccak challenges
+        pe = plonk.prove(inp, vk, transcript="evm")
+        assert len(pe) == 11 * 64 + 17 * 32 and plonk.verify(pr, vk, inp.instances, pe, inp.tau, transcript="evm")["ok"]
+        bad = bytearray(pe); bad[64 * 9 + 40] ^= 2
+        assert not plonk.verify(pr, vk, inp.instances, bytes(bad), inp.tau, transcript="evm")["ok"]
     if layer in (2, 4):       # the same circuit under the transcript the reference proves these layers with
         pp = plonk.prove(inp, vk, transcript="poseidon")
         assert len(pp) == len(proof) and pp != proof and pp[:32 * pr.num_witness[0]] == proof[:32 * pr.num_witness[0]]
