@@ -360,11 +360,11 @@ inline std::unique_ptr<ProvingKey> keygen(const Protocol &P, const Circuit &C, u
 struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 1; int early_intt = -1 /* -1: by column count */;
                       bool sparse_uploads = false /* columns that are at least half zeros cross PCIe as (index, value) pairs */;
                       bool packed_multiplicities = false /* the lookup multiplicities cross PCIe as the 4-byte counts they are (mi355_buf_upload_packed); their blinding rows follow as 32-byte words */;
-                      TranscriptKind transcript = TranscriptKind::Blake2b /* Poseidon: what the reference proves layers 0-5 with (mi355zk_transcript.hpp) */; };
+                      TranscriptKind transcript = TranscriptKind::Blake2b /* Poseidon: what the reference proves layers 0-5 with; Evm: layer 6 (mi355zk_transcript.hpp; reference_transcript below picks by layer) */; };
 // the transcript the reference proves a layer with: Poseidon for every proof the next layer verifies in-circuit (layers 0-5, [REF integration/src/prove.rs:30-43,67,95-97] -> snark-verifier-sdk
-// gen_snark_shplonk), Keccak in the EVM layout for layer 6 (not built: the stock Blake2b transcript stands in there).  Files without a layer number are the reference's fixtures (layers 2, 4).
-inline TranscriptKind reference_transcript(const Protocol &P) { return P.layer == 6 ? TranscriptKind::Blake2b : TranscriptKind::Poseidon; }
-inline const char *transcript_name(TranscriptKind k) { return k == TranscriptKind::Poseidon ? "poseidon" : "blake2b"; }
+// gen_snark_shplonk), Keccak in the EVM layout for layer 6 (gen_evm_proof_shplonk: what the released verifier contract reads).  Files without a layer number are the reference's fixtures (layers 2, 4).
+inline TranscriptKind reference_transcript(const Protocol &P) { return P.layer == 6 ? TranscriptKind::Evm : TranscriptKind::Poseidon; }
+inline const char *transcript_name(TranscriptKind k) { return k == TranscriptKind::Poseidon ? "poseidon" : k == TranscriptKind::Evm ? "evm" : "blake2b"; }
 struct ProofResult {
   std::vector<uint8_t> proof;
   double step_ms[11] = {0}; double total_ms = 0;

@@ -10,8 +10,11 @@
 //            chunk is followed by a 1, an exact multiple of RATE by one more permutation of an empty chunk, and state word 1 is the answer (a full field element).
 //            The Python restatement of the same sponge (oracle/poseidon.py) makes the reference's RELEASED chunk and batch proofs verify
 //            (tests/test_plonk_protocol.py::test_reference_released_proofs_verify); this C++ one is compared with it word for word (--transcript-selftest).
-//            Layer 6's Keccak transcript (EVM layout, uncompressed points) is not built: it is the last 1.3 s of a bundle and its proof format differs.
-// Both refuse the identity (halo2's common_point fails on it).
+//   Evm      [EXT-recalled snark-verifier system/halo2/transcript/evm.rs EvmTranscript; spelled out by REF release-v0.13.1/evm_verifier.yul:66-100], layer 6: everything is 32-byte
+//            BIG-endian words appended to a buffer -- a scalar one word, a point two (x, y), and the PROOF carries points uncompressed (64 bytes) and scalars big-endian --; a
+//            challenge = Keccak-256 of the buffer (plus one byte 0x01 when the buffer is exactly one word: a squeeze right after a squeeze) mod r; the hash is the new buffer.
+//            oracle/keccak.py + oracle/plonk.py EvmTranscript make the RELEASED BUNDLE PROOF verify (test_released_bundle_evm_proof_verifies); compared word for word as above.
+// All refuse the identity (halo2's common_point fails on it).
 // The GPU library sees none of this: 96-byte commitments and 32-byte evaluations arrive from the C-ABI and are hashed here, on the calling thread.
 #pragma once
 #include <cstring>
@@ -144,31 +147,71 @@ struct PoseidonSponge {
   }
 };
 
-enum class TranscriptKind { Blake2b, Poseidon };
+// Keccak-256 (original padding 0x01 ... 0x80, rate 136): one-shot over a byte vector
+inline std::array<uint8_t, 32> keccak256(const std::vector<uint8_t> &data) {
+  static const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull, 0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+                                  0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull, 0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
+                                  0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  static const int ROT[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};   // [x][y]
+  auto rol = [](uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; };
+  std::vector<uint8_t> p(data); p.push_back(0x01); while (p.size() % 136) p.push_back(0); p.back() |= 0x80;
+  uint64_t A[5][5] = {};   // [x][y]
+  for (size_t off = 0; off < p.size(); off += 136) {
+    for (int i = 0; i < 17; i++) { uint64_t w; std::memcpy(&w, p.data() + off + 8 * i, 8); A[i % 5][i / 5] ^= w; }
+    for (int rnd = 0; rnd < 24; rnd++) {
+      uint64_t C[5], D[5], B[5][5];
+      for (int x = 0; x < 5; x++) C[x] = A[x][0] ^ A[x][1] ^ A[x][2] ^ A[x][3] ^ A[x][4];
+      for (int x = 0; x < 5; x++) D[x] = C[(x + 4) % 5] ^ rol(C[(x + 1) % 5], 1);
+      for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) A[x][y] ^= D[x];
+      for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) B[y][(2 * x + 3 * y) % 5] = rol(A[x][y], ROT[x][y]);
+      for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) A[x][y] = B[x][y] ^ (~B[(x + 1) % 5][y] & B[(x + 2) % 5][y]);
+      A[0][0] ^= RC[rnd];
+    }
+  }
+  std::array<uint8_t, 32> out; for (int i = 0; i < 4; i++) std::memcpy(out.data() + 8 * i, &A[i % 5][i / 5], 8);
+  return out;
+}
+
+enum class TranscriptKind { Blake2b, Poseidon, Evm };
 inline TranscriptKind transcript_kind_from_name(const std::string &s) {
   if (s == "blake2b") return TranscriptKind::Blake2b;
   if (s == "poseidon") return TranscriptKind::Poseidon;
-  throw std::invalid_argument("transcript: blake2b or poseidon expected, got " + s);
+  if (s == "evm") return TranscriptKind::Evm;
+  throw std::invalid_argument("transcript: blake2b, poseidon or evm expected, got " + s);
 }
 
 struct Transcript {
   TranscriptKind kind;
   Blake2b state{"Halo2-Transcript"};
   PoseidonSponge sponge;
+  std::vector<uint8_t> evm_buf;                                 // Evm: the words waiting for the next Keccak
   std::vector<uint8_t> proof;                                   // what the transcript's writer receives: the proof, in the reference's layout
   explicit Transcript(TranscriptKind k = TranscriptKind::Blake2b) : kind(k) {}
+  static void be32(const zk::fe_t &canonical, uint8_t out[32]) { const uint8_t *le = reinterpret_cast<const uint8_t *>(&canonical); for (int i = 0; i < 32; i++) out[i] = le[31 - i]; }
   halo2::Fr squeeze_challenge() {
     if (kind == TranscriptKind::Poseidon) return sponge.squeeze();
+    if (kind == TranscriptKind::Evm) {
+      if (evm_buf.size() == 32) evm_buf.push_back(1);
+      const std::array<uint8_t, 32> h = keccak256(evm_buf);
+      evm_buf.assign(h.begin(), h.end());
+      zk::fe_t c; uint8_t *le = reinterpret_cast<uint8_t *>(&c); for (int i = 0; i < 32; i++) le[i] = h[31 - i];      // the hash as a big-endian 256-bit integer, mod r (2^256 < 6 r)
+      uint32_t m[8]; for (int i = 0; i < 8; i++) m[i] = zk::FrP::mod(i);
+      while (zk::Fr::w_geq(c.l, m)) zk::Fr::w_sub(c.l, m);
+      return halo2::detail::from_fe(zk::Fr::from_canonical(c));
+    }
     const uint8_t z = 0; state.update(&z, 1); return fr_from_uniform_bytes(state.digest());
   }
   void common_scalar(const halo2::Fr &s) {
     if (kind == TranscriptKind::Poseidon) { sponge.update(s); return; }
-    const uint8_t tag = 2; state.update(&tag, 1);
-    const zk::fe_t c = zk::Fr::to_canonical(halo2::detail::to_fe(s)); state.update(&c, 32);
+    const zk::fe_t c = zk::Fr::to_canonical(halo2::detail::to_fe(s));
+    if (kind == TranscriptKind::Evm) { uint8_t w[32]; be32(c, w); evm_buf.insert(evm_buf.end(), w, w + 32); return; }
+    const uint8_t tag = 2; state.update(&tag, 1); state.update(&c, 32);
   }
   void write_scalar(const halo2::Fr &s) {
     common_scalar(s);
-    const zk::fe_t c = zk::Fr::to_canonical(halo2::detail::to_fe(s)); const uint8_t *p = reinterpret_cast<const uint8_t *>(&c); proof.insert(proof.end(), p, p + 32);
+    const zk::fe_t c = zk::Fr::to_canonical(halo2::detail::to_fe(s));
+    if (kind == TranscriptKind::Evm) { uint8_t w[32]; be32(c, w); proof.insert(proof.end(), w, w + 32); return; }
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(&c); proof.insert(proof.end(), p, p + 32);
   }
   // g: a commitment as the C-ABI returns it (normalised Jacobian: x, y, z = R; all-zero = identity)
   void write_point(const halo2::G1 &g) {
@@ -177,6 +220,11 @@ struct Transcript {
     if (ident) throw std::invalid_argument("transcript: the identity has no coordinates (halo2's common_point fails on it)");
     zk::fe_t x, y; std::memcpy(&x, a.data(), 32); std::memcpy(&y, a.data() + 4, 32);
     const zk::fe_t xc = zk::Fq::to_canonical(x), yc = zk::Fq::to_canonical(y);
+    if (kind == TranscriptKind::Evm) {
+      uint8_t w[64]; be32(xc, w); be32(yc, w + 32);
+      evm_buf.insert(evm_buf.end(), w, w + 64); proof.insert(proof.end(), w, w + 64);
+      return;
+    }
     if (kind == TranscriptKind::Poseidon) {
       auto base_to_scalar = [](zk::fe_t c) {   // a base-field coordinate as a scalar: its value mod r (q < 2 r: one subtraction at most)
         uint32_t m[8]; for (int i = 0; i < 8; i++) m[i] = zk::FrP::mod(i);

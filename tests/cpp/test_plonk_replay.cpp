@@ -49,14 +49,19 @@ int main(int argc, char **argv) {
       S.write_point(g); S.write_scalar(fr_u64(0xDEADBEEFull)); const Fr p2 = fr_to_canonical(S.squeeze_challenge());
       std::string lens; Transcript L(TranscriptKind::Poseidon);
       for (int len = 0; len < 10; len++) { for (int i = 0; i < len; i++) L.common_scalar(fr_u64(1000 * len + i)); lens += (len ? ", \"" : "\"") + hex(fr_to_canonical(L.squeeze_challenge())) + "\""; }
+      Transcript E(TranscriptKind::Evm); E.common_scalar(fr_u64(5)); const Fr e1 = fr_to_canonical(E.squeeze_challenge()); const Fr e1b = fr_to_canonical(E.squeeze_challenge());   // the second: hash | 0x01
+      E.write_point(g); E.write_scalar(fr_u64(0xDEADBEEFull)); const Fr e2 = fr_to_canonical(E.squeeze_challenge());
+      std::string eh; for (uint8_t b : E.proof) { char t[3]; std::snprintf(t, sizeof t, "%02x", b); eh += t; }
+      std::vector<uint8_t> kin(200); for (size_t i = 0; i < kin.size(); i++) kin[i] = (uint8_t)(i * 7 + 1);
+      std::string kh; for (uint8_t b : keccak256(kin)) { char t[3]; std::snprintf(t, sizeof t, "%02x", b); kh += t; }
       const PoseidonSpec &PS = PoseidonSpec::get();
-      std::printf("{\"c1\": \"%s\", \"c2\": \"%s\", \"vk_repr\": \"%s\", \"proof\": \"%s\", \"poseidon\": {\"c1\": \"%s\", \"c2\": \"%s\", \"by_length\": [%s], \"rc0\": \"%s\", \"rc_last\": \"%s\", \"mds00\": \"%s\", \"mds44\": \"%s\", \"proof_equal\": %s}}\n",
+      std::printf("{\"c1\": \"%s\", \"c2\": \"%s\", \"vk_repr\": \"%s\", \"proof\": \"%s\", \"poseidon\": {\"c1\": \"%s\", \"c2\": \"%s\", \"by_length\": [%s], \"rc0\": \"%s\", \"rc_last\": \"%s\", \"mds00\": \"%s\", \"mds44\": \"%s\", \"proof_equal\": %s}, \"evm\": {\"c1\": \"%s\", \"c1b\": \"%s\", \"c2\": \"%s\", \"proof\": \"%s\", \"keccak_200\": \"%s\"}}\n",
                   hex(c1).c_str(), hex(c2).c_str(), hex(c3).c_str(), ph.c_str(), hex(p1).c_str(), hex(p2).c_str(), lens.c_str(), hex(fr_to_canonical(PS.rc.front())).c_str(), hex(fr_to_canonical(PS.rc.back())).c_str(),
-                  hex(fr_to_canonical(PS.mds[0][0])).c_str(), hex(fr_to_canonical(PS.mds[4][4])).c_str(), S.proof == T.proof ? "true" : "false");
+                  hex(fr_to_canonical(PS.mds[0][0])).c_str(), hex(fr_to_canonical(PS.mds[4][4])).c_str(), S.proof == T.proof ? "true" : "false", hex(e1).c_str(), hex(e1b).c_str(), hex(e2).c_str(), eh.c_str(), kh.c_str());
       return 0;
     }
     else { std::printf("usage: %s --protocol FILE --out DIR [--builder-only] [--dump-inputs] [--devices D] [--threads T] [--proofs N] [--upload-threads U] [--early-intt 0|1] [--pinned-witness]\n"
-                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--no-packed-multiplicities] [--transcript auto|blake2b|poseidon] [--assign-density D] | --transcript-selftest\n", argv[0]); return 1; }
+                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--no-packed-multiplicities] [--transcript auto|blake2b|poseidon|evm] [--assign-density D] | --transcript-selftest\n", argv[0]); return 1; }
   }
   if (protocol_path.empty() || out_dir.empty()) { std::printf("--protocol and --out are required\n"); return 1; }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;

@@ -265,6 +265,14 @@ def test_cpp_poseidon_transcript_equals_the_restatement_that_verifies_the_releas
         for i in range(ln):
             L.common_scalar(1000 * ln + i)
         assert "%064x" % L.squeeze() == got["by_length"][ln], ln
+    # layer 6's Keccak transcript in the EVM layout, same stream; Keccak-256 itself on 200 bytes (two blocks)
+    from oracle import keccak
+    ev = json.loads(subprocess.run([exe(), "--transcript-selftest"], capture_output=True, text=True, timeout=60).stdout)["evm"]
+    E = plonk.EvmTranscript(); E.common_scalar(5)
+    assert "%064x" % E.squeeze() == ev["c1"] and "%064x" % E.squeeze() == ev["c1b"]
+    E.write_point((1, 2)); E.write_scalar(0xDEADBEEF)
+    assert "%064x" % E.squeeze() == ev["c2"] and E.out.hex() == ev["proof"] and len(E.out) == 96
+    assert keccak.keccak256(bytes((i * 7 + 1) & 255 for i in range(200))).hex() == ev["keccak_200"]
     # a coordinate above r is absorbed reduced: (x mod r, y mod r)
     big = plonk.PoseidonTranscript(); big.common_point((pyref.R_MOD + 5, 7)); ref = plonk.PoseidonTranscript(); ref.common_scalar(5); ref.common_scalar(7)
     assert big.squeeze() == ref.squeeze()
@@ -340,7 +348,7 @@ def check_against_restatement(rec):
     inp, man = plonk.ProofInputs.load(rec["out_dir"])
     vk = plonk.keygen_vk(inp.pr, inp.pre, inp.tau)
     assert rec["vk"] == vk, "verifying key (commit_lagrange of the fixed / sigma columns) differs"
-    assert rec["transcript"] == ("blake2b" if inp.pr.d.get("layer") == 6 else "poseidon")       # the reference's choice per layer (Keccak at layer 6: Blake2b stands in)
+    assert rec["transcript"] == ("evm" if inp.pr.d.get("layer") == 6 else "poseidon")           # the reference's choice per layer
     want = plonk.prove(inp, vk, transcript=rec["transcript"])
     got = rec["proof"]
     first = next((i // 32 for i in range(0, min(len(got), len(want)), 32) if got[i:i + 32] != want[i:i + 32]), None)
@@ -371,8 +379,8 @@ GPU_CASES = [
 @pytest.mark.parametrize("layer,k,args,env,shape", GPU_CASES)
 def test_gpu_proof_bytes_equal_the_cpu_restatement(tmp_path, layer, k, args, env, shape):
     rec = check_against_restatement(zk.replay.run(layer, k, out_dir=str(tmp_path), args=["--dump-inputs"] + args, env=env, **shape))
-    if layer in (2, 6):
-        assert (rec["msm"], rec["intt"], rec["evals"], rec["proof_bytes"]) == (11, 5, 17, 896) and rec["coset_ntt"] >= 20
+    if layer in (2, 6):   # layer 6 in the EVM layout: 11 uncompressed points + 17 words = 1 248 bytes, the 39 words that follow the accumulator in [REF release-v0.13.1/proof.data]
+        assert (rec["msm"], rec["intt"], rec["evals"], rec["proof_bytes"]) == (11, 5, 17, 896 if layer == 2 else 1248) and rec["coset_ntt"] >= 20
     if layer == 4:
         assert (rec["msm"], rec["intt"], rec["evals"], rec["proof_bytes"]) == (14, 8, 27, 1312) and rec["coset_ntt"] >= 32
 
