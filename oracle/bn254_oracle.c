@@ -15,10 +15,18 @@
  * anchored on the reference's own call sites ([REF integration/src/prove.rs:37,67,96])
  * and on the golden vectors decoded from the reference's fixtures (tests/golden/,
  * SURVEY.md Appendix A).  Those fixtures pin the encodings and the field / curve
- * arithmetic; there is no MSM/NTT known-answer vector anywhere in the reference, so at
- * the MSM/NTT function boundary the oracle is "parity unpinned": it is validated
- * instead by (i) an independent pure-Python big-int oracle (oracle/pyref.py) that
- * shares no code with this file and (ii) algebraic invariants (tests/).
+ * arithmetic; there is no MSM/NTT known-answer vector anywhere in the reference (the
+ * reference's proofs hold commitments of witnesses nobody has), so the OUTPUT of one
+ * best_multiexp / best_fft call has no reference value to compare with.  What pins this
+ * file instead: (i) an independent pure-Python big-int oracle (oracle/pyref.py) that
+ * shares no code with it, (ii) algebraic invariants (tests/), and (iii) since round 5 the
+ * reference's own proofs: oracle/plonk.py's verifier -- built on pyref's curve and this
+ * file's transforms -- ACCEPTS all 318 stored chunk proofs, both batch proofs and the
+ * released bundle proof under a real pairing check, and its prover, whose commitments are
+ * this file's multiexp and whose polynomials go through this file's best_fft, produces
+ * proofs that same verifier accepts (tests/test_plonk_protocol.py).  The group law, the
+ * field arithmetic, the domain and the encodings are therefore the reference's; the
+ * bucket schedule inside multiexp is a restatement (it cannot change a group element).
  *
  * Data conventions (proved by fixture KAT A1/A2): field elements are
  * 4 x u64 little-endian limbs, Montgomery form (R = 2^256), fully reduced.

@@ -10,16 +10,24 @@ sum-of-products compiler, no launches), which is what makes it an independent ch
   evaluate()          the expression tree over scalars (verifier: at the challenge x) or numpy object arrays (prover: over the extended domain)
   Transcript          halo2's Blake2bWrite / Blake2bRead [EXT-recalled halo2_proofs src/transcript/blake2b.rs]: Blake2b-512, personalisation
                       "Halo2-Transcript", prefix bytes 0 / 1 / 2 for challenge / point / scalar, challenges = 64 output bytes reduced mod r
+  PoseidonTranscript  what the reference proves layers 0-5 with (snark-verifier's PoseidonTranscript<NativeLoader>; oracle/poseidon.py)
+  EvmTranscript       what it proves layer 6 with (Keccak-256, big-endian words, uncompressed points; oracle/keccak.py)
   prove()             create_proof's steps by definition: commit, grand products, quotient over the whole extended coset domain at
                       once, evaluations in the protocol's order, SHPLONK over the rotation sets the protocol's `queries` imply
   verify()            verify_proof from the proof BYTES (the reference's layout: compressed G1 commitments, canonical Fr evaluations, two
                       SHPLONK points): recomputes every challenge, evaluates the numerator from the evaluations,
-                      checks h(x) (x^n - 1) == numerator(x) through the opening, and the final pairing equation with the synthetic SRS's
-                      trapdoor in G1 (e(W, [tau]_2) == e(E, [1]_2)  <=>  tau W == E)
+                      checks h(x) (x^n - 1) == numerator(x) through the opening, and the final equation -- with the synthetic SRS's trapdoor
+                      in G1 (tau W == E) for our own proofs, with a real pairing against -[s]G2 (oracle/pairing.py) for the reference's
 
-Parity: no halo2 source is in the container, so the conventions that do not show in the fixtures (which power of y / v meets which polynomial in
-SHPLONK, the vk's transcript representation) are this file's, stated where they are made; what the fixtures do pin -- the constraint system, the
-opened (polynomial, rotation) pairs, the order of commitments and evaluations in the proof, the byte layout -- is followed exactly.
+PARITY: PINNED BY THE REFERENCE'S OWN PROOFS.  No halo2 source is in the container; what pins this file instead is that verify() ACCEPTS every proof the
+reference holds -- all 318 stored chunk proofs and both batch proofs (Poseidon transcript, the fixtures' protocols), and the released bundle proof (Keccak
+transcript, the GENERATED layer-6 protocol, vk_bundle.vkey) -- under a real pairing check, and rejects each of them with one word or one instance changed
+(tests/test_plonk_protocol.py::test_reference_released_proofs_verify, test_more_stored_proofs_verify, test_released_bundle_evm_proof_verifies;
+tests/golden/make_golden.py --verify-all).  That fixes, against the real prover: the transcript order and both hash constructions, the challenge derivation,
+the evaluation of the numerator tree, the instance polynomial, the rotation sets, WHICH POWER OF y / v MEETS WHICH POLYNOMIAL IN SHPLONK (ascending: the i-th
+set carries v^i, its j-th polynomial y^j -- round 5's first guess, descending, was wrong and these proofs showed it), the proof layouts and the .vkey order.
+prove() is tied to the same conventions by producing proofs this verifier accepts; the device's proofs are compared with prove() byte for byte.  What stays a
+convention of this file: the verifying key's transcript scalar of OUR keys (halo2 hashes a Rust Debug string; vk_transcript_repr hashes the .vkey bytes).
 """
 from __future__ import annotations
 
