@@ -118,32 +118,68 @@ struct PoseidonSpec {
     for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) mds[i][j] = halo2::detail::fr_inv(halo2::detail::from_fe(zk::Fr::add(halo2::detail::to_fe(xs[i]), halo2::detail::to_fe(ys[j]))));
   }
 };
+// Host arithmetic of the sponge: 4 x 64-bit Montgomery words (the ABI form: R = 2^256, what halo2curves holds), one CIOS product = 32 64x64 multiplications.  The library's
+// 8 x 32 host code costs 280 us per permutation here; a layer-0 proof absorbs ~3 300 words = 830 permutations, a quarter of a second on the calling thread.  This form: ~45 us.
+struct Fr64 {
+  uint64_t l[4];
+  static constexpr uint64_t M[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+  static constexpr uint64_t INV = 0xc2e1f593efffffffull;   // -r^-1 mod 2^64
+  static bool geq_m(const uint64_t *a) { for (int i = 3; i >= 0; i--) if (a[i] != M[i]) return a[i] > M[i]; return true; }
+  static void sub_m(uint64_t *a) { unsigned __int128 b = 0; for (int i = 0; i < 4; i++) { const unsigned __int128 d = (unsigned __int128)a[i] - M[i] - (uint64_t)b; a[i] = (uint64_t)d; b = (d >> 64) & 1; } }
+  static Fr64 add(const Fr64 &a, const Fr64 &b) {
+    Fr64 r; unsigned __int128 c = 0; for (int i = 0; i < 4; i++) { c += (unsigned __int128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+    if (c || geq_m(r.l)) sub_m(r.l);      // a, b < r < 2^254: no carry out; kept for form
+    return r;
+  }
+  static Fr64 mul(const Fr64 &a, const Fr64 &b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 c = 0;
+      for (int j = 0; j < 4; j++) { c += (unsigned __int128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+      c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+      const uint64_t m = t[0] * INV;
+      c = (unsigned __int128)m * M[0] + t[0]; c >>= 64;
+      for (int j = 1; j < 4; j++) { c += (unsigned __int128)m * M[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+      c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    Fr64 r{{t[0], t[1], t[2], t[3]}};
+    if (t[4] || geq_m(r.l)) sub_m(r.l);
+    return r;
+  }
+  static Fr64 from(const halo2::Fr &a) { Fr64 r; std::memcpy(r.l, a.data(), 32); return r; }
+  halo2::Fr fr() const { halo2::Fr r; std::memcpy(r.data(), l, 32); return r; }
+};
 struct PoseidonSponge {
   static constexpr int T = PoseidonSpec::T, RATE = PoseidonSpec::RATE;
-  zk::fe_t state[T]; std::vector<zk::fe_t> buf;
-  PoseidonSponge() { for (auto &w : state) w = zk::Fr::zero(); zk::fe_t c = zk::Fr::zero(); c.l[2] = 1; state[0] = zk::Fr::from_canonical(c); }   // [2^64, 0, 0, 0, 0]
-  void update(const halo2::Fr &w) { buf.push_back(halo2::detail::to_fe(w)); }
-  static zk::fe_t pow5(const zk::fe_t &a) { const zk::fe_t a2 = zk::Fr::mul(a, a); return zk::Fr::mul(zk::Fr::mul(a2, a2), a); }
+  Fr64 state[T]; std::vector<Fr64> buf;
+  PoseidonSponge() { for (auto &w : state) w = Fr64{{0, 0, 0, 0}}; zk::fe_t c = zk::Fr::zero(); c.l[2] = 1; state[0] = Fr64::from(halo2::detail::from_fe(zk::Fr::from_canonical(c))); }   // [2^64, 0, 0, 0, 0]
+  void update(const halo2::Fr &w) { buf.push_back(Fr64::from(w)); }
+  static Fr64 pow5(const Fr64 &a) { const Fr64 a2 = Fr64::mul(a, a); return Fr64::mul(Fr64::mul(a2, a2), a); }
+  struct Tables { std::vector<Fr64> rc; Fr64 mds[T][T]; };
+  static const Tables &tables() {
+    static const Tables t = [] { Tables x; const PoseidonSpec &S = PoseidonSpec::get(); for (const auto &c : S.rc) x.rc.push_back(Fr64::from(c)); for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) x.mds[i][j] = Fr64::from(S.mds[i][j]); return x; }();
+    return t;
+  }
   void permute() {
-    const PoseidonSpec &S = PoseidonSpec::get();
+    const Tables &S = tables();
     for (int r = 0; r < PoseidonSpec::RF + PoseidonSpec::RP; r++) {
-      for (int i = 0; i < T; i++) state[i] = zk::Fr::add(state[i], halo2::detail::to_fe(S.rc[(size_t)r * T + i]));
+      for (int i = 0; i < T; i++) state[i] = Fr64::add(state[i], S.rc[(size_t)r * T + i]);
       if (r < PoseidonSpec::RF / 2 || r >= PoseidonSpec::RF / 2 + PoseidonSpec::RP) { for (auto &w : state) w = pow5(w); } else state[0] = pow5(state[0]);
-      zk::fe_t nx[T];
-      for (int i = 0; i < T; i++) { zk::fe_t acc = zk::Fr::zero(); for (int j = 0; j < T; j++) acc = zk::Fr::add(acc, zk::Fr::mul(halo2::detail::to_fe(S.mds[i][j]), state[j])); nx[i] = acc; }
+      Fr64 nx[T];
+      for (int i = 0; i < T; i++) { Fr64 acc = Fr64::mul(S.mds[i][0], state[0]); for (int j = 1; j < T; j++) acc = Fr64::add(acc, Fr64::mul(S.mds[i][j], state[j])); nx[i] = acc; }
       for (int i = 0; i < T; i++) state[i] = nx[i];
     }
   }
-  void absorb_and_permute(const zk::fe_t *chunk, size_t len) {
-    for (size_t i = 0; i < len; i++) state[1 + i] = zk::Fr::add(state[1 + i], chunk[i]);
-    if (len < (size_t)RATE) state[len + 1] = zk::Fr::add(state[len + 1], zk::Fr::one());
+  void absorb_and_permute(const Fr64 *chunk, size_t len) {
+    for (size_t i = 0; i < len; i++) state[1 + i] = Fr64::add(state[1 + i], chunk[i]);
+    if (len < (size_t)RATE) state[len + 1] = Fr64::add(state[len + 1], Fr64::from(halo2::detail::from_fe(zk::Fr::one())));
     permute();
   }
   halo2::Fr squeeze() {
-    std::vector<zk::fe_t> b; b.swap(buf);
+    std::vector<Fr64> b; b.swap(buf);
     for (size_t i = 0; i < b.size(); i += RATE) absorb_and_permute(b.data() + i, std::min<size_t>(RATE, b.size() - i));
     if (b.size() % RATE == 0) absorb_and_permute(nullptr, 0);
-    return halo2::detail::from_fe(state[1]);
+    return state[1].fr();
   }
 };
 

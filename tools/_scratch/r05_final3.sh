@@ -1,0 +1,23 @@
+#!/bin/bash
+# closing validation after the transcript / SHPLONK-order change: the files that exercise what changed first, then smoke, a reduced bench (all proof-mix legs, small headline), then the rest
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+A="tests/test_plonk_protocol.py tests/test_gpu_buffers.py tests/test_cpp_mirror.py"
+timeout 330 python -m pytest $A -q -m gpu --durations=5 -p no:cacheprovider > gpurun_out/r05_suite_a.log 2>&1; echo "suite A rc=$?" | tee -a gpurun_out/r05_suite_a.log
+tail -4 gpurun_out/r05_suite_a.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05_smoke3.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/r05_smoke3.log
+tail -3 gpurun_out/r05_smoke3.log
+timeout 300 python bench.py --logn 22 --steps 3 --warmup 1 --no-cpu-baseline --no-batch-legs --no-sizes --no-host-api --no-table-free --no-witness-like --no-ntt > gpurun_out/r05_bench_mini.json 2> gpurun_out/r05_bench_mini.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+try:
+    l = json.loads(open("gpurun_out/r05_bench_mini.json").read().strip().splitlines()[-1])
+    c = l["config"]
+    print("bench-mini:", l["metric"], c.get("proxies_ms"), c.get("layer_ms"), c.get("all_checks"))
+except Exception as e:
+    print("bench-mini unreadable:", e); print(open("gpurun_out/r05_bench_mini.err").read()[-1500:])
+PY
+IGN="--ignore=tests/test_plonk_protocol.py --ignore=tests/test_gpu_buffers.py --ignore=tests/test_cpp_mirror.py"
+timeout 330 python -m pytest tests $IGN -q -m gpu --durations=5 -p no:cacheprovider > gpurun_out/r05_suite_b.log 2>&1; echo "suite B rc=$?" | tee -a gpurun_out/r05_suite_b.log
+tail -4 gpurun_out/r05_suite_b.log
