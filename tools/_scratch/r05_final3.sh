@@ -8,7 +8,7 @@ timeout 330 python -m pytest $A -q -m gpu --durations=5 -p no:cacheprovider > gp
 tail -4 gpurun_out/r05_suite_a.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05_smoke3.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/r05_smoke3.log
 tail -3 gpurun_out/r05_smoke3.log
-timeout 300 python bench.py --logn 22 --steps 3 --warmup 1 --no-cpu-baseline --no-batch-legs --no-sizes --no-host-api --no-table-free --no-witness-like --no-ntt > gpurun_out/r05_bench_mini.json 2> gpurun_out/r05_bench_mini.err; echo "bench rc=$?"
+timeout 300 python bench.py --logn 20 --steps 3 --warmup 1 --no-precompute --no-cpu-baseline --no-batch-legs --no-sizes --no-host-api --no-table-free --no-witness-like --no-ntt > gpurun_out/r05_bench_mini.json 2> gpurun_out/r05_bench_mini.err; echo "bench rc=$?"
 python - <<'PY'
 import json
 try:
