@@ -268,7 +268,7 @@ struct Protocol {
 };
 
 // SHPLONK's rotation sets [EXT-recalled halo2_proofs poly/kzg/multiopen/shplonk.rs construct_intermediate_sets]: polynomials opened at the same SET of rotations
-// share one set.  Order: first appearance in `queries` (halo2 orders the sets by a BTreeSet of evaluation points, i.e. by the challenge; only powers of v move).
+// share one set.  Order: first appearance in `queries`, for the sets and inside a set (snark-verifier's query_sets; the order under which all of the reference's stored proofs verify).
 struct RotationSet { std::vector<int32_t> rots; std::vector<uint32_t> polys; };
 inline std::vector<RotationSet> rotation_sets(const std::vector<PolyRot> &queries) {
   std::vector<uint32_t> order; std::map<uint32_t, std::vector<int32_t>> rots;

@@ -356,8 +356,8 @@ def lagrange_at(pr: Protocol, i: int, x: int) -> int:
 
 def rotation_sets(queries):
     """SHPLONK's grouping [EXT-recalled halo2_proofs poly/kzg/multiopen/shplonk.rs construct_intermediate_sets]: polynomials opened at the same SET of
-    rotations share one rotation set.  Order here: first appearance in `queries` (halo2 orders the sets by a BTreeSet of the evaluation POINTS, which
-    depends on the challenge; the order only permutes powers of v)."""
+    rotations share one rotation set.  Order: first appearance in `queries`, both of the sets and of the polynomials inside a set -- snark-verifier's `query_sets`; a fixed order is
+    what the reference's real prover uses too: all 318 stored chunk proofs verify with set i at v^i in THIS order (a data-dependent order would fail most of them)"""
     rots = {}
     order = []
     for p, r in queries:

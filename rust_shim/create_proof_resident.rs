@@ -10,7 +10,7 @@
 //! are collected into plain `Vec<*const c_void>` first.
 //!
 //! What stays in prover.rs: the transcript (every `write_point` / `write_scalar` / `squeeze_challenge` happens on the host between the calls below, on
-//! the 96-byte / 32-byte results: include/mi355zk_transcript.hpp is the C++ stand-in), witness synthesis (`parallel_syn`), the rng (blinding rows, the
+//! the 96-byte / 32-byte results: include/mi355zk_transcript.hpp holds the C++ counterparts: Poseidon, Keccak / EVM, Blake2b), witness synthesis (`parallel_syn`), the rng (blinding rows, the
 //! z / phi blinding values, the random polynomial), and the compilation of the circuit's `Expression` graph into `Launch`es.  In the C++ twin the graph
 //! arrives as the snark-verifier PlonkProtocol JSON the reference ships with its proofs ([REF release-v0.13.1/chunk.protocol]); in the fork it is
 //! `pk.vk.cs` itself -- the same tree (gates, permutation, lookups folded with y), so the compiler of mi355zk_plonk.hpp (`Compiler`: cost model per
