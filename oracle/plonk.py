@@ -716,6 +716,7 @@ def verify(pr: Protocol, vk_bytes: bytes | None, instances, proof: bytes, tau: i
     r_acc = 0
     zd0 = None
     vp = 1
+    msm_terms = {}                                                          # polynomial -> its scalar in lhs (before the 1 / zd_0 scaling): the verifier's one multi-scalar multiplication
     for s in sets:                                                          # the i-th set carries v^i, its j-th polynomial y^j (snark-verifier: powers_of_mu, gamma.powers)
         points = [rot_pt(r) for r in s["rots"]]
         zd = 1
@@ -731,11 +732,28 @@ def verify(pr: Protocol, vk_bytes: bytes | None, instances, proof: bytes, tau: i
             inner_r = (inner_r * ys + r_u) % R
         E = g1_add(E, g1_mul(inner_c, vp * zd % R))
         r_acc = (r_acc + vp * zd % R * inner_r) % R
+        yp = 1
+        for p_ in s["polys"]:
+            msm_terms[p_] = (msm_terms.get(p_, 0) + vp * zd % R * yp) % R
+            yp = yp * ys % R
         vp = vp * v % R
     zi = inv(zd0)
     E = g1_add(g1_mul(E, zi), g1_of_scalar((-r_acc * zi) % R))
     E = g1_add(E, g1_mul(c_h, (-zt * zi) % R))
     lhs = g1_add(E, g1_mul(c_w, uu))
+    # the same lhs as ONE multi-scalar multiplication over the proof's own points (what snark-verifier's Msm evaluates): sum_p coeff_p C_p, the quotient's commitment spread
+    # over its pieces with x^(n q), the generator with -r, the two SHPLONK points.  tests/golden/make_golden.py stores it for the released proofs: an MSM instance whose
+    # RESULT the pairing equation certifies
+    scal, pts = [], []
+    for p_, c_ in msm_terms.items():
+        if p_ == pr.quotient_poly:
+            f = 1
+            for pc in pieces:
+                scal.append(c_ * zi % R * f % R); pts.append(pc); f = f * xn % R
+        else:
+            scal.append(c_ * zi % R); pts.append(com[p_])
+    scal += [(-r_acc * zi) % R, (-zt * zi) % R, uu]; pts += [pyref.G1_GEN, c_h, c_w]
+    res["msm"] = {"scalars": scal, "points": pts, "result": lhs, "w_prime": c_w}
     if tau is not None:
         res["pairing_with_trapdoor"] = lhs == g1_mul(c_w, tau)
         res["ok"] = res["pairing_with_trapdoor"]

@@ -122,6 +122,37 @@ for name, pr, src in (("protocol_layer2.json", l2, "release-v0.13.1/chunk.protoc
                    "_stored_proofs_with_this_constraint_system": same_system if name == "protocol_layer2.json" else 2,
                    "protocol": pr}, f, separators=(",", ":"))
     print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+# ---- known-answer vectors DERIVED from the released proofs (needs this repository's oracle/ and scroll-prover_amd/protocols.py: the script is run from a checkout).  The verifier's final
+# step is one multi-scalar multiplication over the proof's own points, and the pairing equation certifies its RESULT -- so (scalars, points) -> result is an MSM instance whose answer the
+# reference's data vouches for; likewise the value of the instance polynomial at the challenge x (the verifier needs exactly it) is what an inverse transform of the instance column,
+# evaluated at x, must give.  tests/test_released_kats.py feeds both to the C oracle's best_multiexp / best_fft and, under -m gpu, to the device.
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import plonk as _plonk, pyref as _pyref, pairing as _pairing
+import importlib.util as _ilu
+_spec = _ilu.spec_from_file_location("protocols", os.path.join(os.path.dirname(os.path.dirname(HERE)), "scroll-prover_amd", "protocols.py")); _protocols = _ilu.module_from_spec(_spec); _spec.loader.exec_module(_protocols)
+_neg = _pyref.g2_from_evm_words([int(w, 16) for w in out["yul"]["s_g2_words"]])
+_words = lambda b: [int.from_bytes(b[i:i + 32], "big") for i in range(0, len(b), 32)]
+_hx = lambda v: "%064x" % v
+kats = {"_generated_by": "tests/golden/make_golden.py", "_what": "MSM and instance-polynomial known answers derived from the reference's released proofs: every `result` satisfies e(result, G2) e(w_prime, -[s]G2) == 1"}
+_pd, _pi, _vkb = bytes.fromhex(out["bundle_proof_data"]), bytes.fromhex(out["bundle_pi_data"]), bytes.fromhex(out["vk_bundle"])
+for name, pr_json, inst, proof, kw in (
+        ("chunk_proof", l2, _words(bytes.fromhex(out["chunk_proof"]["instances"])), bytes.fromhex(out["chunk_proof"]["proof"]), dict(transcript="poseidon")),
+        ("batch_proof", l4, _words(bytes.fromhex(out["batch_proof"]["instances"])), bytes.fromhex(out["batch_proof"]["proof"]), dict(transcript="poseidon")),
+        ("bundle_proof", _protocols.layer_protocol(6), _words(_pd[:384]) + _words(_pi), _pd[384:],
+         dict(transcript="evm", preprocessed=[_pyref.g1_decompress(_vkb[8 + 32 * i:8 + 32 * i + 32]) for i in range(7)], initial_state=int(out["yul"]["transcript_initial_state"])))):
+    _pr = _plonk.Protocol(pr_json)
+    res = _plonk.verify(_pr, None, inst, proof, neg_s_g2=_neg, **kw)
+    assert res["ok"], name
+    m = res["msm"]
+    assert _pairing.pairing_product_is_one([(m["result"], _pyref.G2_GEN), (m["w_prime"], _neg)])
+    x = res["challenges"]["x"]
+    kats[name] = {"k": _pr.k,
+                  "msm": {"scalars": [_hx(v) for v in m["scalars"]], "points": [[_hx(p_[0]), _hx(p_[1])] for p_ in m["points"]], "result": [_hx(m["result"][0]), _hx(m["result"][1])],
+                          "w_prime": [_hx(m["w_prime"][0]), _hx(m["w_prime"][1])]},
+                  "instance_eval": {"x": _hx(x), "instances": [_hx(v) for v in inst], "value": _hx(sum(v * _plonk.lagrange_at(_pr, i, x) for i, v in enumerate(inst)) % _pyref.R_MOD)}}
+with open(os.path.join(HERE, "released_kats.json"), "w") as f:
+    json.dump(kats, f, indent=1)
+print("wrote released_kats.json:", {k_: len(v["msm"]["scalars"]) for k_, v in kats.items() if not k_.startswith("_")}, "MSM terms")
 with open(os.path.join(HERE, "layer_configs.json"), "w") as f:
     json.dump({str(i): json.loads(rd(f"integration/configs/layer{i}.config", "r")) for i in range(1, 7)}, f, indent=1)
 with open(os.path.join(HERE, "kat.json"), "w") as f:
