@@ -27,6 +27,10 @@
  * proofs that same verifier accepts (tests/test_plonk_protocol.py).  The group law, the
  * field arithmetic, the domain and the encodings are therefore the reference's; the
  * bucket schedule inside multiexp is a restatement (it cannot change a group element).
+ * (iv) tests/test_released_kats.py: orc_best_multiexp / orc_multiexp_serial reproduce the
+ * verifier's final multi-scalar multiplication of each released proof -- a result the
+ * pairing equation certifies --, and orc_ifft + orc_eval_polynomial at 2^25 reproduce the
+ * instance polynomial's value at the chunk proof's challenge.
  *
  * Data conventions (proved by fixture KAT A1/A2): field elements are
  * 4 x u64 little-endian limbs, Montgomery form (R = 2^256), fully reduced.
