@@ -313,6 +313,12 @@ def test_cpu_prove_and_verify(tmp_path, layer, k, shape):
         assert not ok, f"a proof with word {word} altered was accepted"
     wrong_inst = list(inp.instances); wrong_inst[0] = (wrong_inst[0] + 1) % pyref.R_MOD
     assert not plonk.verify(pr, vk, wrong_inst, proof, inp.tau)["ok"]
+    if layer == 2:            # the trapdoor check and the pairing check are the same statement: with -[tau]G2 of this synthetic SRS the pairing accepts the proof, and not a tampered one
+        sg2 = pyref.g2_mul(pyref.G2_GEN, inp.tau)
+        neg = (sg2[0], tuple((-c) % pyref.P_MOD for c in sg2[1]))
+        assert plonk.verify(pr, vk, inp.instances, proof, None, neg_s_g2=neg)["pairing"]
+        bad = bytearray(proof); bad[32 * nc + 7] ^= 1
+        assert not plonk.verify(pr, vk, inp.instances, bytes(bad), None, neg_s_g2=neg)["ok"]
     if layer == 6:            # layer 6 in the EVM layout: points uncompressed, big-endian words, Keccak challenges
         pe = plonk.prove(inp, vk, transcript="evm")
         assert len(pe) == 11 * 64 + 17 * 32 and plonk.verify(pr, vk, inp.instances, pe, inp.tau, transcript="evm")["ok"]
