@@ -196,6 +196,22 @@ def test_released_bundle_evm_proof_verifies():
     assert pairing.pairing_product_is_one([((c[0], c[1]), pyref.G2_GEN), ((c[2], c[3]), NEG_S_G2)])
 
 
+def test_pairing_is_bilinear_and_non_degenerate():
+    """oracle/pairing.py on its own: e(aP, bQ) == e(P, Q)^(ab) == e(abP, Q) == e(P, abQ), e(P, Q) != 1 of order r, e(P, Q) e(-P, Q) == 1, and the product form with several pairs"""
+    from oracle import pairing
+    G1, G2 = pyref.G1_GEN, pyref.G2_GEN
+    a, b = 0x1234567890ABCDEF1234567, 0xFEDCBA0987654321
+    e = pairing.pairing(G2, G1)
+    assert not (e == pairing.F12.one()) and (e ** pyref.R_MOD) == pairing.F12.one()
+    lhs = pairing.pairing(pyref.g2_mul(G2, b), pyref.g1_mul(G1, a))
+    assert lhs == e ** (a * b % pyref.R_MOD) == pairing.pairing(G2, pyref.g1_mul(G1, a * b % pyref.R_MOD)) == pairing.pairing(pyref.g2_mul(G2, a * b % pyref.R_MOD), G1)
+    assert pairing.pairing_product_is_one([(G1, G2), (pyref.g1_neg(G1), G2)])
+    assert pairing.pairing_product_is_one([(pyref.g1_mul(G1, a), pyref.g2_mul(G2, b)), (pyref.g1_mul(G1, 3), pyref.g2_mul(G2, 5)), (pyref.g1_neg(pyref.g1_mul(G1, (a * b + 15) % pyref.R_MOD)), G2)])
+    assert pairing.miller_loop(None, G1) == pairing.F12.one() and pairing.miller_loop(G2, None) == pairing.F12.one()
+    x = pairing.F12([3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8])
+    assert x * x.inv() == pairing.F12.one()
+
+
 def test_keccak256_vectors():
     from oracle import keccak
     assert keccak.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
