@@ -166,6 +166,10 @@ def test_vkey_files_hold_the_protocols_preprocessed_commitments_in_order():
     pts = [pyref.g1_decompress(vk[8 + 32 * i:8 + 32 * i + 32]) for i in range(7)]
     assert pts == [(plonk.fq_limbs_mont_to_int(p["x"]), plonk.fq_limbs_mont_to_int(p["y"])) for p in fixture(2)["preprocessed"]]
     assert int.from_bytes(vk[:4], "big") == 25 and len(vk) == 8 + 7 * 32
+    # and the batch proof's key [REF integration/tests/test_data/vk_batch_agg.vkey] (== the `vk` stored with full_proof_batch_agg_1.json) against the layer-4 protocol: nine commitments, same order
+    vk4 = bytes.fromhex(KAT["vk_batch_agg"])
+    assert vk4.hex() == KAT["batch_proof"]["vk"] and int.from_bytes(vk4[:4], "big") == 26 and len(vk4) == 8 + 9 * 32
+    assert [pyref.g1_decompress(vk4[8 + 32 * i:8 + 32 * i + 32]) for i in range(9)] == [(plonk.fq_limbs_mont_to_int(p["x"]), plonk.fq_limbs_mont_to_int(p["y"])) for p in fixture(4)["preprocessed"]]
 
 
 def bundle_inputs():
