@@ -118,3 +118,40 @@ def test_ctypes_table_names_exactly_the_header_functions():
     sig = set(zk._capi.SIGNATURES)
     hdr = set(HEADER)
     assert sig == hdr, f"only in _capi.SIGNATURES: {sorted(sig - hdr)}; only in the header: {sorted(hdr - sig)}"
+
+
+def test_rust_sources_have_balanced_delimiters():
+    """no Rust toolchain in the image: the least a maintainer should be spared is an unbalanced brace.  String-, char- and comment-aware scan of every rust_shim/*.rs"""
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for path in sorted(glob.glob(os.path.join(ROOT, "rust_shim", "*.rs"))):
+        s = open(path).read()
+        i, n, line, stack = 0, len(s), 1, []
+        while i < n:
+            c = s[i]
+            if c == "\n":
+                line += 1
+            if s.startswith("//", i):
+                j = s.find("\n", i); i = n if j < 0 else j
+                continue
+            if s.startswith("/*", i):
+                j = s.find("*/", i + 2); assert j >= 0, f"{path}:{line}: unterminated block comment"
+                line += s.count("\n", i, j); i = j + 2
+                continue
+            if c == '"':
+                j = i + 1
+                while j < n and s[j] != '"':
+                    j += 2 if s[j] == "\\" else 1
+                assert j < n, f"{path}:{line}: unterminated string"
+                line += s.count("\n", i, j); i = j + 1
+                continue
+            if c == "'":
+                m = re.match(r"'(\\.|[^\\'])'", s[i:])
+                i += m.end() if m else 1          # a char literal, else a lifetime
+                continue
+            if c in "([{":
+                stack.append((c, line))
+            elif c in ")]}":
+                assert stack and stack[-1][0] == pairs[c], f"{path}:{line}: '{c}' closes {stack[-1] if stack else 'nothing'}"
+                stack.pop()
+            i += 1
+        assert not stack, f"{path}: unclosed {stack[-3:]}"
