@@ -360,7 +360,7 @@ inline std::unique_ptr<ProvingKey> keygen(const Protocol &P, const Circuit &C, u
 struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 0 /* 0: by column count */; int upload_threads = 1; int early_intt = -1 /* -1: by column count */;
                       bool sparse_uploads = false /* columns that are at least half zeros cross PCIe as (index, value) pairs */;
                       bool packed_multiplicities = false /* the lookup multiplicities cross PCIe as the 4-byte counts they are (mi355_buf_upload_packed); their blinding rows follow as 32-byte words */;
-                      TranscriptKind transcript = TranscriptKind::Blake2b /* Poseidon: what the reference proves layers 0-5 with; Evm: layer 6 (mi355zk_transcript.hpp; reference_transcript below picks by layer) */; };
+                      TranscriptKind transcript = TranscriptKind::ByLayer /* the reference's choice for the protocol's layer (reference_transcript below): Poseidon for 0-5, Evm for 6; or name one */; };
 // the transcript the reference proves a layer with: Poseidon for every proof the next layer verifies in-circuit (layers 0-5, [REF integration/src/prove.rs:30-43,67,95-97] -> snark-verifier-sdk
 // gen_snark_shplonk), Keccak in the EVM layout for layer 6 (gen_evm_proof_shplonk: what the released verifier contract reads).  Files without a layer number are the reference's fixtures (layers 2, 4).
 inline TranscriptKind reference_transcript(const Protocol &P) { return P.layer == 6 ? TranscriptKind::Evm : TranscriptKind::Poseidon; }
@@ -403,7 +403,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   auto ms_since = [](Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); };
   const auto t_start = Clock::now(); auto tl = t_start;
   auto lap = [&](int step) { R.step_ms[step] += ms_since(tl); tl = Clock::now(); };
-  Transcript T(opt.transcript);
+  Transcript T(opt.transcript == TranscriptKind::ByLayer ? reference_transcript(P) : opt.transcript);
   T.common_scalar(vk_transcript_repr(pk.vk));
   for (const auto &v : wit.instances) T.common_scalar(v);
   std::map<uint32_t, DevicePoly> poly;   // protocol index -> Lagrange values until step 6, coefficients afterwards

@@ -208,7 +208,7 @@ inline std::array<uint8_t, 32> keccak256(const std::vector<uint8_t> &data) {
   return out;
 }
 
-enum class TranscriptKind { Blake2b, Poseidon, Evm };
+enum class TranscriptKind { Blake2b, Poseidon, Evm, ByLayer /* not a transcript: ProofOptions' default, resolved by plonk::reference_transcript */ };
 inline TranscriptKind transcript_kind_from_name(const std::string &s) {
   if (s == "blake2b") return TranscriptKind::Blake2b;
   if (s == "poseidon") return TranscriptKind::Poseidon;
@@ -222,7 +222,7 @@ struct Transcript {
   PoseidonSponge sponge;
   std::vector<uint8_t> evm_buf;                                 // Evm: the words waiting for the next Keccak
   std::vector<uint8_t> proof;                                   // what the transcript's writer receives: the proof, in the reference's layout
-  explicit Transcript(TranscriptKind k = TranscriptKind::Blake2b) : kind(k) {}
+  explicit Transcript(TranscriptKind k = TranscriptKind::Blake2b) : kind(k) { if (k == TranscriptKind::ByLayer) throw std::invalid_argument("transcript: ByLayer must be resolved with reference_transcript(protocol) first"); }
   static void be32(const zk::fe_t &canonical, uint8_t out[32]) { const uint8_t *le = reinterpret_cast<const uint8_t *>(&canonical); for (int i = 0; i < 32; i++) out[i] = le[31 - i]; }
   halo2::Fr squeeze_challenge() {
     if (kind == TranscriptKind::Poseidon) return sponge.squeeze();
