@@ -98,6 +98,30 @@ def witness_like_scalars(n: int, seed: int, device, h2) -> torch.Tensor:
     return a.contiguous()
 
 
+def released_proofs_check():
+    """CHECKER leg (oracle/ is test infrastructure; nothing here is timed or shipped): the verifier that judges this run's proofs (oracle/plonk.py) on the proofs the REFERENCE released --
+    the ten committed under tests/golden/ (7 chunk proofs, 2 batch proofs under the Poseidon transcript; the bundle proof under Keccak with the generated layer-6 protocol) --, each under
+    a real pairing check.  Returns how many were accepted, or None if the check could not run (it must never take the bench line down)."""
+    try:
+        from oracle import plonk, pyref
+        import importlib.util as ilu
+        spec = ilu.spec_from_file_location("_protocols", os.path.join(ROOT, "scroll-prover_amd", "protocols.py")); protocols = ilu.module_from_spec(spec); spec.loader.exec_module(protocols)
+        gold = os.path.join(ROOT, "tests", "golden")
+        kat = json.load(open(os.path.join(gold, "kat.json")))
+        neg = pyref.g2_from_evm_words([int(w, 16) for w in kat["yul"]["s_g2_words"]])
+        words = lambda b: [int.from_bytes(b[i:i + 32], "big") for i in range(0, len(b), 32)]
+        l2 = plonk.Protocol(json.load(open(os.path.join(gold, "protocol_layer2.json")))); l4 = plonk.Protocol(json.load(open(os.path.join(gold, "protocol_layer4.json"))))
+        cases = [(l2, kat["chunk_proof"])] + [(l2, m) for m in kat["more_chunk_proofs"]] + [(l4, kat["batch_proof"]), (l4, kat["batch_proof_2"])]
+        n = sum(bool(plonk.verify(pr, None, words(bytes.fromhex(c["instances"])), bytes.fromhex(c["proof"]), transcript="poseidon", neg_s_g2=neg)["ok"]) for pr, c in cases)
+        pd, pi, vk = bytes.fromhex(kat["bundle_proof_data"]), bytes.fromhex(kat["bundle_pi_data"]), bytes.fromhex(kat["vk_bundle"])
+        n += bool(plonk.verify(plonk.Protocol(protocols.layer_protocol(6)), None, words(pd[:384]) + words(pi), pd[384:], transcript="evm", neg_s_g2=neg,
+                               preprocessed=[pyref.g1_decompress(vk[8 + 32 * i:8 + 32 * i + 32]) for i in range(7)], initial_state=int(kat["yul"]["transcript_initial_state"]))["ok"])
+        return int(n), len(cases) + 1
+    except Exception as e:   # noqa: BLE001 -- a checker problem is reported, not raised
+        sys.stderr.write(f"released_proofs_check could not run: {e!r}\n")
+        return None
+
+
 def replay_create_proof(layer: int, k: int | None = None, host_api: bool = False, timeout: int = 1500, devices: int = 1, **shape):
     """One layer of scroll-prover's proof stack, proven on the device from the layer's PlonkProtocol by the compiled caller tests/cpp/test_plonk_replay.cpp
     (mi355zk::plonk::create_proof, include/mi355zk_plonk.hpp; its own process, run BEFORE this process binds the GPU), then VERIFIED here from the bytes it
@@ -692,6 +716,11 @@ def main() -> None:
             if cpp_ is not None:
                 cfg["chunk_prover_process_ms"] = cpp_.get("round_ms"); cfg["chunk_prover_process_peak_hbm_gib"] = (cpp_.get("hbm") or {}).get("peak_used_gib")
                 checks.append(bool(cpp_.get("ok")))
+        if proof_mix is not None and "chunk_proof_proxy" in proof_mix:
+            rp = released_proofs_check()     # the verifier that accepted this run's proofs, on the reference's own released proofs (about 10 s of CPU, after all timing)
+            if rp is not None:
+                cfg["verifier_accepts_released_reference_proofs"] = "%d of %d" % rp
+                checks.append(rp[0] == rp[1])
         cfg["all_checks"] = all(bool(c) for c in checks)
         print(json.dumps(line), flush=True)
     if world > 1:
