@@ -66,6 +66,107 @@ def recorded_traffic(key: str, kind: str):
     return rec.get(key), rec.get("source")
 
 
+LINE_BUDGET = 4096   # bytes of the ONE stdout line (the driver keeps a bounded tail of the output: round 5's 25 KB line was not parsed)
+
+
+def _clean(x, nd=6):
+    """strict-JSON value: no NaN / Infinity (-> null), floats to `nd` significant digits, numpy scalars to Python ones"""
+    import math
+    if isinstance(x, dict):
+        return {str(k_): _clean(v, nd) for k_, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clean(v, nd) for v in x]
+    if isinstance(x, (bool, type(None), str, int)):
+        return x
+    if isinstance(x, np.generic):
+        x = x.item()
+        if isinstance(x, (bool, int, str)):
+            return x
+    if isinstance(x, float):
+        if not math.isfinite(x):
+            return None
+        if x.is_integer() and abs(x) < 2.0 ** 53:
+            return int(x)   # counts that travelled as floats (pairs per launch, bytes) keep every digit
+        return float(f"{x:.{nd}g}")
+    return str(x)
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 3] + "..."
+
+
+def compact_line(full: dict, detail_file: str | None) -> str:
+    """The ONE line the driver reads: the contract's keys, `config` (workload + the other two legs of BASELINE.json's metric), `roofline`, `cpu_baseline` -- at most
+    LINE_BUDGET bytes of strict JSON whatever the run produced.  Everything else (proof mix, sizes, batched commitments, witness-like column, host route, phase
+    breakdowns) is in `detail_file`.  tests/test_bench_line.py holds a worst-case record against the budget."""
+    cfg = full.get("config") or {}
+    keep_cfg = ("workload", "log_n", "window_bits", "windows", "parallelism", "srs_window_tables", "ntt_k26_ms", "ntt_k26_butterflies_per_s", "ntt_roofline_frac_hbm",
+                "proxies_ms", "proxies_shape", "proxies_separate_processes_ms", "layer_ms", "chunk_prover_process_ms", "chunk_prover_process_peak_hbm_gib",
+                "verifier_accepts_released_reference_proofs", "all_checks")
+    c = {k_: cfg[k_] for k_ in keep_cfg if k_ in cfg}
+    for k_ in list(cfg):   # the NTT keys carry the size in their name when --logn is not 26
+        if k_.startswith("ntt_k") and k_ not in c:
+            c[k_] = cfg[k_]
+    for k_ in ("workload", "parallelism", "proxies_shape"):
+        if k_ in c:
+            c[k_] = _short(c[k_], 200)
+    rf = full.get("roofline") or {}
+    r = {k_: rf.get(k_) for k_ in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "pairs_per_launch")}
+    r["traffic_source"] = _short(rf.get("traffic_source"), 120) if rf.get("traffic_source") else None
+    alu = rf.get("alu") or {}
+    r["alu"] = {k_: alu.get(k_) for k_ in ("frac", "achieved", "peak", "unit")}
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        cb = {k_: cb.get(k_) for k_ in ("value", "unit", "cores", "kind", "sample", "pairs_per_s")}
+        cb["sample"] = _short(cb.get("sample"), 200)
+    out = {k_: full.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["dtype"] = _short(out["dtype"], 80)
+    out.update({"config": c, "roofline": r, "cpu_baseline": cb, "pairs_per_s": full.get("pairs_per_s"), "verified_against_field_check": full.get("verified_against_field_check")})
+    mg = full.get("multi_gpu")
+    if mg is not None:
+        m = {k_: mg.get(k_) for k_ in ("distinct_devices", "backend", "rccl_version", "mode", "exchange") if k_ in mg}
+        if "exchange" in m:
+            m["exchange"] = _short(m["exchange"], 100)
+        if isinstance(mg.get("devices"), int):
+            m["devices"] = mg["devices"]
+        if mg.get("per_rank_ms_per_step"):
+            m["per_rank_ms_per_step"] = [round(float(x), 2) for x in mg["per_rank_ms_per_step"]][:16]
+        out["multi_gpu"] = m
+    out["detail_file"] = detail_file
+    out = _clean(out)
+    line = json.dumps(out, allow_nan=False, separators=(", ", ": "))
+    # whatever the run produced, the line stays inside the budget: drop the optional keys first, last the long strings
+    for victim in (("config", "layer_ms"), ("multi_gpu",), ("roofline", "alu"), ("config", "proxies_shape"), ("roofline", "traffic_source"), ("cpu_baseline", "sample"), ("config", "parallelism")):
+        if len(line.encode()) <= LINE_BUDGET:
+            break
+        d = out
+        for k_ in victim[:-1]:
+            d = d.get(k_) or {}
+        d.pop(victim[-1], None)
+        line = json.dumps(out, allow_nan=False, separators=(", ", ": "))
+    assert len(line.encode()) <= LINE_BUDGET, len(line)
+    return line
+
+
+def emit(full: dict) -> None:
+    """full record -> bench_detail.json (repo root, and gpurun_out/ when that directory exists so that it travels back from a GPU box); compact line -> stdout, last"""
+    full = _clean(full, nd=9)
+    detail_file = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                json.dump(full, f, allow_nan=False, indent=1)
+            detail_file = detail_file or os.path.relpath(os.path.join(d, "bench_detail.json"), ROOT)
+        except OSError as e:   # a read-only tree must not cost the line
+            sys.stderr.write(f"bench.py: could not write {d}/bench_detail.json: {e}\n")
+    sys.stderr.write(f"bench.py: full record ({len(json.dumps(full))} bytes) in {detail_file}; the line below is its summary\n")
+    sys.stderr.flush()
+    print(compact_line(full, detail_file), flush=True)
+
+
 def rand_scalars(n: int, seed: int, device) -> torch.Tensor:
     """n field elements as [n,4] int64 limbs (Montgomery form of uniformly random elements), generated on the device."""
     gen = torch.Generator(device=device)
@@ -191,7 +292,8 @@ def main() -> None:
     ap.add_argument("--no-precompute", action="store_true", help="skip the registration-time window tables (mi355_srs_precompute)")
     ap.add_argument("--no-proof-mix", action="store_true", help="skip the compiled create_proof replays (all seven layers from their PlonkProtocols, each proof verified from its bytes)")
     ap.add_argument("--proxy-chunk-proof", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--prover-process", action="store_true", help="additionally run layers 0 + 1 + 2 inside ONE process (tests/cpp/test_prover_process.cpp: three SRS degrees, three proving keys under plan_residency, proofs back to back; ~80 s)")
+    ap.add_argument("--prover-process", action="store_true", help=argparse.SUPPRESS)   # accepted for older command lines: on by default since round 6
+    ap.add_argument("--no-prover-process", action="store_true", help="skip the chunk prover as ONE process (layers 0 + 1 + 2 in tests/cpp/test_prover_process.cpp: three SRS degrees, three proving keys under plan_residency, proofs back to back; ~80 s).  Without it config.proxies_ms[0] falls back to the sum of three single-layer processes and says so")
     ap.add_argument("--single-process", action="store_true", help="N GPUs behind ONE process (mi355_init_multi: shards, worker threads, ncclAllGather inside the library) instead of one rank per GPU")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer leg (mi355_msm_g1_host: scalars cross PCIe inside the call; reported next to, never as, the headline value)")
     ap.add_argument("--no-table-free", action="store_true", help="skip the leg without window tables")
@@ -275,8 +377,8 @@ def main() -> None:
                      "bundle_proof_proxy": proxy("layer 5 (k = 21) + layer 6 (k = 26, layer 2's constraint system at the bundle's degree): gen_bundle_proof", (5, 6)),
                      "every_proof_verified": ok_all,
                      # optional (--prover-process): the chunk prover as ONE process -- the three layers' SRS, proving keys and witnesses resident together under the HBM plan
-                     "chunk_prover_process": prover_process((0, 1, 2)) if args.prover_process else None,
-                     "excludes": "witness synthesis of the real circuits (the circuit instances are built to satisfy each protocol), layer 6's Keccak transcript and EVM proof layout (halo2's Blake2b transcript stands in there; layers 0-5 run the reference's Poseidon transcript)"}
+                     "chunk_prover_process": prover_process((0, 1, 2)) if not args.no_prover_process else None,
+                     "excludes": "witness synthesis of the real circuits (the circuit instances are built to satisfy each protocol; layers 0-5 run the reference's Poseidon transcript, layer 6 its Keccak transcript and EVM proof layout)"}
     if single and args.gpus > 1 and not args.no_proof_mix and args.logn == 26:
         # N devices behind ONE prover process: witness columns live round-robin on the devices, commitments take scalars from whichever device
         # holds them (shards of the basis everywhere), the iNTT batch and the coset parts of the quotient run concurrently on different devices
@@ -670,7 +772,7 @@ def main() -> None:
         line = {
             "metric": "BN254 MSM G1-adds/sec at k=%d" % k, "value": value, "unit": "G1-adds/s", "n_gpus": args.gpus if single else world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32 limbs (254-bit Montgomery integers: 9x29-bit unsaturated compute form, 8x32 storage; v_mad_u64_u32)", "data": "synthetic",
+            "dtype": "u32 (9x29-bit limbs of 254-bit Montgomery integers; v_mad_u64_u32)", "data": "synthetic",
             "config": {"workload": f"BN254 G1 Pippenger MSM, 2^{k} uniform random scalars x synthetic SRS points, inputs resident in HBM; "
                                    f"point-range shards over {world} GPU(s), RCCL all-gather of 96-B partials",
                        "log_n": k, "window_bits": c, "windows": W, "parallelism": (f"point-range x{args.gpus} inside one process (mi355_init_multi: per-device shards, ncclAllGather of the partials in the library)" if single else f"point-range x{world}, one rank per GPU"),
@@ -708,11 +810,17 @@ def main() -> None:
             cfg["ntt_k%d_ms" % k] = round(ntt["ms_per_transform"], 3); cfg["ntt_k%d_butterflies_per_s" % k] = ntt["butterflies_per_s"]; cfg["ntt_roofline_frac_hbm"] = round(ntt["roofline"]["frac"], 4)
             checks += [ntt["roundtrip_ok"], ntt.get("full_vector_equals_cpu_baseline", True)]
         if proof_mix is not None and "chunk_proof_proxy" in proof_mix:
-            cfg["proxies_ms"] = [proof_mix[x]["resident_ms"] for x in ("chunk_proof_proxy", "batch_proof_proxy", "bundle_proof_proxy")]
-            cfg["proxies"] = "create_proof per layer from its PlonkProtocol (layers 2 / 4: the reference's own), proof verified from its bytes: [chunk = L0 + L1 + L2, batch = L3 + L4, bundle = L5 + L6]"
+            sep = [proof_mix[x]["resident_ms"] for x in ("chunk_proof_proxy", "batch_proof_proxy", "bundle_proof_proxy")]
             cfg["layer_ms"] = {str(x): (proof_mix[p_][f"layer{x}"].get("resident_ms")) for p_, xs in (("chunk_proof_proxy", (0, 1, 2)), ("batch_proof_proxy", (3, 4)), ("bundle_proof_proxy", (5, 6))) for x in xs}
             checks.append(bool(proof_mix["every_proof_verified"]))
+            # the chunk proxy in the REFERENCE's process shape: ChunkProver is ONE process holding layers 0 + 1 + 2 [REF integration/src/prove.rs:30-43]; the sum of
+            # three single-layer processes (each with the whole HBM to itself) is the flattering figure and is reported beside it, never as it
             cpp_ = proof_mix.get("chunk_prover_process")
+            one = cpp_.get("round_ms") if (cpp_ is not None and cpp_.get("ok")) else None
+            cfg["proxies_ms"] = [one if one is not None else sep[0], sep[1], sep[2]]
+            cfg["proxies_separate_processes_ms"] = sep
+            cfg["proxies_shape"] = ("[chunk = L0+L1+L2 in ONE prover process under plan_residency, " if one is not None else "[chunk = L0+L1+L2 as three single-layer processes (one-process run skipped or failed), ") + \
+                "batch = L3+L4, bundle = L5+L6 as single-layer processes]; create_proof per layer from its PlonkProtocol (layers 2 / 4: the reference's own), every proof verified from its bytes"
             if cpp_ is not None:
                 cfg["chunk_prover_process_ms"] = cpp_.get("round_ms"); cfg["chunk_prover_process_peak_hbm_gib"] = (cpp_.get("hbm") or {}).get("peak_used_gib")
                 checks.append(bool(cpp_.get("ok")))
@@ -722,7 +830,7 @@ def main() -> None:
                 cfg["verifier_accepts_released_reference_proofs"] = "%d of %d" % rp
                 checks.append(rp[0] == rp[1])
         cfg["all_checks"] = all(bool(c) for c in checks)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 
