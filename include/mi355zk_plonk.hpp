@@ -364,6 +364,11 @@ struct ProofOptions { int devices = 1; int threads = 8; uint32_t commit_batch = 
 // the transcript the reference proves a layer with: Poseidon for every proof the next layer verifies in-circuit (layers 0-5, [REF integration/src/prove.rs:30-43,67,95-97] -> snark-verifier-sdk
 // gen_snark_shplonk), Keccak in the EVM layout for layer 6 (gen_evm_proof_shplonk: what the released verifier contract reads).  Files without a layer number are the reference's fixtures (layers 2, 4).
 inline TranscriptKind reference_transcript(const Protocol &P) { return P.layer == 6 ? TranscriptKind::Evm : TranscriptKind::Poseidon; }
+// The first scalar of the transcript.  A verifier built from a PlonkProtocol (snark-verifier's PlonkVerifier, the next layer's in-circuit verifier, the EVM contract) absorbs the
+// protocol's `transcript_initial_state`, never the key's bytes -- so when the protocol file carries one (the reference's own files do) the prover MUST start from it, or its
+// proof cannot pass that verifier whatever else is right.  Protocols generated here carry none (halo2 derives it by hashing a Rust Debug string of the
+// pinned key, which does not exist outside Rust): for those keys the scalar is a convention of this repository, the Blake2b hash of the .vkey bytes (vk_transcript_repr).
+inline Fr vk_transcript_scalar(const Protocol &P, const std::vector<uint8_t> &vk_bytes) { return P.has_initial_state ? P.initial_state : vk_transcript_repr(vk_bytes); }
 inline const char *transcript_name(TranscriptKind k) { return k == TranscriptKind::Poseidon ? "poseidon" : k == TranscriptKind::Evm ? "evm" : "blake2b"; }
 struct ProofResult {
   std::vector<uint8_t> proof;
@@ -404,7 +409,7 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   const auto t_start = Clock::now(); auto tl = t_start;
   auto lap = [&](int step) { R.step_ms[step] += ms_since(tl); tl = Clock::now(); };
   Transcript T(opt.transcript == TranscriptKind::ByLayer ? reference_transcript(P) : opt.transcript);
-  T.common_scalar(vk_transcript_repr(pk.vk));
+  T.common_scalar(vk_transcript_scalar(P, pk.vk));
   for (const auto &v : wit.instances) T.common_scalar(v);
   std::map<uint32_t, DevicePoly> poly;   // protocol index -> Lagrange values until step 6, coefficients afterwards
   auto commit_one = [&](uint64_t basis, const void *ptr) { G1 out; check(mi355_msm_g1_dev(basis, 0, ptr, n, out.data())); R.msm++; T.write_point(out); };

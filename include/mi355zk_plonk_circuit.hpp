@@ -111,7 +111,11 @@ struct RowEval {
 };
 }  // namespace detail
 
-struct CircuitOptions { uint64_t seed = 1; int threads = 8; bool pinned = false; double fill = 0.9; double assign_density = 1.0 /* fraction of the usable rows on which the assigned gates' selector is on: the other cells of every dependent column stay zero */; };
+struct CircuitOptions { uint64_t seed = 1; int threads = 8; bool pinned = false; double fill = 0.9; double assign_density = 1.0 /* fraction of the usable rows on which the assigned gates' selector is on: the other cells of every dependent column stay zero */;
+                        // the PROVER's randomness, separable from the witness (in halo2 it comes from the rng handed to create_proof): blind_seed != 0 draws the blinding rows, the z / phi
+                        // blinding values and the random polynomial from their own stream (same witness, other proof bytes); zero_blinding leaves the blinding rows and values zero -- a proof
+                        // the verifier still accepts (it cannot see the choice; zero knowledge is what is lost).  tests/test_plonk_protocol.py::test_gpu_prover_invisible_choices
+                        uint64_t blind_seed = 0; bool zero_blinding = false; };
 
 inline std::unique_ptr<Circuit> build_circuit(const Protocol &P, const CircuitOptions &opt) {
   using namespace detail;
@@ -249,7 +253,9 @@ inline std::unique_ptr<Circuit> build_circuit(const Protocol &P, const CircuitOp
     Column &a = C->advice[vert[gi]]; C->parallel(Bact, [&](uint64_t lo, uint64_t hi) { for (uint64_t b = lo; b < hi; b++) a[4 * b + 3] = ev.at(4 * b, n); });
   }
   // every advice column's blinding rows are drawn BEFORE the assigned gates run: their P may read rotated cells of earlier columns across the wrap-around
-  for (uint32_t a = 0; a < A; a++) { Rng g(top.next()); for (uint64_t r = u + 1; r < n; r++) C->advice[a][r] = g.uniform(); }
+  Rng blind_top(opt.blind_seed * 0xD1B54A32D192ED03ull + 777);
+  auto blind_stream = [&]() { const uint64_t own = top.next(), other = blind_top.next(); return opt.blind_seed ? other : own; };   // `top` advances either way: the witness does not depend on blind_seed
+  for (uint32_t a = 0; a < A; a++) { Rng g(blind_stream()); for (uint64_t r = u + 1; r < n; r++) C->advice[a][r] = opt.zero_blinding ? fr_zero() : g.uniform(); }
   std::set<uint32_t> assign_selectors;
   for (uint32_t a = 0; a < A; a++) if (role[a].kind == ASSIGN) {
     const Gate &g = *role[a].gate;
@@ -270,14 +276,14 @@ inline std::unique_ptr<Circuit> build_circuit(const Protocol &P, const CircuitOp
     Column &mc = C->m[l];
     C->parallel(table_rows, [&](uint64_t lo, uint64_t hi) { for (uint64_t i = lo; i < hi; i++) mc[i] = fr_small(cnt[i]); });
     cnt.resize(n, 0); C->m_counts.push_back(std::move(cnt));
-    Rng g(top.next()); for (uint64_t r = u + 1; r < n; r++) mc[r] = g.uniform();
+    Rng g(blind_stream()); for (uint64_t r = u + 1; r < n; r++) mc[r] = opt.zero_blinding ? fr_zero() : g.uniform();
   }
   // ---- whatever preprocessed polynomial nothing assigned stays all-zero (materialised), the permutation's bookkeeping, the prover's randomness
   for (uint32_t p = 0; p < P.num_pre; p++) { bool sig = false; for (const auto &c : C->pcols) sig = sig || c.sigma == p; if (!sig) (void)pre_col(p); }
   C->omega_pow.resize(n);
   { const int T = C->threads; std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back([&, t]() { const uint64_t lo = n * t / T, hi = n * (t + 1) / T; Fr w = fr_pow(P.omega, lo); for (uint64_t i = lo; i < hi; i++) { C->omega_pow[i] = w; w = fr_mul(w, P.omega); } }); for (auto &t : th) t.join(); }
-  { Rng g(top.next()); C->z_blind.assign(P.perm.size(), std::vector<Fr>(P.blind)); for (auto &v : C->z_blind) for (auto &x : v) x = g.uniform(); C->phi_blind.assign(L, std::vector<Fr>(P.blind)); for (auto &v : C->phi_blind) for (auto &x : v) x = g.uniform(); }
-  { C->random_poly = Column(alloc); C->random_poly.resize(n); const uint64_t sd = top.next(); C->parallel(n, [&](uint64_t lo, uint64_t hi) { Rng g(sd + lo * 7919); for (uint64_t i = lo; i < hi; i++) C->random_poly[i] = g.uniform(); }); }
+  { Rng g(blind_stream()); C->z_blind.assign(P.perm.size(), std::vector<Fr>(P.blind)); for (auto &v : C->z_blind) for (auto &x : v) x = opt.zero_blinding ? fr_zero() : g.uniform(); C->phi_blind.assign(L, std::vector<Fr>(P.blind)); for (auto &v : C->phi_blind) for (auto &x : v) x = opt.zero_blinding ? fr_zero() : g.uniform(); }
+  { C->random_poly = Column(alloc); C->random_poly.resize(n); const uint64_t sd = blind_stream();   /* the random polynomial stays random under zero_blinding (its commitment must not be the identity) */ C->parallel(n, [&](uint64_t lo, uint64_t hi) { Rng g(sd + lo * 7919); for (uint64_t i = lo; i < hi; i++) C->random_poly[i] = g.uniform(); }); }
   return C;
 }
 

@@ -172,6 +172,9 @@ struct Protocol {
   int32_t last_rot = 0; uint32_t blind = 0; uint64_t usable = 0;   // l_last = Lagrange(last_rot); rows usable+1 .. n-1 are blinding rows
   std::vector<PermChunk> perm; std::vector<Lookup> lookups; std::vector<Gate> gates;
   std::string source;
+  // the scalar a verifier of THIS protocol file absorbs first (snark-verifier's PlonkProtocol::transcript_initial_state = halo2's hash of the verifying key): the
+  // reference's protocol files carry it [REF release-v0.13.1/chunk.protocol "transcript_initial_state"]; generated protocols do not (see vk_transcript_scalar)
+  bool has_initial_state = false; Fr initial_state{};
   Protocol() = default;
   Protocol(const Protocol &) = delete;               // `perm` / `lookups` / `gates` point into `numerator`
   Protocol &operator=(const Protocol &) = delete;
@@ -208,6 +211,7 @@ struct Protocol {
     if (const json::Value *lb = root.find("lookup_bits")) lookup_bits = (uint32_t)lb->u;
     if (const json::Value *ly = root.find("layer")) layer = (int)ly->i64();
     if (const json::Value *sc = root.find("source")) source = sc->s;
+    if (const json::Value *is = root.find("transcript_initial_state")) if (is->type == json::Value::ARR) { initial_state = fr_from_json(*is); has_initial_state = true; }   // JSON null (Option::None) = absent
     recognise();
   }
 

@@ -324,6 +324,14 @@ class EvmTranscript(Transcript):
 TRANSCRIPTS = {"blake2b": Transcript, "poseidon": PoseidonTranscript, "evm": EvmTranscript}
 
 
+def vk_transcript_scalar(pr, vk_bytes: bytes) -> int:
+    """the transcript's first scalar: the protocol file's own `transcript_initial_state` when it carries one (what every verifier built from the file absorbs: snark-verifier reads
+    it from the PlonkProtocol, never from the key's bytes; the reference's files have it [REF release-v0.13.1/chunk.protocol]), else this repository's convention for generated
+    protocols, vk_transcript_repr of the .vkey bytes (include/mi355zk_plonk.hpp vk_transcript_scalar is the same rule)"""
+    st = pr.d.get("transcript_initial_state")
+    return limbs_mont_to_int(st) if st else vk_transcript_repr(vk_bytes)
+
+
 def vk_transcript_repr(vk_bytes: bytes) -> int:
     """halo2 hashes the Debug rendering of the pinned verifying key (Blake2b-512, personalisation "Halo2-Verify-Key") into one scalar; that string is
     not reproducible outside Rust, so the bytes hashed here are the .vkey serialisation (u32 BE k | u32 BE fixed columns | compressed commitments,
@@ -479,7 +487,7 @@ def prove(inp: ProofInputs, vk_bytes: bytes, transcript: str = "blake2b") -> byt
     n, w, u, tau = pr.n, pr.omega, pr.usable, inp.tau
     dom = _Domain(pr)
     T = TRANSCRIPTS[transcript]()
-    T.common_scalar(vk_transcript_repr(vk_bytes))
+    T.common_scalar(vk_transcript_scalar(pr, vk_bytes))
     for v in inp.instances:
         T.common_scalar(v)
     lag = {}                                   # polynomial index -> Lagrange values (witness, instance, preprocessed)
@@ -666,7 +674,7 @@ def verify(pr: Protocol, vk_bytes: bytes | None, instances, proof: bytes, tau: i
     else:
         assert int.from_bytes(vk_bytes[:4], "big") == pr.k and len(vk_bytes) == 8 + 32 * pr.num_pre
         pre_c = [pyref.g1_decompress(vk_bytes[8 + 32 * i:8 + 32 * i + 32]) for i in range(pr.num_pre)]
-        T.common_scalar(vk_transcript_repr(vk_bytes))
+        T.common_scalar(initial_state if initial_state is not None else vk_transcript_scalar(pr, vk_bytes))
     for v_ in instances:
         T.common_scalar(v_)
     com = {i: c for i, c in enumerate(pre_c)}

@@ -25,7 +25,7 @@ static void write_file(const std::string &path, const void *p, size_t bytes) { s
 int main(int argc, char **argv) {
   std::string protocol_path, out_dir, tables = "auto", pk_mode = "auto";
   int devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2, upload_threads = 1, early_intt = -1;
-  bool host_api = false, builder_only = false, dump_inputs = false, pinned_witness = false, corrupt = false, sparse_uploads = false, packed_m = true; uint64_t seed = 1; double fill = 0.9, assign_density = 1.0; TranscriptKind transcript = TranscriptKind::Blake2b; bool transcript_auto = true;
+  bool host_api = false, builder_only = false, dump_inputs = false, pinned_witness = false, corrupt = false, sparse_uploads = false, packed_m = true; uint64_t seed = 1, blind_seed = 0; bool zero_blinding = false; double fill = 0.9, assign_density = 1.0; TranscriptKind transcript = TranscriptKind::Blake2b; bool transcript_auto = true;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto next = [&]() -> long { return i + 1 < argc ? std::atol(argv[++i]) : 0; };
@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
     else if (a == "--threads") threads = (int)next(); else if (a == "--host-api") host_api = true; else if (a == "--builder-only") builder_only = true; else if (a == "--dump-inputs") dump_inputs = true;
     else if (a == "--no-tables") tables = "off"; else if (a == "--tables") tables = nexts(); else if (a == "--pk-cosets") pk_mode = nexts(); else if (a == "--proofs") proofs = (int)next();
     else if (a == "--upload-threads") upload_threads = (int)next(); else if (a == "--early-intt") early_intt = (int)next(); else if (a == "--pinned-witness") pinned_witness = true;
-    else if (a == "--seed") seed = (uint64_t)next(); else if (a == "--fill") fill = std::atof(nexts().c_str()); else if (a == "--corrupt-witness") corrupt = true;
+    else if (a == "--seed") seed = (uint64_t)next(); else if (a == "--blind-seed") blind_seed = (uint64_t)next(); else if (a == "--zero-blinding") zero_blinding = true; else if (a == "--fill") fill = std::atof(nexts().c_str()); else if (a == "--corrupt-witness") corrupt = true;
     else if (a == "--sparse-uploads") sparse_uploads = true; else if (a == "--packed-multiplicities") packed_m = true; else if (a == "--no-packed-multiplicities") packed_m = false; else if (a == "--assign-density") assign_density = std::atof(nexts().c_str());
     else if (a == "--transcript") { const std::string tn = nexts(); if (tn == "auto") continue; transcript_auto = false; try { transcript = transcript_kind_from_name(tn); } catch (const std::exception &e) { std::printf("%s\n", e.what()); return 1; } }
     else if (a == "--transcript-selftest") {   // host only: a fixed byte stream through the Blake2b transcript (tests compare with hashlib)
@@ -61,7 +61,7 @@ int main(int argc, char **argv) {
       return 0;
     }
     else { std::printf("usage: %s --protocol FILE --out DIR [--builder-only] [--dump-inputs] [--devices D] [--threads T] [--proofs N] [--upload-threads U] [--early-intt 0|1] [--pinned-witness]\n"
-                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--no-packed-multiplicities] [--transcript auto|blake2b|poseidon|evm] [--assign-density D] | --transcript-selftest\n", argv[0]); return 1; }
+                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--no-packed-multiplicities] [--transcript auto|blake2b|poseidon|evm] [--assign-density D] [--blind-seed S] [--zero-blinding] | --transcript-selftest\n", argv[0]); return 1; }
   }
   if (protocol_path.empty() || out_dir.empty()) { std::printf("--protocol and --out are required\n"); return 1; }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;
@@ -74,7 +74,7 @@ int main(int argc, char **argv) {
   const Fr tau = fr_u64(0x5343524F4C4C0001ull + (uint64_t)(P.layer < 0 ? 0 : P.layer));
   if (builder_only) {
     try {
-      CircuitOptions co; co.seed = seed; co.threads = threads; co.fill = fill; co.assign_density = assign_density;
+      CircuitOptions co; co.seed = seed; co.threads = threads; co.fill = fill; co.assign_density = assign_density; co.blind_seed = blind_seed; co.zero_blinding = zero_blinding;
       auto C = build_circuit(P, co);
       dump_circuit(*C, out_dir, tau, protocol_path);
       std::printf("{\"builder_only\": true, \"layer\": %d, \"k\": %u, \"copy_pairs\": %zu, \"gates_active\": %llu}\n", P.layer, k, C->pairs.size(), (unsigned long long)C->gates_active);
@@ -112,7 +112,7 @@ int main(int argc, char **argv) {
     else if (pk_mode == "auto" && sz.base_bytes + sz.coset_bytes + working > usable) resident = false;
     // ---- the circuit instance (host side: what keygen and create_proof are handed) and keygen
     const auto t_build = Clock::now();
-    CircuitOptions co; co.seed = seed; co.threads = threads; co.pinned = pinned_witness; co.fill = fill; co.assign_density = assign_density;
+    CircuitOptions co; co.seed = seed; co.threads = threads; co.pinned = pinned_witness; co.fill = fill; co.assign_density = assign_density; co.blind_seed = blind_seed; co.zero_blinding = zero_blinding;
     auto C = build_circuit(P, co);
     const double build_ms = ms_since(t_build);
     if (corrupt) C->advice[0][3] = fr_add(C->advice[0][3], fr_one());   // one cell off: the first gate no longer holds, the verifier must reject what comes out

@@ -350,6 +350,44 @@ def test_cpu_prove_and_verify(tmp_path, layer, k, shape):
         assert plonk.verify(pr, vk, inp.instances, pp, inp.tau, transcript="poseidon")["ok"] and not plonk.verify(pr, vk, inp.instances, pp, inp.tau)["ok"]
 
 
+REF_INITIAL_STATE = json.load(open(os.path.join(GOLD, "protocol_layer2.json")))["protocol"]["transcript_initial_state"]   # [REF release-v0.13.1/chunk.protocol]
+
+
+def with_initial_state(tmp_path, layer, k):
+    """a generated protocol that CARRIES a transcript_initial_state, as the reference's protocol files do"""
+    d = str(tmp_path / "stated"); os.makedirs(d, exist_ok=True)
+    proto = protocols.layer_protocol(layer, k)
+    assert not proto.get("transcript_initial_state")
+    proto["transcript_initial_state"] = REF_INITIAL_STATE
+    path = os.path.join(d, "p.json")
+    json.dump(proto, open(path, "w"), separators=(",", ":"))
+    return d, path
+
+
+def test_a_protocol_s_own_initial_state_keys_the_transcript(tmp_path):
+    """a verifier built from a PlonkProtocol absorbs the file's `transcript_initial_state` (snark-verifier never hashes key bytes), so prover and verifier
+    start from it whenever the file carries one; the .vkey hash is the convention for generated protocols only.  Same circuit, same randomness: the proofs agree up to the first
+    challenge (the advice commitments) and differ afterwards; each verifies under its own protocol only -- also by the file-only route the released proofs take (vk_bytes = None)."""
+    assert REF_INITIAL_STATE and len(REF_INITIAL_STATE) == 4
+    d, path = with_initial_state(tmp_path, 2, 6)
+    out = subprocess.run([exe(), "--protocol", path, "--out", d, "--builder-only", "--threads", "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    inp, _ = plonk.ProofInputs.load(d)
+    stated = inp.pr
+    plain = plonk.Protocol({k_: v for k_, v in stated.d.items() if k_ != "transcript_initial_state"})
+    vk = plonk.keygen_vk(stated, inp.pre, inp.tau)
+    assert plonk.vk_transcript_scalar(stated, vk) == plonk.limbs_mont_to_int(REF_INITIAL_STATE) != plonk.vk_transcript_repr(vk) == plonk.vk_transcript_scalar(plain, vk)
+    p_stated = plonk.prove(inp, vk, transcript="poseidon")
+    inp.pr = plain
+    p_plain = plonk.prove(inp, vk, transcript="poseidon")
+    na = 32 * stated.num_witness[0]
+    assert p_stated[:na] == p_plain[:na] and p_stated[na:] != p_plain[na:]
+    assert plonk.verify(stated, vk, inp.instances, p_stated, inp.tau, transcript="poseidon")["ok"] and plonk.verify(plain, vk, inp.instances, p_plain, inp.tau, transcript="poseidon")["ok"]
+    assert not plonk.verify(plain, vk, inp.instances, p_stated, inp.tau, transcript="poseidon")["ok"] and not plonk.verify(stated, vk, inp.instances, p_plain, inp.tau, transcript="poseidon")["ok"]
+    pre = [pyref.g1_decompress(vk[8 + 32 * i:8 + 32 * i + 32]) for i in range(stated.num_pre)]
+    assert plonk.verify(stated, None, inp.instances, p_stated, inp.tau, transcript="poseidon", preprocessed=pre)["ok"]       # nothing but the protocol file and the commitments
+
+
 def test_a_witness_that_breaks_a_gate_yields_a_rejected_proof(tmp_path):
     """the quotient of a violated constraint system is no polynomial: the 4n extended evaluations still interpolate to SOMETHING, the proof has its 1 312 bytes,
     and the verifier's identity h(x) (x^n - 1) == numerator(x) fails at the random x"""
@@ -412,6 +450,17 @@ def test_gpu_proof_bytes_equal_the_cpu_restatement(tmp_path, layer, k, args, env
 
 
 @pytest.mark.gpu
+def test_gpu_proof_starts_from_the_protocol_s_initial_state(tmp_path):
+    """the device prover under a protocol file that carries `transcript_initial_state` (as [REF release-v0.13.1/chunk.protocol] does): bytes equal the CPU restatement, which
+    starts from the file's scalar (test_a_protocol_s_own_initial_state_keys_the_transcript), and differ from the proof of the same circuit under the .vkey-hash convention"""
+    d, path = with_initial_state(tmp_path, 2, 7)
+    stated = check_against_restatement(zk.replay.run(2, None, out_dir=d, args=["--dump-inputs", "--proofs", "1"], protocol_file=path))
+    plain = check_against_restatement(zk.replay.run(2, 7, out_dir=str(tmp_path / "plain"), args=["--dump-inputs", "--proofs", "1"]))
+    na = 32 * 1
+    assert stated["vk"] == plain["vk"] and stated["proof"][:na] == plain["proof"][:na] and stated["proof"][na:] != plain["proof"][na:]
+
+
+@pytest.mark.gpu
 def test_gpu_proof_of_a_broken_witness_is_rejected(tmp_path):
     """one advice cell off by one: the device still emits 1 312 well-formed bytes, and the verifier refuses them (the quotient is no polynomial)"""
     rec = zk.replay.run(4, 8, out_dir=str(tmp_path), args=["--corrupt-witness", "--proofs", "1"])
@@ -449,6 +498,36 @@ def test_gpu_full_size_many_column_layers_verify(tmp_path, layer):
     """layer 3 (k = 21, 93 advice columns, 32 grand products) and the layer-0 stand-in (k = 20, 800 advice columns, degree 9) at full size"""
     rec = zk.replay.run(layer, out_dir=str(tmp_path), timeout=1500)
     verify_record(rec, layer)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layer", [1, 5, 6])
+def test_gpu_full_size_remaining_layers_verify(tmp_path, layer):
+    """the layers round 5 verified at full size only inside bench.py: layer 1 (k = 24, halo2-base rule on layer1.config), layer 5 (k = 21) and
+    layer 6 -- k = 26, the Keccak transcript and the EVM proof layout of the bundle proof [REF integration/src/prove.rs:95-103]: 11 uncompressed points + 17 words = 1 248 bytes,
+    the 39 words that follow the accumulator in [REF release-v0.13.1/proof.data] -- proven on the device, verified from the bytes"""
+    rec = zk.replay.run(layer, out_dir=str(tmp_path), timeout=1500)
+    pr = verify_record(rec, layer)
+    assert pr.k == {1: 24, 5: 21, 6: 26}[layer] and rec["transcript"] == ("evm" if layer == 6 else "poseidon")
+    if layer == 6:
+        assert (rec["msm"], rec["intt"], rec["evals"], rec["proof_bytes"], rec["rotation_sets"]) == (11, 5, 17, 1248, 3)
+
+
+@pytest.mark.gpu
+def test_gpu_prover_invisible_choices(tmp_path):
+    """What the verifier cannot pin: the prover's own randomness.  The SAME witness proven with another blinding stream gives other proof bytes that verify
+    just as well, and with the blinding rows and the z / phi blinding values left ZERO the proof still verifies -- so `verify() accepts` says nothing about how blinding is
+    drawn or placed (only that the rows it occupies are the protocol's unusable rows); each variant still equals the CPU restatement byte for byte on the same inputs."""
+    base = check_against_restatement(zk.replay.run(4, 9, out_dir=str(tmp_path / "a"), args=["--dump-inputs", "--proofs", "1"]))
+    other = check_against_restatement(zk.replay.run(4, 9, out_dir=str(tmp_path / "b"), args=["--dump-inputs", "--proofs", "1", "--blind-seed", "77"]))
+    zero = check_against_restatement(zk.replay.run(4, 9, out_dir=str(tmp_path / "c"), args=["--dump-inputs", "--proofs", "1", "--zero-blinding"]))
+    assert base["vk"] == other["vk"] == zero["vk"] and base["instances"] == other["instances"] == zero["instances"]      # same circuit, same public inputs
+    assert len({base["proof"], other["proof"], zero["proof"]}) == 3                                                      # three different proofs of it
+    ia, _ = plonk.ProofInputs.load(str(tmp_path / "a")); ib, _ = plonk.ProofInputs.load(str(tmp_path / "b")); ic, _ = plonk.ProofInputs.load(str(tmp_path / "c"))
+    u = ia.pr.usable
+    for x, y in zip(ia.advice, ib.advice):
+        assert x[: u - 8] == y[: u - 8]                                                                                  # the witness proper is the same (cells next to the wrap-around may follow the blinding rows)
+    assert all(v == 0 for col in ic.advice for v in col[u + 1:]) and all(v == 0 for zb in ic.z_blind for v in zb)
 
 
 @pytest.mark.gpu
