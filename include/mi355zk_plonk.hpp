@@ -404,6 +404,9 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   const uint32_t k = P.k, Q = P.Q; const uint64_t n = P.n, u = P.usable;
   const uint32_t A = P.num_advice(), NL = (uint32_t)P.lookups.size(), NZ = (uint32_t)P.perm.size();
   ProofResult R;
+  // resident coset parts were placed by keygen at q % pk.devices: the gate kernel on device d must find part q on d, so the proof runs on the key's device count
+  // (a differing opt.devices would read a coset that sits on another device)
+  if (pk.resident_cosets && pk.devices != std::max(1, opt.devices)) throw std::invalid_argument("create_proof: ProofOptions::devices (" + std::to_string(opt.devices) + ") differs from the proving key's (" + std::to_string(pk.devices) + ") while its coset parts are resident");
   const int D = std::max(1, std::min<int>(opt.devices, (int)Q));
   auto ms_since = [](Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); };
   const auto t_start = Clock::now(); auto tl = t_start;

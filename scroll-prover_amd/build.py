@@ -96,3 +96,32 @@ def build(force: bool = False, verbose: bool = False, lib: str = LIB, extra_flag
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+
+
+CPP_PROGRAMS = ("test_halo2_mirror", "test_shim_replay", "test_plonk_replay", "test_prover_process")
+
+
+def build_cpp(name: str) -> str:
+    """g++-compiled callers of the C-ABI under tests/cpp/ (the C++ mirror of the halo2_proofs interface, the replay of rust_shim's behaviour, and create_proof for a
+    PlonkProtocol over resident buffers -- the last one is also what bench.py times as `proof_mix`).  Rebuilt when the source, the public headers or the library changed
+    (content hash).  The programs link the oracle's C restatement for their own host-side CHECKS (never in a timed region): a tree without it cannot build them."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "cpp", name + ".cpp")
+    exe = os.path.join(root, "tests", "cpp", name)
+    orc = os.path.join(root, "oracle")
+    h = hashlib.sha256()
+    inc = os.path.join(root, "include")
+    for f in [src, os.path.join(HERE, "csrc", "fp.hpp"), os.path.join(HERE, "csrc", "slab_ranges.hpp"), os.path.join(orc, "bn254_oracle.c")] + sorted(os.path.join(inc, x) for x in os.listdir(inc)):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    tag = exe + ".srchash"
+    try:
+        fresh = os.path.exists(exe) and open(tag).read().strip() == h.hexdigest()
+    except OSError:
+        fresh = False
+    if not fresh:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wno-unknown-pragmas", "-I", inc, src, "-o", exe,
+                               "-L", HERE, "-lmi355zk", "-L", orc, "-loracle_bn254", f"-Wl,-rpath,{HERE}", f"-Wl,-rpath,{orc}", "-Wl,-rpath,/opt/rocm/lib"])
+        with open(tag, "w") as fh:
+            fh.write(h.hexdigest())
+    return exe

@@ -238,6 +238,8 @@ int mi355_buf_upload_packed(void *dst_dev, const void *src_host, uint64_t n, uin
   if (n == 0) return MI355_OK;
   if (!dst_dev || !src_host) return fail(MI355_EBADARG, "buf_upload_packed: null pointer");
   if (width_bytes != 1 && width_bytes != 2 && width_bytes != 4 && width_bytes != 8) return fail(MI355_EBADARG, "buf_upload_packed: width must be 1, 2, 4 or 8 bytes");
+  if (n > (1ull << 32)) return fail(MI355_EBADARG, "buf_upload_packed: more than 2^32 cells");   // also keeps n * width_bytes and n * 32 far from overflow
+  CHK(buf_check_range(dst_dev, n * sizeof(fe_t), "buf_upload_packed"));
   const int slot = slot_of(dst_dev);
   void *stage = nullptr; CHK(mi355_buf_alloc(n * width_bytes, slot, &stage));
   int rc = mi355_buf_upload(stage, src_host, n * width_bytes);
@@ -261,6 +263,7 @@ int mi355_buf_upload_sparse(void *dst_dev, uint64_t n, const uint32_t *idx_host,
   if (n == 0) return MI355_OK;
   if (!dst_dev || (count && (!idx_host || !vals_host))) return fail(MI355_EBADARG, "buf_upload_sparse: null pointer");
   if (count > n || n > (1ull << 32)) return fail(MI355_EBADARG, "buf_upload_sparse: more pairs than cells, or more than 2^32 cells");
+  CHK(buf_check_range(dst_dev, n * sizeof(fe_t), "buf_upload_sparse"));
   const int slot = slot_of(dst_dev);
   CHK(need_init(slot));
   hipStream_t s = g_ctx[slot].stream;

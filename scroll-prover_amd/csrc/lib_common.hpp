@@ -252,6 +252,7 @@ int srs_gather_to_primary(const Srs &sr, uint64_t n, const g1_affine_t **out);
 // looked up in the registry; anything else (a torch tensor, an SRS pointer) is asked of the HIP runtime when several devices are bound.
 // `touch` marks a registered block as used by queued work (an upload into it must then wait for the compute stream).
 int slot_of(const void *dev_ptr, bool touch = true);
+int buf_check_range(const void *dev_ptr, uint64_t bytes, const char *who);   // MI355_EBADARG when [dev_ptr, dev_ptr + bytes) leaves the library block that holds dev_ptr
 // the slot that owns ALL of the given device pointers (null pointers ignored); MI355_EBADARG when they live on different devices
 int common_slot(std::initializer_list<const void *> ptrs, int *slot_out, const char *who);
 // round-robin choice of a device for a host-pointer call (replicas: any bound device can run it); prefers a device whose lock is free

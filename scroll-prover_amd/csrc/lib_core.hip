@@ -178,6 +178,16 @@ static BufBlock *buf_find_locked(const void *p) {
   if ((uintptr_t)p < it->first + it->second.bytes) return &it->second;
   return nullptr;
 }
+// a write of `bytes` starting at dev_ptr must stay inside the library block that holds dev_ptr (blocks are carved next to each other inside slabs: an overrun lands
+// in a neighbouring LIVE polynomial, not in a fault).  Pointers the library did not hand out (torch tensors, caller allocations) cannot be checked and pass.
+int buf_check_range(const void *dev_ptr, uint64_t bytes, const char *who) {
+  std::lock_guard<std::mutex> lk(g_buf_mu);
+  if (BufBlock *b = buf_find_locked(dev_ptr)) {
+    const uint64_t off = (uint64_t)((uintptr_t)dev_ptr - (uintptr_t)b->p);
+    if (bytes > b->bytes - off) return fail(MI355_EBADARG, std::string(who) + ": range exceeds the block");
+  }
+  return MI355_OK;
+}
 int slot_of(const void *dev_ptr, bool touch) {
   if (!dev_ptr) return 0;
   {

@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def exe_path() -> str:
-    import __graft_entry__ as ge
-    return ge.build_cpp("test_plonk_replay")
+    from . import build
+    return build.build_cpp("test_plonk_replay")
 
 
 def write_protocol(layer: int, directory: str, k: int | None = None, protocol_file: str | None = None, **shape) -> str:
@@ -58,7 +58,7 @@ def run(layer: int, k: int | None = None, out_dir: str | None = None, args=(), e
 def run_process(layers, ks=None, out_dir: str | None = None, args=(), env=None, timeout: int = 2400, shapes=None) -> dict:
     """tests/cpp/test_prover_process.cpp: ONE process holding the SRS, proving keys and witnesses of several layers (a chunk prover {0, 1, 2}, a batch prover {3, 4}), under the HBM
     plan of plan_residency, proofs back to back.  Returns the program's record with, per layer, the bytes it wrote."""
-    import __graft_entry__ as ge
+    from . import build
     out_dir = out_dir or tempfile.mkdtemp(prefix="mi355_prover_process_")
     os.makedirs(out_dir, exist_ok=True)
     protos = []
@@ -66,7 +66,7 @@ def run_process(layers, ks=None, out_dir: str | None = None, args=(), env=None, 
         fx = os.path.join(ROOT, "tests", "golden", f"protocol_layer{layer}.json")
         k = (ks or {}).get(layer)
         protos.append(fx if (os.path.exists(fx) and not k) else write_protocol(layer, out_dir, k, None, **((shapes or {}).get(layer) or {})))
-    cmd = [ge.build_cpp("test_prover_process"), "--out", out_dir] + [x for p in protos for x in ("--protocol", p)] + list(args)
+    cmd = [build.build_cpp("test_prover_process"), "--out", out_dir] + [x for p in protos for x in ("--protocol", p)] + list(args)
     e = dict(os.environ); e.update(env or {})
     t0 = time.perf_counter()
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e)
