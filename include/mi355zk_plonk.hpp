@@ -195,12 +195,19 @@ struct Compiler {
 
 // what the fused kernel was asked to do, summed over every launch of this process: the ALGORITHMIC side of its roofline (profiles/r05_gate_eval.md compares it with
 // the FETCH_SIZE / WRITE_SIZE and SQ counters of the same run).  bytes = 32 B x rows x (distinct operand polynomials + dst written + dst read when accumulating)
-struct GateStats { std::atomic<uint64_t> launches{0}, bytes{0}, factor_rows{0}, term_rows{0}; };
+// distinct_rows: (polynomial, rotation) pairs a launch names, times its rows -- what a launch would load if every operand were re-sliced ONCE and kept in registers across its
+// terms; hot_repeat_rows: the loads beyond the first of operands that appear in >= 4 terms of one launch (selectors, l_active, a prefix polynomial): what a register cache of a
+// few hot operands could save (measure the operand cache instead of arguing it away -- profiles/r06_gate_operand_reuse.md)
+struct GateStats { std::atomic<uint64_t> launches{0}, bytes{0}, factor_rows{0}, term_rows{0}, distinct_rows{0}, hot_repeat_rows{0}; };
 inline GateStats &gate_stats() { static GateStats g; return g; }
 inline void gate_eval(void *dst, const void *const *polys, uint32_t n_polys, const Fr *coeffs, const uint32_t *term_len, uint32_t n_terms, const uint32_t *factor_poly, const int32_t *factor_rot, uint64_t n, int accumulate) {
   check(mi355_fr_gate_eval_dev(dst, polys, n_polys, coeffs, term_len, n_terms, factor_poly, factor_rot, n, accumulate));
   uint64_t nf = 0; for (uint32_t j = 0; j < n_terms; j++) nf += term_len[j];
   GateStats &g = gate_stats(); g.launches++; g.bytes += 32 * n * (uint64_t)(n_polys + 1 + (accumulate ? 1 : 0)); g.factor_rows += nf * n; g.term_rows += (uint64_t)n_terms * n;
+  { std::map<std::pair<uint32_t, int32_t>, uint32_t> uses; uint32_t f = 0;
+    for (uint32_t j = 0; j < n_terms; j++) { std::set<std::pair<uint32_t, int32_t>> in_term; for (uint32_t q = 0; q < term_len[j]; q++, f++) if (in_term.insert({factor_poly[f], factor_rot[f]}).second) uses[{factor_poly[f], factor_rot[f]}]++; }
+    uint64_t hot = 0; for (const auto &kv : uses) if (kv.second >= 4) hot += kv.second - 1;
+    g.distinct_rows += (uint64_t)uses.size() * n; g.hot_repeat_rows += hot * n; }
 }
 // one Launch through mi355_fr_gate_eval_dev; resolve(Atom) -> device pointer of the operand on the domain the launch runs on
 template <class Resolve> inline void run_launch(const Launch &L, void *dst, uint64_t n, const Fr &scale, bool accumulate, Resolve resolve) {
@@ -555,7 +562,9 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
       poly.at(lk.phi) = std::move(phi);
     }
     std::vector<uint32_t> made; for (uint32_t c = 0; c < NZ; c++) made.push_back(P.perm[c].z); for (uint32_t l = 0; l < NL; l++) made.push_back(P.lookups[l].phi);
-    if (made.size() < 8) for (uint32_t r : made) commit_one(h_g_lagrange, poly.at(r).p); else commit_many(h_g_lagrange, made);
+    // small domains: one pass whatever the count (round 6: one reduction tail per batch); big ones keep one commitment per pass -- a batch of two at 2^24 doubles the sorter's
+    // workspace (8.8 GB) for no gain, and a multi-layer prover process has no HBM to spare
+    if (made.size() >= 8 || n <= (uint64_t(1) << 22)) commit_many(h_g_lagrange, made); else for (uint32_t r : made) commit_one(h_g_lagrange, poly.at(r).p);
     inst_lagrange.release();
   }
   lap(4);
@@ -633,7 +642,13 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
     check(mi355_extended_to_coeff_dev(h.p, dom.extended_k, dom.g_coset.data(), dom.g_coset_inv.data(), dom.extended_omega_inv.data(), dom.extended_ifft_divisor.data()));
   }
   lap(7);
-  for (uint32_t q = 0; q < Q; q++) commit_one(h_g, h.at((uint64_t)q * n));              // step 8
+  if (n > (uint64_t(1) << 22)) { for (uint32_t q = 0; q < Q; q++) commit_one(h_g, h.at((uint64_t)q * n)); }   // step 8, big domains: one commitment per pass (see step 4)
+  else {                                                                                // step 8: the Q pieces of h, one batched pass (at k = 20 / 21 one reduction tail instead of Q)
+    std::vector<const void *> ptrs(Q); std::vector<G1> outs(Q);
+    for (uint32_t q = 0; q < Q; q++) ptrs[q] = h.at((uint64_t)q * n);
+    check(mi355_msm_g1_batch_dev(h_g, 0, ptrs.data(), Q, n, outs.data())); R.msm += Q;
+    for (uint32_t q = 0; q < Q; q++) T.write_point(outs[q]);
+  }
   const Fr x = T.squeeze_challenge();
   lap(8);
   auto coeff_ptr = [&](uint32_t p) -> const void * { return P.is_pre(p) ? pk.pre_coeff.at(p).p : poly.at(p).p; };

@@ -233,6 +233,12 @@ int mi355_g2_mul_host(const void *p_affine_host, const void *scalar, void *out_a
 // ---- narrow uploads: a witness column as W-byte integers or as (index, value) pairs of its non-zero cells instead of n 32-byte words.  The narrow data crosses PCIe through
 // mi355_buf_upload (copy stream, no device lock) into a pooled staging block; the expansion kernel is queued on the owner's compute stream WITHOUT the device lock (it touches
 // no context state; HIP streams accept work from several threads) and the call returns without waiting for it: calls issued afterwards on that device are ordered behind it.
+// staging blocks come in size classes (powers of two up to 1 MiB, then whole MiB): column after column of slightly different size -- the pairs of a sparse column -- then hits
+// the exact-size pool instead of missing it and recycling the pool (which synchronises the copy stream and the free events on the uploader thread)
+static uint64_t stage_class(uint64_t bytes) {
+  if (bytes <= (1ull << 20)) { uint64_t c = 4096; while (c < bytes) c <<= 1; return c; }
+  return (bytes + (1ull << 20) - 1) & ~((1ull << 20) - 1);
+}
 int mi355_buf_upload_packed(void *dst_dev, const void *src_host, uint64_t n, uint32_t width_bytes) {
   return guarded([&]() -> int {
   if (n == 0) return MI355_OK;
@@ -241,7 +247,7 @@ int mi355_buf_upload_packed(void *dst_dev, const void *src_host, uint64_t n, uin
   if (n > (1ull << 32)) return fail(MI355_EBADARG, "buf_upload_packed: more than 2^32 cells");   // also keeps n * width_bytes and n * 32 far from overflow
   CHK(buf_check_range(dst_dev, n * sizeof(fe_t), "buf_upload_packed"));
   const int slot = slot_of(dst_dev);
-  void *stage = nullptr; CHK(mi355_buf_alloc(n * width_bytes, slot, &stage));
+  void *stage = nullptr; CHK(mi355_buf_alloc(stage_class(n * width_bytes), slot, &stage));
   int rc = mi355_buf_upload(stage, src_host, n * width_bytes);
   if (rc == MI355_OK) rc = need_init(slot);
   if (rc == MI355_OK) {
@@ -269,7 +275,7 @@ int mi355_buf_upload_sparse(void *dst_dev, uint64_t n, const uint32_t *idx_host,
   hipStream_t s = g_ctx[slot].stream;
   if (count == 0) { HIPCHK(hipMemsetAsync(dst_dev, 0, n * sizeof(fe_t), s)); return MI355_OK; }
   const uint64_t idx_bytes = (count * 4 + 31) & ~31ull;
-  void *stage = nullptr; CHK(mi355_buf_alloc(idx_bytes + count * sizeof(fe_t), slot, &stage));
+  void *stage = nullptr; CHK(mi355_buf_alloc(stage_class(idx_bytes + count * sizeof(fe_t)), slot, &stage));
   int rc = mi355_buf_upload(stage, idx_host, count * 4);
   if (rc == MI355_OK) rc = mi355_buf_upload((char *)stage + idx_bytes, vals_host, count * sizeof(fe_t));
   if (rc == MI355_OK) rc = need_init(slot);

@@ -639,7 +639,9 @@ int mi355_buf_alloc(uint64_t bytes, int device_slot, void **dev_ptr_out) {
       if (sbytes > want && dev_malloc(&base, sbytes, "buf_alloc (slab)") != MI355_OK) { base = nullptr; sbytes = want; }
       if (!base) CHK(dev_malloc(&base, sbytes, "buf_alloc"));
       std::lock_guard<std::mutex> bl(g_buf_mu);
-      g_arena[device_slot].add_slab((uintptr_t)base, sbytes);
+      // a slab made for this one (large) request is dedicated: small blocks are never carved out of it, so it is whole again as soon as its polynomial comes back (slab_ranges.hpp)
+      g_arena[device_slot].small_limit = slab_min_bytes() / 64;   // 16 MiB with the default 1 GiB slabs: staging blocks, pointer tables, short vectors
+      g_arena[device_slot].add_slab((uintptr_t)base, sbytes, want >= slab_min_bytes());
       p = (void *)g_arena[device_slot].carve(want);
       if (!p) return fail(MI355_EHIP, "buf_alloc: slab bookkeeping");   // another thread took the new range: cannot happen with best fit on a range >= want, kept as a guard
     }

@@ -5,6 +5,9 @@
 // Rules: a free range never spans two slabs (slabs are separate hipMalloc regions even when their addresses happen to touch); adjacent free ranges of one slab are always merged, so a
 // slab whose blocks have all come back is exactly one range [base, base + bytes) and can be returned to HIP; carve is best fit (the smallest range that holds the request) and takes
 // the front of the range, so blocks of one size pack from the slab's start and the tail stays one large range for the next layer's larger blocks.
+// Segregation by size (round 6): a slab made for ONE request larger than the shared slab size is `dedicated`; a request below `small_limit` is never carved out of a dedicated
+// slab (a 4 KiB staging block cut from the front of a freed n x 32-byte polynomial slab would keep that slab from ever being whole again: mi355_buf_trim and the out-of-memory
+// retry could not return it, and the next polynomial of that size would need a fresh hipMalloc next to it).  Small blocks live in shared slabs only.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -14,13 +17,14 @@
 namespace mi355zk {
 
 struct SlabRanges {
-  struct Slab { uintptr_t base; size_t bytes; };
+  struct Slab { uintptr_t base; size_t bytes; bool dedicated = false; };
+  size_t small_limit = 0;                    // requests below this never go into a dedicated slab (0: no segregation)
   std::vector<Slab> slabs;
   std::map<uintptr_t, size_t> free_ranges;   // start -> length, by address
 
   const Slab *slab_of(uintptr_t p) const { for (const auto &s : slabs) if (p >= s.base && p < s.base + s.bytes) return &s; return nullptr; }
   // a new slab, entirely free
-  void add_slab(uintptr_t base, size_t bytes) { slabs.push_back({base, bytes}); free_ranges[base] = bytes; }
+  void add_slab(uintptr_t base, size_t bytes, bool dedicated = false) { slabs.push_back({base, bytes, dedicated}); free_ranges[base] = bytes; }
   // [p, p + len) comes back; it must lie inside one slab and must not overlap a free range (the caller hands back exactly what carve returned)
   void insert(uintptr_t p, size_t len) {
     const Slab *s = slab_of(p);
@@ -32,7 +36,12 @@ struct SlabRanges {
   // best fit; 0 = no range holds `want`
   uintptr_t carve(size_t want) {
     auto best = free_ranges.end();
-    for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it) if (it->second >= want && (best == free_ranges.end() || it->second < best->second)) best = it;
+    const bool small = want < small_limit;
+    for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it) {
+      if (it->second < want || (best != free_ranges.end() && it->second >= best->second)) continue;
+      if (small) { const Slab *s = slab_of(it->first); if (s && s->dedicated) continue; }
+      best = it;
+    }
     if (best == free_ranges.end()) return 0;
     const uintptr_t p = best->first; const size_t len = best->second; free_ranges.erase(best);
     if (len > want) free_ranges[p + want] = len - want;

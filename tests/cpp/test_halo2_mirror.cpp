@@ -207,6 +207,26 @@ int main(int argc, char **argv) {
     EXPECT(B.carve(0x3000) == 0x200000); EXPECT(B.carve(0x1000) == 0x203000); EXPECT(B.carve(0x1000) == 0x100000);
     EXPECT(B.carve(0x20000) == 0 && B.free_bytes() == 0xF000);
     B.insert(0x203000, 0x1000); B.insert(0x200000, 0x3000); EXPECT(B.free_ranges.at(0x200000) == 0x4000);
+    // segregation by size: a small request never goes into a dedicated slab (one made for a single large block), even when that slab is entirely free and nothing else is
+    { mi355zk::SlabRanges S; S.small_limit = 0x1000; S.add_slab(0x100000, 0x40000, /*dedicated=*/true);
+      EXPECT(S.carve(0x100) == 0);                                                       // -> the caller opens a shared slab
+      S.add_slab(0x200000, 0x10000); EXPECT(S.carve(0x100) == 0x200000);
+      const uintptr_t big = S.carve(0x40000); EXPECT(big == 0x100000);                   // the large block takes the dedicated slab whole
+      S.insert(big, 0x40000); std::vector<uintptr_t> gone; EXPECT(S.take_whole_slabs(gone) == 0x40000 && gone.size() == 1 && gone[0] == 0x100000);   // and the slab goes back whole
+      EXPECT(S.carve(0x2000) == 0x200100);                                               // at or above the limit: best fit anywhere
+      // random traffic with the rule on: small blocks are always found in shared slabs
+      std::mt19937_64 r2(7); mi355zk::SlabRanges R; R.small_limit = 4096; uintptr_t nb = 1 << 24; std::map<uintptr_t, size_t> live2;
+      for (int step = 0; step < 4000; step++) {
+        if (live2.empty() || r2() % 100 < 55) {
+          const size_t want = (r2() % 3 == 0) ? (size_t)(1 << 18) * (1 + r2() % 3) : (size_t)256 * (1 + r2() % 8);
+          uintptr_t q = R.carve(want);
+          if (!q) { const size_t sb = std::max<size_t>(want, 1 << 17); R.add_slab(nb, sb, want >= (1u << 17)); nb += sb + 4096; q = R.carve(want); }
+          EXPECT(q != 0); if (!q) break;
+          if (want < 4096) { const auto *sl = R.slab_of(q); EXPECT(sl && !sl->dedicated); }
+          live2[q] = want;
+        } else { auto it = live2.begin(); std::advance(it, (long)(r2() % live2.size())); R.insert(it->first, it->second); live2.erase(it); }
+      }
+    }
     // two slabs whose addresses touch stay two ranges
     mi355zk::SlabRanges T; T.add_slab(0x1000, 0x1000); T.add_slab(0x2000, 0x1000);
     const uintptr_t t0 = T.carve(0x1000), t1 = T.carve(0x1000); T.insert(t0, 0x1000); T.insert(t1, 0x1000);

@@ -25,7 +25,7 @@ static void write_file(const std::string &path, const void *p, size_t bytes) { s
 int main(int argc, char **argv) {
   std::string protocol_path, out_dir, tables = "auto", pk_mode = "auto";
   int devices = 1, threads = (int)std::thread::hardware_concurrency(), proofs = 2, upload_threads = 1, early_intt = -1;
-  bool host_api = false, builder_only = false, dump_inputs = false, pinned_witness = false, corrupt = false, sparse_uploads = false, packed_m = true; uint64_t seed = 1, blind_seed = 0; bool zero_blinding = false; double fill = 0.9, assign_density = 1.0; TranscriptKind transcript = TranscriptKind::Blake2b; bool transcript_auto = true;
+  bool host_api = false, phase_profile = false, builder_only = false, dump_inputs = false, pinned_witness = false, corrupt = false, sparse_uploads = false, packed_m = true; uint64_t seed = 1, blind_seed = 0; bool zero_blinding = false; double fill = 0.9, assign_density = 1.0; TranscriptKind transcript = TranscriptKind::Blake2b; bool transcript_auto = true;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto next = [&]() -> long { return i + 1 < argc ? std::atol(argv[++i]) : 0; };
@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
     else if (a == "--threads") threads = (int)next(); else if (a == "--host-api") host_api = true; else if (a == "--builder-only") builder_only = true; else if (a == "--dump-inputs") dump_inputs = true;
     else if (a == "--no-tables") tables = "off"; else if (a == "--tables") tables = nexts(); else if (a == "--pk-cosets") pk_mode = nexts(); else if (a == "--proofs") proofs = (int)next();
     else if (a == "--upload-threads") upload_threads = (int)next(); else if (a == "--early-intt") early_intt = (int)next(); else if (a == "--pinned-witness") pinned_witness = true;
-    else if (a == "--seed") seed = (uint64_t)next(); else if (a == "--blind-seed") blind_seed = (uint64_t)next(); else if (a == "--zero-blinding") zero_blinding = true; else if (a == "--fill") fill = std::atof(nexts().c_str()); else if (a == "--corrupt-witness") corrupt = true;
+    else if (a == "--seed") seed = (uint64_t)next(); else if (a == "--blind-seed") blind_seed = (uint64_t)next(); else if (a == "--zero-blinding") zero_blinding = true; else if (a == "--phase-profile") phase_profile = true; else if (a == "--fill") fill = std::atof(nexts().c_str()); else if (a == "--corrupt-witness") corrupt = true;
     else if (a == "--sparse-uploads") sparse_uploads = true; else if (a == "--packed-multiplicities") packed_m = true; else if (a == "--no-packed-multiplicities") packed_m = false; else if (a == "--assign-density") assign_density = std::atof(nexts().c_str());
     else if (a == "--transcript") { const std::string tn = nexts(); if (tn == "auto") continue; transcript_auto = false; try { transcript = transcript_kind_from_name(tn); } catch (const std::exception &e) { std::printf("%s\n", e.what()); return 1; } }
     else if (a == "--transcript-selftest") {   // host only: a fixed byte stream through the Blake2b transcript (tests compare with hashlib)
@@ -61,7 +61,7 @@ int main(int argc, char **argv) {
       return 0;
     }
     else { std::printf("usage: %s --protocol FILE --out DIR [--builder-only] [--dump-inputs] [--devices D] [--threads T] [--proofs N] [--upload-threads U] [--early-intt 0|1] [--pinned-witness]\n"
-                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--no-packed-multiplicities] [--transcript auto|blake2b|poseidon|evm] [--assign-density D] [--blind-seed S] [--zero-blinding] | --transcript-selftest\n", argv[0]); return 1; }
+                       "          [--tables auto|on|lagrange|off] [--pk-cosets auto|resident|on-the-fly] [--host-api] [--seed S] [--fill F] [--corrupt-witness] [--sparse-uploads] [--no-packed-multiplicities] [--transcript auto|blake2b|poseidon|evm] [--assign-density D] [--blind-seed S] [--zero-blinding] [--phase-profile] | --transcript-selftest\n", argv[0]); return 1; }
   }
   if (protocol_path.empty() || out_dir.empty()) { std::printf("--protocol and --out are required\n"); return 1; }
   if (threads < 1) threads = 1; if (threads > 16) threads = 16;
@@ -134,6 +134,20 @@ int main(int argc, char **argv) {
     // ---- the proofs: a prover process runs proof after proof; the first one grows the workspace arena and the buffer pool, the last one is reported
     ProofResult R; double first_ms = 0;
     for (int it = 0; it < proofs; it++) { R = create_proof(hg, hl, *pk, *C, opt); if (it == 0) first_ms = R.total_ms; }
+    // --phase-profile: one MORE proof with the library's phase events on (a few microseconds per phase: kept out of the timed proofs), so that the commitment tail, the
+    // transform passes and the evaluations of ONE proof -- keygen excluded -- can be read next to its wall time (how much of a proof is the MSM reduction tail)
+    std::string phases = "null";
+    if (phase_profile) {
+      check(mi355_profile_reset()); check(mi355_profile_enable(1));
+      const ProofResult RP = create_proof(hg, hl, *pk, *C, opt);
+      check(mi355_synchronize()); check(mi355_profile_enable(0));
+      char buf[160]; phases = "{\"proof_ms\": "; std::snprintf(buf, sizeof buf, "%.2f", RP.total_ms); phases += buf;
+      for (const char *nm : {"msm_total", "msm_digits", "msm_sort", "msm_accumulate", "msm_reduce", "ntt_total", "ntt_pass", "eval_poly"}) {
+        double ms = 0; uint64_t cnt = 0; check(mi355_profile_get(nm, &ms, &cnt));
+        std::snprintf(buf, sizeof buf, ", \"%s\": {\"ms\": %.2f, \"launches\": %llu}", nm, ms, (unsigned long long)cnt); phases += buf;
+      }
+      phases += "}";
+    }
     uint64_t live = 0, pooled = 0, ws = 0, fr_end = 0; check(mi355_mem_info(0, &fr_end, nullptr, &live, &pooled, &ws));
     write_file(out_dir + "/proof.bin", R.proof.data(), R.proof.size());
     write_file(out_dir + "/vk.bin", pk->vk.data(), pk->vk.size());
@@ -161,28 +175,28 @@ int main(int argc, char **argv) {
       for (uint32_t done = 0; done < n_ntt; done += B) check(mi355_ntt_fr_batch_host(ptrs.data(), std::min(B, n_ntt - done), k, dom.omega.data(), nullptr));
       host_fft_batched_ms = ms_since(t3);
     }
-    char line[4096];
+    char line[6144];
     std::snprintf(line, sizeof line,
       "{\"replay\": \"mi355zk::plonk::create_proof (include/mi355zk_plonk.hpp): the layer's PlonkProtocol compiled and proven through the C-ABI, polynomials and proving key resident\", \"layer\": %d, \"k\": %u, \"devices\": %d, "
       "\"protocol\": {\"num_preprocessed\": %u, \"num_witness\": [%u, %u, %u], \"quotient_pieces\": %u, \"evaluations\": %zu, \"queries\": %zu, \"permutation_chunks\": %zu, \"lookups\": %zu, \"gates\": %zu, \"last_rotation\": %d}, "
       "\"circuit\": {\"copy_pairs\": %zu, \"gates_active\": %llu, \"lookup_rows\": %llu, \"build_ms\": %.1f, \"keygen_ms\": %.1f}, "
       "\"plan\": {\"constraints\": %u, \"launches_per_part\": %u, \"terms\": %u, \"temporaries\": %u, \"prefix_groups\": %u, \"common_polynomials\": %zu}, "
-      "\"gate_eval_process_totals\": {\"launches\": %llu, \"algorithmic_bytes\": %llu, \"factor_rows\": %llu, \"term_rows\": %llu}, "
+      "\"gate_eval_process_totals\": {\"launches\": %llu, \"algorithmic_bytes\": %llu, \"factor_rows\": %llu, \"term_rows\": %llu, \"distinct_operand_rows\": %llu, \"hot_repeat_rows\": %llu}, "
       "\"window_tables\": %s, \"window_table_bases\": %d, \"pk_cosets\": \"%s\", \"upload_threads\": %d, \"pinned_witness\": %s, \"sparse_uploads\": {\"on\": %s, \"columns\": %llu, \"packed_columns\": %llu, \"witness_link_gib\": %.2f, \"assign_density\": %.2f}, "
       "\"msm\": %u, \"intt\": %u, \"coset_ntt\": %u, \"gate_launches\": %u, \"evals\": %u, \"rotation_sets\": %u, \"proof_bytes\": %zu, \"resident_ms\": %.3f, \"first_proof_ms\": %.3f, \"proofs\": %d, "
       "\"host_api_ms\": %.3f, \"host_api_fft_ms\": %.3f, \"host_api_fft_batched_ms\": %.3f, "
       "\"step_ms\": {\"1_instance\": %.2f, \"2_3_advice_lookup_commits\": %.2f, \"4_products\": %.2f, \"5_random\": %.2f, \"6_to_coeff\": %.2f, \"7_quotient\": %.2f, \"8_commit_h\": %.2f, \"9_evals\": %.2f, \"10_shplonk\": %.2f}, "
       "\"hbm\": {\"total_gib\": %.1f, \"peak_used_gib\": %.1f, \"proving_key_gib\": %.1f, \"live_buffers_gib\": %.1f, \"pooled_gib\": %.1f, \"workspace_gib\": %.1f, \"planned\": {\"pk_base_gib\": %.1f, \"pk_cosets_gib\": %.1f, \"working_set_gib\": %.1f, \"one_table_gib\": %.1f, \"usable_gib\": %.1f}}, "
-      "\"transcript\": \"%s\", \"ok\": true}",
+      "\"transcript\": \"%s\", \"phase_profile\": %s, \"ok\": true}",
       P.layer, k, devices, P.num_pre, P.num_witness[0], P.num_witness[1], P.num_witness[2], Q, P.evaluations.size(), P.queries.size(), P.perm.size(), P.lookups.size(), P.gates.size(), P.last_rot,
       C->pairs.size(), (unsigned long long)C->gates_active, (unsigned long long)C->lookup_rows, build_ms, keygen_ms,
       R.plan_constraints, R.plan_launches, R.plan_terms, R.plan_tmps, R.plan_prefix_groups, pk->commons.defs.size(),
-      (unsigned long long)gate_stats().launches.load(), (unsigned long long)gate_stats().bytes.load(), (unsigned long long)gate_stats().factor_rows.load(), (unsigned long long)gate_stats().term_rows.load(),
+      (unsigned long long)gate_stats().launches.load(), (unsigned long long)gate_stats().bytes.load(), (unsigned long long)gate_stats().factor_rows.load(), (unsigned long long)gate_stats().term_rows.load(), (unsigned long long)gate_stats().distinct_rows.load(), (unsigned long long)gate_stats().hot_repeat_rows.load(),
       n_tables ? "true" : "false", n_tables, resident ? "resident" : "on-the-fly", upload_threads, pinned_witness ? "true" : "false", sparse_uploads ? "true" : "false", (unsigned long long)R.sparse_columns, (unsigned long long)R.packed_columns, R.witness_link_bytes / GiB, assign_density,
       R.msm, R.intt, R.coset_ntt, R.gate_launches, R.evals, R.rotation_sets, R.proof.size(), R.total_ms, first_ms, proofs,
       host_ms, host_fft_ms, host_fft_batched_ms,
       R.step_ms[1], R.step_ms[2], R.step_ms[4], R.step_ms[5], R.step_ms[6], R.step_ms[7], R.step_ms[8], R.step_ms[9], R.step_ms[10],
-      hbm_total / GiB, (hbm_total - fr_end) / GiB, pk->bytes / GiB, live / GiB, pooled / GiB, ws / GiB, sz.base_bytes / GiB, sz.coset_bytes / GiB, working / GiB, table_one / GiB, usable / GiB, transcript_name(transcript));
+      hbm_total / GiB, (hbm_total - fr_end) / GiB, pk->bytes / GiB, live / GiB, pooled / GiB, ws / GiB, sz.base_bytes / GiB, sz.coset_bytes / GiB, working / GiB, table_one / GiB, usable / GiB, transcript_name(transcript), phases.c_str());
     std::printf("%s\n", line);
     write_file(out_dir + "/result.json", line, std::strlen(line));
     pk.reset();

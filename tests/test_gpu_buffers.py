@@ -402,13 +402,14 @@ def test_narrow_uploads_equal_the_plain_upload(zk):
     assert lib.mi355_buf_upload_packed(C.c_void_p(big.data_ptr()), capi.ptr(col), n, 3) == capi.EBADARG
     assert lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr()), n, capi.ptr(idx), capi.ptr(vals), n + 1) == capi.EBADARG
     # a column longer than the block that receives it is refused (blocks are carved next to each other inside slabs, an overrun would land in a neighbouring live
-    # polynomial): n + 64 cells fit `big` exactly, one more does not, nor does a column that starts 64 cells in
-    packed = np.zeros(n + 65, np.uint8)
+    # polynomial).  Block sizes are rounded up to 256 bytes = 8 cells, so "too long" starts 8 cells past the n + 64 cells `big` was asked for
+    packed = np.zeros(n + 80, np.uint8)
     check(lib.mi355_buf_upload_packed(C.c_void_p(big.data_ptr()), capi.ptr(packed), n + 64, 1))
-    assert lib.mi355_buf_upload_packed(C.c_void_p(big.data_ptr()), capi.ptr(packed), n + 65, 1) == capi.EBADARG and b"exceeds the block" in lib.mi355_last_error()
-    assert lib.mi355_buf_upload_packed(C.c_void_p(big.data_ptr() + 32 * 64), capi.ptr(packed), n + 1, 1) == capi.EBADARG
-    assert lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr()), n + 65, capi.ptr(idx), capi.ptr(vals), idx.shape[0]) == capi.EBADARG and b"exceeds the block" in lib.mi355_last_error()
-    assert lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr() + 32 * 65), n, None, None, 0) == capi.EBADARG
+    assert lib.mi355_buf_upload_packed(C.c_void_p(big.data_ptr()), capi.ptr(packed), n + 72, 1) == capi.EBADARG and b"exceeds the block" in lib.mi355_last_error()
+    assert lib.mi355_buf_upload_packed(C.c_void_p(big.data_ptr() + 32 * 64), capi.ptr(packed), n + 8, 1) == capi.EBADARG
+    assert lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr()), n + 72, capi.ptr(idx), capi.ptr(vals), idx.shape[0]) == capi.EBADARG and b"exceeds the block" in lib.mi355_last_error()
+    assert lib.mi355_buf_upload_sparse(C.c_void_p(big.data_ptr() + 32 * 72), n, None, None, 0) == capi.EBADARG
+    assert (big.fr()[:n + 64] == 0).all()                                                # the refused calls wrote nothing; the accepted one zeroed the block
     b.free(); big.free()
 
 
