@@ -119,7 +119,8 @@ struct PoseidonSpec {
   }
 };
 // Host arithmetic of the sponge: 4 x 64-bit Montgomery words (the ABI form: R = 2^256, what halo2curves holds), one CIOS product = 32 64x64 multiplications.  The library's
-// 8 x 32 host code costs 280 us per permutation here; a layer-0 proof absorbs ~3 300 words = 830 permutations, a quarter of a second on the calling thread.  This form: ~45 us.
+// 8 x 32 host code costs 280 us per permutation here; a layer-0 proof absorbs ~3 300 words = 830 permutations, a quarter of a second on the calling thread.  This form: ~45 us
+// (round 6, MDS rows with one reduction each: see mac / redc).
 struct Fr64 {
   uint64_t l[4];
   static constexpr uint64_t M[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
@@ -146,6 +147,26 @@ struct Fr64 {
     if (t[4] || geq_m(r.l)) sub_m(r.l);
     return r;
   }
+  // t[0..8] += a * b (plain 512-bit product, no reduction) and the Montgomery reduction of a sum of up to FIVE such products (5 r^2 < r 2^256, so the result is below 2 r):
+  // a row of the MDS product costs five multiplications and ONE reduction instead of five (round 6: 0.62 of the 64-bit multiplications of the sponge's permutation)
+  static void mac(uint64_t *t, const Fr64 &a, const Fr64 &b) {
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 c = 0;
+      for (int j = 0; j < 4; j++) { c += (unsigned __int128)a.l[j] * b.l[i] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+      for (int k = i + 4; c && k < 9; k++) { c += t[k]; t[k] = (uint64_t)c; c >>= 64; }
+    }
+  }
+  static Fr64 redc(uint64_t *t) {
+    for (int i = 0; i < 4; i++) {
+      const uint64_t m = t[i] * INV;
+      unsigned __int128 c = 0;
+      for (int j = 0; j < 4; j++) { c += (unsigned __int128)m * M[j] + t[i + j]; t[i + j] = (uint64_t)c; c >>= 64; }
+      for (int k = i + 4; c && k < 9; k++) { c += t[k]; t[k] = (uint64_t)c; c >>= 64; }
+    }
+    Fr64 r{{t[4], t[5], t[6], t[7]}};
+    if (t[8] || geq_m(r.l)) sub_m(r.l);
+    return r;
+  }
   static Fr64 from(const halo2::Fr &a) { Fr64 r; std::memcpy(r.l, a.data(), 32); return r; }
   halo2::Fr fr() const { halo2::Fr r; std::memcpy(r.data(), l, 32); return r; }
 };
@@ -153,22 +174,89 @@ struct PoseidonSponge {
   static constexpr int T = PoseidonSpec::T, RATE = PoseidonSpec::RATE;
   Fr64 state[T]; std::vector<Fr64> buf;
   PoseidonSponge() { for (auto &w : state) w = Fr64{{0, 0, 0, 0}}; zk::fe_t c = zk::Fr::zero(); c.l[2] = 1; state[0] = Fr64::from(halo2::detail::from_fe(zk::Fr::from_canonical(c))); }   // [2^64, 0, 0, 0, 0]
-  void update(const halo2::Fr &w) { buf.push_back(Fr64::from(w)); }
+  // Eager absorption (round 6): a full RATE-word chunk is permuted as soon as it is complete instead of at the next squeeze -- the same chunks in the same order, so the same
+  // state -- which moves the hashing of a many-column layer's commitments (layer 0: 1 600 words before theta) from one serial block at the squeeze, with the device idle, into the
+  // gaps between the commitment batches while the witness still crosses PCIe
+  void update(const halo2::Fr &w) { buf.push_back(Fr64::from(w)); if (buf.size() == (size_t)RATE) { absorb_and_permute(buf.data(), RATE); buf.clear(); } }
   static Fr64 pow5(const Fr64 &a) { const Fr64 a2 = Fr64::mul(a, a); return Fr64::mul(Fr64::mul(a2, a2), a); }
-  struct Tables { std::vector<Fr64> rc; Fr64 mds[T][T]; };
+  static Fr64 sub(const Fr64 &a, const Fr64 &b) { Fr64 nb{{0, 0, 0, 0}}; bool z = !(b.l[0] | b.l[1] | b.l[2] | b.l[3]); if (!z) { unsigned __int128 br = 0; for (int i = 0; i < 4; i++) { const unsigned __int128 d = (unsigned __int128)Fr64::M[i] - b.l[i] - (uint64_t)br; nb.l[i] = (uint64_t)d; br = (d >> 64) & 1; } } return Fr64::add(a, nb); }
+  static Fr64 inv(const Fr64 &a) { return Fr64::from(halo2::detail::fr_inv(a.fr())); }
+  // Partial rounds with SPARSE matrices (round 6; the schedule of the Poseidon paper's appendix B, which the `poseidon` crate the reference links also runs): a dense matrix D
+  // splits as D = D' D'' with D' = [[1, 0], [0, D^]] and D'' = [[D00, D[0, 1:]], [w^, I]], w^ = D^^-1 D[1:, 0]; D' leaves element 0 alone, so it commutes with the partial
+  // round's S-box and is pushed through the next round's constants into the next round's matrix (M D', split again).  Round k then costs the S-box, ONE dot product and T - 1
+  // multiply-adds instead of T dot products; what is left of D' after the last partial round is applied once, densely.  The tables are checked against the plain schedule on a
+  // fixed state when they are built (and the transcript tests compare every squeeze with the Python restatement that verifies the reference's released proofs).
+  struct Tables { std::vector<Fr64> rc; Fr64 mds[T][T]; std::vector<Fr64> prc /* RP x T adjusted constants */, row0 /* RP x T */, what /* RP x (T - 1) */; Fr64 left[T][T]; };
+  static void plain_rounds(const Tables &S, Fr64 *st, int r0, int r1) {
+    for (int r = r0; r < r1; r++) {
+      for (int i = 0; i < T; i++) st[i] = Fr64::add(st[i], S.rc[(size_t)r * T + i]);
+      if (r < PoseidonSpec::RF / 2 || r >= PoseidonSpec::RF / 2 + PoseidonSpec::RP) { for (int i = 0; i < T; i++) st[i] = pow5(st[i]); } else st[0] = pow5(st[0]);
+      Fr64 nx[T];
+      for (int i = 0; i < T; i++) { uint64_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; for (int j = 0; j < T; j++) Fr64::mac(t, S.mds[i][j], st[j]); nx[i] = Fr64::redc(t); }   // canonical operands: five products, one reduction
+      for (int i = 0; i < T; i++) st[i] = nx[i];
+    }
+  }
+  static void sparse_rounds(const Tables &S, Fr64 *st) {
+    constexpr int RP = PoseidonSpec::RP;
+    for (int k = 0; k < RP; k++) {
+      for (int i = 0; i < T; i++) st[i] = Fr64::add(st[i], S.prc[(size_t)k * T + i]);
+      st[0] = pow5(st[0]);
+      uint64_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; for (int j = 0; j < T; j++) Fr64::mac(t, S.row0[(size_t)k * T + j], st[j]);
+      const Fr64 s0 = st[0];
+      for (int i = 1; i < T; i++) st[i] = Fr64::add(st[i], Fr64::mul(S.what[(size_t)k * (T - 1) + (i - 1)], s0));
+      st[0] = Fr64::redc(t);
+    }
+    Fr64 nx[T];
+    for (int i = 0; i < T; i++) { uint64_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; for (int j = 0; j < T; j++) Fr64::mac(t, S.left[i][j], st[j]); nx[i] = Fr64::redc(t); }
+    for (int i = 0; i < T; i++) st[i] = nx[i];
+  }
   static const Tables &tables() {
-    static const Tables t = [] { Tables x; const PoseidonSpec &S = PoseidonSpec::get(); for (const auto &c : S.rc) x.rc.push_back(Fr64::from(c)); for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) x.mds[i][j] = Fr64::from(S.mds[i][j]); return x; }();
+    static const Tables t = [] {
+      Tables x; const PoseidonSpec &S = PoseidonSpec::get();
+      for (const auto &c : S.rc) x.rc.push_back(Fr64::from(c));
+      for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) x.mds[i][j] = Fr64::from(S.mds[i][j]);
+      constexpr int RP = PoseidonSpec::RP, R0 = PoseidonSpec::RF / 2, N = T - 1;
+      const Fr64 zero{{0, 0, 0, 0}}, one = Fr64::from(halo2::detail::from_fe(zk::Fr::one()));
+      Fr64 D[T][T]; for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) D[i][j] = x.mds[i][j];
+      Fr64 hinv[N][N];                                           // D^^-1 of the PREVIOUS round's split: applied to this round's constants
+      x.prc.assign((size_t)RP * T, zero); x.row0.assign((size_t)RP * T, zero); x.what.assign((size_t)RP * N, zero);
+      for (int k = 0; k < RP; k++) {
+        // this round's constants: c_0 as they are; later ones with D'^-1 of the previous split pushed through: [c_0, D^^-1 c_1..]
+        for (int i = 0; i < T; i++) x.prc[(size_t)k * T + i] = x.rc[(size_t)(R0 + k) * T + i];
+        if (k > 0) for (int i = 0; i < N; i++) { Fr64 acc = zero; for (int j = 0; j < N; j++) acc = Fr64::add(acc, Fr64::mul(hinv[i][j], x.rc[(size_t)(R0 + k) * T + 1 + j])); x.prc[(size_t)k * T + 1 + i] = acc; }
+        // invert D^ = D[1:, 1:] (Gauss-Jordan over the field; N = 4)
+        Fr64 A[N][2 * N];
+        for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) { A[i][j] = D[1 + i][1 + j]; A[i][N + j] = i == j ? one : zero; }
+        for (int c = 0; c < N; c++) {
+          int piv = c; while (piv < N && !(A[piv][c].l[0] | A[piv][c].l[1] | A[piv][c].l[2] | A[piv][c].l[3])) piv++;
+          if (piv == N) throw std::runtime_error("poseidon: singular sub-matrix in the sparse schedule");
+          if (piv != c) for (int j = 0; j < 2 * N; j++) std::swap(A[piv][j], A[c][j]);
+          const Fr64 iv = inv(A[c][c]);
+          for (int j = 0; j < 2 * N; j++) A[c][j] = Fr64::mul(A[c][j], iv);
+          for (int i = 0; i < N; i++) if (i != c) { const Fr64 f = A[i][c]; for (int j = 0; j < 2 * N; j++) A[i][j] = sub(A[i][j], Fr64::mul(f, A[c][j])); }
+        }
+        for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) hinv[i][j] = A[i][N + j];
+        for (int j = 0; j < T; j++) x.row0[(size_t)k * T + j] = D[0][j];
+        for (int i = 0; i < N; i++) { Fr64 acc = zero; for (int j = 0; j < N; j++) acc = Fr64::add(acc, Fr64::mul(hinv[i][j], D[1 + j][0])); x.what[(size_t)k * N + i] = acc; }
+        // D' = [[1, 0], [0, D^]]: the next round's dense matrix is M D'; after the last round D' itself is what is left
+        Fr64 Dp[T][T]; for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) Dp[i][j] = (i == 0 || j == 0) ? (i == j ? one : zero) : D[i][j];
+        if (k + 1 < RP) { for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) { Fr64 acc = zero; for (int q = 0; q < T; q++) acc = Fr64::add(acc, Fr64::mul(x.mds[i][q], Dp[q][j])); D[i][j] = acc; } }
+        else for (int i = 0; i < T; i++) for (int j = 0; j < T; j++) x.left[i][j] = Dp[i][j];
+      }
+      // self-check against the plain schedule on a fixed state
+      Fr64 a[T], b[T]; for (int i = 0; i < T; i++) a[i] = b[i] = x.rc[(size_t)(7 * i + 3) % x.rc.size()];
+      plain_rounds(x, a, R0, R0 + RP); sparse_rounds(x, b);
+      for (int i = 0; i < T; i++) if (std::memcmp(a[i].l, b[i].l, 32) != 0) throw std::runtime_error("poseidon: the sparse partial-round schedule disagrees with the plain one");
+      return x;
+    }();
     return t;
   }
   void permute() {
     const Tables &S = tables();
-    for (int r = 0; r < PoseidonSpec::RF + PoseidonSpec::RP; r++) {
-      for (int i = 0; i < T; i++) state[i] = Fr64::add(state[i], S.rc[(size_t)r * T + i]);
-      if (r < PoseidonSpec::RF / 2 || r >= PoseidonSpec::RF / 2 + PoseidonSpec::RP) { for (auto &w : state) w = pow5(w); } else state[0] = pow5(state[0]);
-      Fr64 nx[T];
-      for (int i = 0; i < T; i++) { Fr64 acc = Fr64::mul(S.mds[i][0], state[0]); for (int j = 1; j < T; j++) acc = Fr64::add(acc, Fr64::mul(S.mds[i][j], state[j])); nx[i] = acc; }
-      for (int i = 0; i < T; i++) state[i] = nx[i];
-    }
+    constexpr int R0 = PoseidonSpec::RF / 2, RP = PoseidonSpec::RP;
+    plain_rounds(S, state, 0, R0);
+    sparse_rounds(S, state);
+    plain_rounds(S, state, R0 + RP, PoseidonSpec::RF + RP);
   }
   void absorb_and_permute(const Fr64 *chunk, size_t len) {
     for (size_t i = 0; i < len; i++) state[1 + i] = Fr64::add(state[1 + i], chunk[i]);
@@ -176,9 +264,9 @@ struct PoseidonSponge {
     permute();
   }
   halo2::Fr squeeze() {
+    // what is left is the partial last chunk (padded), or nothing -- then the words since the last squeeze were a multiple of RATE (possibly zero) and the sponge takes the empty chunk
     std::vector<Fr64> b; b.swap(buf);
-    for (size_t i = 0; i < b.size(); i += RATE) absorb_and_permute(b.data() + i, std::min<size_t>(RATE, b.size() - i));
-    if (b.size() % RATE == 0) absorb_and_permute(nullptr, 0);
+    absorb_and_permute(b.data(), b.size());
     return state[1].fr();
   }
 };

@@ -154,8 +154,33 @@ static int fold_divisor(NttPlan *p, uint32_t log_n, const fe_t *pre3_host, const
   return MI355_OK;
 }
 
+// The coset shift a[i] *= f^i of coeff_to_extended_part folded into the FIRST strided pass (round 6): i = m 2^log_t + column there, so f^i = (f^(2^log_t))^m --
+// a table of 2^log_m entries applied on load -- times f^column, which rides on the pass's inter-level twiddles (one [k][column] table per coset factor, the layout big levels
+// already read).  One multiplication per element inside an ALU-bound pass instead of a pass of its own (2 multiplications + 64 B of HBM traffic per element).  Returns nullptr
+// where the fold does not apply (single-pass plans, sizes above MI355_NTT_COSET_FOLD_MAX_LOG, the A/B kernels, no memory for the table, more than 16 factors on one plan): the
+// caller then runs k_distribute_powers first, as before.  Same bits either way (exact field arithmetic, canonical output).
+static const NttPlan::CosetTw *coset_fold_tables(NttPlan *p, uint32_t log_n, const void *omega, const void *factor) {
+  if (!g.ntt29 || g.ntt_raw_scratch || p->levels < 2 || log_n > g.ntt_coset_fold_max_log) return nullptr;
+  const std::string key((const char *)factor, 32);
+  auto it = p->coset.find(key);
+  if (it != p->coset.end()) return &it->second;
+  if (p->coset.size() >= 16) return nullptr;
+  const uint32_t lm = p->log_m[0], log_t = log_n - lm; const uint64_t cnt = 1ull << log_n;
+  fe_t f, w; memcpy(&f, factor, 32); memcpy(&w, omega, 32);
+  NttPlan::CosetTw T;
+  uint4 *lo, *hi; uint32_t *top;
+  if (!alloc_tw29(cnt, &lo, &hi, &top)) return nullptr;
+  p->owned.push_back(lo); p->owned.push_back(hi); p->owned.push_back(top);
+  hipLaunchKernelGGL(k_pow_table29_2d, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, g.stream, lo, hi, top, w, log_t, cnt, f, 1);   // level 0: w_S = omega (S = N)
+  if (hipGetLastError() != hipSuccess) return nullptr;
+  T.s2d.lo = lo; T.s2d.hi = hi; T.s2d.top = top;
+  if (pow_table29(*p, &T.in, Fr::pow_u64(f, 1ull << log_t), 1, 1u << lm) != MI355_OK) return nullptr;
+  return &p->coset.emplace(key, T).first->second;
+}
+
 // dst[2^log_n] = NTT_omega( pre3-scaled, zero-padded src[src_len] ), then optional post3 scaling.  src may equal dst.
-int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, const void *omega, const fe_t *pre3_host, const fe_t *post3_host) {
+// coset: the tables of coset_fold_tables -- the transform is then of src[i] f^i (first pass; multi-pass plans only)
+int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, const void *omega, const fe_t *pre3_host, const fe_t *post3_host, const NttPlan::CosetTw *coset = nullptr) {
   if (log_n > 28) return fail(MI355_EBADARG, "ntt: log_n > 28 (BN254 Fr two-adicity)");
   const uint64_t N = 1ull << log_n;
   hipStream_t s = g.stream;
@@ -174,6 +199,7 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
   NttPlan *p; CHK(get_plan(log_n, omega, &p));
   const Tw29 *fold_tw = nullptr;
   CHK(fold_divisor(p, log_n, pre3_host, post3_host, &fold_tw, &post3));
+  if (coset && (p->levels < 2 || !g.ntt29 || fold_tw || pre3)) return fail(MI355_EBADARG, "ntt: a folded coset shift needs a multi-pass plan of the 29-bit kernels and no other scaling");
   CallTrace tr("ntt_fr", N, 64.0);
   Scope total("ntt_total");
   if (p->levels == 1) {
@@ -200,6 +226,7 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
       if (g.ntt29) {
         Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l]; L9.direct = p->direct2[l] ? 2u : (p->split[l] == log_s) ? 1u : 0u;
         if (fold_tw && l + 2 == p->levels) L9.tw_s_lo = *fold_tw;
+        if (coset && l == 0) { L9.tw_in = coset->in; L9.has_in = 1; L9.tw_s_lo = coset->s2d; L9.tw_s_hi = coset->s2d; L9.direct = 2; }
         if (raw_mode) {
           const uint32_t th = std::max(64u, std::min(512u, tile / 4));
           if (l == 0) hipLaunchKernelGGL((k_ntt29_strided<2, 1>), dim3((uint32_t)blocks), dim3(th), (size_t)36 * tile, s, cur, scratch, L9, lc, cur_len, cur_pre, raw);
@@ -229,9 +256,11 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
 
 // `data.size()` in-place transforms of 2^log_n elements (optionally times a divisor) as batched launches: blockIdx.y = vector.  Used by the batch entry
 // points for small transforms; falls back to the loop of single transforms where the batched kernels do not apply.  Same results.
-int ntt_batch_inplace(const std::vector<fe_t *> &data, uint32_t log_n, const void *omega, const void *divisor) {
+// srcs / coset: data[i] = transform of srcs[i][j] f^j (the folded coset shift; srcs[i] is only read, so it may be the coefficient vector itself)
+int ntt_batch_inplace(const std::vector<fe_t *> &data, uint32_t log_n, const void *omega, const void *divisor, const std::vector<const fe_t *> *srcs = nullptr, const NttPlan::CosetTw *coset = nullptr) {
   const size_t cnt = data.size();
   auto single_loop = [&]() -> int {
+    if (coset) { for (size_t i = 0; i < cnt; i++) CHK(ntt_dev_impl((*srcs)[i], 1ull << log_n, data[i], log_n, omega, nullptr, nullptr, coset)); return MI355_OK; }
     for (fe_t *d : data) {
       if (!divisor) CHK(ntt_dev_impl(d, 1ull << log_n, d, log_n, omega, nullptr, nullptr));
       else { fe_t post[3]; for (int i = 0; i < 3; i++) memcpy(&post[i], divisor, 32); CHK(ntt_dev_impl(d, 1ull << log_n, d, log_n, omega, nullptr, post)); }
@@ -256,10 +285,10 @@ int ntt_batch_inplace(const std::vector<fe_t *> &data, uint32_t log_n, const voi
   const size_t chunk = std::min<size_t>(std::min<size_t>(cnt, 65535), std::max<size_t>(1, (size_t)((1ull << 30) / (N * sizeof(fe_t)))));   // at most 1 GiB of scratch, and gridDim.y <= 65535
   fe_t *scratch; CHK(ws_get("ntt.scratch.batch", chunk * N * sizeof(fe_t), (void **)&scratch));
   // pointer tables for the whole list: data[i] and the scratch slot of i (slots repeat chunk by chunk; the stream orders their reuse)
-  std::vector<const fe_t *> tab(2 * cnt);
-  for (size_t i = 0; i < cnt; i++) { tab[i] = data[i]; tab[cnt + i] = scratch + (i % chunk) * N; }
-  const fe_t **dtab; CHK(ws_get("ntt.batch.ptrs", 2 * cnt * sizeof(void *), (void **)&dtab));
-  HIPCHK(hipMemcpyAsync(dtab, tab.data(), 2 * cnt * sizeof(void *), hipMemcpyHostToDevice, s));
+  std::vector<const fe_t *> tab(3 * cnt);
+  for (size_t i = 0; i < cnt; i++) { tab[i] = data[i]; tab[cnt + i] = scratch + (i % chunk) * N; tab[2 * cnt + i] = coset ? (*srcs)[i] : data[i]; }   // [destination | scratch slot | first-pass source]
+  const fe_t **dtab; CHK(ws_get("ntt.batch.ptrs", 3 * cnt * sizeof(void *), (void **)&dtab));
+  HIPCHK(hipMemcpyAsync(dtab, tab.data(), 3 * cnt * sizeof(void *), hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));   // `tab` is a stack-lifetime vector
   CallTrace tr("ntt_fr_batch", N * cnt, 64.0);
   for (size_t base = 0; base < cnt; base += chunk) {
@@ -270,10 +299,11 @@ int ntt_batch_inplace(const std::vector<fe_t *> &data, uint32_t log_n, const voi
       Ntt29Level L9; L9.log_m = p->log_m[l]; L9.log_t = log_s - L9.log_m; L9.split = p->split[l]; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l];
       L9.direct = p->direct2[l] ? 2u : (p->split[l] == log_s) ? 1u : 0u;
       if (fold_tw && l + 2 == p->levels) L9.tw_s_lo = *fold_tw;
+      if (coset && l == 0) { L9.tw_in = coset->in; L9.has_in = 1; L9.tw_s_lo = coset->s2d; L9.tw_s_hi = coset->s2d; L9.direct = 2; }
       const uint32_t lc = std::min(cols_for(L9.log_m), L9.log_t), tile = 1u << (L9.log_m + lc);
       const uint64_t blocks = (N >> log_s) << (L9.log_t - lc);
       Scope sc("ntt_pass");
-      const NttBatch B{l == 0 ? d_data : (const fe_t *const *)d_scr, d_scr};
+      const NttBatch B{l == 0 ? (const fe_t *const *)(dtab + 2 * cnt + base) : (const fe_t *const *)d_scr, d_scr};
       hipLaunchKernelGGL((k_ntt29_strided<2, 0>), dim3((uint32_t)blocks, c), dim3(std::max(64u, std::min(512u, tile / 4))), (size_t)36 * tile, s, (const fe_t *)nullptr, (fe_t *)nullptr, L9, lc, N, (const fe_t *)nullptr, Raw29{nullptr, nullptr, nullptr}, B);
       log_s -= L9.log_m;
     }
@@ -531,6 +561,11 @@ int mi355_coset_ntt_fr_dev(void *dst_dev, const void *coeffs_dev, uint32_t log_n
   int slot; CHK(common_slot({dst_dev, coeffs_dev}, &slot, "coset_ntt")); DevGuard lk(slot);
   CHK(need_init(slot)); CHK(check_ntt_args(dst_dev, log_n, omega));
   if (!coeffs_dev || !coset_factor) return fail(MI355_EBADARG, "coset_ntt: null pointer");
+  NttPlan *p; CHK(get_plan(log_n, omega, &p));
+  if (const NttPlan::CosetTw *ct = coset_fold_tables(p, log_n, omega, coset_factor)) {
+    CHK(ntt_dev_impl((const fe_t *)coeffs_dev, 1ull << log_n, (fe_t *)dst_dev, log_n, omega, nullptr, nullptr, ct));   // the shift rides on the first pass: no k_distribute_powers
+    return finish_async();
+  }
   CHK(distribute_powers_locked(dst_dev, 1ull << log_n, coset_factor, coeffs_dev));   // dst = coeffs[i] * factor^i (one pass, no copy first)
   CHK(ntt_dev_impl((const fe_t *)dst_dev, 1ull << log_n, (fe_t *)dst_dev, log_n, omega, nullptr, nullptr));
   return finish_async();
@@ -583,8 +618,13 @@ int mi355_coset_ntt_fr_batch_dev(void *const *dst_dev, const void *const *coeffs
   return run_per_device_lists(items, [&](int, const std::vector<uint32_t> &idx) -> int {
     std::vector<const void *> src; std::vector<void *> dst;
     for (uint32_t i : idx) { src.push_back(coeffs_dev[i]); dst.push_back(dst_dev[i]); }
-    CHK(distribute_powers_batch_locked(src, dst, 1ull << log_n, coset_factor));
     std::vector<fe_t *> list; for (void *d : dst) list.push_back((fe_t *)d);
+    NttPlan *p; CHK(get_plan(log_n, omega, &p));
+    if (const NttPlan::CosetTw *ct = coset_fold_tables(p, log_n, omega, coset_factor)) {   // round 6: the shift rides on the first pass of every transform of the list
+      std::vector<const fe_t *> from; for (const void *q : src) from.push_back((const fe_t *)q);
+      return ntt_batch_inplace(list, log_n, omega, nullptr, &from, ct);
+    }
+    CHK(distribute_powers_batch_locked(src, dst, 1ull << log_n, coset_factor));
     return ntt_batch_inplace(list, log_n, omega, nullptr);
   });
   });

@@ -31,7 +31,9 @@ namespace zk {
 #ifndef ZK_NTT_CHAIN
 #define ZK_NTT_CHAIN true    // limb products of the NTT butterflies as column blocks of chained v_mad (fp29.hpp mul_c): 8.61 vs 8.86 ms at 2^26 in round 3 (round 2 measured no gain; false restores the C++ multiplier for A/B builds)
 #endif
-struct Ntt29Level { uint32_t log_m, log_t, split; Tw29 tw_m, tw_s_lo, tw_s_hi; uint32_t direct; };   // direct 1: tw_s_lo holds every inter-level twiddle w_S^e (small levels), no lo x hi product; direct 2: tw_s_lo is the table [k][column] = w_S^(column k) of a big level, read like the data (8 adjacent columns per row)
+// tw_in / has_in (round 6, the coset shift folded into the first pass): element (m, column) of the FIRST strided pass is multiplied by tw_in[m] = (f^(2^log_t))^m on load, and the
+// pass's inter-level table (direct 2 layout) carries f^column next to w_S^(column k) -- together the f^i of distribute_powers, for one multiplication per element and no pass of its own
+struct Ntt29Level { uint32_t log_m, log_t, split; Tw29 tw_m, tw_s_lo, tw_s_hi; uint32_t direct; Tw29 tw_in = {nullptr, nullptr, nullptr}; uint32_t has_in = 0; };   // direct 1: tw_s_lo holds every inter-level twiddle w_S^e (small levels), no lo x hi product; direct 2: tw_s_lo is the table [k][column] = w_S^(column k) of a big level, read like the data (8 adjacent columns per row)
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ fe29_t tw29_load(const Tw29 &T, uint32_t i) {
@@ -182,7 +184,10 @@ template <int RMAX, int MODE = 0> __global__ void __launch_bounds__(RMAX >= 2 ? 
   const uint64_t base = (sub << (L.log_m + L.log_t)) + ((uint64_t)cb << log_c);
   for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
     const uint32_t c = e & (C - 1), m = e >> log_c;
-    lds29_put(S, e, MODE == 2 ? raw29_load(raw, base + ((uint64_t)m << L.log_t) + c) : load_input29(src, base + ((uint64_t)m << L.log_t) + c, src_len, pre3));
+    fe29_t v = MODE == 2 ? raw29_load(raw, base + ((uint64_t)m << L.log_t) + c) : load_input29(src, base + ((uint64_t)m << L.log_t) + c, src_len, pre3);
+    // canonical input (< r, exact limbs) times a canonical table entry: tight (< 1.4 r), what a pass may start from (header); uniform branch (kernel argument)
+    if (L.has_in) v = Fr29::mul_t<ZK_NTT_CHAIN>(v, tw29_load(L.tw_in, m));
+    lds29_put(S, e, v);
   }
   __syncthreads();
   lds_dif29<RMAX>(S, L.log_m, log_c, C, 1, L.tw_m, true, true);
@@ -413,12 +418,15 @@ __global__ void __launch_bounds__(256) k_fr_sum(const fe_t *__restrict__ in_all,
 }
 
 // table [k][col] (col < 2^log_t) of base^(col k) * 2^261 mod r: the inter-level twiddles of a big level in the order the pass reads them
-__global__ void k_pow_table29_2d(uint4 *lo, uint4 *hi, uint32_t *top, fe_t base, uint32_t log_t, uint64_t count) {
+// use_col: the entry also carries colbase^col (the column part f^col of a folded coset shift; colbase in Montgomery form)
+__global__ void k_pow_table29_2d(uint4 *lo, uint4 *hi, uint32_t *top, fe_t base, uint32_t log_t, uint64_t count, fe_t colbase = fe_t{}, int use_col = 0) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const uint64_t k = i >> log_t, col = i & ((1ull << log_t) - 1);
   fe_t m32; { constexpr uint32_t c[8] = {0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u, 0x819caa80u, 0x5301fa84u, 0x563d4475u, 0xdc83629u}; for (int q = 0; q < 8; q++) m32.l[q] = c[q]; }   // 32 in Montgomery form
-  const fe29_t w = Fr29::from_sat_plain(fr_mul_ps(Fr::pow_u64(base, k * col), m32));
+  fe_t e = Fr::pow_u64(base, k * col);
+  if (use_col) e = fr_mul_ps(e, Fr::pow_u64(colbase, col));
+  const fe29_t w = Fr29::from_sat_plain(fr_mul_ps(e, m32));
   lo[i] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]); hi[i] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]); top[i] = w.l[8];
 }
 // dst[i] = src[i] * d (d: Montgomery form of the ABI): a twiddle table with a constant folded in -- the inverse transform's divisor rides on

@@ -312,3 +312,47 @@ def test_host_alloc_is_page_locked_memory_the_entry_points_accept(zk):
     capi.check(lib.mi355_host_free(p))
     capi.check(lib.mi355_host_free(None))
     assert lib.mi355_host_alloc(0, C.byref(p)) == capi.EBADARG
+
+
+def _factor_powers(factor_int, n):
+    pw = np.zeros((n, 4), dtype=np.uint64); pw[0] = cref.fr_mont(1)
+    m = 1
+    while m < n:
+        pw[m:2 * m] = cref.f_mul_vec(cref.FR, pw[:m], np.tile(cref.fr_mont(pow(factor_int, m, R)), (m, 1)))
+        m *= 2
+    return pw
+
+
+@pytest.mark.parametrize("k", [8, 9, 10, 13, 16, 18, 19, 20, 21, 22, 24])
+def test_coset_shift_folded_into_the_first_pass_matches_oracle(zk, k):
+    """round 6: up to 2^24 the coset shift a[i] *= f^i rides on the first pass of the transform (a 2^log_m-entry table on load, f^column on the inter-level
+    twiddles) instead of running as k_distribute_powers; k = 8 (one pass) still takes the separate kernel, as does everything under MI355_NTT_COSET_FOLD_MAX_LOG=0 (a proof
+    with that setting is one of tests/test_plonk_protocol.py's byte-equality cases).  Every word against the
+    oracle (the scaling by plain field multiplications, the transform by best_fft), single and batched entry points, two coset factors (two table sets on one plan), in place
+    and out of place, sources untouched."""
+    h2 = zk.halo2
+    lib, capi = zk._capi.lib(), zk._capi
+    n = 1 << k
+    dom = h2.EvaluationDomain(9, k)                                                   # Q = 8 parts
+    srcs = [dev_scalars(n, 6100 + 7 * k + i) for i in range(3)]
+    hosts = [as_host(s, n).copy() for s in srcs]
+    for part in (5, 0):
+        factor_int = h2.FR_ZETA * pow(h2.fr_to_int(dom.extended_omega), part, R) % R
+        factor = h2.fr(factor_int)
+        pw = _factor_powers(factor_int, n)
+        wants = [cref.best_fft(cref.f_mul_vec(cref.FR, hsrc, pw), dom.omega, k, threads=NPROC) for hsrc in hosts]
+        out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+        capi.check(lib.mi355_coset_ntt_fr_dev(capi.ptr(out), capi.ptr(srcs[0]), k, capi.ptr(factor), capi.ptr(dom.omega)))
+        assert (as_host(out, n) == wants[0]).all(), f"single coset transform, part {part}"
+        dsts = [torch.empty((n, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+        capi.check(lib.mi355_coset_ntt_fr_batch_dev((C.c_void_p * 3)(*[d.data_ptr() for d in dsts]), (C.c_void_p * 3)(*[s.data_ptr() for s in srcs]), 3, k, capi.ptr(factor), capi.ptr(dom.omega)))
+        for i in range(3):
+            assert (as_host(dsts[i], n) == wants[i]).all(), f"batched coset transform {i}, part {part}"
+            assert (as_host(srcs[i], n) == hosts[i]).all(), "a source was modified"
+        inplace = srcs[1].clone()
+        capi.check(lib.mi355_coset_ntt_fr_dev(capi.ptr(inplace), capi.ptr(inplace), k, capi.ptr(factor), capi.ptr(dom.omega)))
+        assert (as_host(inplace, n) == wants[1]).all(), "in place"
+    # the plain transform of the same plan is untouched by the coset tables it now owns
+    plain = srcs[2].clone()
+    dom.coeff_to_lagrange(plain)
+    assert (as_host(plain, n) == cref.best_fft(hosts[2], dom.omega, k, threads=NPROC)).all()

@@ -436,6 +436,7 @@ GPU_CASES = [
     (3, 12, ["--sparse-uploads"], {"MI355_PLAN_PREFIX_MIN": "0"}, {}),
     (4, 11, ["--no-packed-multiplicities"], {}, {}),                                                                                                           # by default the multiplicity columns cross PCIe as 4-byte counts + their blinding rows; here as 32-byte words                                                                                         # and the plan without common-prefix groups
     (0, 7, [], {}, dict(advice=70, fixed=9, lookups=10, perm_columns=30, degree=9)),
+    (3, 10, [], {"MI355_NTT_COSET_FOLD_MAX_LOG": "0"}, {}),                                                                                                    # the coset shift as its own k_distribute_powers pass (round 5's schedule; by default it rides on the first pass of the transform)
 ]
 
 
