@@ -28,6 +28,9 @@ namespace zk {
 #ifndef ZK_NTT_LAZY_LAST
 #define ZK_NTT_LAZY_LAST true   // trivial-twiddle differences of a tile's last stage stay un-reduced (see lds_dif29_round)
 #endif
+#ifndef ZK_GATE_CHAIN
+#define ZK_GATE_CHAIN true   // k_fr_gate_eval's products as column blocks of chained v_mad (fp29.hpp mul_c), as in the NTT butterflies and the bucket accumulation: 16 instructions fewer per multiplication (round 6 A/B: profiles/r06_gate_chain_ab.json)
+#endif
 #ifndef ZK_NTT_CHAIN
 #define ZK_NTT_CHAIN true    // limb products of the NTT butterflies as column blocks of chained v_mad (fp29.hpp mul_c): 8.61 vs 8.86 ms at 2^26 in round 3 (round 2 measured no gain; false restores the C++ multiplier for A/B builds)
 #endif
@@ -382,10 +385,10 @@ __global__ void __launch_bounds__(256) k_fr_gate_eval(fe_t *dst, GatePlan G, uin
         // unit coefficients (the common case in halo2 gates: a - b, z(wX) prod - z(X) prod): no multiplication by c_j; -1 negates the canonical first
         // factor instead (r - x, zero stays zero), so the term value stays a tight non-negative representative (< r) like every other
         const uint32_t kind = G.coeff_kind[j];
-        if (kind == 0) t = Fr29::mul(Fr29::from_sat_plain(x0), G.coeff29[j]);
+        if (kind == 0) t = Fr29::mul_t<ZK_GATE_CHAIN>(Fr29::from_sat_plain(x0), G.coeff29[j]);
         else t = Fr29::from_sat_plain(kind == 2 ? Fr::neg(x0) : x0);
         for (uint32_t q = 1; q < len; q++)
-          t = Fr29::mul(t, Fr29::from_sat(g_load(&G.poly[G.factor_poly[f + q]][(i + (uint64_t)(int64_t)G.factor_rot[f + q]) & mask])));
+          t = Fr29::mul_t<ZK_GATE_CHAIN>(t, Fr29::from_sat(g_load(&G.poly[G.factor_poly[f + q]][(i + (uint64_t)(int64_t)G.factor_rot[f + q]) & mask])));
       }
       f += len;
       acc = Fr29::add(acc, t);
