@@ -169,6 +169,15 @@ static const NttPlan::CosetTw *coset_fold_tables(NttPlan *p, uint32_t log_n, con
   fe_t f, w; memcpy(&f, factor, 32); memcpy(&w, omega, 32);
   NttPlan::CosetTw T;
   uint4 *lo, *hi; uint32_t *top;
+  // big tables (0.6 GB per factor at 2^24, 2.4 GB at 2^26) are built only into HBM that is really spare: the first coset transform of a proof runs when most of the proof's
+  // working set is already allocated, so what is free here is close to what stays free; below the margin the shift stays the separate pass (a table that a later allocation
+  // would have to compete with is worth less than the 1-2 % of a k = 26 proof it saves)
+  if (cnt * 36 >= (256ull << 20)) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const size_t margin = std::max<size_t>((size_t)16 << 30, tot / 12);   // 24 GiB on a 288-GiB device: a multi-layer prover process that peaks at 274 GiB builds none of the big tables
+    if (fr < cnt * 36 + margin) return nullptr;
+  }
   if (!alloc_tw29(cnt, &lo, &hi, &top)) return nullptr;
   p->owned.push_back(lo); p->owned.push_back(hi); p->owned.push_back(top);
   hipLaunchKernelGGL(k_pow_table29_2d, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, g.stream, lo, hi, top, w, log_t, cnt, f, 1);   // level 0: w_S = omega (S = N)

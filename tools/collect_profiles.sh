@@ -4,7 +4,8 @@
 #      pass, and gpurun refuses --pmc together with sys / hip / hsa tracing); SQ counters
 #   B  one create_proof of the reference's layer-4 protocol (k = 26; tests/cpp/test_plonk_replay): the NTT passes THROUGH THE BATCHED ENTRY POINTS and k_fr_gate_eval,
 #      same three counter passes + kernel statistics; the program's own record carries the algorithmic side (gate_eval_process_totals)
-#   C  kernel statistics of a layer-0 and a layer-3 proof (kernel time vs wall)
+#   C  kernel statistics of a layer-0 and a layer-3 proof (kernel time vs wall; the process includes keygen)
+#   D  the same proofs' own phase totals without a profiler (keygen excluded)
 # Raw per-dispatch lines go to gpurun_out/<tag>_*.txt; tools/pmc_report.py <tag> turns them into profiles/<tag>_pmc_k26.md, profiles/<tag>_gate_eval.md and
 # profiles/pmc_latest.json (with the source hash bench.py checks before it re-emits the recorded traffic).
 TAG=${1:-r05}
@@ -50,4 +51,7 @@ for L in 0 3; do
   rocprofv3 --kernel-trace --stats -d /tmp/c_stats -o l -- $EXE --protocol /tmp/${TAG}_layer$L.json --out /tmp/${TAG}_l$L --proofs 1 > $OUT/${TAG}_L${L}_stats_record.json 2> /dev/null
   python $ROOT/tools/rocpd_summary.py $(find /tmp/c_stats -name "*.db" | head -1) > $OUT/${TAG}_L${L}_kernel_stats.txt
 done
+# ---- D  one proof's own phase totals (the library's events, keygen excluded, no profiler attached): the replay's --phase-profile
+for L in 0 3; do $EXE --protocol /tmp/${TAG}_layer$L.json --out /tmp/${TAG}_l$L --phase-profile > $OUT/${TAG}_L${L}_phase_record.json 2> /dev/null; done
+$EXE --protocol $ROOT/tests/golden/protocol_layer4.json --out /tmp/${TAG}_l4 --phase-profile > $OUT/${TAG}_L4_phase_record.json 2> /dev/null
 tail -5 $OUT/${TAG}_kernel_stats.txt; head -3 $OUT/${TAG}_pmc_FETCH_SIZE.txt; head -3 $OUT/${TAG}_L4_pmc_FETCH_SIZE.txt; wc -l $OUT/${TAG}_*

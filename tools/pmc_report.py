@@ -71,7 +71,7 @@ fetch, write, sq = parse("pmc_FETCH_SIZE.txt"), parse("pmc_WRITE_SIZE.txt"), par
 ks = lines("kernel_stats.txt")
 if ks:
     with open(os.path.join(PROF, f"{TAG}_kernel_stats.md"), "w") as f:
-        f.write(f"# Round 5 -- per-kernel statistics of the headline legs (`rocprofv3 --kernel-trace --stats`)\n\n"
+        f.write(f"# Round {TAG[1:].lstrip('0')} -- per-kernel statistics of the headline legs (`rocprofv3 --kernel-trace --stats`)\n\n"
                 "`cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-api --no-table-free --no-proof-mix "
                 "--no-sizes --no-witness-like --no-batch-legs` (`tools/collect_profiles.sh`): six uniform MSMs at 2^26 (1 warm-up + 5 timed) and the NTT leg.  `k_msm_accumulate`'s average is the "
                 "figure `roofline.avg_launch_ms` of the bench line must agree with; `k_srs_precompute` / `k_fixed_base_mul` / `k_srs_scalars` are registration-time set-up.\n\n")
@@ -79,12 +79,12 @@ if ks:
         bl = record("stats_bench_line.json")
         if bl:
             f.write(f"\nThe run's own line: ms_per_step {bl['ms_per_step']:.3f}, roofline.avg_launch_ms {bl['roofline']['avg_launch_ms']:.3f}, roofline.frac {bl['roofline']['frac']:.5f}, "
-                    f"NTT {bl['ntt']['ms_per_transform']:.3f} ms per transform ({bl['ntt']['passes_per_transform']:.0f} passes).\n")
+                    f"NTT {(bl['ntt']['ms_per_transform'] if 'ntt' in bl else bl['config'].get('ntt_k26_ms', float('nan'))):.3f} ms per transform (three passes).\n")   # round 6: the stdout line is the compact one
 
 # ------------------------------------------------------------------------------------------------ MSM + NTT traffic at 2^26
 acc_f, acc_w = by_kernel(fetch, "k_msm_accumulate"), by_kernel(write, "k_msm_accumulate")
 acc_bytes = None
-md = [f"# Round 5 -- HBM traffic counters at 2^26 on the round-5 tree: the MSM kernels, the three NTT passes, and the same passes through the batched entry points\n",
+md = [f"# Round {TAG[1:].lstrip('0')} -- HBM traffic counters at 2^26 on the {TAG} tree: the MSM kernels, the three NTT passes, and the same passes through the batched entry points\n",
       "`tools/collect_profiles.sh r05` (FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --kernel-trace --pmc` passes over `bench.py --steps 1 --warmup 0` with the headline legs only, "
       "then over one layer-4 `create_proof`); per-dispatch sums by `tools/pmc_query.py`, this table by `tools/pmc_report.py`.  Counter units are KiB.  Corrections: wide coalesced "
       "streaming reads are counted at 1/2 (doubled below), 64-byte gathers and strided 128-byte runs 1:1, writes 1:1 (guide, \"HBM\"; calibration in `profiles/r01_pmc_msm_k26.md`).\n",
@@ -157,7 +157,7 @@ if gf and gw and gs and rec:
     insts = sum(r[3]["SQ_INSTS_VALU"] for r in gs) * 64
     active = sum(r[3]["SQ_ACTIVE_INST_VALU"] for r in gs)
     ms_s = sum(r[2] for r in gs)
-    g = [f"# Round 5 -- the roofline of `k_fr_gate_eval` (VERDICT r4 next #6)\n",
+    g = [f"# Round {TAG[1:].lstrip('0')} -- the roofline of `k_fr_gate_eval`\n",
          "One `create_proof` of the reference's layer-4 protocol at k = 26 (`tests/cpp/test_plonk_replay --protocol tests/golden/protocol_layer4.json --proofs 1`) under "
          "`rocprofv3 --kernel-trace --pmc` (FETCH_SIZE, WRITE_SIZE, SQ counters in three separate runs; `tools/collect_profiles.sh`).  The program counts the ALGORITHMIC side itself "
          "(`gate_eval_process_totals` of its record: per launch 32 B x rows x (distinct operand polynomials + dst written + dst read when accumulating), and factor-rows = rows x factors).\n",
@@ -188,7 +188,7 @@ if gf and gw and gs and rec:
         f.write("\n".join(g) + "\n")
 
 # ------------------------------------------------------------------------------------------------ kernel vs wall
-kv = [f"# Round 5 -- kernel time vs wall for one proof of layers 0, 3 and 4 (`rocprofv3 --kernel-trace --stats`, `--proofs 1`: the first proof of the process, plus its keygen)\n"]
+kv = [f"# Round {TAG[1:].lstrip('0')} -- kernel time vs wall for one proof of layers 0, 3 and 4 (`rocprofv3 --kernel-trace --stats`, `--proofs 1`)\n\n**The tables cover the whole PROCESS: the first proof AND the keygen before it** (keygen commits every fixed / sigma column one by one -- 270 single, table-free MSMs at layer 0 -- and transforms every key polynomial onto every coset part, one call each): call counts and totals of `k_msm_*`, `k_ntt29_*` and (where it still runs) `k_distribute_powers` are NOT those of a proof.  One proof's own phase totals, keygen excluded, are in `profiles/{TAG}_phase_profile.json` (the replay's `--phase-profile`): at layer 0 a proof issues 34 MSM passes, not 311.\n"]
 for L in (0, 3, 4):
     st, r = lines(f"L{L}_kernel_stats.txt"), record(f"L{L}_stats_record.json")
     if st and r:
@@ -196,9 +196,19 @@ for L in (0, 3, 4):
 with open(os.path.join(PROF, f"{TAG}_kernel_vs_wall.md"), "w") as f:
     f.write("\n".join(kv) + "\n")
 
+# ------------------------------------------------------------------------------------------------ one proof's own phase totals (keygen excluded)
+ph = {}
+for L in (0, 3, 4):
+    r = record(f"L{L}_phase_record.json")
+    if r.get("phase_profile"):
+        ph[f"layer{L}"] = {"k": r["k"], "resident_ms": r["resident_ms"], "step_ms": r["step_ms"], "msm": r["msm"], "intt": r["intt"], "coset_ntt": r["coset_ntt"], "phase_profile": r["phase_profile"],
+                          "reduction_tail_share_of_proof": round(r["phase_profile"]["msm_reduce"]["ms"] / r["phase_profile"]["proof_ms"], 4)}
+if ph:
+    json.dump(ph, open(os.path.join(PROF, f"{TAG}_phase_profile.json"), "w"), indent=1)
+
 # ------------------------------------------------------------------------------------------------ the recorded figures bench.py re-emits
 if acc_bytes and ntt_bytes:
     json.dump({"msm_accumulate_k26_hbm_bytes_per_launch": float(f"{acc_bytes:.4g}"), "ntt_k26_hbm_bytes_per_transform": float(f"{ntt_bytes:.4g}"),
-               "source": f"profiles/{TAG}_pmc_k26.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, round 5 tree; recorded, not measured inside the bench run)",
+               "source": f"profiles/{TAG}_pmc_k26.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {TAG} tree; recorded, not measured inside the bench run)",
                "source_sha16": {"msm": source_hash("msm"), "ntt": source_hash("ntt")}}, open(os.path.join(PROF, "pmc_latest.json"), "w"))
 print("wrote", [f for f in os.listdir(PROF) if f.startswith(TAG + "_") or f == "pmc_latest.json"])
