@@ -55,16 +55,13 @@ struct Srs { uint64_t n = 0; std::shared_ptr<SrsMem> mem; std::shared_ptr<SrsTab
 struct Buf { void *p = nullptr; size_t cap = 0; };
 struct NttPlan {
   uint32_t log_n = 0, levels = 0, log_m[3] = {0, 0, 0};
-  fe_t *tw_m[3] = {nullptr, nullptr, nullptr};
-  fe_t *tw_s_lo[2] = {nullptr, nullptr}, *tw_s_hi[2] = {nullptr, nullptr};
   uint32_t split[2] = {0, 0};
   uint32_t direct2[2] = {0, 0};
   std::map<std::string, Tw29> scaled;   // the last strided level's direct twiddle table times a constant (key: the 32 bytes of the constant)
   // the tables of a coset shift folded into the first pass, per coset factor f (key: its 32 bytes): in[m] = (f^(2^log_t))^m, s2d[k][column] = w_S^(column k) f^column
   struct CosetTw { Tw29 in, s2d; };
   std::map<std::string, CosetTw> coset;
-  // the same tables as w * 2^261 mod r in 29-bit limbs (SoA) for the unsaturated kernels (ntt29.hpp); tw29_s_lo[l] of a big level is the
-  // 2^log_s-entry table [k][column]
+  // twiddles as w * 2^261 mod r in 29-bit limbs (SoA) for the kernels of ntt29.hpp; tw29_s_lo[l] of a big level is the 2^log_s-entry table [k][column]
   Tw29 tw29_m[3] = {}, tw29_s_lo[2] = {}, tw29_s_hi[2] = {};
   std::vector<void *> owned;
 };
@@ -103,10 +100,9 @@ struct Ctx {
   g1_affine_t *fixed_base_table = nullptr;
   uint32_t sort_t2 = 0;         // MI355_SORT_T2 = 8192 | 16384 (0: by size)
   uint32_t debug_gather_mask = 0x7fffffffu;   // MI355_DEBUG_GATHER_MASK (timing experiments only: results become wrong)
-  uint32_t acc_variant = 4;     // MI355_ACC_VARIANT: 4 = limb products of k_msm_accumulate as column blocks of chained v_mad (fp29_asm_gen.inc): 57.1 vs 59.5 ms at 2^26, bit-identical; 0 = the plain C++ multiplier
   uint32_t seg_factor = 16;
   uint32_t sort_fb = 11;        // MI355_SORT_FB: fine (level-2) key bits of the sorter, 9..12
-  uint32_t sort_split = 1;      // MI355_SORT_SPLIT: level-1 output as two streams (payload u32 + fine key u16) instead of one u64 per entry; 0 = the u64 records
+  uint32_t sort_split = 1;      // MI355_SORT_SPLIT: the level-1 output is two streams (payload u32 + fine key u16); 1 = 24 576-entry tiles where the bin bookkeeping leaves room, 2 = 16 384-entry tiles (the single-stream u64 records were an A/B path of round 3 and left the library in round 6)
   uint32_t reduce_chains = 131072;   // MI355_REDUCE_CHAINS: target number of running-sum chains of the bucket reduction
   uint32_t seg_fill = 40, seg_fill_segfix = 40;   // MI355_SEG_FILL / MI355_SEG_FILL_SEGFIX (even, 2..100 %: above 100 the segments would no longer cover the entries): share of the launched accumulate threads the actual entries are spread over
   uint32_t seg_min = 16;             // MI355_SEG_MIN: shortest accumulate segment (entries per thread) when few digits are non-zero
@@ -122,11 +118,8 @@ struct Ctx {
   uint32_t ntt_coset_fold_max_log = 26;  // MI355_NTT_COSET_FOLD_MAX_LOG: coset transforms up to 2^this fold distribute_powers into their first pass (one 36 B x 2^log_n table per coset factor: 38 MB at 2^20, 0.6 GB at 2^24, 2.4 GB at 2^26; tables of 256 MB and more are only built while HBM has the table + max(16 GiB, 1/12 of the device) to spare -- otherwise, and above the cap, the separate pass runs); 0: always the separate k_distribute_powers pass
   uint32_t ntt_fold_scale = 1;  // MI355_NTT_FOLD_SCALE=0: the inverse transform's divisor stays a multiplication in the closing pass
   uint32_t ntt_batch_max_log = 22;       // MI355_NTT_BATCH_MAX_LOG: the batch entry points run transforms up to 2^this as batched launches (blockIdx.y = polynomial); 0: always the loop of single transforms
-  uint32_t ntt_raw_scratch = 0;          // MI355_NTT_RAW_SCRATCH=1: elements stay in 9 x 29-bit limbs (36 B, three planes) between passes instead of being re-sliced to 8 x 32 and back (A/B, round 4)
   uint32_t ntt_two_level_max_log = 18;   // MI355_NTT_TWO_LEVEL_MAX_LOG (18..20): transforms up to 2^this run as two passes instead of three
-  uint32_t ntt_radix_log = 2;   // MI355_NTT_RADIX_LOG
   uint32_t ntt_tile_log = 11;   // log2 of the LDS tile in elements (MI355_NTT_TILE_LOG)
-  bool ntt29 = true;   // unsaturated 29-bit NTT kernels (MI355_NTT_SAT=1 selects the saturated 8x32 ones for A/B runs)
   bool profiling = false;
   bool trace = false;           // MI355_TRACE=1: one stderr line per MSM / NTT call (host wall time; device transforms are synchronised for it)
   std::map<std::string, Prof> prof;

@@ -282,11 +282,9 @@ static int init_ctx(int slot, int device_id) {
   CHK(ntt_tu_init_device());
   CHK(aux_tu_init_device());
   { const char *e = getenv("MI355_TRACE"); g.trace = e && e[0] == '1'; }
-  { const char *e = getenv("MI355_NTT_SAT"); g.ntt29 = !(e && e[0] == '1'); }
 #ifdef MI355_DEBUG_KNOBS
   { const char *e = getenv("MI355_DEBUG_GATHER_MASK"); if (e) g.debug_gather_mask = (uint32_t)strtoul(e, nullptr, 0); }
 #endif
-  { const char *e = getenv("MI355_ACC_VARIANT"); if (e) g.acc_variant = (uint32_t)atoi(e) & 7; }
   { const char *e = getenv("MI355_REDUCE_CHAINS"); if (e) { int v = atoi(e); if (v >= 1024) g.reduce_chains = (uint32_t)v; } }
   { const char *e = getenv("MI355_SEG_FILL"); if (e) { int v = atoi(e); if (v >= 2 && v <= 100) g.seg_fill = (uint32_t)v; } }
   { const char *e = getenv("MI355_SEG_FILL_SEGFIX"); if (e) { int v = atoi(e); if (v >= 2 && v <= 100) g.seg_fill_segfix = (uint32_t)v; } }
@@ -299,7 +297,7 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_TAIL_COOP_MAX"); if (e) { long v = atol(e); if (v >= 0 && v <= (1l << 24)) g.tail_coop_max = (uint32_t)v; } }
   { const char *e = getenv("MI355_REDUCE_MIN_CHUNK"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) g.reduce_min_chunk = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_FB"); if (e) { int v = atoi(e); if (v >= 9 && v <= 12) g.sort_fb = (uint32_t)v; } }
-  { const char *e = getenv("MI355_SORT_SPLIT"); if (e && e[0] >= '0' && e[0] <= '2') g.sort_split = (uint32_t)(e[0] - '0'); }
+  { const char *e = getenv("MI355_SORT_SPLIT"); if (e && e[0] >= '1' && e[0] <= '2') g.sort_split = (uint32_t)(e[0] - '0'); }
   { const char *e = getenv("MI355_SEG_FACTOR"); if (e) { int v = atoi(e); if (v >= 1 && v <= 256) g.seg_factor = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T2"); if (e) { int v = atoi(e); if (v == 8192 || v == 16384) g.sort_t2 = (uint32_t)v; } }
   { const char *e = getenv("MI355_SORT_T1"); if (e && atoi(e) == 8192) g.sort_t1 = 8192; }
@@ -307,9 +305,7 @@ static int init_ctx(int slot, int device_id) {
   { const char *e = getenv("MI355_NTT_FOLD_SCALE"); if (e) g.ntt_fold_scale = e[0] == '0' ? 0u : 1u; }
   { const char *e = getenv("MI355_NTT_COSET_FOLD_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 0 && v <= 28) g.ntt_coset_fold_max_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_BATCH_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 0 && v <= 28) g.ntt_batch_max_log = (uint32_t)v; } }
-  { const char *e = getenv("MI355_NTT_RAW_SCRATCH"); if (e) g.ntt_raw_scratch = e[0] == '1' ? 1u : 0u; }
   { const char *e = getenv("MI355_NTT_TWO_LEVEL_MAX_LOG"); if (e) { int v = atoi(e); if (v >= 9 && v <= 20) g.ntt_two_level_max_log = (uint32_t)v; } }
-  { const char *e = getenv("MI355_NTT_RADIX_LOG"); if (e) { int v = atoi(e); if (v >= 1 && v <= 3) g.ntt_radix_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_NTT_TILE_LOG"); if (e) { int v = atoi(e); if (v >= 8 && v <= 12) g.ntt_tile_log = (uint32_t)v; } }
   { const char *e = getenv("MI355_HOST_BATCH_OVERLAP"); if (e) g.host_batch_overlap = atoi(e) != 0; }
   { const char *e = getenv("MI355_HOST_CHUNKS"); if (e) { int v = atoi(e); if (v >= 1 && v <= 64) g.host_chunks = (uint32_t)v; } }
@@ -325,7 +321,7 @@ static void destroy_ctx(int slot) {
   if (g.copy_stream) (void)hipStreamSynchronize(g.copy_stream);
   for (auto &kv : g.ws) if (kv.second.p) (void)hipFree(kv.second.p);
   g.ws.clear();
-  for (auto &kv : g.ntt_plans) { for (void *q : kv.second.owned) (void)hipFree(q); for (int i = 0; i < 3; i++) if (kv.second.tw_m[i]) (void)hipFree(kv.second.tw_m[i]); for (int i = 0; i < 2; i++) { if (kv.second.tw_s_lo[i]) (void)hipFree(kv.second.tw_s_lo[i]); if (kv.second.tw_s_hi[i]) (void)hipFree(kv.second.tw_s_hi[i]); } }
+  for (auto &kv : g.ntt_plans) for (void *q : kv.second.owned) (void)hipFree(q);
   g.ntt_plans.clear();
   if (g.fixed_base_table) { (void)hipFree(g.fixed_base_table); g.fixed_base_table = nullptr; }
   if (g.comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(g.comm); g.comm = nullptr; }

@@ -13,10 +13,6 @@ static_assert(sizeof(fe_t) == 32 && sizeof(g1_affine_t) == 64 && sizeof(g1_jac_t
 static_assert(sizeof(g1_xyzz_t) == 128 && sizeof(g1_xyzz29_t) == 144, "device record sizes (workspace layout, 16-byte vector accesses)");
 
 int msm_tu_init_device() {
-  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_sort_l2_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter_split<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter_split<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_sort_l1_scatter_split<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -160,7 +156,6 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   S.t1 = g.sort_t1;                           // level-1 tile: 1024 threads x 8 or 16 entries (64 / 128 KiB of LDS staging)
   // split records (payload u32 + fine key u16 as two streams, MI355_SORT_SPLIT): 6 bytes of staging per entry -> 24 576-entry tiles where the bin
   // bookkeeping leaves room (<= 1024 coarse bins)
-  const bool split = g.sort_split != 0;
   if (g.sort_split == 1 && S.t1 == 16384 && (1u << S.cb_bits) <= 1024 && emax >= (1ull << 24)) S.t1 = 24576;   // MI355_SORT_SPLIT=2: split records, 16 384-entry tiles
   // level-2 tile (6 B of LDS per entry next to the 3 x 2^fb words of bin bookkeeping): 16384 entries give twice the run length in
   // `sorted` (fewer partial-line store transactions, the limiter of this kernel) at one workgroup per CU; worth it for big sorts
@@ -168,13 +163,12 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
   const uint32_t tiles1 = ceil_div(n, S.t1), l2_tiles_max = ceil_div(emax, S.t2) + S.regions + 8;   // + 8: the XCD-aware tile order rounds the tile count up to a multiple of 8
   const uint32_t vwindows = M * P.windows;   // (polynomial, window) pairs
 
-  uint32_t *enc, *hist, *offsets, *cursor, *sorted, *scan_sums, *coarse_hist, *coarse_off, *coarse_cursor, *tile_start; uint64_t *pairs;
+  uint32_t *enc, *hist, *offsets, *cursor, *sorted, *scan_sums, *coarse_hist, *coarse_off, *coarse_cursor, *tile_start;
   g1_xyzz29_t *buckets, *part; int32_t *part_id;
   // stage-A-only buffers are shared by all slots (the sort stages of successive chunks run one after the other on st.a)
   CHK(ws_get("msm.digits", emax * 4, (void **)&enc));
   uint32_t *pairs_lo = nullptr; uint16_t *pairs_hi = nullptr;
-  if (g.sort_split) { CHK(ws_get("msm.pairs_lo", emax * 4 + 64, (void **)&pairs_lo)); CHK(ws_get("msm.pairs_hi", emax * 2 + 64, (void **)&pairs_hi)); pairs = nullptr; }
-  else CHK(ws_get("msm.pairs", emax * 8, (void **)&pairs));
+  CHK(ws_get("msm.pairs_lo", emax * 4 + 64, (void **)&pairs_lo)); CHK(ws_get("msm.pairs_hi", emax * 2 + 64, (void **)&pairs_hi));
   CHK(ws_get("msm.hist", ((size_t)nbuckets + 1) * 4, (void **)&hist));
   CHK(ws_get("msm.cursor", ((size_t)nbuckets + 1) * 4, (void **)&cursor));
   CHK(ws_get("msm.coarse_hist", ((size_t)S.regions + 1) * 4, (void **)&coarse_hist));
@@ -220,31 +214,22 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
       {
         Scope s1("sort_l1", s);
         const uint32_t CBp = ((1u << S.cb_bits) + 1) & ~1u;
-        if (split) {
-          const size_t lds1 = (size_t)(3 * CBp + 32 + SORT_SPLIT_TMAX) * 4 + (size_t)S.t1 * 6;
-          if (S.t1 == 24576) hipLaunchKernelGGL(k_sort_l1_scatter_split<24>, dim3(tiles1 * vwindows), dim3(1024), lds1, s, enc, coarse_cursor, pairs_lo, pairs_hi, S);
-          else if (S.t1 == 16384) hipLaunchKernelGGL(k_sort_l1_scatter_split<16>, dim3(tiles1 * vwindows), dim3(1024), lds1, s, enc, coarse_cursor, pairs_lo, pairs_hi, S);
-          else hipLaunchKernelGGL(k_sort_l1_scatter_split<8>, dim3(tiles1 * vwindows), dim3(1024), lds1, s, enc, coarse_cursor, pairs_lo, pairs_hi, S);
-        }
-        else if (S.t1 == 16384) hipLaunchKernelGGL(k_sort_l1_scatter<16>, dim3(tiles1 * vwindows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
-        else hipLaunchKernelGGL(k_sort_l1_scatter<8>, dim3(tiles1 * vwindows), dim3(1024), (size_t)(3 * CBp + 32) * 4 + (size_t)S.t1 * 8, s, enc, coarse_cursor, pairs, S);
+        const size_t lds1 = (size_t)(3 * CBp + 32 + SORT_SPLIT_TMAX) * 4 + (size_t)S.t1 * 6;
+        if (S.t1 == 24576) hipLaunchKernelGGL(k_sort_l1_scatter_split<24>, dim3(tiles1 * vwindows), dim3(1024), lds1, s, enc, coarse_cursor, pairs_lo, pairs_hi, S);
+        else if (S.t1 == 16384) hipLaunchKernelGGL(k_sort_l1_scatter_split<16>, dim3(tiles1 * vwindows), dim3(1024), lds1, s, enc, coarse_cursor, pairs_lo, pairs_hi, S);
+        else hipLaunchKernelGGL(k_sort_l1_scatter_split<8>, dim3(tiles1 * vwindows), dim3(1024), lds1, s, enc, coarse_cursor, pairs_lo, pairs_hi, S);
       }
       hipLaunchKernelGGL(k_sort_tile_prefix, dim3(1), dim3(SCAN_BLOCK), 0, s, coarse_off, tile_start, S);
       { Scope s2("sort_hist", s);
-      if (split) hipLaunchKernelGGL(k_sort_l2_hist_split, dim3(l2_tiles_max), dim3(256), 0, s, (const uint16_t *)pairs_hi, coarse_off, tile_start, hist, S);
-      else hipLaunchKernelGGL(k_sort_l2_hist, dim3(l2_tiles_max), dim3(256), 0, s, pairs, coarse_off, tile_start, hist, S); }
+      hipLaunchKernelGGL(k_sort_l2_hist_split, dim3(l2_tiles_max), dim3(256), 0, s, (const uint16_t *)pairs_hi, coarse_off, tile_start, hist, S); }
       hipLaunchKernelGGL(k_scan_partial, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, scan_n);
       hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scan_sums, scan_blocks);
       hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_BLOCK), 0, s, hist, scan_sums, offsets, cursor, scan_n);
       {
         Scope s3("sort_l2", s);
         const size_t lds2 = (size_t)(3 * (1u << S.fb) + 32) * 4 + (size_t)S.t2 * 6;   // histogram / offsets / bases + staged indices (4 B) and their bins (2 B)
-        if (split) {
-          if (S.t2 == 8192) hipLaunchKernelGGL(k_sort_l2_scatter_split<8>, dim3(l2_tiles_max), dim3(1024), lds2, s, (const uint32_t *)pairs_lo, (const uint16_t *)pairs_hi, coarse_off, tile_start, cursor, sorted, S);
-          else hipLaunchKernelGGL(k_sort_l2_scatter_split<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, (const uint32_t *)pairs_lo, (const uint16_t *)pairs_hi, coarse_off, tile_start, cursor, sorted, S);
-        }
-        else if (S.t2 == 8192) hipLaunchKernelGGL(k_sort_l2_scatter<8>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
-        else hipLaunchKernelGGL(k_sort_l2_scatter<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, pairs, coarse_off, tile_start, cursor, sorted, S);
+        if (S.t2 == 8192) hipLaunchKernelGGL(k_sort_l2_scatter_split<8>, dim3(l2_tiles_max), dim3(1024), lds2, s, (const uint32_t *)pairs_lo, (const uint16_t *)pairs_hi, coarse_off, tile_start, cursor, sorted, S);
+        else hipLaunchKernelGGL(k_sort_l2_scatter_split<16>, dim3(l2_tiles_max), dim3(1024), lds2, s, (const uint32_t *)pairs_lo, (const uint16_t *)pairs_hi, coarse_off, tile_start, cursor, sorted, S);
       }
     }
     if (piped) { HIPCHK(hipEventRecord(slot.sorted, s)); HIPCHK(hipStreamWaitEvent(st.b, slot.sorted, 0)); }
@@ -257,7 +242,7 @@ int msm_enqueue(const g1_affine_t *bases, const PolyPtrs &inl, const fe_t *const
       Scope sc("msm_accumulate", s);
       HIPCHK(hipMemsetAsync(buckets, 0, (size_t)nbuckets * sizeof(g1_xyzz29_t), s));
 #define ACC_LAUNCH(V) hipLaunchKernelGGL(k_msm_accumulate<V>, dim3(acc_blocks), dim3(256), 0, s, bases, sorted, offsets, nbuckets, buckets, part, part_id, seg_arg, S.nshift, shared ? pre->row_stride : (uint64_t)0, g.debug_gather_mask)
-      if (g.acc_variant & 4) ACC_LAUNCH(4); else ACC_LAUNCH(0);   // 4: limb products as explicitly chained v_mad (fp29.hpp mac_*); the older A/B variants (index stream further ahead, prefetched bucket ends) did not help and are no longer instantiated
+      ACC_LAUNCH(4);   // <4>: limb products as explicitly chained v_mad (fp29.hpp mac_*).  The C++-multiplier variant <0> (59.5 vs 57.1 ms at 2^26, round 3) and the older A/B variants are no longer instantiated (round 6)
 #undef ACC_LAUNCH
     }
     if (piped) { HIPCHK(hipEventRecord(slot.acc_done, s)); HIPCHK(hipStreamWaitEvent(st.c, slot.acc_done, 0)); }

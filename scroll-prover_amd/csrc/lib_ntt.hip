@@ -1,4 +1,4 @@
-// lib_ntt.hip -- libmi355zk.so, the Fr translation unit: launch orchestration of ntt.hpp / ntt29.hpp (plan cache, <= 3 global passes), the
+// lib_ntt.hip -- libmi355zk.so, the Fr translation unit: launch orchestration of ntt29.hpp (plan cache, <= 3 global passes), the
 // EvaluationDomain wrappers (ifft, coset extension and its inverse), distribute_powers, the element-wise vector operations, the gate-shaped
 // fused evaluation (mi355_fr_gate_eval_dev), eval_polynomial, and the batched / replicated entry points that spread independent transforms
 // over the bound devices.  Host logic only; all arithmetic runs in the kernels.
@@ -10,30 +10,14 @@
 namespace mi355 {
 
 int ntt_tu_init_device() {
-  HIPCHK(hipFuncSetAttribute((const void *)k_ntt_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_ntt_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)(k_ntt29_strided<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)(k_ntt29_strided<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)(k_ntt29_final<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_strided<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void *)k_ntt29_final<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return MI355_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ NTT
 constexpr uint32_t NTT_DIRECT_TW_MAX_LOG = 20;   // 2^20 x 36 B = 38 MB per table at most
 std::string plan_key(uint32_t log_n, const void *omega) { std::string k((const char *)omega, 32); k.push_back((char)log_n); return k; }
-
-int pow_table(fe_t **out, const fe_t &base, uint64_t step, uint32_t count) {
-  CHK(dev_malloc((void **)out, (size_t)count * sizeof(fe_t), "ntt twiddles"));
-  hipLaunchKernelGGL(k_pow_table, dim3(ceil_div(count, 256)), dim3(256), 0, g.stream, *out, base, step, count);
-  HIPCHK(hipGetLastError());
-  return MI355_OK;
-}
 
 int pow_table29(NttPlan &p, Tw29 *out, const fe_t &base, uint64_t step, uint32_t count) {
   uint4 *lo, *hi; uint32_t *top;
@@ -55,8 +39,6 @@ int launch_pow_table(fe_t *out, const fe_t &base, uint64_t step, uint32_t count)
 static void free_plan_tables(NttPlan &p) {
   for (void *q : p.owned) (void)hipFree(q);
   p.owned.clear();
-  for (int i = 0; i < 3; i++) if (p.tw_m[i]) { (void)hipFree(p.tw_m[i]); p.tw_m[i] = nullptr; }
-  for (int i = 0; i < 2; i++) { if (p.tw_s_lo[i]) { (void)hipFree(p.tw_s_lo[i]); p.tw_s_lo[i] = nullptr; } if (p.tw_s_hi[i]) { (void)hipFree(p.tw_s_hi[i]); p.tw_s_hi[i] = nullptr; } }
 }
 // three device arrays of one 29-bit table (SoA), all or nothing
 static bool alloc_tw29(uint64_t cnt, uint4 **lo, uint4 **hi, uint32_t **top) {
@@ -75,16 +57,13 @@ static int build_plan(NttPlan &p, uint32_t log_n, const void *omega) {
   uint32_t log_s = log_n;
   for (uint32_t l = 0; l < p.levels; l++) {
     const uint32_t lm = p.log_m[l];
-    if (lm >= 1) CHK(pow_table(&p.tw_m[l], w, N >> lm, std::max(1u, 1u << (lm - 1))));
     CHK(pow_table29(p, &p.tw29_m[l], w, N >> lm, std::max(1u, (1u << lm) >> 1)));
     if (l + 1 < p.levels) {
       // inter-level twiddles w_S^e, e < 2^log_s: ONE table when it is small enough to live in L2 (no lo x hi product per element),
       // otherwise the usual two half-size tables
       p.split[l] = log_s <= NTT_DIRECT_TW_MAX_LOG ? log_s : (log_s + 1) / 2;
-      CHK(pow_table(&p.tw_s_lo[l], w, N >> log_s, 1u << p.split[l]));
-      CHK(pow_table(&p.tw_s_hi[l], w, (N >> log_s) << p.split[l], 1u << (log_s - p.split[l])));
       bool direct = false;
-      if (g.ntt29 && log_s > NTT_DIRECT_TW_MAX_LOG && log_s <= g.ntt_direct2_max_log) {
+      if (log_s > NTT_DIRECT_TW_MAX_LOG && log_s <= g.ntt_direct2_max_log) {
         // big level: every twiddle w_S^(column k) once, in the order the pass reads them (36 B x 2^log_s: 2.4 GB at 2^26, read coalesced
         // next to the data by a pass that is ALU-bound); saves the lo x hi product per element.  HBM may be full of window tables: when the
         // allocation fails the level falls back to the lo x hi pair, which is functionally equivalent.
@@ -117,13 +96,9 @@ int get_plan(uint32_t log_n, const void *omega, NttPlan **out) {
   return MI355_OK;
 }
 
-// radix-2^R register rounds: R = g.ntt_radix_log (1..3); one work item per 2^R elements
-#define NTT29_LAUNCH(KERN, BLOCKS, TILE, LDS, ...)                                                                                          \
-  do {                                                                                                                                     \
-    if (g.ntt_radix_log == 3) hipLaunchKernelGGL(KERN<3>, dim3(BLOCKS), dim3(std::max(64u, std::min(512u, (TILE) / 8))), LDS, s, __VA_ARGS__);       \
-    else if (g.ntt_radix_log == 2) hipLaunchKernelGGL(KERN<2>, dim3(BLOCKS), dim3(std::max(64u, std::min(512u, (TILE) / 4))), LDS, s, __VA_ARGS__);  \
-    else hipLaunchKernelGGL(KERN<1>, dim3(BLOCKS), dim3(std::max(64u, std::min(1024u, (TILE) / 2))), LDS, s, __VA_ARGS__);                            \
-  } while (0)
+// radix-4 register rounds (two DIF stages per LDS round trip): one work item per 4 elements.  (The radix-2 and radix-8 instantiations and the raw-scratch modes were A/B paths
+// of rounds 3-4 -- results in HISTORY.md section 5 -- and left the library in round 6.)
+#define NTT29_LAUNCH(KERN, BLOCKS, TILE, LDS, ...) hipLaunchKernelGGL(KERN<2>, dim3(BLOCKS), dim3(std::max(64u, std::min(512u, (TILE) / 4))), LDS, s, __VA_ARGS__)
 
 uint32_t cols_for(uint32_t log_m) { uint32_t lc = 3; while (lc > 0 && log_m + lc > g.ntt_tile_log) lc--; return lc; }
 
@@ -132,7 +107,7 @@ uint32_t cols_for(uint32_t log_m) { uint32_t lc = 3; while (lc > 0 && log_m + lc
 // On success *fold_tw names the scaled table and *post3_dev is cleared; otherwise both stay as they were (the divisor remains a multiplication).
 static int fold_divisor(NttPlan *p, uint32_t log_n, const fe_t *pre3_host, const fe_t *post3_host, const Tw29 **fold_tw, fe_t **post3_dev) {
   hipStream_t s = g.stream;
-  if (post3_host && !pre3_host && g.ntt29 && g.ntt_fold_scale && p->levels >= 2 && memcmp(&post3_host[0], &post3_host[1], 32) == 0 && memcmp(&post3_host[0], &post3_host[2], 32) == 0) {
+  if (post3_host && !pre3_host && g.ntt_fold_scale && p->levels >= 2 && memcmp(&post3_host[0], &post3_host[1], 32) == 0 && memcmp(&post3_host[0], &post3_host[2], 32) == 0) {
     const uint32_t l = p->levels - 2;
     uint32_t log_sl = log_n; for (uint32_t q = 0; q < l; q++) log_sl -= p->log_m[q];
     if (p->split[l] == log_sl && !p->direct2[l]) {   // that level reads ONE direct table
@@ -160,7 +135,7 @@ static int fold_divisor(NttPlan *p, uint32_t log_n, const fe_t *pre3_host, const
 // where the fold does not apply (single-pass plans, sizes above MI355_NTT_COSET_FOLD_MAX_LOG, the A/B kernels, no memory for the table, more than 16 factors on one plan): the
 // caller then runs k_distribute_powers first, as before.  Same bits either way (exact field arithmetic, canonical output).
 static const NttPlan::CosetTw *coset_fold_tables(NttPlan *p, uint32_t log_n, const void *omega, const void *factor) {
-  if (!g.ntt29 || g.ntt_raw_scratch || p->levels < 2 || log_n > g.ntt_coset_fold_max_log) return nullptr;
+  if (p->levels < 2 || log_n > g.ntt_coset_fold_max_log) return nullptr;
   const std::string key((const char *)factor, 32);
   auto it = p->coset.find(key);
   if (it != p->coset.end()) return &it->second;
@@ -208,53 +183,33 @@ int ntt_dev_impl(const fe_t *src, uint64_t src_len, fe_t *dst, uint32_t log_n, c
   NttPlan *p; CHK(get_plan(log_n, omega, &p));
   const Tw29 *fold_tw = nullptr;
   CHK(fold_divisor(p, log_n, pre3_host, post3_host, &fold_tw, &post3));
-  if (coset && (p->levels < 2 || !g.ntt29 || fold_tw || pre3)) return fail(MI355_EBADARG, "ntt: a folded coset shift needs a multi-pass plan of the 29-bit kernels and no other scaling");
+  if (coset && (p->levels < 2 || fold_tw || pre3)) return fail(MI355_EBADARG, "ntt: a folded coset shift needs a multi-pass plan and no other scaling");
   CallTrace tr("ntt_fr", N, 64.0);
   Scope total("ntt_total");
   if (p->levels == 1) {
     const uint32_t lm = p->log_m[0], tile = 1u << lm;
-    const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
-    const size_t lds = (size_t)2 * 16 * (tile + 1);
     Scope sc("ntt_pass");
-    if (g.ntt29) NTT29_LAUNCH(k_ntt29_final, 1u, tile, (size_t)36 * (tile + 1), src, dst, lm, 0u, 0u, 0u, p->tw29_m[0], src_len, pre3, post3);
-    else hipLaunchKernelGGL(k_ntt_final, dim3(1), dim3(threads), lds, s, src, dst, lm, 0u, 0u, 0u, p->tw_m[0], src_len, pre3, post3);
+    NTT29_LAUNCH(k_ntt29_final, 1u, tile, (size_t)36 * (tile + 1), src, dst, lm, 0u, 0u, 0u, p->tw29_m[0], src_len, pre3, post3);
   } else {
-    // raw scratch (A/B knob): 36 bytes per element in three planes; only with the 29-bit kernels at the default radix
-    const bool raw_mode = g.ntt_raw_scratch && g.ntt29 && g.ntt_radix_log == 2;
-    fe_t *scratch; CHK(ws_get("ntt.scratch", N * (raw_mode ? 36 : sizeof(fe_t)), (void **)&scratch));
-    Raw29 raw{(uint4 *)scratch, (uint4 *)scratch + N, (uint32_t *)((uint4 *)scratch + 2 * N)};
+    fe_t *scratch; CHK(ws_get("ntt.scratch", N * sizeof(fe_t), (void **)&scratch));
     uint32_t log_s = log_n;
     const fe_t *cur = src; uint64_t cur_len = src_len; const fe_t *cur_pre = pre3;
     for (uint32_t l = 0; l + 1 < p->levels; l++) {
-      NttLevel L; L.log_m = p->log_m[l]; L.log_t = log_s - L.log_m; L.tw_m = p->tw_m[l]; L.tw_s_lo = p->tw_s_lo[l]; L.tw_s_hi = p->tw_s_hi[l]; L.split = p->split[l];
-      const uint32_t lc = std::min(cols_for(L.log_m), L.log_t), tile = 1u << (L.log_m + lc);
-      const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
-      const size_t lds = (size_t)2 * 16 * tile;
-      const uint64_t blocks = (N >> log_s) << (L.log_t - lc);
+      Ntt29Level L9; L9.log_m = p->log_m[l]; L9.log_t = log_s - L9.log_m; L9.split = p->split[l]; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l];
+      L9.direct = p->direct2[l] ? 2u : (p->split[l] == log_s) ? 1u : 0u;
+      if (fold_tw && l + 2 == p->levels) L9.tw_s_lo = *fold_tw;
+      if (coset && l == 0) { L9.tw_in = coset->in; L9.has_in = 1; L9.tw_s_lo = coset->s2d; L9.tw_s_hi = coset->s2d; L9.direct = 2; }
+      const uint32_t lc = std::min(cols_for(L9.log_m), L9.log_t), tile = 1u << (L9.log_m + lc);
+      const uint64_t blocks = (N >> log_s) << (L9.log_t - lc);
       Scope sc("ntt_pass");
-      if (g.ntt29) {
-        Ntt29Level L9; L9.log_m = L.log_m; L9.log_t = L.log_t; L9.split = L.split; L9.tw_m = p->tw29_m[l]; L9.tw_s_lo = p->tw29_s_lo[l]; L9.tw_s_hi = p->tw29_s_hi[l]; L9.direct = p->direct2[l] ? 2u : (p->split[l] == log_s) ? 1u : 0u;
-        if (fold_tw && l + 2 == p->levels) L9.tw_s_lo = *fold_tw;
-        if (coset && l == 0) { L9.tw_in = coset->in; L9.has_in = 1; L9.tw_s_lo = coset->s2d; L9.tw_s_hi = coset->s2d; L9.direct = 2; }
-        if (raw_mode) {
-          const uint32_t th = std::max(64u, std::min(512u, tile / 4));
-          if (l == 0) hipLaunchKernelGGL((k_ntt29_strided<2, 1>), dim3((uint32_t)blocks), dim3(th), (size_t)36 * tile, s, cur, scratch, L9, lc, cur_len, cur_pre, raw);
-          else hipLaunchKernelGGL((k_ntt29_strided<2, 2>), dim3((uint32_t)blocks), dim3(th), (size_t)36 * tile, s, cur, scratch, L9, lc, cur_len, cur_pre, raw);
-        } else
-        NTT29_LAUNCH(k_ntt29_strided, (uint32_t)blocks, tile, (size_t)36 * tile, cur, scratch, L9, lc, cur_len, cur_pre);
-      } else
-      hipLaunchKernelGGL(k_ntt_strided, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, scratch, L, lc, cur_len, cur_pre);
-      cur = scratch; cur_len = N; cur_pre = nullptr; log_s -= L.log_m;
+      NTT29_LAUNCH(k_ntt29_strided, (uint32_t)blocks, tile, (size_t)36 * tile, cur, scratch, L9, lc, cur_len, cur_pre);
+      cur = scratch; cur_len = N; cur_pre = nullptr; log_s -= L9.log_m;
     }
     const uint32_t lm = p->log_m[p->levels - 1], log_a = p->log_m[0], log_b = p->levels == 3 ? p->log_m[1] : 0;
     const uint32_t lc = std::min(cols_for(lm), log_a), tile = 1u << (lm + lc);
-    const uint32_t threads = std::max(64u, std::min(1024u, tile / 2));
-    const size_t lds = (size_t)2 * 16 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc);
     const uint64_t blocks = ((uint64_t)1 << log_b) << (log_a - lc);
     Scope sc("ntt_pass");
-    if (raw_mode) hipLaunchKernelGGL((k_ntt29_final<2, 2>), dim3((uint32_t)blocks), dim3(std::max(64u, std::min(512u, tile / 4))), (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), s, cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3, raw);
-    else if (g.ntt29) NTT29_LAUNCH(k_ntt29_final, (uint32_t)blocks, tile, (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
-    else hipLaunchKernelGGL(k_ntt_final, dim3((uint32_t)blocks), dim3(threads), lds, s, cur, dst, lm, log_a, log_b, lc, p->tw_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
+    NTT29_LAUNCH(k_ntt29_final, (uint32_t)blocks, tile, (size_t)36 * (((size_t)1 << lm) + 1) * ((size_t)1 << lc), cur, dst, lm, log_a, log_b, lc, p->tw29_m[p->levels - 1], N, (const fe_t *)nullptr, post3);
   }
   HIPCHK(hipGetLastError());
   total.close();
@@ -276,7 +231,7 @@ int ntt_batch_inplace(const std::vector<fe_t *> &data, uint32_t log_n, const voi
     }
     return MI355_OK;
   };
-  if (cnt < 2 || !g.ntt29 || g.ntt_radix_log != 2 || g.ntt_raw_scratch || log_n > g.ntt_batch_max_log || log_n > 28) return single_loop();
+  if (cnt < 2 || log_n > g.ntt_batch_max_log || log_n > 28) return single_loop();
   NttPlan *p; CHK(get_plan(log_n, omega, &p));
   if (p->levels < 2) return single_loop();
   const uint64_t N = 1ull << log_n;

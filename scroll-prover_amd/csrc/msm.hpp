@@ -274,53 +274,11 @@ __device__ __forceinline__ void tile_bin_publish(uint32_t *gbase, const uint32_t
 }
 // Level-1 scatter, LDS-staged: the tile is counting-sorted inside LDS first so that the global stores are coalesced runs
 // (the direct version wrote 8-byte records at random: 3.4x write amplification measured with WRITE_SIZE).
-// 1024 threads, tile = 1024 * EPT entries, dynamic LDS = 3 * CB * 4 + 128 + tile * 8 bytes.
-template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter(const uint32_t *__restrict__ enc, uint32_t *__restrict__ coarse_cursor, uint64_t *__restrict__ pairs, SortPlan S) {
-  extern __shared__ uint32_t sm[];
-  const uint32_t CB = 1u << S.cb_bits, CBp = (CB + 1) & ~1u, fmask = (1u << S.fb) - 1;
-  uint32_t *h = sm, *lstart = sm + CBp, *gbase = sm + 2 * CBp, *scratch32 = sm + 3 * CBp;
-  uint64_t *stage = reinterpret_cast<uint64_t *>(sm + 3 * CBp + 32);
-  const uint32_t tiles1 = (S.n + S.t1 - 1) / S.t1;
-  const uint32_t w = blockIdx.x / tiles1, j = blockIdx.x - w * tiles1;
-  for (uint32_t b = threadIdx.x; b < CB; b += 1024) h[b] = 0;
-  __syncthreads();
-  const uint32_t i0 = j * S.t1, i1 = min(S.n, i0 + S.t1);
-  const uint32_t *plane = enc + (uint64_t)w * S.n;
-  uint32_t e[EPT], rank[EPT];
-#pragma unroll
-  for (int k = 0; k < EPT; k++) {
-    const uint32_t i = i0 + k * 1024 + threadIdx.x;
-    e[k] = i < i1 ? plane[i] : 0;
-  }
-  // all EPT loads are in flight before the first returning LDS atomic: in one fused loop the compiler keeps program order
-  // (load k, wait, atomic k, load k + 1, ...) and the tile pays EPT memory round trips -- measured 15 us against 5.9 us per tile
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int k = 0; k < EPT; k++) if (e[k]) rank[k] = atomicAdd(&h[((e[k] & 0x7fffffffu) - 1) >> S.fb], 1u);
-  __syncthreads();
-  // w = m * W + w_in: polynomial m of the batch, window w_in.  shared buckets: one bucket set per polynomial, payload names row w_in of the table
-  const uint32_t m_poly = w / S.wpp, w_in = w - m_poly * S.wpp;
-  uint32_t gb[4];
-  const uint32_t total = tile_bin_offsets(h, lstart, gb, CB, coarse_cursor + (S.shared ? m_poly * CB : w * CB), scratch32);
-  const uint32_t idx_base = S.shared ? w_in << S.nshift : 0;   // (row, point) packed by shift: the accumulation unpacks with a shift and a mask
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < EPT; k++) if (e[k]) {
-    const uint32_t bucket = (e[k] & 0x7fffffffu) - 1, i = i0 + k * 1024 + threadIdx.x;
-    stage[lstart[bucket >> S.fb] + rank[k]] = ((uint64_t)bucket << 32) | (uint64_t)((idx_base + i) | (e[k] & 0x80000000u));
-  }
-  tile_bin_publish(gbase, lstart, gb, CB);
-  __syncthreads();
-  for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
-    const uint64_t pr = stage[sidx];
-    const uint32_t bucket = (uint32_t)(pr >> 32), bin = bucket >> S.fb;
-    pairs[gbase[bin] + sidx] = ((uint64_t)(bucket & fmask) << 32) | (uint64_t)(uint32_t)pr;
-  }
-}
 // ---- split records (round 3, MI355_SORT_SPLIT): the level-1 output as TWO streams, payload (u32) and fine key (u16), instead of one u64 per
 // entry of which 43 bits carry information.  The histogram pass then reads 2 bytes per entry instead of 8, the level-2 scatter 6 instead of 8, and
 // with 6-byte staging a level-1 tile holds 24 576 entries (147 KB of LDS) -- runs of 24 entries per (tile, coarse bin) instead of 16.  The
 // staged record no longer names its coarse bin; the write-out recovers it from the key's spare bits and a 32-entry table of block starts.
+// (The single-stream u64 kernels k_sort_l1_scatter / k_sort_l2_hist / k_sort_l2_scatter were the A/B baseline of round 3 and left the library in round 6.)
 template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l1_scatter_split(const uint32_t *__restrict__ enc, uint32_t *__restrict__ coarse_cursor, uint32_t *__restrict__ pairs_lo,
                                                                                     uint16_t *__restrict__ pairs_hi, SortPlan S) {
   extern __shared__ uint32_t sm[];
@@ -403,53 +361,8 @@ __device__ __forceinline__ bool sort_l2_tile(const uint32_t *__restrict__ coarse
   e = min(coarse_off[lo + 1], s + S.t2);
   return true;
 }
-__global__ void __launch_bounds__(256) k_sort_l2_hist(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ hist, SortPlan S) {
-  __shared__ uint32_t h[SORT_MAX_BINS];
-  uint32_t region, s, e;
-  if (!sort_l2_tile(coarse_off, tile_start, S, region, s, e)) return;
-  const uint32_t FB = 1u << S.fb;
-  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) h[b] = 0;
-  __syncthreads();
-  for (uint32_t p = s + threadIdx.x; p < e; p += blockDim.x) atomicAdd(&h[(uint32_t)(pairs[p] >> 32)], 1u);
-  __syncthreads();
-  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) if (h[b]) atomicAdd(&hist[(region << S.fb) + b], h[b]);
-}
-// Level-2 scatter, LDS-staged (same idea): tile <= 1024 * EPT entries of one coarse region, 2^fb fine bins.
-// dynamic LDS = 3 * 2^fb * 4 + 128 + tile * 4 bytes.
-template <int EPT> __global__ void __launch_bounds__(1024) k_sort_l2_scatter(const uint64_t *__restrict__ pairs, const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ sorted, SortPlan S) {
-  extern __shared__ uint32_t sm[];
-  const uint32_t FB = 1u << S.fb;
-  uint32_t *h = sm, *lstart = sm + FB, *gbase = sm + 2 * FB, *scratch32 = sm + 3 * FB, *stage = sm + 3 * FB + 32;
-  uint32_t region, s, e;
-  if (!sort_l2_tile(coarse_off, tile_start, S, region, s, e)) return;
-  for (uint32_t b = threadIdx.x; b < FB; b += 1024) h[b] = 0;
-  __syncthreads();
-  uint32_t idx[EPT], fine[EPT], rank[EPT];
-#pragma unroll
-  for (int k = 0; k < EPT; k++) {
-    const uint32_t p = s + k * 1024 + threadIdx.x;
-    fine[k] = 0xffffffffu;
-    if (p < e) { const uint64_t pr = pairs[p]; idx[k] = (uint32_t)pr; fine[k] = (uint32_t)(pr >> 32); }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // as in the level-1 kernel: every load in flight before the first returning LDS atomic
-#pragma unroll
-  for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) rank[k] = atomicAdd(&h[fine[k]], 1u);
-  __syncthreads();
-  uint32_t gb[4];
-  const uint32_t total = tile_bin_offsets(h, lstart, gb, FB, cursor + (region << S.fb), scratch32);
-  __syncthreads();
-  // the bin of every staged entry travels in a 16-bit side array (fine < 4096): the write-out needs no search over lstart
-  uint16_t *stage_bin = reinterpret_cast<uint16_t *>(stage + 1024 * EPT);
-#pragma unroll
-  for (int k = 0; k < EPT; k++) if (fine[k] != 0xffffffffu) { const uint32_t pos = lstart[fine[k]] + rank[k]; stage[pos] = idx[k]; stage_bin[pos] = (uint16_t)fine[k]; }
-  tile_bin_publish(gbase, lstart, gb, FB);
-  __syncthreads();
-  for (uint32_t sidx = threadIdx.x; sidx < total; sidx += 1024) {
-    const uint32_t b = stage_bin[sidx];
-    sorted[gbase[b] + sidx] = stage[sidx];
-  }
-}
-
+// Level-2 scatter, LDS-staged (same idea as level 1): tile <= 1024 * EPT entries of one coarse region, 2^fb fine bins; the bin of every staged entry travels in a 16-bit
+// side array (fine < 4096), so the write-out needs no search over lstart.
 // level-2 histogram and scatter over the split records
 __global__ void __launch_bounds__(256) k_sort_l2_hist_split(const uint16_t *__restrict__ pairs_hi, const uint32_t *__restrict__ coarse_off, const uint32_t *__restrict__ tile_start,
                                                             uint32_t *__restrict__ hist, SortPlan S) {
