@@ -107,6 +107,32 @@ for it in range(iters):
     f = b.copy(); h2.best_fft(f, w, k)
     if not (f == cref.best_fft(b, w, k)).all():
         fails += 1; print("MISMATCH ntt", k, flush=True)
+    # coset transforms (round 6: the shift a[i] *= f^i rides on the first pass for multi-pass plans, the separate kernel below 2^9): ANY field element as the factor -- zero and one
+    # included --, single and batched entry points, in place and out of place, against the scaling by plain multiplications + best_fft
+    kc = int(rng.integers(0, 15))
+    nc = 1 << kc
+    f_int = [0, 1, R - 1, int(rng.integers(2, 2**62)), int.from_bytes(rng.bytes(31), "little") % R][int(rng.integers(0, 5))]
+    fac = cref.fr_mont(f_int)
+    wc = h2.fr(pow(h2.FR_ROOT_OF_UNITY, 1 << (28 - kc), R))
+    Mc = int(rng.integers(1, 5))
+    srcs_h = [scalars(nc, ["uniform", "sparse", "extreme"][int(rng.integers(0, 3))]) for _ in range(Mc)]
+    pw = np.zeros((nc, 4), dtype=np.uint64); pw[0] = cref.fr_mont(1)
+    mm = 1
+    while mm < nc:
+        pw[mm:2 * mm] = cref.f_mul_vec(cref.FR, pw[:mm], np.tile(cref.fr_mont(pow(f_int, mm, R)), (mm, 1))); mm *= 2
+    wants = [cref.best_fft(cref.f_mul_vec(cref.FR, hsrc, pw), wc, kc) for hsrc in srcs_h]
+    srcs_d = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in srcs_h]
+    inplace = rng.random() < 0.3
+    dsts_d = srcs_d if inplace else [torch.empty((nc, 4), dtype=torch.int64, device="cuda") for _ in range(Mc)]
+    if Mc == 1 and rng.random() < 0.5:
+        check(lib.mi355_coset_ntt_fr_dev(ptr(dsts_d[0]), ptr(srcs_d[0]), kc, ptr(fac), ptr(wc)))
+    else:
+        check(lib.mi355_coset_ntt_fr_batch_dev((C.c_void_p * Mc)(*[x.data_ptr() for x in dsts_d]), (C.c_void_p * Mc)(*[x.data_ptr() for x in srcs_d]), Mc, kc, ptr(fac), ptr(wc)))
+    for i_ in range(Mc):
+        if not (dsts_d[i_].cpu().numpy().view(np.uint64).reshape(nc, 4) == wants[i_]).all():
+            fails += 1; print("MISMATCH coset_ntt", dict(k=kc, f=hex(f_int), M=Mc, i=i_, inplace=inplace), flush=True)
+        if not inplace and not (srcs_d[i_].cpu().numpy().view(np.uint64).reshape(nc, 4) == srcs_h[i_]).all():
+            fails += 1; print("MISMATCH coset_ntt modified its source", dict(k=kc, M=Mc, i=i_), flush=True)
     if it % 25 == 24:
         print(f"{it + 1} iterations, {fails} mismatches, {time.time() - t0:.0f} s", flush=True)
 print("FUZZ DONE", iters, "iterations", fails, "mismatches")
