@@ -271,8 +271,13 @@ inline PkSizes pk_sizes(const Protocol &P) {
 // A prover process holds several layers at once (a chunk prover the degrees {20, 24, 25}, a batch prover {21, 26} [REF bin/src/trace_prover.rs:35-36]): the
 // SRS of every degree, every layer's proving key, and the working set of the ONE proof that runs.  Everything resident does not fit 288 GiB; this is the
 // rule of section 7c as code.  What each optional resident buys per proof: window tables of a basis ~8 % of every commitment on it (W x the basis of HBM);
-// the Q coset parts of a proving key one coset transform per polynomial and part.  So cosets are kept before tables, smaller keys first (more layers stay
+// the Q coset parts of a proving key one coset transform per polynomial and part.  So cosets are kept before tables, the subset of keys that saves the most proof time and fits (round 6; round 5: smaller keys first, so that more layers stay
 // fully resident), then tables go to the Lagrange bases (they carry most commitments), the largest degree first.
+// one coset transform of 2^k on an MI355X, batched (0.109 ms at 2^20, 0.228 at 2^21, 0.479 at 2^22, 2.03 at 2^24, 4.3 at 2^25, 9.0 at 2^26)
+inline double coset_transform_ms(uint32_t k) {
+  static const double t[7] = {0.109, 0.228, 0.479, 1.0, 2.03, 4.3, 9.0};
+  return k < 20 ? 0.109 / (double)(1u << (20 - k)) : k <= 26 ? t[k - 20] : 9.0 * (double)(1u << (k - 26));
+}
 struct LayerResidency { const Protocol *P; PkSizes sz; bool cosets_resident = false, table_lagrange = false, table_coeff = false; };
 struct ResidencyPlan { std::vector<LayerResidency> layers; double srs_gib = 0, keys_gib = 0, tables_gib = 0, working_gib = 0, total_gib = 0, budget_gib = 0; bool fits = false; };
 inline ResidencyPlan plan_residency(const std::vector<const Protocol *> &protos, double hbm_gib, double reserve_fraction = 0.08) {
@@ -281,15 +286,45 @@ inline ResidencyPlan plan_residency(const std::vector<const Protocol *> &protos,
   std::set<uint32_t> degrees;
   for (const Protocol *p : protos) { LayerResidency L{p, pk_sizes(*p)}; R.working_gib = std::max(R.working_gib, L.sz.working_bytes / GiB); degrees.insert(p->k); R.keys_gib += L.sz.base_bytes / GiB; R.layers.push_back(L); }
   for (uint32_t k : degrees) R.srs_gib += 2.0 * (double)(uint64_t(64) << k) / GiB;                       // two bases of 64-byte points
-  double used = R.srs_gib + R.keys_gib + R.working_gib, lean_tmp = 0;                                     // lean_tmp: one part's cosets of the largest key that recomputes them
-  std::vector<size_t> order(R.layers.size()); for (size_t i = 0; i < order.size(); i++) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return R.layers[a].sz.coset_bytes < R.layers[b].sz.coset_bytes; });
-  for (size_t i : order) {
-    const double c = R.layers[i].sz.coset_bytes / GiB;
-    if (used + c + lean_tmp <= R.budget_gib) { R.layers[i].cosets_resident = true; used += c; R.keys_gib += c; }
-    else lean_tmp = std::max(lean_tmp, R.layers[i].sz.lean_tmp_bytes / GiB);
+  // Which keys keep their coset parts (round 6): the subset that SAVES THE MOST PROOF TIME and fits -- a resident key saves one coset transform per polynomial, part and proof
+  // (coset_transform_ms: measured, section 5).  Round 5 took "smaller keys first"; by value a chunk prover would rather keep layer 1's 80 GiB (160 transforms of 2^24 = 0.33 s)
+  // than layer 0's 68.5 GiB (2 192 transforms of 2^20 = 0.24 s) -- but that plan ran OUT OF MEMORY inside layer 0's quotient on the device (288 GiB), because a lean layer 0
+  // adds its recomputed part (8.6 GiB) to the LARGEST working set of the process.  So the accounting of a multi-layer process is the measured one (chunk prover: 276 GiB real):
+  //   * the buffer pool keeps the high-water mark of the largest per-layer demand = that layer's blocks + (if ITS key is lean) one part's cosets, plus ~10 % that another
+  //     layer's block sizes cannot reuse;
+  //   * the MSM workspace and the transform scratch are sized by the LARGEST degree / extended domain of the process, whichever layer has the largest working set;
+  //   * the folded coset shift keeps one table per coset factor for degrees up to 2^24 (bigger ones are only built into spare memory: lib_ntt.hip).
+  // At most 7 layers: all subsets are tried.
+  const size_t NL = R.layers.size();
+  std::vector<double> core(NL), msm_ws(NL), ntt_scr(NL);
+  double max_msm = 0, max_scr = 0, fold_tables = 0;
+  for (size_t i = 0; i < NL; i++) {
+    const Protocol &P = *R.layers[i].P;
+    msm_ws[i] = (double)P.n * 13 * 22 / GiB; ntt_scr[i] = (double)P.n * 32 * P.Q / GiB;
+    core[i] = R.layers[i].sz.working_bytes / GiB - msm_ws[i] - ntt_scr[i];
+    max_msm = std::max(max_msm, msm_ws[i]); max_scr = std::max(max_scr, ntt_scr[i]);
   }
-  used += lean_tmp;
+  if (NL > 1) for (uint32_t k : degrees) if (k <= 24) { uint32_t q = 0; for (const auto &L : R.layers) if (L.P->k == k) q = std::max(q, L.P->Q); fold_tables += (double)q * 36 * (double)(uint64_t(1) << k) / GiB; }
+  auto demand = [&](uint32_t mask, double &mem, double &val) {          // GiB a process needs with the keys of `mask` resident; val = ms of transforms saved per round
+    mem = 0; val = 0; double pool = 0;
+    for (size_t i = 0; i < NL; i++) {
+      const LayerResidency &L = R.layers[i];
+      const bool res = mask >> i & 1;
+      if (res) { mem += L.sz.coset_bytes / GiB; val += (double)L.sz.polys * L.P->Q * coset_transform_ms(L.P->k); }
+      pool = std::max(pool, core[i] + (res ? 0.0 : L.sz.lean_tmp_bytes / GiB));
+    }
+    return (NL > 1 ? 1.10 : 1.0) * pool + max_msm + max_scr + fold_tables;
+  };
+  uint32_t best_mask = 0; double best_val = -1, best_mem = 0, best_work = 0;
+  for (uint32_t mask = 0; mask < (1u << NL); mask++) {
+    double mem, val; const double work = demand(mask, mem, val);
+    if (R.srs_gib + R.keys_gib + mem + work > R.budget_gib) continue;
+    if (val > best_val + 1e-9 || (val > best_val - 1e-9 && mem + work < best_mem + best_work)) { best_val = val; best_mask = mask; best_mem = mem; best_work = work; }
+  }
+  if (best_val < 0) { double mem, val; best_work = demand(0, mem, val); best_mem = 0; best_mask = 0; }   // not even every key lean fits: the caller sees fits == false
+  for (size_t i = 0; i < NL; i++) if (best_mask >> i & 1) R.layers[i].cosets_resident = true;
+  R.working_gib = best_work; R.keys_gib += best_mem;
+  double used = R.srs_gib + R.keys_gib + R.working_gib;
   std::vector<uint32_t> ks(degrees.rbegin(), degrees.rend());
   for (int pass = 0; pass < 2; pass++) for (uint32_t k : ks) {
     const double t = (double)(uint64_t(64) << k) * (k >= 24 ? 12 : 15) / GiB;                               // W x 64 bytes per point
@@ -610,13 +645,15 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
           std::vector<void *> dst(NP); std::vector<const void *> src(NP);
           for (uint32_t i = 0; i < NP; i++) { dst[i] = part_on[d].at(wrefs[i]).p; src[i] = d == 0 ? poly.at(wrefs[i]).p : coeff_on[d].at(wrefs[i]).p; }
           check(mi355_coset_ntt_fr_batch_dev(dst.data(), src.data(), NP, k, factor.data(), dom.omega.data())); cosets[d] += NP;
-          if (!pk.resident_cosets) {   // the HBM-lean proving key: this part's cosets are recomputed from the coefficients
+          if (!pk.resident_cosets) {   // the HBM-lean proving key: this part's cosets are recomputed from the coefficients, in ONE batched call (round 6: a lean many-column key
+            std::vector<void *> kd; std::vector<const void *> ks;   // used to issue one transform per polynomial -- 2 192 single 2^20 launches per layer-0 proof)
             for (const auto &a : pkset) {
               auto it = pkpart_on[d].find(a); if (it == pkpart_on[d].end()) it = pkpart_on[d].emplace(a, DevicePoly(n, d)).first;
-              if (d == 0) check(mi355_coset_ntt_fr_dev(it->second.p, pk.coeff(a).p, k, factor.data(), dom.omega.data()));
-              else { check(mi355_buf_copy(it->second.p, pk.coeff(a).p, n * 32)); check(mi355_coset_ntt_fr_dev(it->second.p, it->second.p, k, factor.data(), dom.omega.data())); }
-              cosets[d]++;
+              if (d != 0) check(mi355_buf_copy(it->second.p, pk.coeff(a).p, n * 32));   // another device: copy first, then in place
+              kd.push_back(it->second.p); ks.push_back(d == 0 ? pk.coeff(a).p : it->second.p);
             }
+            if (!kd.empty()) check(mi355_coset_ntt_fr_batch_dev(kd.data(), ks.data(), (uint32_t)kd.size(), k, factor.data(), dom.omega.data()));
+            cosets[d] += (uint32_t)kd.size();
           }
           auto resolve = [&](const Atom &a) -> const void * {
             if (a.kind == A_TMP) return tmp_on[d].at(a.idx).p;

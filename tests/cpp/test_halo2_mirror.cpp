@@ -144,6 +144,10 @@ int main(int argc, char **argv) {
     EXPECT(C.fits && C.total_gib <= 265.0);
     int resident = 0; for (const auto &L : C.layers) resident += L.cosets_resident;
     EXPECT(resident >= 2);
+    // round 6: WHICH keys stay is decided by the proof time they save among the subsets that FIT under the measured accounting of a multi-layer process.  By value alone layers
+    // 1 + 2 would stay and layer 0 recompute -- that plan ran out of memory on the device (a lean layer 0 adds its recomputed part to the largest working set); what fits and
+    // saves most is layers 0 + 2 resident, layer 1 lean
+    EXPECT(C.layers[0].cosets_resident && !C.layers[1].cosets_resident && C.layers[2].cosets_resident);
     const ResidencyPlan B = plan_residency({protos[3].get(), protos[4].get()}, 288.0);
     EXPECT(B.fits && B.layers[0].cosets_resident && !B.layers[1].cosets_resident);   // with the reference's real layer-4 system (13 key polynomials: 42 GiB + 104 GiB of cosets) a batch prover
     EXPECT(!B.layers[1].table_coeff);                                                // keeps layer 3's cosets and recomputes layer 4's per part; the k = 26 bases stay table-free
