@@ -505,6 +505,14 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
       }
     } catch (const std::exception &e) { { std::lock_guard<std::mutex> lk(mu); upload_error = e.what(); std::fill(arrived.begin(), arrived.end(), 1); } cv.notify_all(); }
   };
+  {                                                                                     // step 1's input, made NOW: the instance column (public values, zero below).  Its few words must
+    // cross PCIe before the uploader threads fill the copy stream: that stream is first-in first-out, and queued behind the witness this 1 KiB upload waited for the random polynomial
+    // of step 5 (2 GiB at k = 26) -- 33 ms of host time in step 1 of every k = 26 proof until round 6 (17 ms at k = 25).  No device-wide synchronisation either: mi355_buf_upload
+    // orders itself behind the zeroing of its block, and the compute stream behind the copy.
+    DevicePoly inst(n, 0); check(mi355_buf_zero(inst.p, n * 32));
+    if (!wit.instances.empty()) check(mi355_buf_upload(inst.p, wit.instances.data(), wit.instances.size() * 32));
+    poly.at(P.inst0) = std::move(inst);
+  }
   struct Joiner { std::vector<std::thread> th; void join() { for (auto &t : th) if (t.joinable()) t.join(); } ~Joiner() { join(); } } uploaders;
   for (size_t w = 0; w < UT; w++) uploaders.th.emplace_back(upload_worker, w);
   auto wait_for = [&](size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return arrived[i] != 0; }); if (!upload_error.empty()) throw Error(MI355_EHIP, "witness upload: " + upload_error); };
@@ -533,11 +541,6 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
   for (uint32_t i = 0; i < P.num_challenge[1]; i++) ch.push_back(T.squeeze_challenge()); // beta, gamma
   const Fr beta = ch.at(1), gamma = ch.at(2);
   lap(2);
-  {                                                                                     // step 1: the instance column (public values, zero below) to coefficients
-    DevicePoly inst(n, 0); check(mi355_buf_zero(inst.p, n * 32)); check(mi355_synchronize());
-    if (!wit.instances.empty()) check(mi355_buf_upload(inst.p, wit.instances.data(), wit.instances.size() * 32));
-    poly.at(P.inst0) = std::move(inst);
-  }
   DevicePoly inst_lagrange = clone(poly.at(P.inst0), 0);
   check(mi355_intt_fr_dev(poly.at(P.inst0).p, k, dom.omega_inv.data(), dom.ifft_divisor.data())); R.intt++;
   lap(1);
@@ -574,7 +577,6 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
       check(mi355_fr_prefix_product_dev(z.p, tmp_at(0).p, n, nullptr));                  // z[0] = 1, z[i + 1] = z[i] prod u / prod v
       if (c > 0) check(mi355_fr_vec_axpy_dev(z.p, nullptr, z.p, carry.data(), n));       // chunk c starts where chunk c - 1 ended: z_c(1) = z_(c-1)(w^last)
       if (c + 1 < NZ) check(mi355_buf_download(carry.data(), z.at(u), 32));
-      else check(mi355_synchronize());
       if (P.blind) check(mi355_buf_upload(z.at(u + 1), wit.z_blind.at(c).data(), P.blind * 32));
       poly.at(chunk.z) = std::move(z);
     }
@@ -592,7 +594,6 @@ inline ProofResult create_proof(uint64_t h_g, uint64_t h_g_lagrange, const Provi
       check(mi355_fr_vec_op_dev(2, tmp_at(3).p, tmp_at(3).p, tmp_at(2).p, n));
       DevicePoly phi(n, 0);
       check(mi355_fr_prefix_sum_dev(phi.p, tmp_at(3).p, n, nullptr));
-      check(mi355_synchronize());
       if (P.blind) check(mi355_buf_upload(phi.at(u + 1), wit.phi_blind.at(l).data(), P.blind * 32));
       poly.at(lk.phi) = std::move(phi);
     }
