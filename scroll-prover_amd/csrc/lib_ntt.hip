@@ -63,7 +63,7 @@ static int build_plan(NttPlan &p, uint32_t log_n, const void *omega) {
       // otherwise the usual two half-size tables
       p.split[l] = log_s <= NTT_DIRECT_TW_MAX_LOG ? log_s : (log_s + 1) / 2;
       bool direct = false;
-      if (log_s > NTT_DIRECT_TW_MAX_LOG && log_s <= g.ntt_direct2_max_log) {
+      if (log_s >= g.ntt_direct2_min_log && log_s <= g.ntt_direct2_max_log) {
         // big level: every twiddle w_S^(column k) once, in the order the pass reads them (36 B x 2^log_s: 2.4 GB at 2^26, read coalesced
         // next to the data by a pass that is ALU-bound); saves the lo x hi product per element.  HBM may be full of window tables: when the
         // allocation fails the level falls back to the lo x hi pair, which is functionally equivalent.
@@ -110,7 +110,7 @@ static int fold_divisor(NttPlan *p, uint32_t log_n, const fe_t *pre3_host, const
   if (post3_host && !pre3_host && g.ntt_fold_scale && p->levels >= 2 && memcmp(&post3_host[0], &post3_host[1], 32) == 0 && memcmp(&post3_host[0], &post3_host[2], 32) == 0) {
     const uint32_t l = p->levels - 2;
     uint32_t log_sl = log_n; for (uint32_t q = 0; q < l; q++) log_sl -= p->log_m[q];
-    if (p->split[l] == log_sl && !p->direct2[l]) {   // that level reads ONE direct table
+    if ((p->split[l] == log_sl && !p->direct2[l]) || (p->direct2[l] && log_sl <= 22)) {   // that level reads ONE table of 2^log_sl entries (gathered by e = column k, or laid out [k][column]: scaling is element-wise either way; a big level's 2-D table is not duplicated per divisor)
       const std::string key((const char *)&post3_host[0], 32);
       auto it = p->scaled.find(key);
       if (it == p->scaled.end()) {
