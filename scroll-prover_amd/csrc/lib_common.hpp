@@ -114,7 +114,7 @@ struct Ctx {
   uint32_t tail_coop_max = 65536;    // MI355_TAIL_COOP_MAX: reduction-tail kernels with at most this many logical threads run the quad-cooperative (latency) form of the point addition; 0 disables
   uint32_t reduce_min_chunk = 4;     // MI355_REDUCE_MIN_CHUNK: shortest running-sum chain (buckets per reduce thread) small bucket sets are cut into
   uint32_t sort_t1 = 16384;     // MI355_SORT_T1=8192 selects the smaller level-1 tile (2 workgroups per CU)
-  uint32_t ntt_direct2_max_log = 25;   // MI355_NTT_DIRECT2_MAX_LOG: levels up to 2^this elements read their inter-level twiddles from a full table (36 B per element of the level: 2^24 transform 2.41 -> 2.28 ms for 0.6 GB; at 2^26 the 2.4 GB table only buys 1.7 %, so the default stops at 2^25); 0 disables
+  uint32_t ntt_direct2_max_log = 25;   // MI355_NTT_DIRECT2_MAX_LOG: levels up to 2^this elements read their inter-level twiddles from a full [k][column] table (36 B per element of the level: 0.6 GB at 2^24; tables of 256 MB and more only while HBM has the table + max(16 GiB, 1/12 of the device) to spare, lib_ntt.hip hbm_spare_for_table; otherwise, and above the cap, the level multiplies two half-size table entries per element).  At 2^26 the 2.4 GB table buys 0.5 % (8.53 vs 8.58 ms, profiles/r06_direct2_k26_ab.json; round 3 had measured 1.7 %), so the default stops at 2^25; 0 disables
   uint32_t ntt_coset_fold_max_log = 26;  // MI355_NTT_COSET_FOLD_MAX_LOG: coset transforms up to 2^this fold distribute_powers into their first pass (one 36 B x 2^log_n table per coset factor: 38 MB at 2^20, 0.6 GB at 2^24, 2.4 GB at 2^26; tables of 256 MB and more are only built while HBM has the table + max(16 GiB, 1/12 of the device) to spare -- otherwise, and above the cap, the separate pass runs); 0: always the separate k_distribute_powers pass
   uint32_t ntt_direct2_min_log = 0;   // MI355_NTT_DIRECT2_MIN_LOG: levels of at least 2^this elements read their inter-level twiddles from the [k][column] table (coalesced, next to the data); smaller ones gather from ONE 1-D table w_S^e by e = column k.  Round 6: 0 (every level) -- the gather cost more than it looked: 2^20 transform 111.5 -> 103 us, 2^18 26.1 -> 25.3, 2^24 1 965 -> 1 932, 2^26 8.89 -> 8.73 ms (profiles/r06_direct2_small_levels_ab.json; 21 restores round 5)
   uint32_t ntt_fold_scale = 1;  // MI355_NTT_FOLD_SCALE=0: the inverse transform's divisor stays a multiplication in the closing pass

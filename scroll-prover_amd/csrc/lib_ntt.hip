@@ -40,6 +40,14 @@ static void free_plan_tables(NttPlan &p) {
   for (void *q : p.owned) (void)hipFree(q);
   p.owned.clear();
 }
+// big twiddle tables (256 MB and more) are only built into HBM that is really spare: the table plus max(16 GiB, 1/12 of the device) must be free -- a multi-layer prover process
+// that peaks at 274 GiB of 288 builds none of them and takes the table-free form of the same pass (the lo x hi product, or the separate coset shift)
+static bool hbm_spare_for_table(uint64_t entries) {
+  if (entries * 36 < (256ull << 20)) return true;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return fr >= entries * 36 + std::max<size_t>((size_t)16 << 30, tot / 12);
+}
 // three device arrays of one 29-bit table (SoA), all or nothing
 static bool alloc_tw29(uint64_t cnt, uint4 **lo, uint4 **hi, uint32_t **top) {
   *lo = *hi = nullptr; *top = nullptr;
@@ -68,7 +76,7 @@ static int build_plan(NttPlan &p, uint32_t log_n, const void *omega) {
         // next to the data by a pass that is ALU-bound); saves the lo x hi product per element.  HBM may be full of window tables: when the
         // allocation fails the level falls back to the lo x hi pair, which is functionally equivalent.
         const uint64_t cnt = 1ull << log_s; uint4 *lo, *hi; uint32_t *top;
-        if (alloc_tw29(cnt, &lo, &hi, &top)) {
+        if (hbm_spare_for_table(cnt) && alloc_tw29(cnt, &lo, &hi, &top)) {
           p.owned.push_back(lo); p.owned.push_back(hi); p.owned.push_back(top);
           hipLaunchKernelGGL(k_pow_table29_2d, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, g.stream, lo, hi, top, Fr::pow_u64(w, N >> log_s), log_s - lm, cnt);
           HIPCHK(hipGetLastError());
@@ -144,15 +152,9 @@ static const NttPlan::CosetTw *coset_fold_tables(NttPlan *p, uint32_t log_n, con
   fe_t f, w; memcpy(&f, factor, 32); memcpy(&w, omega, 32);
   NttPlan::CosetTw T;
   uint4 *lo, *hi; uint32_t *top;
-  // big tables (0.6 GB per factor at 2^24, 2.4 GB at 2^26) are built only into HBM that is really spare: the first coset transform of a proof runs when most of the proof's
-  // working set is already allocated, so what is free here is close to what stays free; below the margin the shift stays the separate pass (a table that a later allocation
-  // would have to compete with is worth less than the 1-2 % of a k = 26 proof it saves)
-  if (cnt * 36 >= (256ull << 20)) {
-    size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    const size_t margin = std::max<size_t>((size_t)16 << 30, tot / 12);   // 24 GiB on a 288-GiB device: a multi-layer prover process that peaks at 274 GiB builds none of the big tables
-    if (fr < cnt * 36 + margin) return nullptr;
-  }
+  // big tables (0.6 GB per factor at 2^24, 2.4 GB at 2^26) are built only into HBM that is really spare (hbm_spare_for_table): the first coset transform of a proof runs when most
+  // of the proof's working set is already allocated, so what is free here is close to what stays free; below the margin the shift stays the separate pass
+  if (!hbm_spare_for_table(cnt)) return nullptr;
   if (!alloc_tw29(cnt, &lo, &hi, &top)) return nullptr;
   p->owned.push_back(lo); p->owned.push_back(hi); p->owned.push_back(top);
   hipLaunchKernelGGL(k_pow_table29_2d, dim3((uint32_t)((cnt + 255) / 256)), dim3(256), 0, g.stream, lo, hi, top, w, log_t, cnt, f, 1);   // level 0: w_S = omega (S = N)
